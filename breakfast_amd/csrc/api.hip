@@ -1,0 +1,487 @@
+// C ABI of libbreakfast_hip.so (include/breakfast_hip.h): context, genome image, read residency,
+// stage orchestration and the .sv renderer.  All compute is in localise.hip / cluster.hip; there is
+// no CPU implementation of the path in this library.
+
+#include "bf_internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <numeric>
+
+static thread_local std::string g_create_error;
+
+namespace bf {
+
+int fail(bf_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+int ensure(bf_ctx* ctx, DevBuf& b, size_t bytes, bool keep) {
+    if (bytes <= b.cap && b.p) return BF_OK;
+    if (bytes == 0) bytes = 16;
+    size_t cap = keep ? std::max(bytes, b.cap + b.cap / 2) : bytes;
+    cap = (cap + 255) & ~(size_t)255;
+    void* np = nullptr;
+    hipError_t e = hipMalloc(&np, cap);
+    if (e != hipSuccess) return fail(ctx, BF_ERR_NOMEM, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+    if (b.p) {
+        if (keep && b.cap) {
+            e = hipMemcpyAsync(np, b.p, b.cap, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { (void)hipFree(np); return fail(ctx, BF_ERR_HIP, "device copy failed: %s", hipGetErrorString(e)); }
+        } else {
+            (void)hipStreamSynchronize(ctx->stream);
+        }
+        (void)hipFree(b.p);
+        ctx->device_bytes -= b.cap;
+    }
+    b.p = np; b.cap = cap;
+    ctx->device_bytes += cap;
+    return BF_OK;
+}
+
+void release(bf_ctx* ctx, DevBuf& b) {
+    if (b.p) { (void)hipFree(b.p); ctx->device_bytes -= b.cap; }
+    b.p = nullptr; b.cap = 0;
+}
+
+struct PendingEvent { std::string name; hipEvent_t a, b; };
+static std::vector<PendingEvent>& pending(bf_ctx* ctx) {
+    return *reinterpret_cast<std::vector<PendingEvent>*>(ctx->timing_pending);
+}
+
+Scope::Scope(bf_ctx* c, const char* n) : ctx(c), name(n) {
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+    (void)hipEventRecord(a, ctx->stream);
+}
+Scope::~Scope() {
+    if (!a) return;
+    (void)hipEventRecord(b, ctx->stream);
+    if (pending(ctx).size() >= 8192) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); return; }
+    pending(ctx).push_back(PendingEvent{name, a, b});
+}
+
+void Timing::clear() { names.clear(); ms.clear(); launches.clear(); view.clear(); }
+void Timing::add(const char* name, float ms_) {
+    for (size_t i = 0; i < names.size(); i++)
+        if (names[i] == name) { ms[i] += ms_; launches[i]++; return; }
+    names.push_back(name); ms.push_back(ms_); launches.push_back(1);
+}
+
+static void drop_pending(bf_ctx* ctx) {
+    for (auto& p : pending(ctx)) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    pending(ctx).clear();
+}
+
+static OwnerView local_view(bf_ctx* ctx) {
+    OwnerView v;
+    v.n = ctx->n_reads;
+    v.key = ctx->d_key.as<uint64_t>(); v.lpos = ctx->d_lpos.as<int32_t>(); v.rpos = ctx->d_rpos.as<int32_t>();
+    v.fhash = ctx->d_fhash.as<uint64_t>(); v.bp = ctx->d_bp.as<uint16_t>(); v.len = ctx->d_len.as<uint16_t>();
+    v.flags = ctx->d_flags.as<uint16_t>();
+    v.frag = ctx->d_frag.as<uint8_t>(); v.frag_off = ctx->d_frag_off.as<uint64_t>(); v.frag_len = ctx->d_frag_len.as<uint16_t>();
+    v.sigx = ctx->d_sigx.as<uint8_t>(); v.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
+    return v;
+}
+static OwnerView imported_view(bf_ctx* ctx) {
+    OwnerView v;
+    v.n = ctx->n_imported;
+    v.key = ctx->i_key.as<uint64_t>(); v.lpos = ctx->i_lpos.as<int32_t>(); v.rpos = ctx->i_rpos.as<int32_t>();
+    v.fhash = ctx->i_fhash.as<uint64_t>(); v.bp = ctx->i_bp.as<uint16_t>(); v.len = ctx->i_len.as<uint16_t>();
+    v.flags = ctx->i_flags.as<uint16_t>();
+    v.frag = ctx->i_frag.as<uint8_t>(); v.frag_off = ctx->i_frag_off.as<uint64_t>(); v.frag_len = ctx->i_frag_len.as<uint16_t>();
+    v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
+    v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>();
+    return v;
+}
+
+static void free_all(bf_ctx* ctx) {
+    DevBuf* all[] = {&ctx->g_blocks, &ctx->g_raw, &ctx->g_coarse, &ctx->g_contigs, &ctx->d_seq, &ctx->d_seq_off,
+        &ctx->d_frag, &ctx->d_frag_off, &ctx->d_hits, &ctx->d_planes, &ctx->d_len, &ctx->d_frag_len, &ctx->d_fhash,
+        &ctx->d_key, &ctx->d_lpos, &ctx->d_rpos, &ctx->d_bp, &ctx->d_flags, &ctx->d_mask, &ctx->d_exact_list,
+        &ctx->d_counters, &ctx->d_sigx, &ctx->d_sigx_slot, &ctx->d_send, &ctx->d_part_key, &ctx->d_part_idx,
+        &ctx->d_part_tmp, &ctx->i_key, &ctx->i_lpos, &ctx->i_rpos, &ctx->i_fhash, &ctx->i_bp, &ctx->i_len, &ctx->i_flags,
+        &ctx->i_frag, &ctx->i_frag_off, &ctx->i_frag_len, &ctx->i_sigx, &ctx->i_sigx_slot, &ctx->i_src_rank,
+        &ctx->i_src_idx, &ctx->c_tmp, &ctx->c_a32, &ctx->c_b32, &ctx->c_c32, &ctx->c_d32, &ctx->c_k64a, &ctx->c_k64b,
+        &ctx->c_slpos, &ctx->c_srpos, &ctx->c_reported, &ctx->c_csize, &ctx->c_flag, &ctx->c_scan, &ctx->c_qseed,
+        &ctx->c_qsize, &ctx->c_qoff, &ctx->c_members, &ctx->c_leader, &ctx->c_rep, &ctx->c_qnrep, &ctx->c_sel,
+        &ctx->c_ord, &ctx->c_clusters, &ctx->c_reads, &ctx->c_misc, &ctx->c_joff, &ctx->c_jbytes, &ctx->c_rsrc,
+        &ctx->c_tables, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
+    for (DevBuf* b : all) release(ctx, *b);
+}
+
+}  // namespace bf
+
+using namespace bf;
+
+extern "C" {
+
+int bf_abi_version(void) { return BF_ABI_VERSION; }
+
+const char* bf_last_error(const bf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int bf_ctx_create(const bf_config* cfg, bf_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, BF_ERR_INVALID, "bf_ctx_create: null argument");
+    *out = nullptr;
+    if (cfg->anchor_len < 8 || cfg->anchor_len > 32767)
+        return fail(nullptr, BF_ERR_RANGE, "anchor_len %u outside [8, 32767] (the reference panics below 8, detect.rs:166)", cfg->anchor_len);
+    if (cfg->max_frag_len >= 0x80000000u) return fail(nullptr, BF_ERR_RANGE, "max_frag_len must be < 2^31");
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(nullptr, BF_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    int dev = cfg->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= n_dev) return fail(nullptr, BF_ERR_INVALID, "device %d out of range (have %d)", dev, n_dev);
+    if ((e = hipSetDevice(dev)) != hipSuccess) return fail(nullptr, BF_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return fail(nullptr, BF_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, BF_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+    bf_ctx* ctx = new bf_ctx();
+    ctx->cfg = *cfg; ctx->device = dev;
+    ctx->timing_pending = new std::vector<PendingEvent>();
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete reinterpret_cast<std::vector<PendingEvent>*>(ctx->timing_pending);
+        delete ctx;
+        return fail(nullptr, BF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return BF_OK;
+}
+
+void bf_ctx_destroy(bf_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    drop_pending(ctx);
+    free_all(ctx);
+    (void)hipStreamDestroy(ctx->stream);
+    delete reinterpret_cast<std::vector<PendingEvent>*>(ctx->timing_pending);
+    delete ctx;
+}
+
+int bf_sync(bf_ctx* ctx) {
+    if (!ctx) return BF_ERR_INVALID;
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BF_OK;
+}
+
+int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint8_t* const* seqs,
+                  const uint64_t* lens) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!names || !seqs || !lens || n_contigs == 0) return fail(ctx, BF_ERR_INVALID, "bf_genome_set: null/empty argument");
+    if (n_contigs > (1u << kContigBits)) return fail(ctx, BF_ERR_RANGE, "%u contigs; at most %u are supported", n_contigs, 1u << kContigBits);
+    if (ctx->n_reads) return fail(ctx, BF_ERR_STATE, "bf_genome_set with resident reads; call bf_reset first");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->n_contigs = n_contigs;
+    ctx->contig_names.assign(names, names + n_contigs);
+    // rank by byte-wise name order (Rust String Ord == memcmp order); names must be unique
+    std::vector<uint32_t> order(n_contigs);
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ctx->contig_names[a] < ctx->contig_names[b]; });
+    ctx->contig_rank.assign(n_contigs, 0);
+    ctx->contig_by_rank = order;
+    for (uint32_t r = 0; r < n_contigs; r++) {
+        if (r > 0 && ctx->contig_names[order[r]] == ctx->contig_names[order[r - 1]])
+            return fail(ctx, BF_ERR_INVALID, "duplicate contig name '%s' (the reference keeps only the last record of a name, detect.rs:55; pass it once)", ctx->contig_names[order[r]].c_str());
+        ctx->contig_rank[order[r]] = r;
+    }
+    ctx->contig_host.resize(n_contigs);
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < n_contigs; i++) {
+        if (lens[i] >= 0x80000000ull - (1ull << 17))
+            return fail(ctx, BF_ERR_RANGE, "contig '%s' has %llu bases; the supported maximum is 2^31 - 2^17", names[i], (unsigned long long)lens[i]);
+        ctx->contig_host[i] = ContigDev{off, (uint32_t)lens[i], ctx->contig_rank[i]};
+        off += (lens[i] + 63) & ~63ull;
+    }
+    const uint64_t total = (off + 4095) & ~4095ull;      // whole waves of 64 blocks
+    ctx->genome_bases = total;
+    const uint64_t n_blocks = total / 64;
+    BF_TRY(ensure(ctx, ctx->g_raw, total + 4096));
+    BF_TRY(ensure(ctx, ctx->g_blocks, (n_blocks + 16) * sizeof(GenomeBlock)));
+    BF_TRY(ensure(ctx, ctx->g_coarse, (n_blocks / 64 + 4) * 8));
+    BF_TRY(ensure(ctx, ctx->g_contigs, (size_t)n_contigs * sizeof(ContigDev)));
+    BF_HIP(ctx, hipMemsetAsync(ctx->g_raw.p, 'A', total + 4096, ctx->stream));   // padding is never compared
+    BF_HIP(ctx, hipMemsetAsync(ctx->g_blocks.p, 0, (n_blocks + 16) * sizeof(GenomeBlock), ctx->stream));
+    BF_HIP(ctx, hipMemsetAsync(ctx->g_coarse.p, 0, (n_blocks / 64 + 4) * 8, ctx->stream));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < n_contigs; i++)
+        if (lens[i]) BF_HIP(ctx, hipMemcpy(ctx->g_raw.as<uint8_t>() + ctx->contig_host[i].goff, seqs[i], lens[i], hipMemcpyHostToDevice));
+    BF_HIP(ctx, hipMemcpy(ctx->g_contigs.p, ctx->contig_host.data(), (size_t)n_contigs * sizeof(ContigDev), hipMemcpyHostToDevice));
+    BF_TRY(genome_pack(ctx));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BF_OK;
+}
+
+int bf_reset(bf_ctx* ctx) {
+    if (!ctx) return BF_ERR_INVALID;
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_reads = 0; ctx->seq_bytes = 0; ctx->frag_bytes = 0;
+    ctx->max_len = 0; ctx->min_len = 0xffffffffu; ctx->max_frag = 0;
+    ctx->localised = false; ctx->imported = false; ctx->n_imported = 0; ctx->n_exact = 0;
+    ctx->out = ClusterOut();
+    return BF_OK;
+}
+
+int bf_submit(bf_ctx* ctx, const bf_batch* b) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!b) return fail(ctx, BF_ERR_INVALID, "bf_submit: null batch");
+    if (ctx->n_contigs == 0) return fail(ctx, BF_ERR_STATE, "bf_submit before bf_genome_set");
+    const uint64_t m = b->n_reads;
+    if (m == 0) return BF_OK;
+    if (!b->seq_bytes || !b->seq_off || !b->frag_off || !b->hits) return fail(ctx, BF_ERR_INVALID, "bf_submit: null array");
+    if (ctx->n_reads + m > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "more than 2^32-16 reads in one ctx");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    // validate + rebase offsets
+    std::vector<uint64_t> so(m + 1), fo(m + 1);
+    uint32_t mx = ctx->max_len, mn = ctx->min_len, mf = ctx->max_frag;
+    for (uint64_t i = 0; i <= m; i++) {
+        so[i] = ctx->seq_bytes + (b->seq_off[i] - b->seq_off[0]);
+        fo[i] = ctx->frag_bytes + (b->frag_off[i] - b->frag_off[0]);
+        if (i) {
+            if (b->seq_off[i] < b->seq_off[i - 1] || b->frag_off[i] < b->frag_off[i - 1])
+                return fail(ctx, BF_ERR_INVALID, "bf_submit: offsets not monotone at read %llu", (unsigned long long)(i - 1));
+            const uint64_t L = b->seq_off[i] - b->seq_off[i - 1], fl = b->frag_off[i] - b->frag_off[i - 1];
+            if (L > 65535) return fail(ctx, BF_ERR_RANGE, "read %llu has %llu bases; at most 65535 are supported", (unsigned long long)(i - 1), (unsigned long long)L);
+            if (fl > 65535) return fail(ctx, BF_ERR_RANGE, "fragment id of read %llu has %llu bytes; at most 65535", (unsigned long long)(i - 1), (unsigned long long)fl);
+            mx = std::max<uint32_t>(mx, (uint32_t)L); mn = std::min<uint32_t>(mn, (uint32_t)L); mf = std::max<uint32_t>(mf, (uint32_t)fl);
+        }
+    }
+    if (mn < 2 * ctx->cfg.anchor_len)
+        return fail(ctx, BF_ERR_RANGE, "a read of length %u is shorter than 2 * anchor_len = %u (detect.rs:311 never emits such reads)", mn, 2 * ctx->cfg.anchor_len);
+    for (uint64_t i = 0; i < m; i++) {
+        const bf_hit& h = b->hits[i];
+        if (h.contig5 >= ctx->n_contigs || h.contig3 >= ctx->n_contigs)
+            return fail(ctx, BF_ERR_INVALID, "read %llu names contig id %u/%u but the genome has %u contigs (the reference panics on an unknown contig, detect.rs:115)",
+                        (unsigned long long)i, h.contig5, h.contig3, ctx->n_contigs);
+        if (h.pos5 >= 0x80000000u || h.pos3 >= 0x80000000u)
+            return fail(ctx, BF_ERR_RANGE, "read %llu: anchor position >= 2^31", (unsigned long long)i);
+    }
+    const uint64_t sb = b->seq_off[m] - b->seq_off[0], fb = b->frag_off[m] - b->frag_off[0];
+    if (fb && !b->frag_bytes) return fail(ctx, BF_ERR_INVALID, "bf_submit: null frag_bytes");
+    const uint64_t n0 = ctx->n_reads;
+    BF_TRY(ensure(ctx, ctx->d_seq, ctx->seq_bytes + sb + 64, true));
+    BF_TRY(ensure(ctx, ctx->d_frag, ctx->frag_bytes + fb + 64, true));
+    BF_TRY(ensure(ctx, ctx->d_seq_off, (n0 + m + 1) * 8, true));
+    BF_TRY(ensure(ctx, ctx->d_frag_off, (n0 + m + 1) * 8, true));
+    BF_TRY(ensure(ctx, ctx->d_hits, (n0 + m) * sizeof(bf_hit), true));
+    BF_HIP(ctx, hipMemcpy(ctx->d_seq.as<uint8_t>() + ctx->seq_bytes, b->seq_bytes + b->seq_off[0], sb, hipMemcpyHostToDevice));
+    if (fb) BF_HIP(ctx, hipMemcpy(ctx->d_frag.as<uint8_t>() + ctx->frag_bytes, b->frag_bytes + b->frag_off[0], fb, hipMemcpyHostToDevice));
+    BF_HIP(ctx, hipMemcpy(ctx->d_seq_off.as<uint64_t>() + n0, so.data(), (m + 1) * 8, hipMemcpyHostToDevice));
+    BF_HIP(ctx, hipMemcpy(ctx->d_frag_off.as<uint64_t>() + n0, fo.data(), (m + 1) * 8, hipMemcpyHostToDevice));
+    BF_HIP(ctx, hipMemcpy(ctx->d_hits.as<bf_hit>() + n0, b->hits, m * sizeof(bf_hit), hipMemcpyHostToDevice));
+    ctx->n_reads += m; ctx->seq_bytes += sb; ctx->frag_bytes += fb;
+    ctx->max_len = mx; ctx->min_len = mn; ctx->max_frag = mf;
+    ctx->localised = false; ctx->imported = false;
+    return BF_OK;
+}
+
+int bf_localise(bf_ctx* ctx) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (ctx->n_contigs == 0) return fail(ctx, BF_ERR_STATE, "bf_localise before bf_genome_set");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->imported = false;
+    return run_localise(ctx);
+}
+
+int bf_clusterise(bf_ctx* ctx, bf_result* out) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!out) return fail(ctx, BF_ERR_INVALID, "bf_clusterise: null result");
+    memset(out, 0, sizeof *out);
+    if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_clusterise before bf_localise");
+    if (ctx->n_ranks > 1 && !ctx->imported) return fail(ctx, BF_ERR_STATE, "bf_clusterise on a multi-rank ctx before bf_exchange_import");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    const OwnerView v = ctx->imported ? imported_view(ctx) : local_view(ctx);
+    BF_TRY(run_cluster(ctx, v));
+    const uint64_t nr = ctx->out.reads.size();
+    ctx->junction_host.clear();
+    if (nr) {
+        if (!ctx->imported) {
+            // single rank: the surviving reads are local, render their junction strings now
+            const uint32_t* d_idx = ctx->c_rsrc.as<uint32_t>() + nr;      // out_src_idx
+            uint64_t total = 0;
+            BF_TRY(run_render(ctx, nr, d_idx, ctx->c_joff, ctx->c_jbytes, &total));
+            BF_TRY(patch_reads(ctx, ctx->c_joff.as<uint64_t>(), nr));
+            ctx->junction_host.resize(total);
+            if (total) BF_HIP(ctx, hipMemcpyAsync(ctx->junction_host.data(), ctx->c_jbytes.p, total, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.data(), ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
+        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    out->n_evidence = ctx->n_evidence;
+    out->n_clusters = ctx->out.clusters.size();
+    out->n_reads = nr;
+    out->clusters = ctx->out.clusters.data();
+    out->reads = ctx->out.reads.data();
+    out->junction_bytes = ctx->junction_host.data();
+    out->junction_size = ctx->junction_host.size();
+    return BF_OK;
+}
+
+int bf_finish(bf_ctx* ctx, bf_result* out) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (ctx->n_ranks > 1) return fail(ctx, BF_ERR_STATE, "bf_finish on a multi-rank ctx; use the stage calls");
+    BF_TRY(bf_localise(ctx));
+    return bf_clusterise(ctx, out);
+}
+
+static void put_u64(std::string& s, uint64_t v) {
+    char buf[24]; int n = snprintf(buf, sizeof buf, "%llu", (unsigned long long)v); s.append(buf, (size_t)n);
+}
+
+int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t cap) {
+    if (!ctx || !r) return BF_ERR_INVALID;
+    std::string out;
+    out.reserve(256 + r->junction_size + r->n_clusters * 64 + r->n_reads);
+    out += "CHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tCHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\t"
+           "SUPPORTING READS\tSIGNATURE\tNOTES\n";                                   // detect.rs:201
+    for (uint64_t c = 0; c < r->n_clusters; c++) {
+        const bf_cluster& cl = r->clusters[c];
+        if (cl.contig >= ctx->n_contigs || cl.mcontig >= ctx->n_contigs) return BF_ERR_INVALID;
+        out += ctx->contig_names[cl.contig]; out += '\t'; out += cl.strand ? '+' : '-'; out += '\t';
+        put_u64(out, (uint64_t)cl.lpos); out += "\t\t";
+        out += ctx->contig_names[cl.mcontig]; out += '\t'; out += cl.mstrand ? '+' : '-'; out += '\t';
+        put_u64(out, (uint64_t)cl.rpos); out += "\t\t";                               // detect.rs:233-235
+        for (uint64_t k = cl.read_begin; k < cl.read_end; k++) {
+            if (k > cl.read_begin) out += ';';
+            const bf_read& rd = r->reads[k];
+            if (rd.junction_off + rd.junction_len > r->junction_size) return BF_ERR_INVALID;
+            out.append((const char*)r->junction_bytes + rd.junction_off, rd.junction_len);
+        }
+        out += "\t\t\n";                                                              // detect.rs:240
+    }
+    if (buf) memcpy(buf, out.data(), (size_t)std::min<uint64_t>(cap, out.size()));
+    return (int64_t)out.size();
+}
+
+// ---- multi-GPU stage calls -------------------------------------------------------------------
+
+int bf_set_rank(bf_ctx* ctx, uint32_t rank, uint32_t n_ranks, uint64_t index_base) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (n_ranks == 0 || n_ranks > 256 || rank >= n_ranks) return fail(ctx, BF_ERR_INVALID, "bf_set_rank: rank %u of %u", rank, n_ranks);
+    ctx->rank = rank; ctx->n_ranks = n_ranks; ctx->index_base = index_base;
+    ctx->src_index_base.clear();
+    ctx->imported = false;
+    return BF_OK;
+}
+
+int bf_exchange_local(bf_ctx* ctx, bf_wire_local* out) {
+    if (!ctx || !out) return BF_ERR_INVALID;
+    if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_exchange_local before bf_localise");
+    out->max_frag_len_bytes = ctx->max_frag;
+    out->has_exact_sig = 0;
+    if (ctx->n_exact) {
+        // any evidence with a non-ACGT signature?  flags live on the device; n_exact is small
+        std::vector<uint16_t> fl(ctx->n_reads);
+        BF_HIP(ctx, hipMemcpy(fl.data(), ctx->d_flags.p, ctx->n_reads * 2, hipMemcpyDeviceToHost));
+        for (uint16_t f : fl) if (f & kEvSigx) { out->has_exact_sig = 1; break; }
+    }
+    return BF_OK;
+}
+
+int bf_exchange_pack(bf_ctx* ctx, const bf_wire_local* agreed, uint64_t* counts, void** dev_send, uint32_t* record_bytes) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!agreed || !counts || !dev_send || !record_bytes) return fail(ctx, BF_ERR_INVALID, "bf_exchange_pack: null argument");
+    if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_exchange_pack before bf_localise");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    BF_TRY(run_partition(ctx, *agreed, counts, record_bytes));
+    *dev_send = ctx->d_send.p;
+    return BF_OK;
+}
+
+int bf_exchange_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts, const uint64_t* src_index_base) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!src_counts || !src_index_base) return fail(ctx, BF_ERR_INVALID, "bf_exchange_import: null argument");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->src_index_base.assign(src_index_base, src_index_base + ctx->n_ranks);
+    uint64_t n = 0; for (uint32_t r = 0; r < ctx->n_ranks; r++) n += src_counts[r];
+    if (n && !dev_recv) return fail(ctx, BF_ERR_INVALID, "bf_exchange_import: null receive buffer");
+    return run_import(ctx, dev_recv, src_counts);
+}
+
+int bf_result_sources(bf_ctx* ctx, const uint32_t** src_rank, const uint32_t** src_index) {
+    if (!ctx || !src_rank || !src_index) return BF_ERR_INVALID;
+    *src_rank = ctx->out.src_rank.data(); *src_index = ctx->out.src_idx.data();
+    return BF_OK;
+}
+
+int bf_render_junctions(bf_ctx* ctx, uint64_t n, const uint32_t* local_index, const uint8_t** out_bytes, const uint64_t** out_off) {
+    if (!ctx || !out_bytes || !out_off) return BF_ERR_INVALID;
+    if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_render_junctions before bf_localise");
+    if (n && !local_index) return fail(ctx, BF_ERR_INVALID, "bf_render_junctions: null index list");
+    for (uint64_t i = 0; i < n; i++)
+        if (local_index[i] >= ctx->n_reads) return fail(ctx, BF_ERR_INVALID, "bf_render_junctions: index %u out of range", local_index[i]);
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    BF_TRY(ensure(ctx, ctx->r_idx, std::max<uint64_t>(n, 1) * 4));
+    if (n) BF_HIP(ctx, hipMemcpyAsync(ctx->r_idx.p, local_index, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t total = 0;
+    BF_TRY(run_render(ctx, n, ctx->r_idx.as<uint32_t>(), ctx->r_off, ctx->r_bytes, &total));
+    ctx->render_off_host.resize(n + 1);
+    ctx->render_bytes_host.resize(total);
+    BF_HIP(ctx, hipMemcpyAsync(ctx->render_off_host.data(), ctx->r_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (total) BF_HIP(ctx, hipMemcpyAsync(ctx->render_bytes_host.data(), ctx->r_bytes.p, total, hipMemcpyDeviceToHost, ctx->stream));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out_bytes = ctx->render_bytes_host.data(); *out_off = ctx->render_off_host.data();
+    return BF_OK;
+}
+
+// ---- introspection ---------------------------------------------------------------------------
+
+int bf_evidence_fetch(bf_ctx* ctx, bf_evidence_view* v) {
+    if (!ctx || !v) return BF_ERR_INVALID;
+    if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_evidence_fetch before bf_localise");
+    const uint64_t n = ctx->n_reads;
+    const uint32_t W = ctx->mask_words;
+    ctx->ev_key.resize(n); ctx->ev_lpos.resize(n); ctx->ev_rpos.resize(n); ctx->ev_bp.resize(n); ctx->ev_flags.resize(n);
+    ctx->ev_mask.assign(n * W, 0);
+    if (n) {
+        std::vector<uint64_t> tmp(n * W);
+        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BF_HIP(ctx, hipMemcpy(ctx->ev_key.data(), ctx->d_key.p, n * 8, hipMemcpyDeviceToHost));
+        BF_HIP(ctx, hipMemcpy(ctx->ev_lpos.data(), ctx->d_lpos.p, n * 4, hipMemcpyDeviceToHost));
+        BF_HIP(ctx, hipMemcpy(ctx->ev_rpos.data(), ctx->d_rpos.p, n * 4, hipMemcpyDeviceToHost));
+        BF_HIP(ctx, hipMemcpy(ctx->ev_bp.data(), ctx->d_bp.p, n * 2, hipMemcpyDeviceToHost));
+        BF_HIP(ctx, hipMemcpy(ctx->ev_flags.data(), ctx->d_flags.p, n * 2, hipMemcpyDeviceToHost));
+        BF_HIP(ctx, hipMemcpy(tmp.data(), ctx->d_mask.p, n * W * 8, hipMemcpyDeviceToHost));
+        for (uint32_t w = 0; w < W; w++)
+            for (uint64_t r = 0; r < n; r++) ctx->ev_mask[r * W + w] = tmp[(uint64_t)w * n + r];
+    }
+    v->n = n; v->mask_words = W;
+    v->class_key = ctx->ev_key.data(); v->lpos = ctx->ev_lpos.data(); v->rpos = ctx->ev_rpos.data();
+    v->bp = ctx->ev_bp.data(); v->flags = ctx->ev_flags.data(); v->mask = ctx->ev_mask.data();
+    return BF_OK;
+}
+
+int bf_kernel_times(bf_ctx* ctx, const bf_kernel_time** out, uint32_t* n) {
+    if (!ctx || !out || !n) return BF_ERR_INVALID;
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->timing.clear();
+    for (auto& p : pending(ctx)) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) ctx->timing.add(p.name.c_str(), ms);
+    }
+    drop_pending(ctx);
+    ctx->timing.view.resize(ctx->timing.names.size());
+    for (size_t i = 0; i < ctx->timing.names.size(); i++)
+        ctx->timing.view[i] = bf_kernel_time{ctx->timing.names[i].c_str(), ctx->timing.ms[i], ctx->timing.launches[i]};
+    *out = ctx->timing.view.data(); *n = (uint32_t)ctx->timing.view.size();
+    return BF_OK;
+}
+
+int bf_stats(const bf_ctx* ctx, uint64_t* n_reads, uint64_t* device_bytes) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (n_reads) *n_reads = ctx->n_reads;
+    if (device_bytes) *device_bytes = ctx->device_bytes;
+    return BF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,201 @@
+// Internal declarations shared by the HIP translation units of libbreakfast_hip.so.
+// Device data layout is documented in DESIGN.md ("Data layout in HBM").
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/breakfast_hip.h"
+
+namespace bf {
+
+// ---- genome image ---------------------------------------------------------------------------
+// One 16-byte block per 64 bases of the concatenated genome: bit k of `lo`/`hi` = low/high bit of
+// the 2-bit code of base 64*block + k, code = (ascii >> 1) & 3 (A=0 C=1 T=2 G=3, so complement is
+// code ^ 2).  Bases that are not one of "ACGT" (case-sensitive) get an arbitrary code and set the
+// block's bit in the coarse exception bitmap; such windows are routed to the byte-exact kernel,
+// which reads the raw image.  Every contig starts on a block boundary.
+struct GenomeBlock { uint64_t lo, hi; };
+
+struct ContigDev {      // 16 B, indexed by contig id
+    uint64_t goff;      // global base offset of the contig's first base (multiple of 64)
+    uint32_t len;
+    uint32_t rank;      // rank of the contig name in byte-wise order (Rust String Ord)
+};
+
+constexpr int kContigBits = 14;                 // <= 16384 contigs
+constexpr int kKeySigBits = 32;
+constexpr int kKeySigxBit = 32;                 // signature holds a non-ACGT byte (sig = hash32 of raw)
+constexpr int kKeyMstrandBit = 33;
+constexpr int kKeyStrandBit = 34;
+constexpr int kKeyMrankShift = 35;
+constexpr int kKeyRankShift = 35 + kContigBits; // 49
+constexpr int kKeyBits = kKeyRankShift + kContigBits;  // 63
+
+// evidence flags (low bits mirror BF_EV_*)
+constexpr uint32_t kEvStrand = 1, kEvMstrand = 2, kEvSwapped = 4, kEvExact = 8, kEvSigx = 16;
+
+// ---- wire record of the multi-GPU exchange ---------------------------------------------------
+struct WireHeader {     // 40 B, followed by frag bytes (fixed stride) and optionally 16 raw sig bytes
+    uint64_t key;
+    int32_t lpos, rpos;
+    uint64_t fhash;
+    uint32_t src_idx;
+    uint16_t bp, len;
+    uint16_t frag_len, flags;
+    uint32_t pad1;
+};
+static_assert(sizeof(WireHeader) == 40, "wire header layout");
+
+// ---- device buffer ---------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct KernelTimer;
+
+// Owner-side evidence view: what sort/sweep/dedup consume.  With one rank it aliases the
+// source-side arrays produced by localise; with several it points at imported records.
+struct OwnerView {
+    uint64_t n = 0;
+    const uint64_t* key = nullptr;
+    const int32_t* lpos = nullptr;
+    const int32_t* rpos = nullptr;
+    const uint64_t* fhash = nullptr;
+    const uint16_t* bp = nullptr;
+    const uint16_t* len = nullptr;
+    const uint16_t* flags = nullptr;
+    const uint8_t* frag = nullptr;       // fragment id bytes
+    const uint64_t* frag_off = nullptr;  // byte offset of record i's fragment id
+    const uint16_t* frag_len = nullptr;
+    const uint8_t* sigx = nullptr;       // 16 raw signature bytes per slot
+    const uint32_t* sigx_slot = nullptr; // record -> slot (only read when the key's sigx bit is set)
+    const uint32_t* src_rank = nullptr;  // nullptr = all from this rank
+    const uint32_t* src_idx = nullptr;   // nullptr = identity
+};
+
+struct ClusterOut {                      // device-side results of the cluster stage (host copies)
+    std::vector<bf_cluster> clusters;
+    std::vector<bf_read> reads;
+    std::vector<uint32_t> src_rank, src_idx;   // per supporting read
+    std::vector<uint32_t> owner_rec;           // per supporting read: owner-side record index
+};
+
+struct Timing {
+    std::vector<std::string> names;
+    std::vector<float> ms;
+    std::vector<uint64_t> launches;
+    std::vector<bf_kernel_time> view;
+    void add(const char* name, float ms_);
+    void clear();
+};
+
+}  // namespace bf
+
+struct bf_ctx {
+    bf_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // genome
+    uint32_t n_contigs = 0;
+    std::vector<std::string> contig_names;
+    std::vector<uint32_t> contig_rank;          // by id
+    std::vector<uint32_t> contig_by_rank;       // rank -> id
+    std::vector<bf::ContigDev> contig_host;
+    uint64_t genome_bases = 0;                  // padded total (multiple of 64)
+    bf::DevBuf g_blocks, g_raw, g_coarse, g_contigs;
+
+    // source-side resident reads
+    uint64_t n_reads = 0;
+    uint64_t seq_bytes = 0, frag_bytes = 0;
+    uint32_t max_len = 0, min_len = 0xffffffffu, max_frag = 0;
+    bf::DevBuf d_seq, d_seq_off, d_frag, d_frag_off, d_hits;
+    // derived by localise
+    bool localised = false;
+    uint32_t plane_words = 0, mask_words = 0;
+    uint64_t n_exact = 0;
+    bf::DevBuf d_planes, d_len, d_frag_len, d_fhash;
+    bf::DevBuf d_key, d_lpos, d_rpos, d_bp, d_flags, d_mask;
+    bf::DevBuf d_exact_list, d_counters, d_sigx, d_sigx_slot;
+
+    // multi-rank
+    uint32_t rank = 0, n_ranks = 1;
+    uint64_t index_base = 0;
+    std::vector<uint64_t> src_index_base;
+    bool imported = false;
+    uint32_t wire_frag_stride = 0, wire_has_sigx = 0, wire_rec_bytes = 0;
+    uint64_t n_imported = 0;
+    bf::DevBuf d_send, d_part_key, d_part_idx, d_part_tmp;
+    bf::DevBuf i_key, i_lpos, i_rpos, i_fhash, i_bp, i_len, i_flags, i_frag, i_frag_off, i_frag_len, i_sigx,
+        i_sigx_slot, i_src_rank, i_src_idx;
+
+    // cluster stage scratch + results
+    bf::DevBuf c_tmp, c_a32, c_b32, c_c32, c_d32, c_k64a, c_k64b, c_slpos, c_srpos, c_reported,
+        c_csize, c_flag, c_scan, c_qseed, c_qsize, c_qoff, c_members, c_leader, c_rep, c_qnrep,
+        c_sel, c_ord, c_clusters, c_reads, c_misc, c_joff, c_jbytes, c_rsrc, c_tables;
+    bf::ClusterOut out;
+    std::vector<uint8_t> junction_host;
+    std::vector<uint64_t> render_off_host;
+    std::vector<uint8_t> render_bytes_host;
+    uint64_t n_evidence = 0;
+
+    // evidence fetch staging
+    std::vector<uint64_t> ev_key, ev_mask;
+    std::vector<int32_t> ev_lpos, ev_rpos;
+    std::vector<uint16_t> ev_bp, ev_flags;
+
+    bf::Timing timing;
+    void* timing_pending = nullptr;             // std::vector<PendingEvent>* (api.hip)
+    bf::DevBuf r_idx, r_off, r_bytes;           // bf_render_junctions staging
+    uint64_t device_bytes = 0;
+};
+
+namespace bf {
+
+// error helpers ---------------------------------------------------------------------------------
+int fail(bf_ctx* ctx, int code, const char* fmt, ...);
+#define BF_HIP(ctx, expr)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return bf::fail(ctx, BF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                            __FILE__, __LINE__);                                               \
+    } while (0)
+#define BF_TRY(expr)                 \
+    do {                             \
+        int r_ = (expr);             \
+        if (r_ != BF_OK) return r_;  \
+    } while (0)
+
+int ensure(bf_ctx* ctx, DevBuf& b, size_t bytes, bool keep = false);
+void release(bf_ctx* ctx, DevBuf& b);
+
+// timed region helper: records HIP events on the ctx stream around a group of launches
+struct Scope {
+    bf_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
+    Scope(bf_ctx* c, const char* n);
+    ~Scope();
+};
+
+// localise.hip ----------------------------------------------------------------------------------
+int genome_pack(bf_ctx* ctx);                       // raw image -> blocks + coarse bitmap
+int run_localise(bf_ctx* ctx);                      // encode + hash + fast + exact kernels
+int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, DevBuf& d_bytes,
+               uint64_t* total_bytes);              // junction strings for local reads
+
+// cluster.hip -----------------------------------------------------------------------------------
+int run_cluster(bf_ctx* ctx, const OwnerView& v);   // fills ctx->out (without junction text)
+int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, uint64_t* counts, uint32_t* record_bytes);
+int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts);
+int scan_u32_to_u64(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n);  // exclusive, out has n+1
+int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
+
+}  // namespace bf

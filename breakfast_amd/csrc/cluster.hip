@@ -1,0 +1,629 @@
+// Sort -> greedy clustering -> frag-id dedup of the localised evidence, on the GPU.
+// Reference: src/detect.rs:190-231 (stable sort by (chr, pos), greedy seed-and-extend clustering)
+// and :247-287 (remove_frag_id_duplicates).
+//
+// Exact parallel decomposition.  Every membership test of the reference's
+// sweep except the two position windows is an equality on the class
+//   C = (chr, strand, mchr, mstrand, signature),
+// and `reported[]` is only ever set by a seed of the same class.  So the global sweep restricted to
+// one class, over that class's members in (lpos, input index) order, yields exactly the clusters
+// whose seeds are in that class.  We therefore
+//   1. stable-sort evidence by (class key, lpos)                  [input order breaks ties]
+//   2. run the sequential sweep inside each key segment, one segment per lane
+//      (a key segment may be coarser than a class when the signature holds non-ACGT bytes: the
+//       key then carries a hash and the sweep compares the 16 raw bytes, like detect.rs:223)
+//   3. enumerate members, group them by fragment id, keep the longest-flank read per group
+//   4. order surviving clusters by the seed's rank in the reference's sort: (chr, lpos, input index).
+
+#include "bf_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace bf {
+
+constexpr uint32_t kNone = 0xffffffffu;
+
+static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+// ---- rocPRIM wrappers --------------------------------------------------------------------------
+template <class K>
+static int sort_pairs(bf_ctx* ctx, const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, uint64_t n,
+                      unsigned begin_bit, unsigned end_bit) {
+    size_t bytes = 0;
+    BF_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, ctx->stream));
+    BF_TRY(ensure(ctx, ctx->c_tmp, bytes ? bytes : 1, false));
+    BF_HIP(ctx, rocprim::radix_sort_pairs(ctx->c_tmp.p, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, ctx->stream));
+    return BF_OK;
+}
+
+struct WidenU32 { __host__ __device__ uint64_t operator()(uint32_t x) const { return x; } };
+
+// exclusive scan with total: out[0] = 0, out[i+1] = in[0] + ... + in[i]
+int scan_u32_to_u64(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n) {
+    BF_HIP(ctx, hipMemsetAsync(out, 0, 8, ctx->stream));
+    if (n == 0) return BF_OK;
+    auto it = rocprim::make_transform_iterator(in, WidenU32());
+    size_t bytes = 0;
+    BF_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes, it, out + 1, n, rocprim::plus<uint64_t>(), ctx->stream));
+    BF_TRY(ensure(ctx, ctx->c_tmp, bytes ? bytes : 1, false));
+    BF_HIP(ctx, rocprim::inclusive_scan(ctx->c_tmp.p, bytes, it, out + 1, n, rocprim::plus<uint64_t>(), ctx->stream));
+    return BF_OK;
+}
+
+static int fetch_u64(bf_ctx* ctx, const uint64_t* d, uint64_t* h) {
+    BF_HIP(ctx, hipMemcpyAsync(h, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BF_OK;
+}
+
+// ---- small kernels ----------------------------------------------------------------------------
+__global__ void iota_kernel(uint32_t* out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)i;
+}
+__global__ void gather_key_kernel(uint64_t* out, const uint64_t* __restrict__ in, const uint32_t* __restrict__ idx, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[idx[i]];
+}
+__global__ void gather_pos_kernel(int32_t* slpos, int32_t* srpos, const int32_t* __restrict__ lpos,
+                                  const int32_t* __restrict__ rpos, const uint32_t* __restrict__ perm, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t r = perm[i]; slpos[i] = lpos[r]; srpos[i] = rpos[r]; }
+}
+
+struct SweepView {
+    uint64_t n;
+    const uint64_t* skey;     // sorted class keys
+    const int32_t* slpos;     // sorted
+    const int32_t* srpos;     // sorted
+    const uint32_t* perm;     // sorted position -> owner record
+    const uint8_t* sigx;
+    const uint32_t* sigx_slot;
+    int64_t F;                // max_frag_len
+};
+
+__device__ __forceinline__ bool same_sigx(const SweepView& v, uint64_t key, uint64_t p, uint64_t s) {
+    if (!((key >> kKeySigxBit) & 1)) return true;           // plain signature: the key holds all of it
+    const uint8_t* a = v.sigx + (uint64_t)v.sigx_slot[v.perm[p]] * 16;
+    const uint8_t* b = v.sigx + (uint64_t)v.sigx_slot[v.perm[s]] * 16;
+    bool eq = true;
+    for (int k = 0; k < 16; k++) eq = eq && a[k] == b[k];
+    return eq;
+}
+
+// `evidence[s].pos - read.pos > max_frag_len` on the reference's wrapped usize (detect.rs:215)
+__device__ __forceinline__ bool beyond(int32_t ls, int32_t lp, int64_t F) {
+    return (uint64_t)(int64_t)ls - (uint64_t)(int64_t)lp > (uint64_t)F;
+}
+// `(mpos as i64 - read.mpos as i64).abs() > max_frag_len` (detect.rs:220)
+__device__ __forceinline__ bool rpos_far(int32_t rs, int32_t rp, int64_t F) {
+    const int64_t d = (int64_t)rs - (int64_t)rp;
+    return (d < 0 ? -d : d) > F;
+}
+
+// The reference's sweep (detect.rs:203-227) inside one key segment; the lane at the segment head
+// walks it sequentially.  csize[p] = cluster size if p is a seed, else 0.
+__global__ void __launch_bounds__(256) sweep_kernel(const SweepView v, uint8_t* __restrict__ reported,
+                                                    uint32_t* __restrict__ csize) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.n) return;
+    const uint64_t key = v.skey[i];
+    if (i > 0 && v.skey[i - 1] == key) return;
+    for (uint64_t p = i; p < v.n && v.skey[p] == key; p++) {
+        if (reported[p]) { csize[p] = 0; continue; }
+        const int32_t lp = v.slpos[p], rp = v.srpos[p];
+        uint32_t cnt = 1;
+        for (uint64_t s = p + 1; s < v.n && v.skey[s] == key; s++) {
+            if (beyond(v.slpos[s], lp, v.F)) break;
+            if (rpos_far(v.srpos[s], rp, v.F)) continue;
+            if (!same_sigx(v, key, p, s)) continue;
+            cnt++;
+            reported[s] = 1;
+        }
+        csize[p] = cnt;
+    }
+}
+
+__global__ void flag_ge_kernel(uint32_t* flag, const uint32_t* __restrict__ val, uint32_t thr, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = val[i] >= thr ? 1u : 0u;
+}
+__global__ void compact_seeds_kernel(const uint32_t* __restrict__ flag, const uint64_t* __restrict__ scan,
+                                     const uint32_t* __restrict__ csize, uint32_t* qseed, uint32_t* qsize, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) { const uint64_t q = scan[i]; qseed[q] = (uint32_t)i; qsize[q] = csize[i]; }
+}
+__global__ void compact_index_kernel(const uint32_t* __restrict__ flag, const uint64_t* __restrict__ scan,
+                                     uint32_t* out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) out[scan[i]] = (uint32_t)i;
+}
+
+struct MemberView {
+    const uint32_t* qseed; const uint64_t* qoff;
+    uint32_t* members;      // sorted positions
+    uint64_t* mhash;        // fragment hash per member slot
+    uint32_t* mscore;       // longest-flank score per member slot (detect.rs:273-279)
+    const uint64_t* fhash; const uint16_t* bp; const uint16_t* len;
+};
+
+// One wave per qualifying cluster: re-enumerate the seed's members in sweep order.
+__global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, const MemberView m, uint64_t nq) {
+    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const uint64_t p = m.qseed[q];
+    const uint64_t base = m.qoff[q];
+    const uint64_t key = v.skey[p];
+    const int32_t lp = v.slpos[p], rp = v.srpos[p];
+    auto put = [&](uint64_t slot, uint64_t spos) {
+        const uint32_t rec = v.perm[spos];
+        m.members[slot] = (uint32_t)spos;
+        m.mhash[slot] = m.fhash[rec];
+        const uint32_t l = m.bp[rec], r = (uint32_t)m.len[rec] - l;
+        m.mscore[slot] = min(l, r) * 10000u + max(l, r);
+    };
+    if (lane == 0) put(base, p);
+    uint64_t cnt = 1;
+    for (uint64_t s0 = p + 1;; s0 += 64) {
+        const uint64_t s = s0 + lane;
+        bool live = s < v.n && v.skey[s] == key && !beyond(v.slpos[s], lp, v.F);
+        const uint64_t live_mask = __ballot(live);
+        bool take = live && !rpos_far(v.srpos[s], rp, v.F) && same_sigx(v, key, p, s);
+        const uint64_t take_mask = __ballot(take);
+        if (take) put(base + cnt + __popcll(take_mask & ((1ull << lane) - 1)), s);
+        cnt += __popcll(take_mask);
+        if (live_mask != ~0ull) break;        // the break tests are monotone in sorted order
+    }
+}
+
+struct FragView {
+    const uint32_t* perm; const uint8_t* frag; const uint64_t* frag_off; const uint16_t* frag_len;
+};
+__device__ __forceinline__ bool same_frag(const FragView& f, uint32_t ra, uint32_t rb) {
+    const uint32_t la = f.frag_len[ra];
+    if (la != f.frag_len[rb]) return false;
+    const uint8_t* a = f.frag + f.frag_off[ra];
+    const uint8_t* b = f.frag + f.frag_off[rb];
+    for (uint32_t k = 0; k < la; k++) if (a[k] != b[k]) return false;
+    return true;
+}
+
+// leader[i] = first member of i's fragment-id group (redundant_with, detect.rs:249-261).
+// Hash equality is only a filter: groups are decided by comparing the id bytes.
+__global__ void __launch_bounds__(256) leader_kernel(const MemberView m, const FragView f, const uint32_t* __restrict__ qsize,
+                                                     uint32_t* __restrict__ leader, uint64_t nq) {
+    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const uint64_t base = m.qoff[q];
+    const uint32_t c = qsize[q];
+    for (uint32_t i = lane; i < c; i += 64) {
+        const uint64_t h = m.mhash[base + i];
+        uint32_t lead = i;
+        for (uint32_t j = 0; j < i; j++) {
+            if (m.mhash[base + j] == h &&
+                same_frag(f, f.perm[m.members[base + i]], f.perm[m.members[base + j]])) { lead = j; break; }
+        }
+        leader[base + i] = lead;
+    }
+}
+
+// rep[i] for group leaders = the member with the best score, first maximum wins (detect.rs:268-284);
+// kNone for non-leaders.  qnrep[q] = number of groups = cluster size after dedup.
+__global__ void __launch_bounds__(256) best_kernel(const MemberView m, const uint32_t* __restrict__ qsize,
+                                                   const uint32_t* __restrict__ leader, uint32_t* __restrict__ rep,
+                                                   uint32_t* __restrict__ qnrep, uint64_t nq) {
+    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const uint64_t base = m.qoff[q];
+    const uint32_t c = qsize[q];
+    uint32_t groups = 0;
+    for (uint32_t i0 = 0; i0 < c; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        bool lead = false;
+        if (i < c) {
+            lead = leader[base + i] == i;
+            uint32_t best = i, best_score = m.mscore[base + i];
+            if (lead) {
+                for (uint32_t k = i + 1; k < c; k++) {
+                    if (leader[base + k] == i && m.mscore[base + k] > best_score) { best = k; best_score = m.mscore[base + k]; }
+                }
+            }
+            rep[base + i] = lead ? best : kNone;
+        }
+        groups += (uint32_t)__popcll(__ballot(lead));
+    }
+    if (lane == 0) qnrep[q] = groups;
+}
+
+struct OrderView {
+    const uint32_t* qseed; const uint64_t* skey; const int32_t* slpos; const uint32_t* perm;
+    const uint32_t* src_rank; const uint32_t* src_idx;
+};
+// sort keys of surviving clusters: (contig rank, lpos as sorted, input order of the seed)
+__global__ void cluster_keys_kernel(const OrderView o, const uint32_t* __restrict__ sel, uint64_t* kpos, uint64_t* kidx, uint64_t ns) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    const uint32_t p = o.qseed[sel[k]];
+    const uint32_t rec = o.perm[p];
+    kpos[k] = ((o.skey[p] >> kKeyRankShift) << 32) | (uint32_t)o.slpos[p];
+    const uint64_t sr = o.src_rank ? o.src_rank[rec] : 0, si = o.src_idx ? o.src_idx[rec] : rec;
+    kidx[k] = (sr << 32) | si;
+}
+__global__ void gather_u32_kernel(uint32_t* out, const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[idx[i]];
+}
+
+struct EmitView {
+    const uint32_t* ord;        // output order -> q
+    const uint64_t* roff;       // output order -> first supporting read
+    const uint32_t* qseed; const uint32_t* qsize; const uint64_t* qoff;
+    const uint32_t* members; const uint32_t* rep;
+    const uint64_t* skey; const int32_t* slpos; const int32_t* srpos; const uint32_t* perm;
+    const uint32_t* src_rank; const uint32_t* src_idx; const uint64_t* src_base;
+    const uint16_t* bp; const uint16_t* flags;
+    const uint32_t* rank2id;
+    bf_cluster* clusters; bf_read* reads; uint32_t* out_src_rank; uint32_t* out_src_idx; uint32_t* out_rec;
+};
+
+// One wave per reported cluster: the printed row (detect.rs:233-235) and its surviving reads in
+// cluster order (a group's representative sits at the slot of the group's first member, :284).
+__global__ void __launch_bounds__(256) emit_kernel(const EmitView e, uint64_t ns) {
+    const uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (k >= ns) return;
+    const uint32_t q = e.ord[k];
+    const uint64_t base = e.qoff[q];
+    const uint32_t c = e.qsize[q];
+    const uint64_t rbase = e.roff[k];
+    auto source = [&](uint32_t rec, uint32_t& sr, uint32_t& si) {
+        sr = e.src_rank ? e.src_rank[rec] : 0; si = e.src_idx ? e.src_idx[rec] : rec;
+    };
+    if (lane == 0) {
+        const uint32_t p = e.qseed[q];
+        const uint64_t key = e.skey[p];
+        uint32_t sr, si; source(e.perm[p], sr, si);
+        bf_cluster cl;
+        memset(&cl, 0, sizeof cl);
+        cl.lpos = e.slpos[p]; cl.rpos = e.srpos[p];
+        cl.seed_index = e.src_base[sr] + si;
+        cl.read_begin = rbase; cl.read_end = e.roff[k + 1];
+        cl.contig = e.rank2id[(key >> kKeyRankShift) & ((1u << kContigBits) - 1)];
+        cl.mcontig = e.rank2id[(key >> kKeyMrankShift) & ((1u << kContigBits) - 1)];
+        cl.strand = (key >> kKeyStrandBit) & 1; cl.mstrand = (key >> kKeyMstrandBit) & 1;
+        e.clusters[k] = cl;
+    }
+    uint64_t cnt = 0;
+    for (uint32_t i0 = 0; i0 < c; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const uint32_t rp = i < c ? e.rep[base + i] : kNone;
+        const bool lead = rp != kNone;
+        const uint64_t mask = __ballot(lead);
+        if (lead) {
+            const uint64_t slot = rbase + cnt + __popcll(mask & ((1ull << lane) - 1));
+            const uint32_t rec = e.perm[e.members[base + rp]];
+            uint32_t sr, si; source(rec, sr, si);
+            bf_read rd;
+            memset(&rd, 0, sizeof rd);
+            rd.index = e.src_base[sr] + si;
+            rd.bp = e.bp[rec];
+            rd.swapped = (e.flags[rec] & kEvSwapped) ? 1 : 0;
+            e.reads[slot] = rd;
+            e.out_src_rank[slot] = sr; e.out_src_idx[slot] = si; e.out_rec[slot] = rec;
+        }
+        cnt += __popcll(mask);
+    }
+}
+
+// ---- the cluster stage -----------------------------------------------------------------------
+int run_cluster(bf_ctx* ctx, const OwnerView& v) {
+    const uint64_t n = v.n;
+    hipStream_t st = ctx->stream;
+    ctx->out.clusters.clear(); ctx->out.reads.clear();
+    ctx->out.src_rank.clear(); ctx->out.src_idx.clear(); ctx->out.owner_rec.clear();
+    ctx->n_evidence = n;
+    if (n == 0) return BF_OK;
+    if (n > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "too many evidence records for one GPU (%llu)", (unsigned long long)n);
+    const unsigned B = 256;
+
+    // 1. stable sort by (key, lpos): LSD, lpos first
+    BF_TRY(ensure(ctx, ctx->c_a32, n * 4)); BF_TRY(ensure(ctx, ctx->c_b32, n * 4));
+    BF_TRY(ensure(ctx, ctx->c_c32, n * 4));
+    BF_TRY(ensure(ctx, ctx->c_k64a, n * 8)); BF_TRY(ensure(ctx, ctx->c_k64b, n * 8));
+    BF_TRY(ensure(ctx, ctx->c_slpos, n * 4)); BF_TRY(ensure(ctx, ctx->c_srpos, n * 4));
+    uint32_t* perm = ctx->c_a32.as<uint32_t>();
+    {
+        Scope t(ctx, "sort");
+        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_a32.as<uint32_t>(), n);
+        BF_TRY(sort_pairs<uint32_t>(ctx, (const uint32_t*)v.lpos, ctx->c_b32.as<uint32_t>(), ctx->c_a32.as<uint32_t>(),
+                                    ctx->c_c32.as<uint32_t>(), n, 0, 32));
+        hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_k64a.as<uint64_t>(), v.key,
+                           ctx->c_c32.as<uint32_t>(), n);
+        BF_TRY(sort_pairs<uint64_t>(ctx, ctx->c_k64a.as<uint64_t>(), ctx->c_k64b.as<uint64_t>(), ctx->c_c32.as<uint32_t>(),
+                                    perm, n, 0, kKeyBits));
+        hipLaunchKernelGGL(gather_pos_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_slpos.as<int32_t>(),
+                           ctx->c_srpos.as<int32_t>(), v.lpos, v.rpos, perm, n);
+    }
+    BF_HIP(ctx, hipGetLastError());
+
+    SweepView sv{};
+    sv.n = n; sv.skey = ctx->c_k64b.as<uint64_t>(); sv.slpos = ctx->c_slpos.as<int32_t>();
+    sv.srpos = ctx->c_srpos.as<int32_t>(); sv.perm = perm; sv.sigx = v.sigx; sv.sigx_slot = v.sigx_slot;
+    sv.F = (int64_t)ctx->cfg.max_frag_len;
+
+    // 2. sweep
+    BF_TRY(ensure(ctx, ctx->c_reported, n)); BF_TRY(ensure(ctx, ctx->c_csize, n * 4));
+    BF_TRY(ensure(ctx, ctx->c_flag, n * 4)); BF_TRY(ensure(ctx, ctx->c_scan, (n + 1) * 8));
+    uint64_t nq = 0;
+    {
+        Scope t(ctx, "sweep");
+        BF_HIP(ctx, hipMemsetAsync(ctx->c_reported.p, 0, n, st));
+        hipLaunchKernelGGL(sweep_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, sv, ctx->c_reported.as<uint8_t>(),
+                           ctx->c_csize.as<uint32_t>());
+        hipLaunchKernelGGL(flag_ge_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
+                           ctx->c_csize.as<uint32_t>(), ctx->cfg.min_evidence, n);
+        BF_TRY(scan_u32_to_u64(ctx, ctx->c_flag.as<uint32_t>(), ctx->c_scan.as<uint64_t>(), n));
+        BF_TRY(fetch_u64(ctx, ctx->c_scan.as<uint64_t>() + n, &nq));
+    }
+    if (nq == 0) return BF_OK;
+
+    // 3. members of qualifying clusters
+    BF_TRY(ensure(ctx, ctx->c_qseed, nq * 4)); BF_TRY(ensure(ctx, ctx->c_qsize, nq * 4));
+    BF_TRY(ensure(ctx, ctx->c_qoff, (nq + 1) * 8)); BF_TRY(ensure(ctx, ctx->c_qnrep, nq * 4));
+    uint64_t total_m = 0;
+    hipLaunchKernelGGL(compact_seeds_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
+                       ctx->c_scan.as<uint64_t>(), ctx->c_csize.as<uint32_t>(), ctx->c_qseed.as<uint32_t>(),
+                       ctx->c_qsize.as<uint32_t>(), n);
+    BF_TRY(scan_u32_to_u64(ctx, ctx->c_qsize.as<uint32_t>(), ctx->c_qoff.as<uint64_t>(), nq));
+    BF_TRY(fetch_u64(ctx, ctx->c_qoff.as<uint64_t>() + nq, &total_m));
+    BF_TRY(ensure(ctx, ctx->c_members, total_m * 4)); BF_TRY(ensure(ctx, ctx->c_k64a, std::max(total_m, n) * 8, false));
+    BF_TRY(ensure(ctx, ctx->c_d32, total_m * 4));
+    BF_TRY(ensure(ctx, ctx->c_leader, total_m * 4)); BF_TRY(ensure(ctx, ctx->c_rep, total_m * 4));
+    MemberView mv{};
+    mv.qseed = ctx->c_qseed.as<uint32_t>(); mv.qoff = ctx->c_qoff.as<uint64_t>();
+    mv.members = ctx->c_members.as<uint32_t>(); mv.mhash = ctx->c_k64a.as<uint64_t>(); mv.mscore = ctx->c_d32.as<uint32_t>();
+    mv.fhash = v.fhash; mv.bp = v.bp; mv.len = v.len;
+    FragView fv{perm, v.frag, v.frag_off, v.frag_len};
+    {
+        Scope t(ctx, "dedup");
+        hipLaunchKernelGGL(fill_members_kernel, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, sv, mv, nq);
+        hipLaunchKernelGGL(leader_kernel, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, mv, fv, ctx->c_qsize.as<uint32_t>(),
+                           ctx->c_leader.as<uint32_t>(), nq);
+        hipLaunchKernelGGL(best_kernel, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, mv, ctx->c_qsize.as<uint32_t>(),
+                           ctx->c_leader.as<uint32_t>(), ctx->c_rep.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>(), nq);
+    }
+    BF_HIP(ctx, hipGetLastError());
+
+    // 4. surviving clusters in the reference's print order
+    uint64_t ns = 0, total_r = 0;
+    BF_TRY(ensure(ctx, ctx->c_flag, std::max(nq, n) * 4, false));
+    BF_TRY(ensure(ctx, ctx->c_sel, nq * 4)); BF_TRY(ensure(ctx, ctx->c_ord, nq * 4));
+    {
+        Scope t(ctx, "order");
+        hipLaunchKernelGGL(flag_ge_kernel, dim3(grid_for(nq, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
+                           ctx->c_qnrep.as<uint32_t>(), ctx->cfg.min_evidence, nq);
+        BF_TRY(scan_u32_to_u64(ctx, ctx->c_flag.as<uint32_t>(), ctx->c_scan.as<uint64_t>(), nq));
+        BF_TRY(fetch_u64(ctx, ctx->c_scan.as<uint64_t>() + nq, &ns));
+        if (ns == 0) return BF_OK;
+        hipLaunchKernelGGL(compact_index_kernel, dim3(grid_for(nq, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
+                           ctx->c_scan.as<uint64_t>(), ctx->c_sel.as<uint32_t>(), nq);
+        BF_TRY(ensure(ctx, ctx->c_misc, ns * 8 * 4));
+        uint64_t* kpos = ctx->c_misc.as<uint64_t>();
+        uint64_t* kidx = kpos + ns; uint64_t* kpos2 = kidx + ns; uint64_t* kidx2 = kpos2 + ns;
+        OrderView ov{ctx->c_qseed.as<uint32_t>(), sv.skey, sv.slpos, perm, v.src_rank, v.src_idx};
+        hipLaunchKernelGGL(cluster_keys_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, ov, ctx->c_sel.as<uint32_t>(), kpos, kidx, ns);
+        // LSD: input order first, then (contig rank, lpos).  values = positions in sel
+        BF_TRY(ensure(ctx, ctx->c_b32, std::max(n, ns) * 4, false)); BF_TRY(ensure(ctx, ctx->c_c32, std::max(n, ns) * 4, false));
+        uint32_t* va = ctx->c_b32.as<uint32_t>(); uint32_t* vb = ctx->c_c32.as<uint32_t>();
+        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, va, ns);
+        BF_TRY(sort_pairs<uint64_t>(ctx, kidx, kidx2, va, vb, ns, 0, 64));
+        hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, kpos2, kpos, vb, ns);
+        BF_TRY(sort_pairs<uint64_t>(ctx, kpos2, kidx2, vb, va, ns, 0, 32 + kContigBits));
+        // ord[k] = sel[va[k]]; nrep in output order -> read offsets
+        hipLaunchKernelGGL(gather_u32_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, ctx->c_ord.as<uint32_t>(),
+                           ctx->c_sel.as<uint32_t>(), va, ns);
+        hipLaunchKernelGGL(gather_u32_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, vb, ctx->c_qnrep.as<uint32_t>(),
+                           ctx->c_ord.as<uint32_t>(), ns);
+        BF_TRY(scan_u32_to_u64(ctx, vb, ctx->c_scan.as<uint64_t>(), ns));
+        BF_TRY(fetch_u64(ctx, ctx->c_scan.as<uint64_t>() + ns, &total_r));
+    }
+
+    // 5. emit rows + surviving reads
+    BF_TRY(ensure(ctx, ctx->c_clusters, ns * sizeof(bf_cluster)));
+    BF_TRY(ensure(ctx, ctx->c_reads, std::max<uint64_t>(total_r, 1) * sizeof(bf_read)));
+    BF_TRY(ensure(ctx, ctx->c_rsrc, std::max<uint64_t>(total_r, 1) * 4 * 3));
+    std::vector<uint64_t> bases = ctx->src_index_base;
+    if (bases.empty()) bases.assign(1, ctx->index_base);
+    BF_TRY(ensure(ctx, ctx->c_tables, bases.size() * 8 + (size_t)ctx->n_contigs * 4 + 16));
+    BF_HIP(ctx, hipMemcpyAsync(ctx->c_tables.p, bases.data(), bases.size() * 8, hipMemcpyHostToDevice, st));
+    uint32_t* d_rank2id = (uint32_t*)((uint8_t*)ctx->c_tables.p + bases.size() * 8);
+    BF_HIP(ctx, hipMemcpyAsync(d_rank2id, ctx->contig_by_rank.data(), (size_t)ctx->n_contigs * 4, hipMemcpyHostToDevice, st));
+    EmitView ev{};
+    ev.ord = ctx->c_ord.as<uint32_t>(); ev.roff = ctx->c_scan.as<uint64_t>();
+    ev.qseed = ctx->c_qseed.as<uint32_t>(); ev.qsize = ctx->c_qsize.as<uint32_t>(); ev.qoff = ctx->c_qoff.as<uint64_t>();
+    ev.members = ctx->c_members.as<uint32_t>(); ev.rep = ctx->c_rep.as<uint32_t>();
+    ev.skey = sv.skey; ev.slpos = sv.slpos; ev.srpos = sv.srpos; ev.perm = perm;
+    ev.src_rank = v.src_rank; ev.src_idx = v.src_idx; ev.src_base = (const uint64_t*)ctx->c_tables.p;
+    ev.bp = v.bp; ev.flags = v.flags; ev.rank2id = d_rank2id;
+    ev.clusters = ctx->c_clusters.as<bf_cluster>(); ev.reads = ctx->c_reads.as<bf_read>();
+    ev.out_src_rank = ctx->c_rsrc.as<uint32_t>(); ev.out_src_idx = ev.out_src_rank + total_r;
+    ev.out_rec = ev.out_src_idx + total_r;
+    {
+        Scope t(ctx, "emit");
+        hipLaunchKernelGGL(emit_kernel, dim3(grid_for(ns * 64, B)), dim3(B), 0, st, ev, ns);
+    }
+    BF_HIP(ctx, hipGetLastError());
+    ctx->out.clusters.resize(ns);
+    ctx->out.src_rank.resize(total_r); ctx->out.src_idx.resize(total_r); ctx->out.owner_rec.resize(total_r);
+    ctx->out.reads.resize(total_r);
+    BF_HIP(ctx, hipMemcpyAsync(ctx->out.clusters.data(), ctx->c_clusters.p, ns * sizeof(bf_cluster), hipMemcpyDeviceToHost, st));
+    if (total_r) {
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.src_rank.data(), ev.out_src_rank, total_r * 4, hipMemcpyDeviceToHost, st));
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.src_idx.data(), ev.out_src_idx, total_r * 4, hipMemcpyDeviceToHost, st));
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.owner_rec.data(), ev.out_rec, total_r * 4, hipMemcpyDeviceToHost, st));
+    }
+    BF_HIP(ctx, hipStreamSynchronize(st));
+    return BF_OK;
+}
+
+// ---- multi-GPU exchange: pack by owner rank / import ------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+    return x;
+}
+// owner = hash(class key) % n_ranks: the key holds the whole class and no positions, so every
+// member of a cluster (same class, windows of positions) lands on one rank.
+__global__ void owner_kernel(uint32_t* owner, const uint64_t* __restrict__ key, uint32_t n_ranks, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) owner[i] = (uint32_t)(mix64(key[i]) % n_ranks);
+}
+__global__ void bucket_start_kernel(uint64_t* start, const uint32_t* __restrict__ owner_sorted, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (i == 0 || owner_sorted[i - 1] != owner_sorted[i])) start[owner_sorted[i]] = i;
+}
+
+struct PackView {
+    uint64_t n; uint32_t rec_bytes, frag_stride, has_sigx;
+    const uint32_t* order;
+    const uint64_t* key; const int32_t* lpos; const int32_t* rpos; const uint64_t* fhash;
+    const uint16_t* bp; const uint16_t* len; const uint16_t* flags;
+    const uint8_t* frag; const uint64_t* frag_off; const uint16_t* frag_len;
+    const uint8_t* sigx; const uint32_t* sigx_slot;
+    uint8_t* out;
+};
+__global__ void __launch_bounds__(256) pack_kernel(const PackView v) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= v.n) return;
+    const uint32_t i = v.order[j];
+    uint8_t* dst = v.out + j * v.rec_bytes;
+    WireHeader h;
+    h.key = v.key[i]; h.lpos = v.lpos[i]; h.rpos = v.rpos[i]; h.fhash = v.fhash[i]; h.src_idx = i;
+    h.bp = v.bp[i]; h.len = v.len[i]; h.frag_len = v.frag_len[i]; h.flags = v.flags[i]; h.pad1 = 0;
+    *(WireHeader*)dst = h;
+    const uint8_t* f = v.frag + v.frag_off[i];
+    for (uint32_t k = 0; k < v.frag_stride; k++) dst[sizeof(WireHeader) + k] = k < h.frag_len ? f[k] : 0;
+    if (v.has_sigx) {
+        uint8_t* sx = dst + sizeof(WireHeader) + v.frag_stride;
+        const bool x = (h.key >> kKeySigxBit) & 1;
+        const uint8_t* src = x ? v.sigx + (uint64_t)v.sigx_slot[i] * 16 : nullptr;
+        for (int k = 0; k < 16; k++) sx[k] = x ? src[k] : 0;
+    }
+}
+
+struct ImportView {
+    uint64_t n; uint32_t rec_bytes, frag_stride, has_sigx, n_ranks;
+    const uint8_t* in; const uint64_t* src_start;   // n_ranks+1 prefix of src_counts
+    uint64_t* key; int32_t* lpos; int32_t* rpos; uint64_t* fhash; uint16_t* bp; uint16_t* len; uint16_t* flags;
+    uint8_t* frag; uint64_t* frag_off; uint16_t* frag_len; uint8_t* sigx; uint32_t* sigx_slot;
+    uint32_t* src_rank; uint32_t* src_idx;
+};
+__global__ void __launch_bounds__(256) import_kernel(const ImportView v) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= v.n) return;
+    const uint8_t* src = v.in + j * v.rec_bytes;
+    const WireHeader h = *(const WireHeader*)src;
+    v.key[j] = h.key; v.lpos[j] = h.lpos; v.rpos[j] = h.rpos; v.fhash[j] = h.fhash;
+    v.bp[j] = h.bp; v.len[j] = h.len; v.flags[j] = h.flags; v.frag_len[j] = h.frag_len;
+    v.frag_off[j] = j * v.frag_stride;
+    for (uint32_t k = 0; k < v.frag_stride; k++) v.frag[j * v.frag_stride + k] = src[sizeof(WireHeader) + k];
+    v.sigx_slot[j] = (uint32_t)j;
+    if (v.has_sigx) for (int k = 0; k < 16; k++) v.sigx[j * 16 + k] = src[sizeof(WireHeader) + v.frag_stride + k];
+    uint32_t r = 0;
+    while (r + 1 < v.n_ranks && j >= v.src_start[r + 1]) r++;
+    v.src_rank[j] = r; v.src_idx[j] = h.src_idx;
+}
+
+int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, uint64_t* counts, uint32_t* record_bytes) {
+    const uint64_t n = ctx->n_reads;
+    const uint32_t R = ctx->n_ranks;
+    hipStream_t st = ctx->stream;
+    const uint32_t stride = (agreed.max_frag_len_bytes + 7u) & ~7u;
+    const uint32_t rec = (uint32_t)sizeof(WireHeader) + stride + (agreed.has_exact_sig ? 16u : 0u);
+    ctx->wire_frag_stride = stride; ctx->wire_has_sigx = agreed.has_exact_sig ? 1 : 0; ctx->wire_rec_bytes = rec;
+    *record_bytes = rec;
+    for (uint32_t r = 0; r < R; r++) counts[r] = 0;
+    BF_TRY(ensure(ctx, ctx->d_send, std::max<uint64_t>(n, 1) * rec));
+    if (n == 0) return BF_OK;
+    Scope t(ctx, "exchange_pack");
+    BF_TRY(ensure(ctx, ctx->d_part_key, n * 4 * 2)); BF_TRY(ensure(ctx, ctx->d_part_idx, n * 4 * 2));
+    BF_TRY(ensure(ctx, ctx->d_part_tmp, (size_t)(R + 1) * 8));
+    uint32_t* own = ctx->d_part_key.as<uint32_t>(); uint32_t* own_s = own + n;
+    uint32_t* idx = ctx->d_part_idx.as<uint32_t>(); uint32_t* order = idx + n;
+    const unsigned B = 256;
+    hipLaunchKernelGGL(owner_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, own, ctx->d_key.as<uint64_t>(), R, n);
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, idx, n);
+    unsigned bits = 1; while ((1u << bits) < R) bits++;
+    BF_TRY(sort_pairs<uint32_t>(ctx, own, own_s, idx, order, n, 0, bits));   // stable: source order kept per owner
+    std::vector<uint64_t> start(R + 1, n);
+    BF_HIP(ctx, hipMemcpyAsync(ctx->d_part_tmp.p, start.data(), (size_t)(R + 1) * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(bucket_start_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->d_part_tmp.as<uint64_t>(), own_s, n);
+    PackView pv{};
+    pv.n = n; pv.rec_bytes = rec; pv.frag_stride = stride; pv.has_sigx = ctx->wire_has_sigx; pv.order = order;
+    pv.key = ctx->d_key.as<uint64_t>(); pv.lpos = ctx->d_lpos.as<int32_t>(); pv.rpos = ctx->d_rpos.as<int32_t>();
+    pv.fhash = ctx->d_fhash.as<uint64_t>(); pv.bp = ctx->d_bp.as<uint16_t>(); pv.len = ctx->d_len.as<uint16_t>();
+    pv.flags = ctx->d_flags.as<uint16_t>(); pv.frag = ctx->d_frag.as<uint8_t>(); pv.frag_off = ctx->d_frag_off.as<uint64_t>();
+    pv.frag_len = ctx->d_frag_len.as<uint16_t>(); pv.sigx = ctx->d_sigx.as<uint8_t>(); pv.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
+    pv.out = ctx->d_send.as<uint8_t>();
+    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, pv);
+    BF_HIP(ctx, hipGetLastError());
+    BF_HIP(ctx, hipMemcpyAsync(start.data(), ctx->d_part_tmp.p, (size_t)(R + 1) * 8, hipMemcpyDeviceToHost, st));
+    BF_HIP(ctx, hipStreamSynchronize(st));
+    // empty buckets keep the sentinel n: a bucket ends where the next non-empty one starts
+    uint64_t end = n;
+    for (int r = (int)R - 1; r >= 0; r--) {
+        if (start[r] == n) { counts[r] = 0; continue; }
+        counts[r] = end - start[r];
+        end = start[r];
+    }
+    return BF_OK;
+}
+
+int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts) {
+    const uint32_t R = ctx->n_ranks;
+    hipStream_t st = ctx->stream;
+    std::vector<uint64_t> start(R + 1, 0);
+    for (uint32_t r = 0; r < R; r++) start[r + 1] = start[r] + src_counts[r];
+    const uint64_t n = start[R];
+    ctx->n_imported = n; ctx->imported = true;
+    if (n == 0) return BF_OK;
+    if (ctx->wire_rec_bytes == 0) return fail(ctx, BF_ERR_STATE, "bf_exchange_import before bf_exchange_pack");
+    const uint32_t stride = ctx->wire_frag_stride;
+    BF_TRY(ensure(ctx, ctx->i_key, n * 8)); BF_TRY(ensure(ctx, ctx->i_lpos, n * 4)); BF_TRY(ensure(ctx, ctx->i_rpos, n * 4));
+    BF_TRY(ensure(ctx, ctx->i_fhash, n * 8)); BF_TRY(ensure(ctx, ctx->i_bp, n * 2)); BF_TRY(ensure(ctx, ctx->i_len, n * 2));
+    BF_TRY(ensure(ctx, ctx->i_flags, n * 2)); BF_TRY(ensure(ctx, ctx->i_frag, std::max<uint64_t>(n * stride, 1)));
+    BF_TRY(ensure(ctx, ctx->i_frag_off, n * 8)); BF_TRY(ensure(ctx, ctx->i_frag_len, n * 2));
+    BF_TRY(ensure(ctx, ctx->i_sigx, n * 16)); BF_TRY(ensure(ctx, ctx->i_sigx_slot, n * 4));
+    BF_TRY(ensure(ctx, ctx->i_src_rank, n * 4)); BF_TRY(ensure(ctx, ctx->i_src_idx, n * 4));
+    BF_TRY(ensure(ctx, ctx->d_part_tmp, (size_t)(R + 1) * 8));
+    BF_HIP(ctx, hipMemcpyAsync(ctx->d_part_tmp.p, start.data(), (size_t)(R + 1) * 8, hipMemcpyHostToDevice, st));
+    ImportView v{};
+    v.n = n; v.rec_bytes = ctx->wire_rec_bytes; v.frag_stride = stride; v.has_sigx = ctx->wire_has_sigx; v.n_ranks = R;
+    v.in = (const uint8_t*)dev_recv; v.src_start = ctx->d_part_tmp.as<uint64_t>();
+    v.key = ctx->i_key.as<uint64_t>(); v.lpos = ctx->i_lpos.as<int32_t>(); v.rpos = ctx->i_rpos.as<int32_t>();
+    v.fhash = ctx->i_fhash.as<uint64_t>(); v.bp = ctx->i_bp.as<uint16_t>(); v.len = ctx->i_len.as<uint16_t>();
+    v.flags = ctx->i_flags.as<uint16_t>(); v.frag = ctx->i_frag.as<uint8_t>(); v.frag_off = ctx->i_frag_off.as<uint64_t>();
+    v.frag_len = ctx->i_frag_len.as<uint16_t>(); v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
+    v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>();
+    Scope t(ctx, "exchange_import");
+    hipLaunchKernelGGL(import_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, v);
+    BF_HIP(ctx, hipGetLastError());
+    BF_HIP(ctx, hipStreamSynchronize(st));   // dev_recv may be released by the caller on return
+    return BF_OK;
+}
+
+// reads[i].junction_{off,len} from the render offsets
+__global__ void patch_reads_kernel(bf_read* reads, const uint64_t* __restrict__ joff, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { reads[i].junction_off = joff[i]; reads[i].junction_len = (uint32_t)(joff[i + 1] - joff[i]); }
+}
+int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n) {
+    if (n) hipLaunchKernelGGL(patch_reads_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
+                              ctx->c_reads.as<bf_read>(), d_joff, n);
+    BF_HIP(ctx, hipGetLastError());
+    return BF_OK;
+}
+
+}  // namespace bf

@@ -1,0 +1,603 @@
+// Per-read kernels of the `breakfast detect` hot path for gfx950 (MI355X):
+//   genome_pack    raw FASTA bytes -> 2-bit block image + coarse exception bitmap   (detect.rs:48-56)
+//   encode_reads   ASCII reads -> bit planes (lo, hi, exception), transposed         (detect.rs:91)
+//   hash_frags     fragment ids -> 64-bit hashes                                     (detect.rs:90)
+//   localise_fast  reorient + two flank gathers + split scan + signature + coords    (detect.rs:105-187)
+//   localise_exact the same on raw bytes for reads/windows the packed path cannot represent
+//   render         case-marked junction strings of surviving reads                   (detect.rs:155-162)
+//
+// Mapping (wave64): one lane per read.  All per-read state (3 read planes, 2x2 window planes,
+// 2 mismatch masks) lives in registers as W 64-bit words, bit k <-> read base k, so the split scan
+// is popcount + a branch-free running sum and never touches LDS.  Read planes and every output are
+// stored transposed ([word][read]) so that a wave's loads/stores are contiguous; the only
+// uncoalesced traffic is the inherent one, the two 16*(W+1)-byte window gathers per read.
+
+#include "bf_internal.h"
+
+namespace bf {
+
+__constant__ uint8_t kComp[256] = {
+#include "bf_comp_table.inc"
+};
+
+__device__ __forceinline__ uint8_t comp_byte(uint8_t c) { return kComp[c]; }
+__device__ __forceinline__ bool is_acgt(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+
+// ---------------------------------------------------------------------------------------------
+// genome_pack: thread t packs bases [64t, 64t+64).  A wave's 64 exception flags form one word
+// of the coarse bitmap (ballot), so block t's flag is bit t%64 of coarse[t/64].
+__global__ void __launch_bounds__(256) genome_pack_kernel(const uint8_t* __restrict__ raw,
+                                                          GenomeBlock* __restrict__ blocks,
+                                                          uint64_t* __restrict__ coarse,
+                                                          uint64_t n_blocks /* multiple of 64 */) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_blocks) return;  // whole waves only: n_blocks and blockDim are multiples of 64
+    const uint4* src = (const uint4*)(raw + t * 64);
+    uint64_t lo = 0, hi = 0;
+    bool exc = false;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint4 v = src[q];
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint8_t c = (uint8_t)(wds[d] >> (8 * b));
+                const int k = q * 16 + d * 4 + b;
+                const uint64_t code = (c >> 1) & 3;
+                lo |= (code & 1) << k;
+                hi |= (code >> 1) << k;
+                exc |= !is_acgt(c);
+            }
+        }
+    }
+    blocks[t] = GenomeBlock{lo, hi};
+    const uint64_t flags = __ballot(exc);
+    if ((threadIdx.x & 63) == 0) coarse[t >> 6] = flags;
+}
+
+// ---------------------------------------------------------------------------------------------
+// encode_reads: thread (r, w) encodes read bases [64w, 64w+64) into planes[(p*W + w)*N + r],
+// p = 0 lo, 1 hi, 2 exception.  Reads longer than 64*W are left to the exact kernel.
+__global__ void __launch_bounds__(256) encode_reads_kernel(uint64_t n, int W,
+                                                           const uint8_t* __restrict__ seq,
+                                                           const uint64_t* __restrict__ seq_off,
+                                                           uint64_t* __restrict__ planes) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = blockIdx.y;
+    if (r >= n) return;
+    const uint64_t o = seq_off[r];
+    const uint64_t L = seq_off[r + 1] - o;
+    uint64_t lo = 0, hi = 0, ex = 0;
+    if (L <= (uint64_t)64 * W && (uint64_t)64 * w < L) {
+        const int cnt = (int)min((uint64_t)64, L - (uint64_t)64 * w);
+        const uint8_t* p = seq + o + 64 * w;
+        for (int k = 0; k < cnt; k++) {
+            const uint8_t c = p[k];
+            const uint64_t code = (c >> 1) & 3;
+            lo |= (code & 1) << k;
+            hi |= (code >> 1) << k;
+            ex |= (uint64_t)(!is_acgt(c)) << k;
+        }
+    }
+    planes[((uint64_t)(0 * W + w)) * n + r] = lo;
+    planes[((uint64_t)(1 * W + w)) * n + r] = hi;
+    planes[((uint64_t)(2 * W + w)) * n + r] = ex;
+}
+
+// lengths + FNV-1a/64 with a final avalanche of the fragment id bytes
+__global__ void __launch_bounds__(256) read_meta_kernel(uint64_t n, const uint64_t* __restrict__ seq_off,
+                                                        const uint8_t* __restrict__ frag,
+                                                        const uint64_t* __restrict__ frag_off,
+                                                        uint16_t* __restrict__ len,
+                                                        uint16_t* __restrict__ frag_len,
+                                                        uint64_t* __restrict__ fhash) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    len[r] = (uint16_t)(seq_off[r + 1] - seq_off[r]);
+    const uint64_t o = frag_off[r];
+    const uint32_t fl = (uint32_t)(frag_off[r + 1] - o);
+    frag_len[r] = (uint16_t)fl;
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (uint32_t k = 0; k < fl; k++) { h ^= frag[o + k]; h *= 0x100000001b3ull; }
+    h ^= h >> 32; h *= 0xd6e8feb86659fd93ull; h ^= h >> 32;
+    fhash[r] = h;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void reverse_bits(uint64_t (&p)[W], int L) {
+    // p'[k] = p[L-1-k] for k < L, 0 above.  Reverse all 64W bits, then shift right by 64W - L.
+    uint64_t t[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) t[w] = __brevll(p[W - 1 - w]);
+    int s = 64 * W - L;
+#pragma unroll
+    for (int i = 0; i < W - 1; i++) {
+        if (s >= 64) {
+#pragma unroll
+            for (int w = 0; w < W - 1; w++) t[w] = t[w + 1];
+            t[W - 1] = 0;
+            s -= 64;
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const uint64_t up = (w + 1 < W) ? t[w + 1] : 0ull;
+        p[w] = (t[w] >> s) | ((up << 1) << (63 - s));
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void load_window(const GenomeBlock* __restrict__ blocks, uint64_t g,
+                                            uint64_t (&lo)[W], uint64_t (&hi)[W]) {
+    // bits of bases [g, g + 64W): W+1 consecutive 16-byte blocks, funnel-shifted by g % 64
+    const uint64_t b = g >> 6;
+    const int sh = (int)(g & 63);
+    GenomeBlock x[W + 1];
+#pragma unroll
+    for (int i = 0; i <= W; i++) x[i] = blocks[b + i];
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        lo[w] = (x[w].lo >> sh) | ((x[w + 1].lo << 1) << (63 - sh));
+        hi[w] = (x[w].hi >> sh) | ((x[w + 1].hi << 1) << (63 - sh));
+    }
+}
+
+template <int W>
+__device__ __forceinline__ uint32_t extract8(const uint64_t (&p)[W], int off) {
+    // bits [off, off+8) of the multi-word value (off + 8 <= 64W)
+    uint64_t v = 0;
+    const int wi = off >> 6, sh = off & 63;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        if (w == wi) {
+            const uint64_t up = (w + 1 < W) ? p[w + 1] : 0ull;
+            v = (p[w] >> sh) | ((up << 1) << (63 - sh));
+        }
+    }
+    return (uint32_t)(v & 0xff);
+}
+
+__device__ __forceinline__ uint64_t low_mask(int nbits) {   // nbits in [0, 64]
+    return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1);
+}
+
+struct LocaliseArgs {
+    uint64_t n;
+    int A;
+    uint32_t force_exact;
+    const bf_hit* hits;
+    const uint16_t* len;
+    const uint64_t* planes;
+    const ContigDev* contigs;
+    const GenomeBlock* blocks;
+    const uint64_t* coarse;
+    uint64_t* key;
+    int32_t* lpos;
+    int32_t* rpos;
+    uint16_t* bp;
+    uint16_t* flags;
+    uint64_t* mask;          // [mask_words][n]
+    uint32_t* exact_list;
+    uint32_t* counters;      // [0] = number of reads routed to the exact kernel
+};
+
+struct Oriented {            // the read's two anchors after detect.rs:108-113
+    ContigDev c, mc;
+    int64_t pos, mpos;
+    bool strand, mstrand, swapped;
+};
+
+__device__ __forceinline__ Oriented orient(const bf_hit& h, const ContigDev* __restrict__ contigs) {
+    Oriented o;
+    o.c = contigs[h.contig5];
+    o.mc = contigs[h.contig3];
+    o.pos = h.pos5;
+    o.mpos = h.pos3;
+    o.strand = (h.strands & 1) != 0;
+    o.mstrand = (h.strands & 2) != 0;
+    // `chr > mchr || (chr == mchr && pos > mpos)`: names compare byte-wise == ranks compare
+    o.swapped = o.c.rank > o.mc.rank || (o.c.rank == o.mc.rank && o.pos > o.mpos);
+    if (o.swapped) {
+        const ContigDev tc = o.c; o.c = o.mc; o.mc = tc;
+        const int64_t tp = o.pos; o.pos = o.mpos; o.mpos = tp;
+        const bool ts = o.strand; o.strand = !o.mstrand; o.mstrand = !ts;
+    }
+    return o;
+}
+
+__device__ __forceinline__ uint64_t make_key(const Oriented& o, bool sigx, uint32_t sig) {
+    return ((uint64_t)o.c.rank << kKeyRankShift) | ((uint64_t)o.mc.rank << kKeyMrankShift) |
+           ((uint64_t)o.strand << kKeyStrandBit) | ((uint64_t)o.mstrand << kKeyMstrandBit) |
+           ((uint64_t)sigx << kKeySigxBit) | sig;
+}
+
+template <int W>
+__global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n) return;
+    const int L = a.len[r];
+    const int A = a.A;
+    const bf_hit h = a.hits[r];
+    const Oriented o = orient(h, a.contigs);
+
+    // forward-strand window starts, 0-based inside the contig (detect.rs:116-131)
+    const int64_t ls = o.strand ? o.pos - 1 : o.pos + A - 1 - L;
+    const int64_t rs = o.mstrand ? o.mpos + A - 1 - L : o.mpos - 1;
+    bool ok = L <= 64 * W && !a.force_exact;
+    ok = ok && ls >= 0 && ls + L <= (int64_t)o.c.len && rs >= 0 && rs + L <= (int64_t)o.mc.len;
+    const uint64_t lg = o.c.goff + (uint64_t)(ok ? ls : 0);
+    const uint64_t rg = o.mc.goff + (uint64_t)(ok ? rs : 0);
+
+    // issue every load before the first use: planes (coalesced), windows + coarse bits (gathers)
+    uint64_t rlo[W], rhi[W], rex[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        rlo[w] = a.planes[((uint64_t)(0 * W + w)) * a.n + r];
+        rhi[w] = a.planes[((uint64_t)(1 * W + w)) * a.n + r];
+        rex[w] = a.planes[((uint64_t)(2 * W + w)) * a.n + r];
+    }
+    uint64_t llo[W], lhi[W], qlo[W], qhi[W];
+    load_window<W>(a.blocks, lg, llo, lhi);
+    load_window<W>(a.blocks, rg, qlo, qhi);
+    {
+        const uint64_t lb = lg >> 6, rb = rg >> 6;
+        const int lnb = (int)(((lg + L - 1) >> 6) - lb) + 1, rnb = (int)(((rg + L - 1) >> 6) - rb) + 1;
+        const uint64_t c0 = a.coarse[lb >> 6], c1 = a.coarse[(lb >> 6) + 1];
+        const uint64_t d0 = a.coarse[rb >> 6], d1 = a.coarse[(rb >> 6) + 1];
+        const int ls_ = (int)(lb & 63), rs_ = (int)(rb & 63);
+        const uint64_t lbits = ((c0 >> ls_) | ((c1 << 1) << (63 - ls_))) & low_mask(lnb);
+        const uint64_t rbits = ((d0 >> rs_) | ((d1 << 1) << (63 - rs_))) & low_mask(rnb);
+        ok = ok && lbits == 0 && rbits == 0;
+    }
+    if (!ok) {
+        const uint32_t slot = atomicAdd(&a.counters[0], 1u);
+        a.exact_list[slot] = (uint32_t)r;
+        return;
+    }
+
+    uint64_t vm[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) vm[w] = low_mask(min(max(L - 64 * w, 0), 64));
+
+    if (o.swapped) {              // seq = revcomp(seq), detect.rs:112
+        reverse_bits<W>(rlo, L); reverse_bits<W>(rhi, L); reverse_bits<W>(rex, L);
+#pragma unroll
+        for (int w = 0; w < W; w++) rhi[w] ^= vm[w];
+    }
+    if (!o.strand) {              // left flank read backwards + complemented, detect.rs:121
+        reverse_bits<W>(llo, L); reverse_bits<W>(lhi, L);
+#pragma unroll
+        for (int w = 0; w < W; w++) lhi[w] ^= vm[w];
+    }
+    if (!o.mstrand) {             // detect.rs:130
+        reverse_bits<W>(qlo, L); reverse_bits<W>(qhi, L);
+#pragma unroll
+        for (int w = 0; w < W; w++) qhi[w] ^= vm[w];
+    }
+
+    // mismatch masks: a read base outside "ACGT" differs from every packed reference base
+    uint64_t ml[W], mr[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        ml[w] = ((rlo[w] ^ llo[w]) | (rhi[w] ^ lhi[w]) | rex[w]) & vm[w];
+        mr[w] = ((rlo[w] ^ qlo[w]) | (rhi[w] ^ qhi[w]) | rex[w]) & vm[w];
+    }
+
+    // split scan, detect.rs:135-153: mm[A] by popcount, then the running sum; first minimum wins
+    int mm = 0;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const uint64_t lowA = low_mask(min(max(A - 64 * w, 0), 64));
+        mm += __popcll(ml[w] & lowA) + __popcll(mr[w] & ~lowA);
+    }
+    int best = mm, bp = A;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        // j = k-1 runs over [A, L-A-2]; inside word w that is jj in [j0, j1)
+        const int j0 = max(A - 64 * w, 0), j1 = min(L - A - 1 - 64 * w, 64);
+        if (j0 < j1) {
+            uint64_t x = ml[w] >> j0, y = mr[w] >> j0;
+            for (int jj = j0; jj < j1; jj++) {
+                mm += (int)(x & 1) - (int)(y & 1);
+                x >>= 1; y >>= 1;
+                if (mm < best) { best = mm; bp = 64 * w + jj + 1; }
+            }
+        }
+    }
+
+    // signature, detect.rs:165-168: 8 reference bases left of bp and 8 right of it (all ACGT here)
+    const uint32_t sig = extract8<W>(llo, bp - 8) | (extract8<W>(lhi, bp - 8) << 8) |
+                         (extract8<W>(qlo, bp) << 16) | (extract8<W>(qhi, bp) << 24);
+
+    // coordinates, detect.rs:172-181 (signed; a negative value is the reference's wrapped usize)
+    const int64_t lp = o.strand ? o.pos + bp - 1 : o.pos + A - bp;
+    const int64_t rp = o.mstrand ? o.mpos + A - (L - bp) : o.mpos + (L - bp);
+
+    a.key[r] = make_key(o, false, sig);
+    a.lpos[r] = (int32_t)lp;
+    a.rpos[r] = (int32_t)rp;
+    a.bp[r] = (uint16_t)bp;
+    a.flags[r] = (uint16_t)((o.strand ? kEvStrand : 0) | (o.mstrand ? kEvMstrand : 0) |
+                            (o.swapped ? kEvSwapped : 0));
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const uint64_t lowB = low_mask(min(max(bp - 64 * w, 0), 64));
+        a.mask[(uint64_t)w * a.n + r] = (ml[w] & lowB) | (mr[w] & ~lowB);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Byte-exact path: one lane per routed read, straight from the raw images.  Handles windows that
+// leave the contig (-> 'N', detect.rs:118-130), reference bytes outside ACGT (soft-masked, N,
+// IUPAC), and reads longer than the packed path's 64*W.
+struct ExactArgs {
+    uint64_t n_total;
+    int A;
+    const uint32_t* exact_list;
+    const uint32_t* counters;
+    const bf_hit* hits;
+    const uint8_t* seq;
+    const uint64_t* seq_off;
+    const ContigDev* contigs;
+    const uint8_t* raw;
+    uint64_t* key;
+    int32_t* lpos;
+    int32_t* rpos;
+    uint16_t* bp;
+    uint16_t* flags;
+    uint64_t* mask;
+    int mask_words;
+    uint8_t* sigx;           // 16 bytes per slot
+    uint32_t* sigx_slot;     // read -> slot
+};
+
+struct ExactRead {
+    const uint8_t* seq; int L; bool swapped;
+    const uint8_t* lraw; int64_t llen; int64_t lbase; bool lfwd;
+    const uint8_t* rraw; int64_t rlen; int64_t rbase; bool rfwd;
+    __device__ __forceinline__ uint8_t s(int k) const {
+        return swapped ? comp_byte(seq[L - 1 - k]) : seq[k];
+    }
+    __device__ __forceinline__ uint8_t left(int k) const {
+        const int64_t i = lfwd ? lbase + k : lbase - k;
+        const uint8_t c = (i >= 0 && i < llen) ? lraw[i] : (uint8_t)'N';
+        return lfwd ? c : comp_byte(c);
+    }
+    __device__ __forceinline__ uint8_t right(int k) const {
+        const int64_t i = rfwd ? rbase + k : rbase - k;
+        const uint8_t c = (i >= 0 && i < rlen) ? rraw[i] : (uint8_t)'N';
+        return rfwd ? c : comp_byte(c);
+    }
+};
+
+__global__ void __launch_bounds__(64) localise_exact_kernel(const ExactArgs a) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.counters[0]) return;
+    const uint32_t r = a.exact_list[slot];
+    const bf_hit h = a.hits[r];
+    const Oriented o = orient(h, a.contigs);
+    const int A = a.A;
+    ExactRead x;
+    x.seq = a.seq + a.seq_off[r];
+    x.L = (int)(a.seq_off[r + 1] - a.seq_off[r]);
+    x.swapped = o.swapped;
+    const int L = x.L;
+    x.lraw = a.raw + o.c.goff; x.llen = o.c.len; x.lfwd = o.strand;
+    x.lbase = o.strand ? o.pos - 1 : o.pos + A - 2;                 // detect.rs:118,121
+    x.rraw = a.raw + o.mc.goff; x.rlen = o.mc.len; x.rfwd = o.mstrand;
+    x.rbase = o.mstrand ? o.mpos + A - L - 1 : o.mpos + L - 2;      // detect.rs:127,130
+
+    int mm = 0;
+    for (int k = 0; k < A; k++) mm += x.s(k) != x.left(k);
+    for (int k = A; k < L; k++) mm += x.s(k) != x.right(k);
+    int best = mm, bp = A;
+    for (int k = A + 1; k < L - A; k++) {
+        const uint8_t c = x.s(k - 1);
+        mm += (int)(c != x.left(k - 1)) - (int)(c != x.right(k - 1));
+        if (mm < best) { best = mm; bp = k; }
+    }
+    for (int w = 0; w < a.mask_words; w++) {
+        uint64_t m = 0;
+        const int k1 = min(64 * w + 64, L);
+        for (int k = 64 * w; k < k1; k++) {
+            const uint8_t c = x.s(k);
+            const bool mis = k < bp ? c != x.left(k) : c != x.right(k);
+            m |= (uint64_t)mis << (k & 63);
+        }
+        a.mask[(uint64_t)w * a.n_total + r] = m;
+    }
+    uint8_t sigb[16];
+    bool plain = true;
+    uint32_t sig = 0;
+    for (int k = 0; k < 8; k++) {
+        const uint8_t cl = x.left(bp - 8 + k), cr = x.right(bp + k);
+        sigb[k] = cl; sigb[8 + k] = cr;
+        plain = plain && is_acgt(cl) && is_acgt(cr);
+        const uint32_t dl = (cl >> 1) & 3, dr = (cr >> 1) & 3;
+        sig |= ((dl & 1) << k) | ((dl >> 1) << (8 + k)) | ((dr & 1) << (16 + k)) | ((dr >> 1) << (24 + k));
+    }
+    if (!plain) {
+        uint32_t hsh = 0x811c9dc5u;
+        for (int k = 0; k < 16; k++) { hsh ^= sigb[k]; hsh *= 0x01000193u; }
+        sig = hsh;
+        for (int k = 0; k < 16; k++) a.sigx[(uint64_t)slot * 16 + k] = sigb[k];
+        a.sigx_slot[r] = slot;
+    }
+    const int64_t lp = o.strand ? o.pos + bp - 1 : o.pos + A - bp;
+    const int64_t rp = o.mstrand ? o.mpos + A - (L - bp) : o.mpos + (L - bp);
+    a.key[r] = make_key(o, !plain, sig);
+    a.lpos[r] = (int32_t)lp;
+    a.rpos[r] = (int32_t)rp;
+    a.bp[r] = (uint16_t)bp;
+    a.flags[r] = (uint16_t)((o.strand ? kEvStrand : 0) | (o.mstrand ? kEvMstrand : 0) |
+                            (o.swapped ? kEvSwapped : 0) | kEvExact | (plain ? 0 : kEvSigx));
+}
+
+// ---------------------------------------------------------------------------------------------
+// render: one wave per supporting read; lanes stride over the read's bases.
+__global__ void __launch_bounds__(256) render_len_kernel(uint64_t n, const uint32_t* __restrict__ idx,
+                                                         const uint16_t* __restrict__ len,
+                                                         uint32_t* __restrict__ out_len) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out_len[i] = (uint32_t)len[idx[i]] + 1;
+}
+
+__global__ void __launch_bounds__(256) render_kernel(uint64_t n, uint64_t n_total,
+                                                     const uint32_t* __restrict__ idx,
+                                                     const uint64_t* __restrict__ joff,
+                                                     const uint8_t* __restrict__ seq,
+                                                     const uint64_t* __restrict__ seq_off,
+                                                     const uint16_t* __restrict__ bp_,
+                                                     const uint16_t* __restrict__ flags,
+                                                     const uint64_t* __restrict__ mask,
+                                                     uint8_t* __restrict__ out) {
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const uint32_t r = idx[i];
+    const uint64_t o = seq_off[r];
+    const int L = (int)(seq_off[r + 1] - o);
+    const int bp = bp_[r];
+    const bool swapped = (flags[r] & kEvSwapped) != 0;
+    uint8_t* dst = out + joff[i];
+    for (int k0 = 0; k0 < L; k0 += 64) {
+        const uint64_t m = mask[(uint64_t)(k0 >> 6) * n_total + r];
+        const int k = k0 + lane;
+        if (k < L) {
+            uint8_t c = swapped ? comp_byte(seq[o + L - 1 - k]) : seq[o + k];
+            if (((m >> lane) & 1) && c >= 'A' && c <= 'Z') c += 32;   // to_ascii_lowercase, :157,161
+            dst[k < bp ? k : k + 1] = c;
+        }
+    }
+    if (lane == 0) dst[bp] = '|';
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+
+static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+int genome_pack(bf_ctx* ctx) {
+    const uint64_t n_blocks = ctx->genome_bases / 64;     // multiple of 64 by construction
+    Scope t(ctx, "genome_pack");
+    hipLaunchKernelGGL(genome_pack_kernel, dim3(grid_for(n_blocks, 256)), dim3(256), 0, ctx->stream,
+                       ctx->g_raw.as<uint8_t>(), ctx->g_blocks.as<GenomeBlock>(),
+                       ctx->g_coarse.as<uint64_t>(), n_blocks);
+    BF_HIP(ctx, hipGetLastError());
+    return BF_OK;
+}
+
+template <int W>
+static void launch_fast(bf_ctx* ctx, const LocaliseArgs& a) {
+    hipLaunchKernelGGL(localise_fast_kernel<W>, dim3(grid_for(a.n, 256)), dim3(256), 0, ctx->stream, a);
+}
+
+int run_localise(bf_ctx* ctx) {
+    const uint64_t n = ctx->n_reads;
+    ctx->n_exact = 0;
+    ctx->localised = false;
+    if (n == 0) { ctx->localised = true; ctx->plane_words = 1; ctx->mask_words = 1; return BF_OK; }
+    const uint32_t A = ctx->cfg.anchor_len;
+    if (ctx->min_len < 2 * A)
+        return fail(ctx, BF_ERR_RANGE, "a read of length %u is shorter than 2 * anchor_len = %u "
+                    "(the reference only emits reads with len >= 2*anchor_len, detect.rs:311)",
+                    ctx->min_len, 2 * A);
+    const uint32_t Wm = (ctx->max_len + 63) / 64;
+    uint32_t W = Wm <= 2 ? 2 : Wm == 3 ? 3 : 4;
+    ctx->plane_words = W;
+    ctx->mask_words = Wm;
+
+    BF_TRY(ensure(ctx, ctx->d_planes, (size_t)3 * W * n * 8));
+    BF_TRY(ensure(ctx, ctx->d_len, n * 2));
+    BF_TRY(ensure(ctx, ctx->d_frag_len, n * 2));
+    BF_TRY(ensure(ctx, ctx->d_fhash, n * 8));
+    BF_TRY(ensure(ctx, ctx->d_key, n * 8));
+    BF_TRY(ensure(ctx, ctx->d_lpos, n * 4));
+    BF_TRY(ensure(ctx, ctx->d_rpos, n * 4));
+    BF_TRY(ensure(ctx, ctx->d_bp, n * 2));
+    BF_TRY(ensure(ctx, ctx->d_flags, n * 2));
+    BF_TRY(ensure(ctx, ctx->d_mask, (size_t)Wm * n * 8));
+    BF_TRY(ensure(ctx, ctx->d_exact_list, n * 4));
+    BF_TRY(ensure(ctx, ctx->d_sigx_slot, n * 4));
+    BF_TRY(ensure(ctx, ctx->d_counters, 64));
+    BF_HIP(ctx, hipMemsetAsync(ctx->d_counters.p, 0, 64, ctx->stream));
+    if (Wm > W) BF_HIP(ctx, hipMemsetAsync(ctx->d_mask.p, 0, (size_t)Wm * n * 8, ctx->stream));
+
+    {
+        Scope t(ctx, "encode_reads");
+        hipLaunchKernelGGL(encode_reads_kernel, dim3(grid_for(n, 256), W), dim3(256), 0, ctx->stream, n,
+                           (int)W, ctx->d_seq.as<uint8_t>(), ctx->d_seq_off.as<uint64_t>(),
+                           ctx->d_planes.as<uint64_t>());
+        hipLaunchKernelGGL(read_meta_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n,
+                           ctx->d_seq_off.as<uint64_t>(), ctx->d_frag.as<uint8_t>(),
+                           ctx->d_frag_off.as<uint64_t>(), ctx->d_len.as<uint16_t>(),
+                           ctx->d_frag_len.as<uint16_t>(), ctx->d_fhash.as<uint64_t>());
+    }
+    BF_HIP(ctx, hipGetLastError());
+
+    LocaliseArgs a{};
+    a.n = n; a.A = (int)A; a.force_exact = (ctx->cfg.flags & BF_FLAG_FORCE_EXACT) ? 1u : 0u;
+    a.hits = ctx->d_hits.as<bf_hit>(); a.len = ctx->d_len.as<uint16_t>();
+    a.planes = ctx->d_planes.as<uint64_t>(); a.contigs = ctx->g_contigs.as<ContigDev>();
+    a.blocks = ctx->g_blocks.as<GenomeBlock>(); a.coarse = ctx->g_coarse.as<uint64_t>();
+    a.key = ctx->d_key.as<uint64_t>(); a.lpos = ctx->d_lpos.as<int32_t>(); a.rpos = ctx->d_rpos.as<int32_t>();
+    a.bp = ctx->d_bp.as<uint16_t>(); a.flags = ctx->d_flags.as<uint16_t>(); a.mask = ctx->d_mask.as<uint64_t>();
+    a.exact_list = ctx->d_exact_list.as<uint32_t>(); a.counters = ctx->d_counters.as<uint32_t>();
+    {
+        Scope t(ctx, "localise");
+        if (W == 2) launch_fast<2>(ctx, a);
+        else if (W == 3) launch_fast<3>(ctx, a);
+        else launch_fast<4>(ctx, a);
+    }
+    BF_HIP(ctx, hipGetLastError());
+
+    uint32_t n_exact = 0;
+    BF_HIP(ctx, hipMemcpyAsync(&n_exact, ctx->d_counters.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_exact = n_exact;
+    if (n_exact) {
+        BF_TRY(ensure(ctx, ctx->d_sigx, (size_t)n_exact * 16));
+        ExactArgs e{};
+        e.n_total = n; e.A = (int)A; e.exact_list = a.exact_list; e.counters = a.counters; e.hits = a.hits;
+        e.seq = ctx->d_seq.as<uint8_t>(); e.seq_off = ctx->d_seq_off.as<uint64_t>();
+        e.contigs = a.contigs; e.raw = ctx->g_raw.as<uint8_t>();
+        e.key = a.key; e.lpos = a.lpos; e.rpos = a.rpos; e.bp = a.bp; e.flags = a.flags; e.mask = a.mask;
+        e.mask_words = (int)Wm; e.sigx = ctx->d_sigx.as<uint8_t>(); e.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
+        Scope t(ctx, "localise_exact");
+        hipLaunchKernelGGL(localise_exact_kernel, dim3(grid_for(n_exact, 64)), dim3(64), 0, ctx->stream, e);
+        BF_HIP(ctx, hipGetLastError());
+    }
+    ctx->localised = true;
+    return BF_OK;
+}
+
+int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, DevBuf& d_bytes,
+               uint64_t* total_bytes) {
+    *total_bytes = 0;
+    BF_TRY(ensure(ctx, d_off, (n + 1) * 8));
+    if (n == 0) {
+        BF_HIP(ctx, hipMemsetAsync(d_off.p, 0, 8, ctx->stream));
+        return BF_OK;
+    }
+    BF_TRY(ensure(ctx, ctx->c_misc, n * 4));
+    Scope t(ctx, "render");
+    hipLaunchKernelGGL(render_len_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
+                       ctx->d_len.as<uint16_t>(), ctx->c_misc.as<uint32_t>());
+    BF_TRY(scan_u32_to_u64(ctx, ctx->c_misc.as<uint32_t>(), d_off.as<uint64_t>(), n));
+    uint64_t total = 0;
+    BF_HIP(ctx, hipMemcpyAsync(&total, d_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_TRY(ensure(ctx, d_bytes, total ? total : 1));
+    hipLaunchKernelGGL(render_kernel, dim3(grid_for(n * 64, 256)), dim3(256), 0, ctx->stream, n, ctx->n_reads,
+                       d_local_idx, d_off.as<uint64_t>(), ctx->d_seq.as<uint8_t>(), ctx->d_seq_off.as<uint64_t>(),
+                       ctx->d_bp.as<uint16_t>(), ctx->d_flags.as<uint16_t>(), ctx->d_mask.as<uint64_t>(),
+                       d_bytes.as<uint8_t>());
+    BF_HIP(ctx, hipGetLastError());
+    *total_bytes = total;
+    return BF_OK;
+}
+
+}  // namespace bf

@@ -1,0 +1,401 @@
+"""ctypes binding of libbreakfast_hip.so (include/breakfast_hip.h) and the host-side mirror of the
+reference's consume-loop interface (/root/reference/src/detect.rs:76-103).
+
+This module is plumbing: every computation happens in the HIP library.  There is no CPU
+implementation here and no fallback: if the library is missing, or no gfx950 device is usable,
+construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbreakfast_hip.so")
+
+BF_FLAG_KEEP_EVIDENCE = 1
+BF_FLAG_FORCE_EXACT = 2
+BF_EV_STRAND, BF_EV_MSTRAND, BF_EV_SWAPPED, BF_EV_EXACT, BF_EV_SIGX = 1, 2, 4, 8, 16
+
+HIT_DTYPE = np.dtype([("pos5", "<u4"), ("pos3", "<u4"), ("contig5", "<u2"), ("contig3", "<u2"),
+                      ("strands", "u1"), ("pad", "u1", (3,))])
+CLUSTER_DTYPE = np.dtype([("lpos", "<i8"), ("rpos", "<i8"), ("seed_index", "<u8"),
+                          ("read_begin", "<u8"), ("read_end", "<u8"), ("contig", "<u4"),
+                          ("mcontig", "<u4"), ("strand", "u1"), ("mstrand", "u1"), ("pad", "u1", (6,))])
+READ_DTYPE = np.dtype([("index", "<u8"), ("junction_off", "<u8"), ("junction_len", "<u4"),
+                       ("bp", "<u2"), ("swapped", "u1"), ("pad", "u1")])
+assert HIT_DTYPE.itemsize == 16 and CLUSTER_DTYPE.itemsize == 56 and READ_DTYPE.itemsize == 24
+
+
+class BfConfig(C.Structure):
+    _fields_ = [("anchor_len", C.c_uint32), ("max_frag_len", C.c_uint32), ("min_evidence", C.c_uint32),
+                ("device", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+class BfBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("seq_bytes", C.c_void_p), ("seq_off", C.c_void_p),
+                ("frag_bytes", C.c_void_p), ("frag_off", C.c_void_p), ("hits", C.c_void_p)]
+
+
+class BfResult(C.Structure):
+    _fields_ = [("n_evidence", C.c_uint64), ("n_clusters", C.c_uint64), ("n_reads", C.c_uint64),
+                ("clusters", C.c_void_p), ("reads", C.c_void_p), ("junction_bytes", C.c_void_p),
+                ("junction_size", C.c_uint64)]
+
+
+class BfWireLocal(C.Structure):
+    _fields_ = [("max_frag_len_bytes", C.c_uint32), ("has_exact_sig", C.c_uint32)]
+
+
+class BfEvidenceView(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("mask_words", C.c_uint32), ("class_key", C.c_void_p),
+                ("lpos", C.c_void_p), ("rpos", C.c_void_p), ("bp", C.c_void_p), ("flags", C.c_void_p),
+                ("mask", C.c_void_p)]
+
+
+class BfKernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_float), ("launches", C.c_uint64)]
+
+
+# every symbol include/breakfast_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "bf_abi_version", "bf_ctx_create", "bf_ctx_destroy", "bf_last_error", "bf_genome_set", "bf_submit",
+    "bf_localise", "bf_clusterise", "bf_finish", "bf_reset", "bf_sync", "bf_format_sv", "bf_set_rank",
+    "bf_exchange_local", "bf_exchange_pack", "bf_exchange_import", "bf_result_sources",
+    "bf_render_junctions", "bf_evidence_fetch", "bf_kernel_times", "bf_stats",
+]
+
+_lib = None
+
+
+class BreakfastError(RuntimeError):
+    """A C-ABI call returned a negative status.  `.code` is the BF_ERR_* value."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__("breakfast_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Loads the in-tree HIP library.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(or `make -C breakfast_amd/csrc`); there is no CPU fallback" % p)
+    if os.environ.get("BREAKFAST_NO_TORCH") != "1":
+        # torch ships its own libamdhip64.so.7; load it first so that both share ONE HIP runtime
+        # (device pointers, streams) whichever of the two is imported first by the caller.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
+    lib.bf_abi_version.restype = C.c_int
+    lib.bf_ctx_create.argtypes = [C.POINTER(BfConfig), C.POINTER(vp)]
+    lib.bf_ctx_destroy.argtypes = [vp]
+    lib.bf_ctx_destroy.restype = None
+    lib.bf_last_error.argtypes = [vp]
+    lib.bf_last_error.restype = C.c_char_p
+    lib.bf_genome_set.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(vp), u64p]
+    lib.bf_submit.argtypes = [vp, C.POINTER(BfBatch)]
+    lib.bf_localise.argtypes = [vp]
+    lib.bf_clusterise.argtypes = [vp, C.POINTER(BfResult)]
+    lib.bf_finish.argtypes = [vp, C.POINTER(BfResult)]
+    lib.bf_reset.argtypes = [vp]
+    lib.bf_sync.argtypes = [vp]
+    lib.bf_format_sv.argtypes = [vp, C.POINTER(BfResult), vp, C.c_uint64]
+    lib.bf_format_sv.restype = C.c_int64
+    lib.bf_set_rank.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64]
+    lib.bf_exchange_local.argtypes = [vp, C.POINTER(BfWireLocal)]
+    lib.bf_exchange_pack.argtypes = [vp, C.POINTER(BfWireLocal), u64p, C.POINTER(vp), C.POINTER(C.c_uint32)]
+    lib.bf_exchange_import.argtypes = [vp, vp, u64p, u64p]
+    lib.bf_result_sources.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.bf_render_junctions.argtypes = [vp, C.c_uint64, vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.bf_evidence_fetch.argtypes = [vp, C.POINTER(BfEvidenceView)]
+    lib.bf_kernel_times.argtypes = [vp, C.POINTER(C.POINTER(BfKernelTime)), C.POINTER(C.c_uint32)]
+    lib.bf_stats.argtypes = [vp, u64p, u64p]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+@dataclass
+class Batch:
+    """Parsed anchor-hit pairs in input order = bf_batch (what detect.rs:89-103 extracts per read)."""
+    seq_bytes: np.ndarray    # uint8
+    seq_off: np.ndarray      # uint64, n+1
+    frag_bytes: np.ndarray   # uint8
+    frag_off: np.ndarray     # uint64, n+1
+    hits: np.ndarray         # HIT_DTYPE, n
+
+    @property
+    def n(self) -> int:
+        return int(self.hits.shape[0])
+
+    def slice(self, a: int, b: int) -> "Batch":
+        so, fo = self.seq_off, self.frag_off
+        return Batch(self.seq_bytes[int(so[a]):int(so[b])], so[a:b + 1] - so[a],
+                     self.frag_bytes[int(fo[a]):int(fo[b])], fo[a:b + 1] - fo[a], self.hits[a:b])
+
+    def seq(self, i: int) -> bytes:
+        return self.seq_bytes[int(self.seq_off[i]):int(self.seq_off[i + 1])].tobytes()
+
+    def frag(self, i: int) -> bytes:
+        return self.frag_bytes[int(self.frag_off[i]):int(self.frag_off[i + 1])].tobytes()
+
+
+@dataclass
+class Result:
+    """Copy of a bf_result (numpy arrays own their memory)."""
+    n_evidence: int
+    clusters: np.ndarray      # CLUSTER_DTYPE
+    reads: np.ndarray         # READ_DTYPE
+    junction_bytes: np.ndarray
+    src_rank: Optional[np.ndarray] = None
+    src_index: Optional[np.ndarray] = None
+
+    def junction(self, k: int) -> bytes:
+        r = self.reads[k]
+        o, n = int(r["junction_off"]), int(r["junction_len"])
+        return self.junction_bytes[o:o + n].tobytes()
+
+
+def _ptr(a: Optional[np.ndarray]) -> Optional[int]:
+    return None if a is None or a.size == 0 else a.ctypes.data
+
+
+def parse_bowtie_lines(lines: Iterable[bytes], contig_id: Dict[bytes, int]) -> Batch:
+    """Host mirror of the consume loop's pairing + parsing, detect.rs:76-103: a `5p:` line is
+    remembered; a `3p:` line is used only when its read number equals the remembered one.
+    Raises KeyError for a contig the genome lacks (the reference panics, detect.rs:115)."""
+    seqs: List[bytes] = []
+    frags: List[bytes] = []
+    hits: List[Tuple[int, int, int, int, int]] = []
+    prev = b""
+    prev_read_num = 0
+    for line in lines:
+        if line.endswith(b"\n"):
+            line = line[:-1]
+        if line.endswith(b"\r"):
+            line = line[:-1]
+        read_num = int(line.split(b":")[1])
+        if line.startswith(b"5p:"):
+            prev, prev_read_num = line, read_num
+            continue
+        elif line.startswith(b"3p:") and read_num != prev_read_num:
+            continue
+        info = line.split(b":")
+        cols, mcols = prev.split(b"\t"), line.split(b"\t")
+        strands = (1 if cols[1] == b"+" else 0) | (2 if mcols[1] == b"+" else 0)
+        hits.append((int(cols[3]), int(mcols[3]), contig_id[cols[2]], contig_id[mcols[2]], strands))
+        frags.append(info[2])
+        seqs.append(info[3])
+    return make_batch(seqs, frags, hits)
+
+
+def make_batch(seqs: Sequence[bytes], frags: Sequence[bytes],
+               hits: Sequence[Tuple[int, int, int, int, int]]) -> Batch:
+    """Builds a Batch from per-read (seq, frag_id, (pos5, pos3, contig5, contig3, strands))."""
+    n = len(seqs)
+    so = np.zeros(n + 1, np.uint64)
+    fo = np.zeros(n + 1, np.uint64)
+    if n:
+        so[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+        fo[1:] = np.cumsum([len(f) for f in frags], dtype=np.uint64)
+    h = np.zeros(n, HIT_DTYPE)
+    for i, (p5, p3, c5, c3, st) in enumerate(hits):
+        h[i] = (p5, p3, c5, c3, st, (0, 0, 0))
+    return Batch(np.frombuffer(b"".join(seqs), np.uint8).copy(), so,
+                 np.frombuffer(b"".join(frags), np.uint8).copy(), fo, h)
+
+
+class Engine:
+    """One bf_ctx = one GPU.  Mirrors the stages of detect::main (detect.rs:39-242)."""
+
+    def __init__(self, anchor_len: int = 30, max_frag_len: int = 5000, min_evidence: int = 2,
+                 device: int = -1, flags: int = 0, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        cfg = BfConfig(anchor_len, max_frag_len, min_evidence, device, flags, (C.c_uint32 * 3)(0, 0, 0))
+        h = C.c_void_p()
+        rc = self.lib.bf_ctx_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise BreakfastError(rc, (self.lib.bf_last_error(None) or b"").decode())
+        self.h = h
+        self.contig_names: List[bytes] = []
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.bf_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        if rc < 0:
+            raise BreakfastError(rc, (self.lib.bf_last_error(self.h) or b"").decode())
+
+    # -- genome (detect.rs:48-56) --
+    def set_genome(self, names: Sequence[bytes], seqs: Sequence[np.ndarray]) -> None:
+        n = len(names)
+        self.contig_names = [bytes(x) for x in names]
+        arrs = [np.ascontiguousarray(np.frombuffer(s, np.uint8) if isinstance(s, (bytes, bytearray)) else s,
+                                     dtype=np.uint8) for s in seqs]
+        c_names = (C.c_char_p * n)(*self.contig_names)
+        c_seqs = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
+        c_lens = (C.c_uint64 * n)(*[a.size for a in arrs])
+        self._check(self.lib.bf_genome_set(self.h, n, c_names, c_seqs, c_lens))
+
+    @property
+    def contig_id(self) -> Dict[bytes, int]:
+        return {n: i for i, n in enumerate(self.contig_names)}
+
+    # -- hot path --
+    def submit(self, b: Batch) -> None:
+        arrs = [np.ascontiguousarray(b.seq_bytes, np.uint8), np.ascontiguousarray(b.seq_off, np.uint64),
+                np.ascontiguousarray(b.frag_bytes, np.uint8), np.ascontiguousarray(b.frag_off, np.uint64),
+                np.ascontiguousarray(b.hits, HIT_DTYPE)]
+        cb = BfBatch(b.n, *[a.ctypes.data for a in arrs])
+        self._check(self.lib.bf_submit(self.h, C.byref(cb)))
+
+    def localise(self) -> None:
+        self._check(self.lib.bf_localise(self.h))
+
+    def _wrap(self, r: BfResult, copy: bool = True) -> Result:
+        def arr(ptr, n, dt):
+            if not ptr or n == 0:
+                return np.zeros(0, dt)
+            a = np.frombuffer((C.c_uint8 * (n * dt.itemsize)).from_address(ptr), dt)
+            return a.copy() if copy else a
+        return Result(int(r.n_evidence), arr(r.clusters, r.n_clusters, CLUSTER_DTYPE),
+                      arr(r.reads, r.n_reads, READ_DTYPE),
+                      arr(r.junction_bytes, r.junction_size, np.dtype("u1")))
+
+    def clusterise(self, copy: bool = True) -> Result:
+        r = BfResult()
+        self._check(self.lib.bf_clusterise(self.h, C.byref(r)))
+        self._last = r
+        res = self._wrap(r, copy)
+        if copy and r.n_reads:
+            sr, si = C.c_void_p(), C.c_void_p()
+            self._check(self.lib.bf_result_sources(self.h, C.byref(sr), C.byref(si)))
+            res.src_rank = np.frombuffer((C.c_uint32 * r.n_reads).from_address(sr.value), np.uint32).copy()
+            res.src_index = np.frombuffer((C.c_uint32 * r.n_reads).from_address(si.value), np.uint32).copy()
+        return res
+
+    def finish(self, copy: bool = True) -> Result:
+        r = BfResult()
+        self._check(self.lib.bf_finish(self.h, C.byref(r)))
+        self._last = r
+        return self._wrap(r, copy)
+
+    def finish_raw(self) -> BfResult:
+        """bf_finish without copying the result out (timing loops)."""
+        r = BfResult()
+        self._check(self.lib.bf_finish(self.h, C.byref(r)))
+        self._last = r
+        return r
+
+    def reset(self) -> None:
+        self._check(self.lib.bf_reset(self.h))
+
+    def sync(self) -> None:
+        self._check(self.lib.bf_sync(self.h))
+
+    def format_sv(self, res: Result) -> bytes:
+        """stdout bytes of `breakfast detect` for this result (detect.rs:201,233-240)."""
+        cl = np.ascontiguousarray(res.clusters, CLUSTER_DTYPE)
+        rd = np.ascontiguousarray(res.reads, READ_DTYPE)
+        jb = np.ascontiguousarray(res.junction_bytes, np.uint8)
+        r = BfResult(res.n_evidence, cl.shape[0], rd.shape[0], _ptr(cl), _ptr(rd), _ptr(jb), jb.size)
+        n = self.lib.bf_format_sv(self.h, C.byref(r), None, 0)
+        self._check(n)
+        buf = C.create_string_buffer(int(n) + 1)
+        n2 = self.lib.bf_format_sv(self.h, C.byref(r), buf, n)
+        self._check(n2)
+        return buf.raw[:n]
+
+    # -- multi-GPU stage calls --
+    def set_rank(self, rank: int, n_ranks: int, index_base: int) -> None:
+        self._check(self.lib.bf_set_rank(self.h, rank, n_ranks, index_base))
+        self.n_ranks = n_ranks
+
+    def exchange_local(self) -> Tuple[int, int]:
+        w = BfWireLocal()
+        self._check(self.lib.bf_exchange_local(self.h, C.byref(w)))
+        return int(w.max_frag_len_bytes), int(w.has_exact_sig)
+
+    def exchange_pack(self, max_frag_len_bytes: int, has_exact_sig: int, n_ranks: int) -> Tuple[np.ndarray, int, int]:
+        """-> (counts per owner rank, device pointer of the send buffer, record bytes)"""
+        w = BfWireLocal(max_frag_len_bytes, has_exact_sig)
+        counts = np.zeros(n_ranks, np.uint64)
+        ptr, rec = C.c_void_p(), C.c_uint32()
+        self._check(self.lib.bf_exchange_pack(self.h, C.byref(w), counts.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                              C.byref(ptr), C.byref(rec)))
+        return counts, int(ptr.value or 0), int(rec.value)
+
+    def exchange_import(self, dev_ptr: int, src_counts: np.ndarray, src_index_base: np.ndarray) -> None:
+        sc = np.ascontiguousarray(src_counts, np.uint64)
+        sb = np.ascontiguousarray(src_index_base, np.uint64)
+        self._check(self.lib.bf_exchange_import(self.h, C.c_void_p(dev_ptr), sc.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                sb.ctypes.data_as(C.POINTER(C.c_uint64))))
+
+    def render_junctions(self, local_index: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        idx = np.ascontiguousarray(local_index, np.uint32)
+        pb, po = C.c_void_p(), C.c_void_p()
+        self._check(self.lib.bf_render_junctions(self.h, idx.size, _ptr(idx), C.byref(pb), C.byref(po)))
+        off = np.frombuffer((C.c_uint64 * (idx.size + 1)).from_address(po.value), np.uint64).copy()
+        total = int(off[-1])
+        by = (np.frombuffer((C.c_uint8 * total).from_address(pb.value), np.uint8).copy() if total
+              else np.zeros(0, np.uint8))
+        return by, off
+
+    # -- introspection --
+    def evidence(self) -> Dict[str, np.ndarray]:
+        v = BfEvidenceView()
+        self._check(self.lib.bf_evidence_fetch(self.h, C.byref(v)))
+        n, w = int(v.n), int(v.mask_words)
+
+        def arr(ptr, cnt, dt):
+            dt = np.dtype(dt)
+            if cnt == 0:
+                return np.zeros(0, dt)
+            return np.frombuffer((C.c_uint8 * (cnt * dt.itemsize)).from_address(ptr), dt).copy()
+        return {"class_key": arr(v.class_key, n, "<u8"), "lpos": arr(v.lpos, n, "<i4"), "rpos": arr(v.rpos, n, "<i4"),
+                "bp": arr(v.bp, n, "<u2"), "flags": arr(v.flags, n, "<u2"),
+                "mask": arr(v.mask, n * w, "<u8").reshape(n, w)}
+
+    def kernel_times(self) -> Dict[str, Tuple[float, int]]:
+        """name -> (total ms, launches) since the previous call (HIP events on the ctx stream)."""
+        p, n = C.POINTER(BfKernelTime)(), C.c_uint32()
+        self._check(self.lib.bf_kernel_times(self.h, C.byref(p), C.byref(n)))
+        return {p[i].name.decode(): (float(p[i].ms), int(p[i].launches)) for i in range(n.value)}
+
+    def stats(self) -> Tuple[int, int]:
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.bf_stats(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+
+def detect(fasta: Dict[bytes, bytes], bowtie_lines: Iterable[bytes], anchor_len: int = 30,
+           max_frag_len: int = 5000, min_evidence: int = 2, flags: int = 0) -> bytes:
+    """`breakfast detect` on one GPU: genome dict + bowtie's stdout lines -> .sv bytes."""
+    eng = Engine(anchor_len, max_frag_len, min_evidence, flags=flags)
+    try:
+        names = list(fasta.keys())
+        eng.set_genome(names, [np.frombuffer(fasta[n], np.uint8) for n in names])
+        eng.submit(parse_bowtie_lines(bowtie_lines, eng.contig_id))
+        return eng.format_sv(eng.finish())
+    finally:
+        eng.close()

@@ -1,0 +1,257 @@
+"""Seeded synthetic inputs for BASELINE.json's configs.
+
+Neither a genome, a BAM nor `bowtie` exists in the build or GPU image, so inputs are generated:
+a random genome and split reads spanning simulated junctions, together with the anchor alignments
+Bowtie1 (`-v0 -m1 -B1`, detect.rs:61) would report for them: exact, unique hits of the first and
+last `anchor_len` bases, 1-based leftmost offset, strand.  Reads whose anchors are not error-free
+are never emitted (bowtie prints nothing for them).
+
+PRNG: numpy PCG64 seeded with `seed + stream` (seed 20240807 in the BASELINE configs).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .engine import HIT_DTYPE, Batch
+
+SEED = 20240807
+_ACGT = np.frombuffer(b"ACGT", np.uint8)
+_COMP = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b"AGCTYRWSKMDVHBN", b"TCGARYWSMKHBDVN"):
+    _COMP[_a] = _b
+    _COMP[_a + 32] = _b + 32
+
+# hg38 primary assembly lengths (chr1..22, X, Y, M) -- only the sizes are used
+HG38 = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555),
+        ("chr5", 181538259), ("chr6", 170805979), ("chr7", 159345973), ("chr8", 145138636),
+        ("chr9", 138394717), ("chr10", 133797422), ("chr11", 135086622), ("chr12", 133275309),
+        ("chr13", 114364328), ("chr14", 107043718), ("chr15", 101991189), ("chr16", 90338345),
+        ("chr17", 83257441), ("chr18", 80373285), ("chr19", 58617616), ("chr20", 64444167),
+        ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415),
+        ("chrM", 16569)]
+
+
+@dataclass
+class Genome:
+    names: List[bytes]
+    seqs: List[np.ndarray]            # uint8 ASCII, case preserved
+
+    def as_dict(self) -> Dict[bytes, bytes]:
+        return {n: s.tobytes() for n, s in zip(self.names, self.seqs)}
+
+    def fasta(self, width: int = 60) -> bytes:
+        out = []
+        for n, s in zip(self.names, self.seqs):
+            out.append(b">" + n + b"\n")
+            b = s.tobytes()
+            out.extend(b[i:i + width] + b"\n" for i in range(0, len(b), width))
+        return b"".join(out)
+
+
+def make_genome(contigs: Sequence[Tuple[str, int]], seed: int = SEED, end_n: int = 0,
+                n_runs: Sequence[Tuple[int, int, int]] = (), lower_runs: Sequence[Tuple[int, int, int]] = ()
+                ) -> Genome:
+    """Uniform i.i.d. ACGT contigs.  end_n: length of the N run at both contig ends;
+    n_runs / lower_runs: (contig index, start, length) runs of 'N' / of lowercase bases."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    names, seqs = [], []
+    for name, length in contigs:
+        s = _ACGT[rng.integers(0, 4, size=length, dtype=np.uint8)]
+        if end_n and length > 4 * end_n:
+            s[:end_n] = ord("N")
+            s[-end_n:] = ord("N")
+        names.append(name.encode())
+        seqs.append(s)
+    for ci, a, n in n_runs:
+        seqs[ci][a:a + n] = ord("N")
+    for ci, a, n in lower_runs:
+        seqs[ci][a:a + n] |= 0x20
+    return Genome(names, seqs)
+
+
+@dataclass
+class ReadSpec:
+    n_reads: int
+    read_len: int = 150
+    anchor_len: int = 20
+    n_events: int = 1000           # junctions shared by many reads
+    singleton_frac: float = 0.5    # reads from one-off random chimeras (dropped by min_evidence)
+    mate_frac: float = 0.3         # fraction of event reads that re-use the previous read's QNAME
+    subst_rate: float = 0.005      # per-base substitutions outside the anchors
+    n_rate: float = 0.0            # per-base 'N' in the read outside the anchors
+    deletion_frac: float = 0.5     # share of events that are same-contig deletions (rest: random pairs)
+    hot_frac: float = 0.0          # reads piling onto `hot_events` junctions with distinct QNAMEs
+    hot_events: int = 0
+    margin: int = 0                # keep junctions this far from contig ends (0 -> read_len + 8)
+    seed: int = SEED
+    chunk: int = 1 << 20
+
+
+def _digits(ids: np.ndarray, width: int) -> np.ndarray:
+    """ids -> fixed-width ASCII decimal, shape (n, width)."""
+    out = np.empty((ids.shape[0], width), np.uint8)
+    v = ids.astype(np.uint64).copy()
+    for k in range(width - 1, -1, -1):
+        out[:, k] = (v % 10).astype(np.uint8) + 48
+        v //= 10
+    return out
+
+
+def make_reads(genome: Genome, spec: ReadSpec) -> Batch:
+    """Split reads + the bowtie hits of their anchors, in a seeded random input order."""
+    rng = np.random.Generator(np.random.PCG64(spec.seed + 1))
+    L, A, n = spec.read_len, spec.anchor_len, spec.n_reads
+    assert L >= 2 * A and A >= 8
+    lens = np.array([s.shape[0] for s in genome.seqs], np.int64)
+    starts = np.zeros(len(lens) + 1, np.int64)
+    starts[1:] = np.cumsum(lens)
+    cat = np.concatenate(genome.seqs) if len(genome.seqs) > 1 else genome.seqs[0]
+    margin = spec.margin or (L + 8)
+    usable = np.maximum(lens - 2 * margin, 0)
+    assert usable.sum() > 0, "contigs too short for this read length"
+    cw = usable / usable.sum()
+
+    def random_loci(m: int) -> Tuple[np.ndarray, np.ndarray]:
+        c = rng.choice(len(lens), size=m, p=cw)
+        x = margin + (rng.random(m) * usable[c]).astype(np.int64)
+        return c.astype(np.int64), x
+
+    def make_events(m: int):
+        c1, x1 = random_loci(m)
+        c2, y1 = random_loci(m)
+        s1 = rng.random(m) < 0.5
+        s2 = rng.random(m) < 0.5
+        dele = rng.random(m) < spec.deletion_frac          # same-contig deletion, both '+'
+        gap = (50 + rng.random(m) * 1_000_000).astype(np.int64)
+        yd = np.minimum(x1 + 1 + gap, margin + usable[c1] - 1)
+        c2 = np.where(dele, c1, c2)
+        y1 = np.where(dele, yd, y1)
+        s1 = np.where(dele, True, s1)
+        s2 = np.where(dele, True, s2)
+        return c1, x1, s1, c2, y1, s2
+
+    n_sing = int(round(n * spec.singleton_frac))
+    n_hot = int(round(n * spec.hot_frac)) if spec.hot_events else 0
+    n_ev = n - n_sing - n_hot
+    ev = make_events(max(spec.n_events, 1))
+    hot = make_events(max(spec.hot_events, 1))
+    sing = make_events(max(n_sing, 1))
+
+    # per-read junction parameters, grouped (event reads sorted by event so mates are neighbours)
+    eid = np.sort(rng.integers(0, max(spec.n_events, 1), size=n_ev))
+    hid = rng.integers(0, max(spec.hot_events, 1), size=n_hot)
+    cols = []
+    for k in range(6):
+        cols.append(np.concatenate([ev[k][eid], hot[k][hid], sing[k][:n_sing]]))
+    c1, x1, s1, c2, y1, s2 = cols
+    # fragment ids: unique per read, except that a "mate" re-uses the previous read's id when it
+    # covers the same event
+    fid = np.arange(n, dtype=np.int64)
+    is_mate = np.zeros(n, bool)
+    if n_ev > 1:
+        m = (rng.random(n_ev) < spec.mate_frac)
+        m[0] = False
+        m[1:] &= eid[1:] == eid[:-1]
+        m[1:] &= ~m[:-1]                      # pairs, not chains
+        is_mate[:n_ev] = m
+        fid[is_mate] = fid[np.nonzero(is_mate)[0] - 1]
+    b = rng.integers(A, L - A, size=n)          # split offset in [A, L-A-1]
+    flip = rng.random(n) < 0.5
+    perm = rng.permutation(n)
+    c1, x1, s1, c2, y1, s2, fid, b, flip = (a[perm] for a in (c1, x1, s1, c2, y1, s2, fid, b, flip))
+
+    seq = np.empty((n, L), np.uint8)
+    hits = np.zeros(n, HIT_DTYPE)
+    k = np.arange(L, dtype=np.int64)[None, :]
+    for lo in range(0, n, spec.chunk):
+        hi = min(n, lo + spec.chunk)
+        sl = slice(lo, hi)
+        bb = b[sl, None]
+        left = k < bb
+        # 5' part: '+' reads G1[x1-b+1+k]; '-' reads comp(G1[x1+b-1-k]); ends on x1 either way
+        p_left = np.where(s1[sl, None], x1[sl, None] - bb + 1 + k, x1[sl, None] + bb - 1 - k)
+        # 3' part: '+' reads G2[y1+(k-b)]; '-' reads comp(G2[y1-(k-b)])
+        p_right = np.where(s2[sl, None], y1[sl, None] + (k - bb), y1[sl, None] - (k - bb))
+        gpos = np.where(left, starts[c1[sl]][:, None] + p_left, starts[c2[sl]][:, None] + p_right)
+        r = cat[gpos]
+        need_comp = np.where(left, ~s1[sl, None], ~s2[sl, None])
+        r = np.where(need_comp, _COMP[r], r)
+        # bowtie hits of the unflipped read (1-based leftmost offset of each anchor)
+        pos5 = np.where(s1[sl], x1[sl] - b[sl] + 2, x1[sl] + b[sl] - A + 1)
+        pos3 = np.where(s2[sl], y1[sl] + L - A - b[sl] + 1, y1[sl] - L + b[sl] + 2)
+        f = flip[sl]
+        # presenting the read as its reverse complement swaps the anchors and their strands
+        r = np.where(f[:, None], _COMP[r[:, ::-1]], r)
+        h = hits[sl]
+        h["pos5"] = np.where(f, pos3, pos5)
+        h["pos3"] = np.where(f, pos5, pos3)
+        h["contig5"] = np.where(f, c2[sl], c1[sl])
+        h["contig3"] = np.where(f, c1[sl], c2[sl])
+        st5 = np.where(f, ~s2[sl], s1[sl])
+        st3 = np.where(f, ~s1[sl], s2[sl])
+        h["strands"] = st5.astype(np.uint8) | (st3.astype(np.uint8) << 1)
+        # sequencing errors outside the anchors (an error inside an anchor = no bowtie hit)
+        inner = (k >= A) & (k < L - A)
+        if spec.subst_rate > 0:
+            e = (rng.random(r.shape) < spec.subst_rate) & inner & np.isin(r, _ACGT)
+            code = (r >> 1) & 3                      # A0 C1 T2 G3
+            alt = np.frombuffer(b"ACTG", np.uint8)[(code + rng.integers(1, 4, size=r.shape, dtype=np.uint8)) & 3]
+            r = np.where(e, alt, r)
+        if spec.n_rate > 0:
+            e = (rng.random(r.shape) < spec.n_rate) & inner
+            r = np.where(e, np.uint8(ord("N")), r)
+        seq[sl] = r
+    width = 11
+    frag = np.empty((n, width + 1), np.uint8)
+    frag[:, 0] = ord("q")
+    frag[:, 1:] = _digits(fid, width)
+    return Batch(seq.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(L),
+                 frag.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(width + 1), hits)
+
+
+def bowtie_lines(batch: Batch, contig_names: Sequence[bytes], first_read_num: int = 1) -> bytes:
+    """The batch as bowtie's stdout (detect.rs:61 flags: `--suppress 5,6,7,8`): two lines per read."""
+    out = []
+    for i in range(batch.n):
+        h = batch.hits[i]
+        num = first_read_num + i
+        out.append(b"5p:%d:\t%s\t%s\t%d\n" % (num, b"+" if h["strands"] & 1 else b"-",
+                                               contig_names[int(h["contig5"])], int(h["pos5"])))
+        out.append(b"3p:%d:%s:%s:\t%s\t%s\t%d\n" % (num, batch.frag(i), batch.seq(i),
+                                                     b"+" if h["strands"] & 2 else b"-",
+                                                     contig_names[int(h["contig3"])], int(h["pos3"])))
+    return b"".join(out)
+
+
+# ---- BASELINE.json configs ------------------------------------------------------------------------
+
+def config(index: int, scale: float = 1.0, genome_scale: float = 1.0) -> Tuple[List[Tuple[str, int]], dict, ReadSpec]:
+    """(contigs, make_genome kwargs, ReadSpec) for BASELINE.json configs[index].  `scale` shrinks the
+    read count, `genome_scale` the contig lengths (tests use small values; bench uses 1.0)."""
+    seed = SEED + index
+    hg = [(n, max(int(l * genome_scale), 20000)) for n, l in HG38]
+    if index == 0:      # CPU-runnable case: 100k reads, 2x100 bp, one chr22-sized contig
+        ln = max(int(50818468 * genome_scale), 400000)
+        contigs = [("chr22", ln)]
+        gk = dict(seed=seed, n_runs=[(0, ln // 4, 10000)], lower_runs=[(0, ln // 2, 100000)])
+        spec = ReadSpec(n_reads=max(int(100_000 * scale), 200), read_len=100, anchor_len=30, n_events=20,
+                        singleton_frac=0.994, mate_frac=0.3, subst_rate=0.005, seed=seed)
+        return contigs, gk, spec
+    gk = dict(seed=seed, end_n=10000)
+    if index == 1:      # headline: 10M x 150 bp, anchor 20
+        spec = ReadSpec(n_reads=int(10_000_000 * scale), n_events=max(int(100_000 * scale), 10), seed=seed)
+    elif index == 2:    # 100M over 2/4/8 GPUs
+        spec = ReadSpec(n_reads=int(100_000_000 * scale), n_events=max(int(1_000_000 * scale), 10), seed=seed)
+    elif index == 3:    # duplicate-heavy: 50M, 60 % duplicates
+        spec = ReadSpec(n_reads=int(50_000_000 * scale), n_events=max(int(300_000 * scale), 10),
+                        singleton_frac=0.2, mate_frac=0.6, hot_frac=0.3,
+                        hot_events=max(int(5000 * scale), 2), seed=seed)
+    elif index == 4:    # 250 bp, anchor 30, 5 % mismatches + 1 % N
+        spec = ReadSpec(n_reads=int(10_000_000 * scale), read_len=250, anchor_len=30,
+                        n_events=max(int(100_000 * scale), 10), subst_rate=0.05, n_rate=0.01, seed=seed)
+    else:
+        raise ValueError("configs are 0..4")
+    return hg, gk, spec

@@ -1,0 +1,233 @@
+/*
+ * breakfast_hip.h -- C ABI of the MI355X (gfx950) implementation of the `breakfast detect` hot path.
+ *
+ * The reference (annalam/breakfast @ 2024_08_07) has no FFI seam: `detect::main` is one function
+ * (src/detect.rs:39-242).  This ABI is the seam a maintainer would cut into it; each entry point
+ * names the reference lines it replaces.  INTEGRATION.md shows the Rust `extern "C"` block and the
+ * patched consume loop.  Everything is plain C: opaque handle, POD structs, pointers + sizes, int
+ * status codes.  Nothing throws or aborts across the boundary; on failure a function returns a
+ * negative BF_ERR_* code and bf_last_error() describes it (the caller maps that to the reference's
+ * convention `ERROR: <msg>` on stderr + exit(-1), src/common.rs:8-13).
+ *
+ * Threading: like the reference's consume loop (one thread, detect.rs:76) a bf_ctx is
+ * single-caller.  One ctx drives one GPU; multi-GPU runs use one ctx (one process) per GPU and the
+ * bf_exchange_* stage calls below.
+ *
+ * The library has NO CPU fallback: without a usable gfx950 device every compute entry point fails
+ * with BF_ERR_NO_DEVICE.
+ */
+#ifndef BREAKFAST_HIP_H
+#define BREAKFAST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BF_ABI_VERSION 1
+
+enum {
+    BF_OK = 0,
+    BF_ERR_INVALID = -1,     /* bad argument / unsupported configuration            */
+    BF_ERR_NO_DEVICE = -2,   /* no usable HIP device                                */
+    BF_ERR_HIP = -3,         /* a HIP runtime call failed                           */
+    BF_ERR_STATE = -4,       /* call sequence violated (e.g. submit before genome)  */
+    BF_ERR_RANGE = -5,       /* value outside the supported range (see limits)      */
+    BF_ERR_NOMEM = -6
+};
+
+/* Supported ranges (violations -> BF_ERR_RANGE / BF_ERR_INVALID, never silent truncation):
+ *   anchor_len in [8, 32767] (the reference panics below 8: signature index, detect.rs:166)
+ *   max_frag_len < 2^31, contigs <= 16384, contig length < 2^31 - 2^17 (BAM's own limit is 2^31-1),
+ *   anchor positions < 2^31, read length in [2*anchor_len, 65535] (the reference's producer only
+ *   emits reads with len >= 2*anchor_len, detect.rs:311), at most 2^32-1 reads per ctx.           */
+
+typedef struct bf_ctx bf_ctx;
+
+/* Options of `breakfast detect` (detect.rs:28-46).  --anchor-mm is accepted by the reference CLI
+ * but ignored (detect.rs:44 is commented out), so it has no field here. */
+typedef struct {
+    uint32_t anchor_len;     /* --anchor-len   [default 30] */
+    uint32_t max_frag_len;   /* --max-frag-len [default 5000] */
+    uint32_t min_evidence;   /* --min-evidence [default 2] */
+    int32_t  device;         /* HIP device ordinal, -1 = current device */
+    uint32_t flags;          /* BF_FLAG_* */
+    uint32_t reserved[3];
+} bf_config;
+
+#define BF_FLAG_KEEP_EVIDENCE 1u   /* keep per-read evidence readable via bf_evidence_fetch (tests) */
+#define BF_FLAG_FORCE_EXACT   2u   /* route every read through the byte-exact kernel (tests)        */
+
+/* One pair of anchor alignments = the fields the consume loop parses out of a `5p:`/`3p:` line
+ * pair (detect.rs:94-103): bowtie's strand, contig and 1-based leftmost offset (-B1) of each anchor.
+ * Contig ids index the arrays given to bf_genome_set. 16 bytes. */
+typedef struct {
+    uint32_t pos5;           /* `pos`  (detect.rs:102) */
+    uint32_t pos3;           /* `mpos` (detect.rs:103) */
+    uint16_t contig5;        /* `chr`  (detect.rs:100) */
+    uint16_t contig3;        /* `mchr` (detect.rs:101) */
+    uint8_t  strands;        /* bit0: 5p anchor on '+' (detect.rs:98), bit1: 3p on '+' (:99) */
+    uint8_t  pad[3];
+} bf_hit;
+
+/* A batch of candidate reads in input (bowtie output) order, structure-of-arrays. */
+typedef struct {
+    uint64_t        n_reads;
+    const uint8_t*  seq_bytes;   /* full read sequences as received (ASCII), concatenated (detect.rs:91) */
+    const uint64_t* seq_off;     /* n_reads+1 offsets into seq_bytes */
+    const uint8_t*  frag_bytes;  /* fragment ids (QNAME with ':'->'_'), concatenated (detect.rs:90)      */
+    const uint64_t* frag_off;    /* n_reads+1 offsets into frag_bytes */
+    const bf_hit*   hits;        /* n_reads anchor-hit pairs */
+} bf_batch;
+
+/* One reported rearrangement = one printed row (detect.rs:233-240). */
+typedef struct {
+    int64_t  lpos;           /* seed's left breakpoint position; negative values are the reference's */
+    int64_t  rpos;           /* wrapped usize and print as (uint64_t)value (detect.rs:172-181)       */
+    uint64_t seed_index;     /* global input index of the seed read */
+    uint64_t read_begin;     /* supporting reads = reads[read_begin .. read_end) */
+    uint64_t read_end;
+    uint32_t contig;         /* `chr`  of the seed (after reorientation, detect.rs:108-113) */
+    uint32_t mcontig;        /* `mchr` */
+    uint8_t  strand;         /* 1 = '+' */
+    uint8_t  mstrand;
+    uint8_t  pad[6];
+} bf_cluster;
+
+/* One supporting read that survived frag-id dedup (detect.rs:247-287), in printed order. */
+typedef struct {
+    uint64_t index;          /* global input index (position in submit order, + ctx base)          */
+    uint64_t junction_off;   /* its case-marked sequence with '|' (detect.rs:155-162) is            */
+    uint32_t junction_len;   /*   junction_bytes[junction_off .. junction_off+junction_len)          */
+    uint16_t bp;             /* breakpoint offset inside the (re-oriented) read (detect.rs:147-153) */
+    uint8_t  swapped;        /* read was reverse-complemented by the reorient step (detect.rs:108)  */
+    uint8_t  pad;
+} bf_read;
+
+typedef struct {
+    uint64_t          n_evidence;     /* the count the reference logs at detect.rs:190 */
+    uint64_t          n_clusters;
+    uint64_t          n_reads;
+    const bf_cluster* clusters;       /* output order = the reference's print order */
+    const bf_read*    reads;
+    const uint8_t*    junction_bytes;
+    uint64_t          junction_size;
+} bf_result;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+
+/* Replaces option parsing + set-up, detect.rs:40-46.  Fails loudly when no GPU is usable. */
+int bf_ctx_create(const bf_config* cfg, bf_ctx** out);
+void bf_ctx_destroy(bf_ctx* ctx);
+/* Message for the last failing call on this ctx (or, with ctx == NULL, the last failed create). */
+const char* bf_last_error(const bf_ctx* ctx);
+int bf_abi_version(void);
+
+/* Replaces the genome HashMap, detect.rs:48-56 + lookups at :115/:124.  Takes each contig's bytes
+ * exactly as stored in the FASTA (case preserved).  Packs them on the GPU into the resident
+ * 2-bit block image + exception map + raw byte image.  Contig order by byte-wise name compare
+ * (Rust String Ord, detect.rs:108,194) is derived here.  Inputs may be freed on return. */
+int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names,
+                  const uint8_t* const* seqs, const uint64_t* lens);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+
+/* Appends a batch of parsed anchor-hit pairs (what the consume loop holds after detect.rs:89-103)
+ * to the ctx's HBM-resident read set.  Copies synchronously; inputs may be freed on return. */
+int bf_submit(bf_ctx* ctx, const bf_batch* batch);
+
+/* Replaces detect.rs:105-187 (reorient, flank gather, split scan, junction masks, signature,
+ * coordinates) for every resident read: kernels encode_reads + localise (+ exact path). */
+int bf_localise(bf_ctx* ctx);
+
+/* Replaces detect.rs:190-231 + 247-287 (stable sort, greedy clustering, frag-id dedup) and builds
+ * the junction strings of the surviving reads on the GPU (detect.rs:155-162).  The result is owned
+ * by the ctx and valid until the next bf_clusterise/bf_finish/bf_reset/bf_ctx_destroy. */
+int bf_clusterise(bf_ctx* ctx, bf_result* out);
+
+/* bf_localise + bf_clusterise.  Idempotent: may be called repeatedly on the same resident reads. */
+int bf_finish(bf_ctx* ctx, bf_result* out);
+
+/* Drops the resident reads (the genome stays). */
+int bf_reset(bf_ctx* ctx);
+
+/* Blocks until all GPU work queued by this ctx has completed. */
+int bf_sync(bf_ctx* ctx);
+
+/* Replaces the print statements detect.rs:201,233-240: renders `result` as the exact stdout bytes
+ * of `breakfast detect`.  Returns the byte count (or a negative error); writes at most `cap`
+ * bytes.  Call with buf == NULL to query the size. */
+int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* result, char* buf, uint64_t cap);
+
+/* ---- multi-GPU stage calls (one ctx per GPU/process) ------------------ */
+/* The path shards by contiguous input ranges; rank r's reads have global indices
+ * [index_base, index_base + n).  Evidence of one breakpoint class must meet on one rank, so after
+ * bf_localise every rank packs its evidence into per-owner buckets (owner = hash(class) % n_ranks),
+ * the HOST performs one all-to-all of the packed device buffers (RCCL via torch.distributed, or any
+ * transport), and the received records are imported before bf_clusterise.  Supporting reads are then
+ * rendered on their source rank with bf_render_junctions. */
+
+int bf_set_rank(bf_ctx* ctx, uint32_t rank, uint32_t n_ranks, uint64_t index_base);
+
+/* Wire format parameters all ranks must agree on (caller all-reduces MAX of each field). */
+typedef struct {
+    uint32_t max_frag_len_bytes;  /* longest fragment id on this rank */
+    uint32_t has_exact_sig;       /* 1 if any evidence carries a non-ACGT signature */
+} bf_wire_local;
+int bf_exchange_local(bf_ctx* ctx, bf_wire_local* out);
+
+/* Packs evidence into a device send buffer grouped by owner rank.  counts[r] = records for rank r.
+ * *dev_send points at ctx-owned device memory of sum(counts) * *record_bytes bytes. */
+int bf_exchange_pack(bf_ctx* ctx, const bf_wire_local* agreed, uint64_t* counts /* n_ranks */,
+                     void** dev_send, uint32_t* record_bytes);
+
+/* Imports the received records (device pointer, ordered by source rank then source order);
+ * src_counts[r] = how many came from rank r, src_index_base[r] = rank r's index_base. */
+int bf_exchange_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts /* n_ranks */,
+                       const uint64_t* src_index_base /* n_ranks */);
+
+/* After bf_clusterise on an owner rank: for every supporting read, (source rank, source-local index).
+ * Arrays of result.n_reads entries, owned by the ctx. */
+int bf_result_sources(bf_ctx* ctx, const uint32_t** src_rank, const uint32_t** src_index);
+
+/* On a source rank: renders the junction strings of the given local read indices (device work).
+ * out_bytes/out_off (n+1 offsets) are owned by the ctx until the next call. */
+int bf_render_junctions(bf_ctx* ctx, uint64_t n, const uint32_t* local_index,
+                        const uint8_t** out_bytes, const uint64_t** out_off);
+
+/* ---- introspection (tests, bench) ---------------------------------------------------------- */
+
+/* Per-read evidence in input order (needs BF_FLAG_KEEP_EVIDENCE): arrays of n entries each, any
+ * may be NULL.  mask = combined mismatch mask (bit k of word k/64: read base k mismatches the
+ * flank it was assigned to), mask_words u64 per read. */
+typedef struct {
+    uint64_t  n;
+    uint32_t  mask_words;
+    uint64_t* class_key;     /* packed (contig rank, mcontig rank, strands, signature) */
+    int32_t*  lpos;
+    int32_t*  rpos;
+    uint16_t* bp;
+    uint16_t* flags;         /* BF_EV_* */
+    uint64_t* mask;          /* n * mask_words, read-major */
+} bf_evidence_view;
+#define BF_EV_STRAND   1u
+#define BF_EV_MSTRAND  2u
+#define BF_EV_SWAPPED  4u
+#define BF_EV_EXACT    8u     /* went through the byte-exact kernel */
+#define BF_EV_SIGX     16u    /* signature contains a non-ACGT reference byte */
+int bf_evidence_fetch(bf_ctx* ctx, bf_evidence_view* view);
+
+/* Kernel timing of the last bf_localise / bf_clusterise in milliseconds (HIP events on the ctx's
+ * stream): names are stable identifiers, e.g. "encode_reads", "localise", "sort", "sweep". */
+typedef struct { const char* name; float ms; uint64_t launches; } bf_kernel_time;
+int bf_kernel_times(bf_ctx* ctx, const bf_kernel_time** out, uint32_t* n);
+
+/* Number of resident reads / bytes of HBM held by the ctx. */
+int bf_stats(const bf_ctx* ctx, uint64_t* n_reads, uint64_t* device_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BREAKFAST_HIP_H */
