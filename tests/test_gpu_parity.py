@@ -1,0 +1,166 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
+
+Integer/byte work only: every comparison is equality, no tolerance.
+"""
+import numpy as np
+import pytest
+
+import detect_oracle as po
+import oracle_lib as ol
+from conftest import golden_names, load_golden
+
+from breakfast_amd import engine, synth
+from breakfast_amd.engine import BF_FLAG_FORCE_EXACT, BF_FLAG_KEEP_EVIDENCE
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu_text(fa, lines, A, F, E, flags=0):
+    return engine.detect(po.parse_fasta(fa), lines.split(b"\n")[:-1], A, F, E, flags=flags)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fixture(name):
+    fa, lines, (A, F, E), sv = load_golden(name)
+    assert run_gpu_text(fa, lines, A, F, E) == sv
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fixture_exact_kernel(name):
+    # the byte-exact kernel alone must also reproduce every fixture
+    fa, lines, (A, F, E), sv = load_golden(name)
+    assert run_gpu_text(fa, lines, A, F, E, flags=BF_FLAG_FORCE_EXACT) == sv
+
+
+def pack_sig(sig17: np.ndarray) -> np.ndarray:
+    """oracle signature bytes -> the 32-bit packing of the kernels (plain ACGT signatures)."""
+    s = np.concatenate([sig17[:, :8], sig17[:, 9:]], axis=1).astype(np.uint32)
+    code = (s >> 1) & 3
+    out = np.zeros(s.shape[0], np.uint32)
+    for k in range(8):
+        out |= ((code[:, k] & 1) << k) | ((code[:, k] >> 1) << (8 + k))
+        out |= ((code[:, 8 + k] & 1) << (16 + k)) | ((code[:, 8 + k] >> 1) << (24 + k))
+    return out
+
+
+def check_against_oracle(g, b, A, F=5000, E=2, flags=0, expect_exact=None):
+    og = ol.OracleGenome(g.names, g.seqs)
+    ref = ol.detect_batch(og, g.names, b, A, F, E, keep=True)
+    eng = engine.Engine(A, F, E, flags=flags | BF_FLAG_KEEP_EVIDENCE)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        eng.submit(b)
+        res = eng.finish()
+        ev = eng.evidence()
+        n = b.n
+        assert res.n_evidence == ref.n_evidence == n
+        # per-read evidence (detect.rs:105-187)
+        assert np.array_equal(ev["bp"].astype(np.uint32), ref.bp), "breakpoint offsets differ"
+        assert np.array_equal((ev["flags"] & 7).astype(np.uint8), ref.flags), "strand/swap flags differ"
+        assert np.array_equal(ev["lpos"].astype(np.int64).astype(np.uint64), ref.lpos), "left positions differ"
+        assert np.array_equal(ev["rpos"].astype(np.int64).astype(np.uint64), ref.rpos), "right positions differ"
+        plain = np.all(np.isin(np.delete(ref.signature, 8, axis=1), np.frombuffer(b"ACGT", np.uint8)), axis=1)
+        sigx = (ev["flags"] & engine.BF_EV_SIGX) != 0
+        assert np.array_equal(~plain, sigx), "non-ACGT signature flag differs"
+        assert np.array_equal((ev["class_key"] & 0xffffffff).astype(np.uint32)[plain], pack_sig(ref.signature)[plain])
+        if expect_exact is not None:
+            n_exact = int(((ev["flags"] & engine.BF_EV_EXACT) != 0).sum())
+            assert expect_exact(n_exact, n), "unexpected share of reads on the exact path: %d of %d" % (n_exact, n)
+        # case-marked junction strings of ALL reads (detect.rs:155-162), rendered on the GPU
+        by, off = eng.render_junctions(np.arange(n, dtype=np.uint32))
+        assert np.array_equal(off, ref.junction_off)
+        assert np.array_equal(by, ref.junction), "junction strings differ"
+        # sort + cluster + dedup + print (detect.rs:190-241, 247-287)
+        sv = eng.format_sv(res)
+        assert sv == ref.sv, "stdout differs"
+        assert res.clusters.shape[0] == ref.n_clusters
+        return res, ref
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("cfg,scale,gscale", [(0, 0.05, 0.02), (1, 0.004, 0.002), (3, 0.001, 0.002), (4, 0.002, 0.002)])
+def test_scaled_baseline_config(cfg, scale, gscale):
+    contigs, gk, spec = synth.config(cfg, scale=scale, genome_scale=gscale)
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    res, ref = check_against_oracle(g, b, spec.anchor_len)
+    assert ref.n_clusters > 0
+
+
+def test_scaled_config_exact_kernel_only():
+    contigs, gk, spec = synth.config(1, scale=0.0005, genome_scale=0.002)
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    check_against_oracle(g, b, spec.anchor_len, flags=BF_FLAG_FORCE_EXACT, expect_exact=lambda x, n: x == n)
+
+
+def test_packed_path_is_the_one_that_runs():
+    # uppercase ACGT genome, junctions far from N runs: (almost) everything must take the packed kernel
+    contigs, gk, spec = synth.config(1, scale=0.002, genome_scale=0.002)
+    spec.margin = 10000 + 2 * spec.read_len + 128      # whole windows clear of the N runs and their 64-base blocks
+    contigs = [(n, max(l, 60000)) for n, l in contigs]
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    check_against_oracle(g, b, spec.anchor_len, expect_exact=lambda x, n: x == 0)
+
+
+def test_soft_masked_and_n_reference():
+    # lowercase + N runs under the junctions: routed to the exact kernel, same answers
+    contigs = [("chrA", 300000), ("chrB", 200000)]
+    g = synth.make_genome(contigs, seed=5, n_runs=[(0, 50000, 3000), (1, 1000, 500)],
+                          lower_runs=[(0, 100000, 100000), (1, 100000, 50000)])
+    spec = synth.ReadSpec(n_reads=6000, read_len=100, anchor_len=30, n_events=60, singleton_frac=0.3, seed=77)
+    b = synth.make_reads(g, spec)
+    check_against_oracle(g, b, 30, expect_exact=lambda x, n: 0 < x < n)
+
+
+def test_mixed_read_lengths_and_batches():
+    # reads of several lengths submitted in several batches (one longer than the packed path's 256)
+    contigs = [("c%d" % i, 80000) for i in range(3)]
+    g = synth.make_genome(contigs, seed=9)
+    parts = []
+    for i, L in enumerate((64, 100, 151, 250, 300)):
+        spec = synth.ReadSpec(n_reads=700, read_len=L, anchor_len=20, n_events=12, singleton_frac=0.3, seed=100 + i,
+                              margin=400)
+        parts.append(synth.make_reads(g, spec))
+    seqs, frags, hits = [], [], []
+    for p in parts:
+        for i in range(p.n):
+            h = p.hits[i]
+            seqs.append(p.seq(i)); frags.append(p.frag(i))
+            hits.append((int(h["pos5"]), int(h["pos3"]), int(h["contig5"]), int(h["contig3"]), int(h["strands"])))
+    order = np.random.Generator(np.random.PCG64(3)).permutation(len(seqs))
+    whole = engine.make_batch([seqs[i] for i in order], [frags[i] for i in order], [hits[i] for i in order])
+    og = ol.OracleGenome(g.names, g.seqs)
+    ref = ol.detect_batch(og, g.names, whole, 20, 5000, 2)
+    eng = engine.Engine(20, 5000, 2)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        for a in range(0, whole.n, 1000):
+            eng.submit(whole.slice(a, min(whole.n, a + 1000)))
+        assert eng.format_sv(eng.finish()) == ref.sv
+        assert eng.format_sv(eng.finish()) == ref.sv          # idempotent on resident reads
+        eng.reset()
+        assert eng.format_sv(eng.finish()) == po.SV_HEADER    # empty input: header only
+    finally:
+        eng.close()
+
+
+def test_error_behaviour():
+    g = synth.make_genome([("c0", 50000)], seed=2)
+    eng = engine.Engine(30, 5000, 2)
+    try:
+        with pytest.raises(engine.BreakfastError):            # submit before genome
+            eng.submit(engine.make_batch([b"A" * 60], [b"f"], [(1, 100, 0, 0, 3)]))
+        eng.set_genome(g.names, g.seqs)
+        with pytest.raises(engine.BreakfastError) as e:       # unknown contig id (reference: panic)
+            eng.submit(engine.make_batch([b"A" * 60], [b"f"], [(1, 100, 0, 5, 3)]))
+        assert "contig" in str(e.value)
+        with pytest.raises(engine.BreakfastError) as e:       # read shorter than 2 * anchor_len
+            eng.submit(engine.make_batch([b"A" * 59], [b"f"], [(1, 100, 0, 0, 3)]))
+        assert e.value.code == -5
+        with pytest.raises(engine.BreakfastError):            # duplicate contig names
+            eng.set_genome([b"x", b"x"], [b"ACGT" * 100, b"ACGT" * 100])
+    finally:
+        eng.close()
