@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config, one JSON line on rank 0.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config I] [--scale S]
+
+metric   candidate reads/s breakpoint-localised + deduped (whole job, all ranks)
+workload configs[1]: 10M unaligned 2x150 bp reads with anchor hits on an hg38-sized genome,
+         anchor length 20 (per GPU: weak scaling -- with N GPUs every rank holds its own 10M-read
+         input range).  Synthetic, seeded (no genome/BAM exists in the image).
+step     one pass of the hot path over the resident batch: encode + localise (+ exact path) ->
+         [N>1: pack, all-to-all, import] -> sort -> sweep -> dedup -> order -> junction strings ->
+         cluster table in host memory.  Inputs (ASCII reads, fragment ids, hit records, packed
+         genome) are resident in HBM before the timed region starts.
+roofline the dominant kernel, `localise`: algorithmic bytes/read (SURVEY.md section 8d,
+         B_A(L) = ceil(L/2) + 2*ceil(L/4) + 16 + 16 + ceil(L/8) = 202 B at L=150) x reads / its average
+         duration measured with HIP events on the library's stream, against 8 TB/s HBM3E.
+cpu_baseline  the C++ restatement of the reference (oracle/, single thread like detect.rs:76-241)
+         timed on a bounded sample of the same batch on this host's cores.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from breakfast_amd import engine, synth  # noqa: E402
+from breakfast_amd.distributed import DistributedDetect, HipStageEngine, init_from_env  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes_per_read(L: int) -> int:
+    """SURVEY.md section 8d, split-scan stage."""
+    return math.ceil(L / 2) + 2 * math.ceil(L / 4) + 16 + 16 + math.ceil(L / 8)
+
+
+def log(rank, *a):
+    if rank == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=1, help="index into BASELINE.json configs (default 1)")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink reads AND genome (smoke runs only)")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--check", action="store_true", help="also compare the GPU .sv with the oracle's on the sample")
+    args = ap.parse_args()
+
+    rank, world, local = init_from_env()
+    if world != args.gpus:
+        log(rank, "note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # ---- synthetic workload ----------------------------------------------------------------------
+    t0 = time.time()
+    contigs, gk, spec = synth.config(args.config, scale=args.scale, genome_scale=args.scale)
+    L, A = spec.read_len, spec.anchor_len
+    if args.scale >= 0.05:
+        spec.margin = 10000 + 2 * L + 128            # junctions clear of the 10 kb N runs at contig ends
+    genome = synth.make_genome(contigs, **gk)
+    log(rank, "genome: %d contigs, %.3f Gb in %.1fs" % (len(contigs), sum(l for _, l in contigs) / 1e9, time.time() - t0))
+    t1 = time.time()
+    spec.read_seed = spec.seed * 1000 + rank          # same junctions on every rank, different reads
+    spec.frag_base = rank * spec.n_reads
+    batch = synth.make_reads(genome, spec)
+    n_local = batch.n
+    log(rank, "reads: %d x %d bp per rank in %.1fs" % (n_local, L, time.time() - t1))
+
+    # ---- resident inputs -------------------------------------------------------------------------
+    eng = engine.Engine(A, 5000, 2, device=local)
+    t2 = time.time()
+    eng.set_genome(genome.names, genome.seqs)
+    log(rank, "genome packed into HBM in %.1fs" % (time.time() - t2))
+    t3 = time.time()
+    if world > 1:
+        eng.set_rank(rank, world, rank * n_local)
+    chunk = 1 << 21
+    for a in range(0, n_local, chunk):
+        eng.submit(batch.slice(a, min(n_local, a + chunk)))
+    log(rank, "reads resident in HBM in %.1fs (host->device rate %.2f GB/s incl. pageable staging)" %
+        (time.time() - t3, (batch.seq_bytes.nbytes + batch.frag_bytes.nbytes) / 1e9 / max(time.time() - t3, 1e-9)))
+
+    if world > 1:
+        dd = DistributedDetect(HipStageEngine(eng, dev), rank, world, rank * n_local, n_local, dev)
+        step = dd.step
+    else:
+        step = eng.finish_raw
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+
+    for _ in range(args.warmup):
+        step()
+    eng.kernel_times()                                # drop warm-up timings
+    barrier()
+    t_start = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ktimes = eng.kernel_times()
+    n_clusters = int(last.n_clusters) if world == 1 else int(last.clusters.shape[0])
+    n_support = int(last.n_reads) if world == 1 else int(last.reads.shape[0])
+
+    total_reads = n_local * world
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_reads * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel -----------------------------------------------------------
+    loc_ms, loc_n = ktimes.get("localise", (0.0, 0))
+    loc_avg_ms = loc_ms / max(loc_n, 1)
+    bpr = algorithmic_bytes_per_read(L)
+    achieved = n_local * bpr / (loc_avg_ms * 1e-3) / 1e9 if loc_avg_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "localise_fast_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "algorithmic_bytes_per_read": bpr, "reads_per_launch": n_local, "avg_launch_ms": round(loc_avg_ms, 4)}
+    stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in ktimes.items()}
+
+    # ---- CPU baseline (rank 0, single GPU run only) -------------------------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        import oracle_lib as ol
+        ns = min(args.cpu_sample, n_local)
+        sample = batch.slice(0, ns)
+        og = ol.OracleGenome(genome.names, genome.seqs)
+        tc = time.perf_counter()
+        ref = ol.detect_batch(og, genome.names, sample, A, 5000, 2)
+        dt = time.perf_counter() - tc
+        cpu = {"value": round(ns / dt, 1), "unit": "reads/s", "cores": 1, "kind": "port",
+               "sample": "first %d reads of the same batch (localise + sort + cluster + dedup + .sv text), "
+                         "C++ restatement of detect.rs:105-287, single thread, %.1fs" % (ns, dt),
+               "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
+        if args.check:
+            e2 = engine.Engine(A, 5000, 2, device=local)
+            e2.set_genome(genome.names, genome.seqs)
+            e2.submit(sample)
+            same = e2.format_sv(e2.finish()) == ref.sv
+            e2.close()
+            cpu["gpu_output_identical_on_sample"] = bool(same)
+            if not same:
+                raise SystemExit("bench --check: GPU .sv differs from the oracle's on the sample")
+
+    if rank == 0:
+        out = {
+            "metric": "candidate reads/sec breakpoint-localised+deduped", "value": round(value, 1), "unit": "reads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64 bit-planes",
+            "data": "synthetic (seed %d): random hg38-sized genome, simulated junction reads + the Bowtie1 hits of their anchors" % spec.seed,
+            "config": {"workload": "configs[%d]: %d unaligned 2x%d bp reads per GPU with anchor hits on a %.2f Gb genome, anchor length %d"
+                       % (args.config, n_local, L, sum(l for _, l in contigs) / 1e9, A),
+                       "reads_per_gpu": n_local, "read_len": L, "anchor_len": A, "max_frag_len": 5000, "min_evidence": 2,
+                       "parallelism": "shard%d+alltoall" % world if world > 1 else "single"},
+            "result": {"clusters": n_clusters, "supporting_reads": n_support},
+            "stage_ms": stages, "roofline": roofline, "cpu_baseline": cpu,
+            "published_reference": "~40M BAM reads/min/core whole-file scan (README.md:6), a different stage",
+        }
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

@@ -388,14 +388,13 @@ int bf_exchange_local(bf_ctx* ctx, bf_wire_local* out) {
     return BF_OK;
 }
 
-int bf_exchange_pack(bf_ctx* ctx, const bf_wire_local* agreed, uint64_t* counts, void** dev_send, uint32_t* record_bytes) {
+int bf_exchange_pack(bf_ctx* ctx, const bf_wire_local* agreed, void* dev_send, uint64_t dev_send_bytes, uint64_t* counts,
+                     void** dev_out, uint32_t* record_bytes) {
     if (!ctx) return BF_ERR_INVALID;
-    if (!agreed || !counts || !dev_send || !record_bytes) return fail(ctx, BF_ERR_INVALID, "bf_exchange_pack: null argument");
+    if (!agreed || !counts || !dev_out || !record_bytes) return fail(ctx, BF_ERR_INVALID, "bf_exchange_pack: null argument");
     if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_exchange_pack before bf_localise");
     BF_HIP(ctx, hipSetDevice(ctx->device));
-    BF_TRY(run_partition(ctx, *agreed, counts, record_bytes));
-    *dev_send = ctx->d_send.p;
-    return BF_OK;
+    return run_partition(ctx, *agreed, dev_send, dev_send_bytes, counts, dev_out, record_bytes);
 }
 
 int bf_exchange_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts, const uint64_t* src_index_base) {

@@ -193,7 +193,8 @@ int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_o
 
 // cluster.hip -----------------------------------------------------------------------------------
 int run_cluster(bf_ctx* ctx, const OwnerView& v);   // fills ctx->out (without junction text)
-int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, uint64_t* counts, uint32_t* record_bytes);
+int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint64_t dev_send_bytes, uint64_t* counts,
+                  void** dev_out, uint32_t* record_bytes);
 int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts);
 int scan_u32_to_u64(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n);  // exclusive, out has n+1
 int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);

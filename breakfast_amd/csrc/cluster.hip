@@ -536,7 +536,8 @@ __global__ void __launch_bounds__(256) import_kernel(const ImportView v) {
     v.src_rank[j] = r; v.src_idx[j] = h.src_idx;
 }
 
-int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, uint64_t* counts, uint32_t* record_bytes) {
+int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint64_t dev_send_bytes, uint64_t* counts,
+                  void** dev_out, uint32_t* record_bytes) {
     const uint64_t n = ctx->n_reads;
     const uint32_t R = ctx->n_ranks;
     hipStream_t st = ctx->stream;
@@ -545,7 +546,15 @@ int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, uint64_t* counts, ui
     ctx->wire_frag_stride = stride; ctx->wire_has_sigx = agreed.has_exact_sig ? 1 : 0; ctx->wire_rec_bytes = rec;
     *record_bytes = rec;
     for (uint32_t r = 0; r < R; r++) counts[r] = 0;
-    BF_TRY(ensure(ctx, ctx->d_send, std::max<uint64_t>(n, 1) * rec));
+    if (dev_send) {
+        if (dev_send_bytes < n * rec)
+            return fail(ctx, BF_ERR_INVALID, "bf_exchange_pack: send buffer of %llu bytes is smaller than %llu records x %u bytes",
+                        (unsigned long long)dev_send_bytes, (unsigned long long)n, rec);
+        *dev_out = dev_send;
+    } else {
+        BF_TRY(ensure(ctx, ctx->d_send, std::max<uint64_t>(n, 1) * rec));
+        *dev_out = ctx->d_send.p;
+    }
     if (n == 0) return BF_OK;
     Scope t(ctx, "exchange_pack");
     BF_TRY(ensure(ctx, ctx->d_part_key, n * 4 * 2)); BF_TRY(ensure(ctx, ctx->d_part_idx, n * 4 * 2));
@@ -566,7 +575,7 @@ int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, uint64_t* counts, ui
     pv.fhash = ctx->d_fhash.as<uint64_t>(); pv.bp = ctx->d_bp.as<uint16_t>(); pv.len = ctx->d_len.as<uint16_t>();
     pv.flags = ctx->d_flags.as<uint16_t>(); pv.frag = ctx->d_frag.as<uint8_t>(); pv.frag_off = ctx->d_frag_off.as<uint64_t>();
     pv.frag_len = ctx->d_frag_len.as<uint16_t>(); pv.sigx = ctx->d_sigx.as<uint8_t>(); pv.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
-    pv.out = ctx->d_send.as<uint8_t>();
+    pv.out = (uint8_t*)*dev_out;
     hipLaunchKernelGGL(pack_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, pv);
     BF_HIP(ctx, hipGetLastError());
     BF_HIP(ctx, hipMemcpyAsync(start.data(), ctx->d_part_tmp.p, (size_t)(R + 1) * 8, hipMemcpyDeviceToHost, st));

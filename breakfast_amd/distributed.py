@@ -1,0 +1,268 @@
+"""Multi-GPU `breakfast detect`: one process per GPU, one bf_ctx per process.
+
+The path shards by contiguous input ranges: rank r holds reads [index_base, index_base + n).
+Per-read work (localise) needs no communication.  Clustering needs every read of one breakpoint
+class on one rank, so there is exactly one real exchange step:
+
+    localise -> pack records by owner = hash(class) % world  -> ALL-TO-ALL (RCCL over xGMI with the
+    "nccl" backend; CPU staging with "gloo")                 -> import -> sort/sweep/dedup on the owner
+    -> the owner asks each source rank for the junction strings of its surviving reads (a second,
+       small all-to-all pair) because sequences and mismatch masks never leave their source rank.
+
+Only fixed-size records travel in the big exchange (40 B header + padded fragment id).  The engine
+object is duck-typed (`localise`, `exchange_local`, `exchange_pack_tensor`, `exchange_import_tensor`,
+`clusterise`, `render_junctions`) so the orchestration is testable on CPU with gloo.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .engine import CLUSTER_DTYPE, READ_DTYPE, Engine, Result
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Initialises torch.distributed from torchrun's environment.  -> (rank, world, local_rank)"""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class HipStageEngine:
+    """Adapts breakfast_amd.Engine (device pointers) to torch tensors for the exchange."""
+
+    def __init__(self, eng: Engine, device: torch.device):
+        self.eng, self.device = eng, device
+        self._send = None
+
+    def localise(self):
+        self.eng.localise()
+
+    def n_local(self) -> int:
+        return self.eng.stats()[0]
+
+    def exchange_local(self):
+        return self.eng.exchange_local()
+
+    def exchange_pack_tensor(self, max_frag: int, has_sigx: int, world: int):
+        rec = Engine.wire_record_bytes(max_frag, has_sigx)
+        n = self.n_local()
+        send = torch.empty(max(n * rec, 1), dtype=torch.uint8, device=self.device)
+        counts, _, rec2 = self.eng.exchange_pack(max_frag, has_sigx, world, send.data_ptr(), send.numel())
+        assert rec2 == rec
+        return send[:n * rec], counts.astype(np.int64), rec
+
+    def exchange_import_tensor(self, recv: torch.Tensor, src_counts: np.ndarray, bases: np.ndarray):
+        if recv.device != self.device:
+            recv = recv.to(self.device)
+        self._recv = recv      # keep alive until imported (import copies out of it)
+        self.eng.exchange_import(recv.data_ptr() if recv.numel() else 0, src_counts.astype(np.uint64),
+                                 bases.astype(np.uint64))
+        self._recv = None
+
+    def clusterise(self) -> Result:
+        return self.eng.clusterise()
+
+    def render_junctions(self, local_index: np.ndarray):
+        return self.eng.render_junctions(local_index)
+
+
+def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits: Sequence[int], in_splits: Sequence[int], group=None):
+    """all_to_all_single with CPU staging when the backend cannot take the tensors' device."""
+    backend = dist.get_backend(group)
+    if backend == "gloo" and inp.is_cuda:
+        o = torch.empty(out.shape, dtype=out.dtype)
+        _a2a(o, inp.cpu(), out_splits, in_splits, group)
+        out.copy_(o)
+        return
+    if backend == "gloo":
+        # gloo has no alltoallv everywhere: use point-to-point pairs (deadlock-free: all isend first)
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        ins = list(torch.split(inp, list(in_splits)))
+        outs = list(torch.split(out, list(out_splits)))
+        reqs = []
+        for r in range(world):
+            if r == rank:
+                outs[r].copy_(ins[r])
+            else:
+                if ins[r].numel():
+                    reqs.append(dist.isend(ins[r].contiguous(), r, group=group))
+        for r in range(world):
+            if r != rank and outs[r].numel():
+                buf = torch.empty_like(outs[r])
+                dist.recv(buf, r, group=group)
+                outs[r].copy_(buf)
+        for q in reqs:
+            q.wait()
+        return
+    dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=group)
+
+
+@dataclass
+class StepStats:
+    n_local: int = 0
+    n_owned: int = 0
+    record_bytes: int = 0
+    sent_bytes: int = 0
+
+
+class DistributedDetect:
+    """Runs the sharded hot path.  `step()` is the timed unit; `gather_sv()` is output formatting."""
+
+    def __init__(self, stage, rank: int, world: int, index_base: int, n_local: int, device: torch.device, group=None):
+        self.stage, self.rank, self.world, self.group = stage, rank, world, group
+        self.device = device
+        self.index_base, self.n_local = index_base, n_local
+        t = torch.tensor([index_base], dtype=torch.int64)
+        if world > 1:
+            ts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            if dist.get_backend(group) == "nccl":
+                tg = t.to(device)
+                tsg = [x.to(device) for x in ts]
+                dist.all_gather(tsg, tg, group=group)
+                ts = [x.cpu() for x in tsg]
+            else:
+                dist.all_gather(ts, t, group=group)
+            self.bases = np.array([int(x.item()) for x in ts], np.uint64)
+        else:
+            self.bases = np.array([index_base], np.uint64)
+        self.stats = StepStats()
+
+    def _ctl(self, values: List[int]) -> torch.Tensor:
+        dev = self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        return torch.tensor(values, dtype=torch.int64, device=dev)
+
+    def _exchange_counts(self, counts: np.ndarray) -> np.ndarray:
+        inp = self._ctl([int(c) for c in counts])
+        out = torch.empty_like(inp)
+        ones = [1] * self.world
+        _a2a(out, inp, ones, ones, self.group)
+        return out.cpu().numpy().astype(np.int64)
+
+    def step(self) -> Result:
+        st, W = self.stage, self.world
+        st.localise()
+        mf, sx = st.exchange_local()
+        agreed = self._ctl([mf, sx])
+        dist.all_reduce(agreed, op=dist.ReduceOp.MAX, group=self.group)
+        mf, sx = (int(v) for v in agreed.cpu().tolist())
+        send, counts, rec = st.exchange_pack_tensor(mf, sx, W)
+        recv_counts = self._exchange_counts(counts)
+        recv = torch.empty(int(recv_counts.sum()) * rec, dtype=torch.uint8, device=send.device)
+        _a2a(recv, send, [int(c) * rec for c in recv_counts], [int(c) * rec for c in counts], self.group)
+        st.exchange_import_tensor(recv, recv_counts, self.bases)
+        res = st.clusterise()
+        self.stats = StepStats(int(counts.sum()), int(recv_counts.sum()), rec, int(counts.sum()) * rec)
+        self._route_junctions(res)
+        return res
+
+    def _route_junctions(self, res: Result) -> None:
+        """Owners request the junction strings of their surviving reads from the source ranks."""
+        W = self.world
+        nr = res.reads.shape[0]
+        src_rank = res.src_rank if nr else np.zeros(0, np.uint32)
+        src_index = res.src_index if nr else np.zeros(0, np.uint32)
+        order = np.argsort(src_rank, kind="stable")                  # requests grouped by source rank
+        req_counts = np.bincount(src_rank, minlength=W).astype(np.int64)
+        got_counts = self._exchange_counts(req_counts)              # how many each rank asks of me
+        dev = self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        req = torch.from_numpy(src_index[order].astype(np.int32)).to(dev)
+        got = torch.empty(int(got_counts.sum()), dtype=torch.int32, device=dev)
+        _a2a(got, req, [int(c) for c in got_counts], [int(c) for c in req_counts], self.group)
+        # render what the others (and I) asked for, in request order
+        by, off = self.stage.render_junctions(got.cpu().numpy().astype(np.uint32))
+        off = off.astype(np.int64)
+        bounds = np.concatenate([[0], np.cumsum(got_counts)]).astype(np.int64)
+        out_bytes = [int(off[bounds[r + 1]] - off[bounds[r]]) for r in range(W)]
+        # lengths are sent explicitly (4 B per read): the owner then needs no knowledge of read lengths
+        lens = torch.from_numpy((off[1:] - off[:-1]).astype(np.int32)).to(dev)
+        my_lens = torch.empty(nr, dtype=torch.int32, device=dev)
+        _a2a(my_lens, lens, [int(c) for c in req_counts], [int(c) for c in got_counts], self.group)
+        my_lens_np = my_lens.cpu().numpy().astype(np.int64)
+        rb = np.concatenate([[0], np.cumsum(req_counts)]).astype(np.int64)
+        csum = np.concatenate([[0], np.cumsum(my_lens_np)]).astype(np.int64)
+        in_bytes = [int(csum[rb[r + 1]] - csum[rb[r]]) for r in range(W)]
+        payload = torch.from_numpy(by).to(dev) if by.size else torch.empty(0, dtype=torch.uint8, device=dev)
+        mine = torch.empty(int(csum[-1]), dtype=torch.uint8, device=dev)
+        _a2a(mine, payload, in_bytes, out_bytes, self.group)
+        # scatter back to result order
+        joff = np.zeros(nr, np.uint64)
+        jlen = np.zeros(nr, np.uint32)
+        joff[order] = csum[:-1].astype(np.uint64)
+        jlen[order] = my_lens_np.astype(np.uint32)
+        res.reads = res.reads.copy()
+        res.reads["junction_off"] = joff
+        res.reads["junction_len"] = jlen
+        res.junction_bytes = mine.cpu().numpy()
+
+    # ---- output formatting (not part of the timed path) ----
+    def gather_result(self, res: Result, contig_names: Sequence[bytes]) -> Optional[Result]:
+        """Rank 0 merges the per-owner cluster lists by the seed's rank in the reference's sort:
+        (contig by byte-wise name order, left position as wrapped usize, input index)."""
+        payload = (res.n_evidence, res.clusters, res.reads, res.junction_bytes)
+        if self.world > 1:
+            gathered = [None] * self.world if self.rank == 0 else None
+            dist.gather_object(payload, gathered, dst=0, group=self.group)
+        else:
+            gathered = [payload]
+        if self.rank != 0:
+            return None
+        name_rank = {i: r for r, i in enumerate(sorted(range(len(contig_names)), key=lambda i: contig_names[i]))}
+        clusters, reads, jb = [], [], []
+        read_base = junc_base = 0
+        n_ev = 0
+        for (ne, cl, rd, by) in gathered:
+            n_ev += ne
+            cl, rd = cl.copy(), rd.copy()
+            cl["read_begin"] += read_base
+            cl["read_end"] += read_base
+            rd["junction_off"] += junc_base
+            read_base += rd.shape[0]
+            junc_base += by.shape[0]
+            clusters.append(cl); reads.append(rd); jb.append(by)
+        cl = np.concatenate(clusters) if clusters else np.zeros(0, CLUSTER_DTYPE)
+        rd = np.concatenate(reads) if reads else np.zeros(0, READ_DTYPE)
+        by = np.concatenate(jb) if jb else np.zeros(0, np.uint8)
+        key_rank = np.array([name_rank[int(c)] for c in cl["contig"]], np.int64)
+        order = np.lexsort((cl["seed_index"], cl["lpos"].astype(np.uint64), key_rank))
+        cl = cl[order]
+        # re-pack reads in cluster order
+        begin = cl["read_begin"].astype(np.int64)
+        cnt = cl["read_end"].astype(np.int64) - begin
+        new_begin = np.cumsum(cnt) - cnt
+        idx = np.repeat(begin - new_begin, cnt) + np.arange(int(cnt.sum()), dtype=np.int64)
+        rd = rd[idx] if idx.size else np.zeros(0, READ_DTYPE)
+        cl["read_begin"] = new_begin.astype(np.uint64)
+        cl["read_end"] = (new_begin + cnt).astype(np.uint64)
+        return Result(n_ev, cl, rd, by)
+
+
+SV_HEADER = (b"CHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tCHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\t"
+             b"SUPPORTING READS\tSIGNATURE\tNOTES\n")
+
+
+def format_sv(res: Result, contig_names: Sequence[bytes]) -> bytes:
+    """The print statements detect.rs:201,233-240 for a merged multi-rank result (pure formatting;
+    single-GPU runs use the library's bf_format_sv)."""
+    out = [SV_HEADER]
+    jb = res.junction_bytes.tobytes()
+    for c in res.clusters:
+        out.append(b"%s\t%s\t%d\t\t%s\t%s\t%d\t\t" % (
+            contig_names[int(c["contig"])], b"+" if c["strand"] else b"-", int(c["lpos"]) & ((1 << 64) - 1),
+            contig_names[int(c["mcontig"])], b"+" if c["mstrand"] else b"-", int(c["rpos"]) & ((1 << 64) - 1)))
+        rows = res.reads[int(c["read_begin"]):int(c["read_end"])]
+        out.append(b";".join(jb[int(r["junction_off"]):int(r["junction_off"]) + int(r["junction_len"])] for r in rows))
+        out.append(b"\t\t\n")
+    return b"".join(out)

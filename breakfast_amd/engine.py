@@ -115,7 +115,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_format_sv.restype = C.c_int64
     lib.bf_set_rank.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64]
     lib.bf_exchange_local.argtypes = [vp, C.POINTER(BfWireLocal)]
-    lib.bf_exchange_pack.argtypes = [vp, C.POINTER(BfWireLocal), u64p, C.POINTER(vp), C.POINTER(C.c_uint32)]
+    lib.bf_exchange_pack.argtypes = [vp, C.POINTER(BfWireLocal), vp, C.c_uint64, u64p, C.POINTER(vp), C.POINTER(C.c_uint32)]
     lib.bf_exchange_import.argtypes = [vp, vp, u64p, u64p]
     lib.bf_result_sources.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.bf_render_junctions.argtypes = [vp, C.c_uint64, vp, C.POINTER(vp), C.POINTER(vp)]
@@ -336,13 +336,18 @@ class Engine:
         self._check(self.lib.bf_exchange_local(self.h, C.byref(w)))
         return int(w.max_frag_len_bytes), int(w.has_exact_sig)
 
-    def exchange_pack(self, max_frag_len_bytes: int, has_exact_sig: int, n_ranks: int) -> Tuple[np.ndarray, int, int]:
-        """-> (counts per owner rank, device pointer of the send buffer, record bytes)"""
+    @staticmethod
+    def wire_record_bytes(max_frag_len_bytes: int, has_exact_sig: int) -> int:
+        return 40 + ((max_frag_len_bytes + 7) & ~7) + (16 if has_exact_sig else 0)
+
+    def exchange_pack(self, max_frag_len_bytes: int, has_exact_sig: int, n_ranks: int, dev_send: int = 0,
+                      dev_send_bytes: int = 0) -> Tuple[np.ndarray, int, int]:
+        """-> (counts per owner rank, device pointer of the packed records, record bytes)"""
         w = BfWireLocal(max_frag_len_bytes, has_exact_sig)
         counts = np.zeros(n_ranks, np.uint64)
         ptr, rec = C.c_void_p(), C.c_uint32()
-        self._check(self.lib.bf_exchange_pack(self.h, C.byref(w), counts.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                              C.byref(ptr), C.byref(rec)))
+        self._check(self.lib.bf_exchange_pack(self.h, C.byref(w), C.c_void_p(dev_send or None), dev_send_bytes,
+                                              counts.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(ptr), C.byref(rec)))
         return counts, int(ptr.value or 0), int(rec.value)
 
     def exchange_import(self, dev_ptr: int, src_counts: np.ndarray, src_index_base: np.ndarray) -> None:

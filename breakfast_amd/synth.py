@@ -10,6 +10,8 @@ PRNG: numpy PCG64 seeded with `seed + stream` (seed 20240807 in the BASELINE con
 """
 from __future__ import annotations
 
+import os
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -56,15 +58,22 @@ def make_genome(contigs: Sequence[Tuple[str, int]], seed: int = SEED, end_n: int
                 ) -> Genome:
     """Uniform i.i.d. ACGT contigs.  end_n: length of the N run at both contig ends;
     n_runs / lower_runs: (contig index, start, length) runs of 'N' / of lowercase bases."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    names, seqs = [], []
-    for name, length in contigs:
+    def one(ci: int) -> np.ndarray:
+        length = contigs[ci][1]
+        rng = np.random.Generator(np.random.PCG64([seed, 3, ci]))        # one stream per contig
         s = _ACGT[rng.integers(0, 4, size=length, dtype=np.uint8)]
         if end_n and length > 4 * end_n:
             s[:end_n] = ord("N")
             s[-end_n:] = ord("N")
-        names.append(name.encode())
-        seqs.append(s)
+        return s
+
+    names = [name.encode() for name, _ in contigs]
+    workers = max(1, min(8, os.cpu_count() or 1, len(contigs)))
+    if workers == 1:
+        seqs = [one(ci) for ci in range(len(contigs))]
+    else:
+        with ThreadPoolExecutor(workers) as ex:
+            seqs = list(ex.map(one, range(len(contigs))))
     for ci, a, n in n_runs:
         seqs[ci][a:a + n] = ord("N")
     for ci, a, n in lower_runs:
@@ -86,8 +95,10 @@ class ReadSpec:
     hot_frac: float = 0.0          # reads piling onto `hot_events` junctions with distinct QNAMEs
     hot_events: int = 0
     margin: int = 0                # keep junctions this far from contig ends (0 -> read_len + 8)
-    seed: int = SEED
-    chunk: int = 1 << 20
+    seed: int = SEED               # junction tables (shared by all ranks of a sharded run)
+    read_seed: Optional[int] = None  # per-read draws (None -> seed); differs per rank
+    frag_base: int = 0             # first fragment id number (keeps ids unique across ranks)
+    chunk: int = 1 << 18
 
 
 def _digits(ids: np.ndarray, width: int) -> np.ndarray:
@@ -102,7 +113,9 @@ def _digits(ids: np.ndarray, width: int) -> np.ndarray:
 
 def make_reads(genome: Genome, spec: ReadSpec) -> Batch:
     """Split reads + the bowtie hits of their anchors, in a seeded random input order."""
-    rng = np.random.Generator(np.random.PCG64(spec.seed + 1))
+    erng = np.random.Generator(np.random.PCG64(spec.seed + 1))          # junction tables
+    rseed = spec.seed if spec.read_seed is None else spec.read_seed
+    rng = np.random.Generator(np.random.PCG64([rseed, 5]))              # per-read draws
     L, A, n = spec.read_len, spec.anchor_len, spec.n_reads
     assert L >= 2 * A and A >= 8
     lens = np.array([s.shape[0] for s in genome.seqs], np.int64)
@@ -114,18 +127,18 @@ def make_reads(genome: Genome, spec: ReadSpec) -> Batch:
     assert usable.sum() > 0, "contigs too short for this read length"
     cw = usable / usable.sum()
 
-    def random_loci(m: int) -> Tuple[np.ndarray, np.ndarray]:
-        c = rng.choice(len(lens), size=m, p=cw)
-        x = margin + (rng.random(m) * usable[c]).astype(np.int64)
+    def random_loci(g, m: int) -> Tuple[np.ndarray, np.ndarray]:
+        c = g.choice(len(lens), size=m, p=cw)
+        x = margin + (g.random(m) * usable[c]).astype(np.int64)
         return c.astype(np.int64), x
 
-    def make_events(m: int):
-        c1, x1 = random_loci(m)
-        c2, y1 = random_loci(m)
-        s1 = rng.random(m) < 0.5
-        s2 = rng.random(m) < 0.5
-        dele = rng.random(m) < spec.deletion_frac          # same-contig deletion, both '+'
-        gap = (50 + rng.random(m) * 1_000_000).astype(np.int64)
+    def make_events(g, m: int):
+        c1, x1 = random_loci(g, m)
+        c2, y1 = random_loci(g, m)
+        s1 = g.random(m) < 0.5
+        s2 = g.random(m) < 0.5
+        dele = g.random(m) < spec.deletion_frac            # same-contig deletion, both '+'
+        gap = (50 + g.random(m) * 1_000_000).astype(np.int64)
         yd = np.minimum(x1 + 1 + gap, margin + usable[c1] - 1)
         c2 = np.where(dele, c1, c2)
         y1 = np.where(dele, yd, y1)
@@ -136,9 +149,9 @@ def make_reads(genome: Genome, spec: ReadSpec) -> Batch:
     n_sing = int(round(n * spec.singleton_frac))
     n_hot = int(round(n * spec.hot_frac)) if spec.hot_events else 0
     n_ev = n - n_sing - n_hot
-    ev = make_events(max(spec.n_events, 1))
-    hot = make_events(max(spec.hot_events, 1))
-    sing = make_events(max(n_sing, 1))
+    ev = make_events(erng, max(spec.n_events, 1))
+    hot = make_events(erng, max(spec.hot_events, 1))
+    sing = make_events(rng, max(n_sing, 1))
 
     # per-read junction parameters, grouped (event reads sorted by event so mates are neighbours)
     eid = np.sort(rng.integers(0, max(spec.n_events, 1), size=n_ev))
@@ -149,7 +162,7 @@ def make_reads(genome: Genome, spec: ReadSpec) -> Batch:
     c1, x1, s1, c2, y1, s2 = cols
     # fragment ids: unique per read, except that a "mate" re-uses the previous read's id when it
     # covers the same event
-    fid = np.arange(n, dtype=np.int64)
+    fid = spec.frag_base + np.arange(n, dtype=np.int64)
     is_mate = np.zeros(n, bool)
     if n_ev > 1:
         m = (rng.random(n_ev) < spec.mate_frac)
@@ -166,44 +179,60 @@ def make_reads(genome: Genome, spec: ReadSpec) -> Batch:
     seq = np.empty((n, L), np.uint8)
     hits = np.zeros(n, HIT_DTYPE)
     k = np.arange(L, dtype=np.int64)[None, :]
-    for lo in range(0, n, spec.chunk):
+    # 5' part: '+' reads G1[x1-b+1+k]; '-' reads comp(G1[x1+b-1-k]); it ends on x1 either way.
+    # 3' part: '+' reads G2[y1+(k-b)]; '-' reads comp(G2[y1-(k-b)]).  Both are base + dir*k.
+    base1 = starts[c1] + np.where(s1, x1 - b + 1, x1 + b - 1)
+    base2 = starts[c2] + np.where(s2, y1 - b, y1 + b)
+    dir1 = np.where(s1, 1, -1).astype(np.int64)
+    dir2 = np.where(s2, 1, -1).astype(np.int64)
+    # bowtie hits of the unflipped read (1-based leftmost offset of each anchor); presenting the
+    # read as its reverse complement swaps the anchors and flips their strands
+    pos5 = np.where(s1, x1 - b + 2, x1 + b - A + 1)
+    pos3 = np.where(s2, y1 + L - A - b + 1, y1 - L + b + 2)
+    hits["pos5"] = np.where(flip, pos3, pos5)
+    hits["pos3"] = np.where(flip, pos5, pos3)
+    hits["contig5"] = np.where(flip, c2, c1)
+    hits["contig3"] = np.where(flip, c1, c2)
+    hits["strands"] = (np.where(flip, ~s2, s1).astype(np.uint8) | (np.where(flip, ~s1, s2).astype(np.uint8) << 1))
+    def build_chunk(ci: int) -> None:
+        lo = ci * spec.chunk
         hi = min(n, lo + spec.chunk)
         sl = slice(lo, hi)
-        bb = b[sl, None]
-        left = k < bb
-        # 5' part: '+' reads G1[x1-b+1+k]; '-' reads comp(G1[x1+b-1-k]); ends on x1 either way
-        p_left = np.where(s1[sl, None], x1[sl, None] - bb + 1 + k, x1[sl, None] + bb - 1 - k)
-        # 3' part: '+' reads G2[y1+(k-b)]; '-' reads comp(G2[y1-(k-b)])
-        p_right = np.where(s2[sl, None], y1[sl, None] + (k - bb), y1[sl, None] - (k - bb))
-        gpos = np.where(left, starts[c1[sl]][:, None] + p_left, starts[c2[sl]][:, None] + p_right)
+        crng = np.random.Generator(np.random.PCG64([rseed, 7, ci]))   # per-chunk stream: thread-count independent
+        f = flip[sl, None]
+        ko = np.where(f, L - 1 - k, k)                      # position inside the unflipped read
+        left = ko < b[sl, None]
+        gpos = np.where(left, base1[sl, None] + dir1[sl, None] * ko, base2[sl, None] + dir2[sl, None] * ko)
         r = cat[gpos]
-        need_comp = np.where(left, ~s1[sl, None], ~s2[sl, None])
+        del gpos
+        need_comp = np.where(left, ~s1[sl, None], ~s2[sl, None]) ^ f
         r = np.where(need_comp, _COMP[r], r)
-        # bowtie hits of the unflipped read (1-based leftmost offset of each anchor)
-        pos5 = np.where(s1[sl], x1[sl] - b[sl] + 2, x1[sl] + b[sl] - A + 1)
-        pos3 = np.where(s2[sl], y1[sl] + L - A - b[sl] + 1, y1[sl] - L + b[sl] + 2)
-        f = flip[sl]
-        # presenting the read as its reverse complement swaps the anchors and their strands
-        r = np.where(f[:, None], _COMP[r[:, ::-1]], r)
-        h = hits[sl]
-        h["pos5"] = np.where(f, pos3, pos5)
-        h["pos3"] = np.where(f, pos5, pos3)
-        h["contig5"] = np.where(f, c2[sl], c1[sl])
-        h["contig3"] = np.where(f, c1[sl], c2[sl])
-        st5 = np.where(f, ~s2[sl], s1[sl])
-        st3 = np.where(f, ~s1[sl], s2[sl])
-        h["strands"] = st5.astype(np.uint8) | (st3.astype(np.uint8) << 1)
+        del need_comp, left, ko
         # sequencing errors outside the anchors (an error inside an anchor = no bowtie hit)
-        inner = (k >= A) & (k < L - A)
-        if spec.subst_rate > 0:
-            e = (rng.random(r.shape) < spec.subst_rate) & inner & np.isin(r, _ACGT)
-            code = (r >> 1) & 3                      # A0 C1 T2 G3
-            alt = np.frombuffer(b"ACTG", np.uint8)[(code + rng.integers(1, 4, size=r.shape, dtype=np.uint8)) & 3]
-            r = np.where(e, alt, r)
-        if spec.n_rate > 0:
-            e = (rng.random(r.shape) < spec.n_rate) & inner
-            r = np.where(e, np.uint8(ord("N")), r)
+        m = hi - lo
+        for rate, kind in ((spec.subst_rate, 0), (spec.n_rate, 1)):
+            if rate <= 0 or L - 2 * A <= 0:
+                continue
+            ne = crng.binomial(m * (L - 2 * A), rate)
+            rows = crng.integers(0, m, size=ne)
+            colz = crng.integers(A, L - A, size=ne)
+            cur = r[rows, colz]
+            if kind == 0:
+                code = (cur >> 1) & 3                        # A0 C1 T2 G3
+                alt = np.frombuffer(b"ACTG", np.uint8)[(code + crng.integers(1, 4, size=ne, dtype=np.uint8)) & 3]
+                r[rows, colz] = np.where(np.isin(cur, _ACGT), alt, cur)
+            else:
+                r[rows, colz] = ord("N")
         seq[sl] = r
+
+    n_chunks = (n + spec.chunk - 1) // spec.chunk
+    workers = max(1, min(8, (os.cpu_count() or 1), n_chunks))
+    if workers == 1:
+        for ci in range(n_chunks):
+            build_chunk(ci)
+    else:
+        with ThreadPoolExecutor(workers) as ex:
+            list(ex.map(build_chunk, range(n_chunks)))
     width = 11
     frag = np.empty((n, width + 1), np.uint8)
     frag[:, 0] = ord("q")

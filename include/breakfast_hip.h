@@ -178,10 +178,14 @@ typedef struct {
 } bf_wire_local;
 int bf_exchange_local(bf_ctx* ctx, bf_wire_local* out);
 
-/* Packs evidence into a device send buffer grouped by owner rank.  counts[r] = records for rank r.
- * *dev_send points at ctx-owned device memory of sum(counts) * *record_bytes bytes. */
-int bf_exchange_pack(bf_ctx* ctx, const bf_wire_local* agreed, uint64_t* counts /* n_ranks */,
-                     void** dev_send, uint32_t* record_bytes);
+/* Packs evidence into a device send buffer grouped by owner rank (source order kept inside each
+ * group).  counts[r] = records for rank r; every record has *record_bytes bytes (a function of
+ * `agreed` only: 40 + round_up(max_frag_len_bytes, 8) + 16 * has_exact_sig).  If dev_send is not
+ * NULL the records are written there (caller-owned device memory, e.g. a torch tensor, of
+ * dev_send_bytes >= n_resident_reads * record_bytes); otherwise into ctx-owned device memory.
+ * *dev_out receives the buffer actually used. */
+int bf_exchange_pack(bf_ctx* ctx, const bf_wire_local* agreed, void* dev_send, uint64_t dev_send_bytes,
+                     uint64_t* counts /* n_ranks */, void** dev_out, uint32_t* record_bytes);
 
 /* Imports the received records (device pointer, ordered by source rank then source order);
  * src_counts[r] = how many came from rank r, src_index_base[r] = rank r's index_base. */
