@@ -47,6 +47,16 @@ int ensure(bf_ctx* ctx, DevBuf& b, size_t bytes, bool keep) {
     return BF_OK;
 }
 
+int ensure_host(bf_ctx* ctx, HostBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return BF_OK;
+    if (b.p) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t cap = std::max<size_t>(bytes + bytes / 4, 4096);
+    hipError_t e = hipHostMalloc(&b.p, cap, hipHostMallocDefault);
+    if (e != hipSuccess) { b.p = nullptr; return fail(ctx, BF_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e)); }
+    b.cap = cap;
+    return BF_OK;
+}
+
 void release(bf_ctx* ctx, DevBuf& b) {
     if (b.p) { (void)hipFree(b.p); ctx->device_bytes -= b.cap; }
     b.p = nullptr; b.cap = 0;
@@ -115,6 +125,8 @@ static void free_all(bf_ctx* ctx) {
         &ctx->c_ord, &ctx->c_clusters, &ctx->c_reads, &ctx->c_misc, &ctx->c_joff, &ctx->c_jbytes, &ctx->c_rsrc,
         &ctx->c_tables, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
     for (DevBuf* b : all) release(ctx, *b);
+    HostBuf* hosts[] = {&ctx->out.clusters, &ctx->out.reads, &ctx->out.src, &ctx->out.junction};
+    for (HostBuf* h : hosts) { if (h->p) (void)hipHostFree(h->p); h->p = nullptr; h->cap = 0; }
 }
 
 }  // namespace bf
@@ -228,7 +240,7 @@ int bf_reset(bf_ctx* ctx) {
     ctx->n_reads = 0; ctx->seq_bytes = 0; ctx->frag_bytes = 0;
     ctx->max_len = 0; ctx->min_len = 0xffffffffu; ctx->max_frag = 0;
     ctx->localised = false; ctx->imported = false; ctx->n_imported = 0; ctx->n_exact = 0;
-    ctx->out = ClusterOut();
+    ctx->out.n_clusters = ctx->out.n_reads = ctx->out.junction_size = 0;
     return BF_OK;
 }
 
@@ -302,8 +314,7 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     BF_HIP(ctx, hipSetDevice(ctx->device));
     const OwnerView v = ctx->imported ? imported_view(ctx) : local_view(ctx);
     BF_TRY(run_cluster(ctx, v));
-    const uint64_t nr = ctx->out.reads.size();
-    ctx->junction_host.clear();
+    const uint64_t nr = ctx->out.n_reads;
     if (nr) {
         if (!ctx->imported) {
             // single rank: the surviving reads are local, render their junction strings now
@@ -311,19 +322,21 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
             uint64_t total = 0;
             BF_TRY(run_render(ctx, nr, d_idx, ctx->c_joff, ctx->c_jbytes, &total));
             BF_TRY(patch_reads(ctx, ctx->c_joff.as<uint64_t>(), nr));
-            ctx->junction_host.resize(total);
-            if (total) BF_HIP(ctx, hipMemcpyAsync(ctx->junction_host.data(), ctx->c_jbytes.p, total, hipMemcpyDeviceToHost, ctx->stream));
+            ctx->out.junction_size = total;
+            BF_TRY(ensure_host(ctx, ctx->out.junction, total));
+            if (total) BF_HIP(ctx, hipMemcpyAsync(ctx->out.junction.p, ctx->c_jbytes.p, total, hipMemcpyDeviceToHost, ctx->stream));
         }
-        BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.data(), ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
-        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
     }
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     out->n_evidence = ctx->n_evidence;
-    out->n_clusters = ctx->out.clusters.size();
+    out->n_clusters = ctx->out.n_clusters;
     out->n_reads = nr;
-    out->clusters = ctx->out.clusters.data();
-    out->reads = ctx->out.reads.data();
-    out->junction_bytes = ctx->junction_host.data();
-    out->junction_size = ctx->junction_host.size();
+    out->clusters = ctx->out.clusters.as<bf_cluster>();
+    out->reads = ctx->out.reads.as<bf_read>();
+    out->junction_bytes = ctx->out.junction.as<uint8_t>();
+    out->junction_size = ctx->out.junction_size;
     return BF_OK;
 }
 
@@ -409,7 +422,8 @@ int bf_exchange_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_co
 
 int bf_result_sources(bf_ctx* ctx, const uint32_t** src_rank, const uint32_t** src_index) {
     if (!ctx || !src_rank || !src_index) return BF_ERR_INVALID;
-    *src_rank = ctx->out.src_rank.data(); *src_index = ctx->out.src_idx.data();
+    if (!ctx->imported) return fail(ctx, BF_ERR_STATE, "bf_result_sources is only meaningful after bf_exchange_import + bf_clusterise");
+    *src_rank = ctx->out.src.as<uint32_t>(); *src_index = ctx->out.src.as<uint32_t>() + ctx->out.n_reads;
     return BF_OK;
 }
 

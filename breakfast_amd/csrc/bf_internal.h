@@ -80,11 +80,18 @@ struct OwnerView {
     const uint32_t* src_idx = nullptr;   // nullptr = identity
 };
 
-struct ClusterOut {                      // device-side results of the cluster stage (host copies)
-    std::vector<bf_cluster> clusters;
-    std::vector<bf_read> reads;
-    std::vector<uint32_t> src_rank, src_idx;   // per supporting read
-    std::vector<uint32_t> owner_rec;           // per supporting read: owner-side record index
+struct HostBuf {                         // pinned host staging (hipHostMalloc): full-rate D2H copies
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct ClusterOut {                      // host copies of the cluster stage's results
+    uint64_t n_clusters = 0, n_reads = 0, junction_size = 0;
+    HostBuf clusters;                    // bf_cluster[n_clusters]
+    HostBuf reads;                       // bf_read[n_reads]
+    HostBuf src;                         // uint32 src_rank[n_reads], src_idx[n_reads] (multi-rank only)
+    HostBuf junction;                    // junction text
 };
 
 struct Timing {
@@ -142,7 +149,6 @@ struct bf_ctx {
         c_csize, c_flag, c_scan, c_qseed, c_qsize, c_qoff, c_members, c_leader, c_rep, c_qnrep,
         c_sel, c_ord, c_clusters, c_reads, c_misc, c_joff, c_jbytes, c_rsrc, c_tables;
     bf::ClusterOut out;
-    std::vector<uint8_t> junction_host;
     std::vector<uint64_t> render_off_host;
     std::vector<uint8_t> render_bytes_host;
     uint64_t n_evidence = 0;
@@ -176,6 +182,7 @@ int fail(bf_ctx* ctx, int code, const char* fmt, ...);
     } while (0)
 
 int ensure(bf_ctx* ctx, DevBuf& b, size_t bytes, bool keep = false);
+int ensure_host(bf_ctx* ctx, HostBuf& b, size_t bytes);
 void release(bf_ctx* ctx, DevBuf& b);
 
 // timed region helper: records HIP events on the ctx stream around a group of launches

@@ -322,8 +322,7 @@ __global__ void __launch_bounds__(256) emit_kernel(const EmitView e, uint64_t ns
 int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     const uint64_t n = v.n;
     hipStream_t st = ctx->stream;
-    ctx->out.clusters.clear(); ctx->out.reads.clear();
-    ctx->out.src_rank.clear(); ctx->out.src_idx.clear(); ctx->out.owner_rec.clear();
+    ctx->out.n_clusters = ctx->out.n_reads = ctx->out.junction_size = 0;
     ctx->n_evidence = n;
     if (n == 0) return BF_OK;
     if (n > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "too many evidence records for one GPU (%llu)", (unsigned long long)n);
@@ -456,16 +455,14 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
         hipLaunchKernelGGL(emit_kernel, dim3(grid_for(ns * 64, B)), dim3(B), 0, st, ev, ns);
     }
     BF_HIP(ctx, hipGetLastError());
-    ctx->out.clusters.resize(ns);
-    ctx->out.src_rank.resize(total_r); ctx->out.src_idx.resize(total_r); ctx->out.owner_rec.resize(total_r);
-    ctx->out.reads.resize(total_r);
-    BF_HIP(ctx, hipMemcpyAsync(ctx->out.clusters.data(), ctx->c_clusters.p, ns * sizeof(bf_cluster), hipMemcpyDeviceToHost, st));
-    if (total_r) {
-        BF_HIP(ctx, hipMemcpyAsync(ctx->out.src_rank.data(), ev.out_src_rank, total_r * 4, hipMemcpyDeviceToHost, st));
-        BF_HIP(ctx, hipMemcpyAsync(ctx->out.src_idx.data(), ev.out_src_idx, total_r * 4, hipMemcpyDeviceToHost, st));
-        BF_HIP(ctx, hipMemcpyAsync(ctx->out.owner_rec.data(), ev.out_rec, total_r * 4, hipMemcpyDeviceToHost, st));
+    // host copies: the rows now; the reads after the junction offsets are patched in (api.hip)
+    ctx->out.n_clusters = ns; ctx->out.n_reads = total_r;
+    BF_TRY(ensure_host(ctx, ctx->out.clusters, ns * sizeof(bf_cluster)));
+    BF_HIP(ctx, hipMemcpyAsync(ctx->out.clusters.p, ctx->c_clusters.p, ns * sizeof(bf_cluster), hipMemcpyDeviceToHost, st));
+    if (total_r && v.src_rank) {          // multi-rank: the caller routes junction requests to the source ranks
+        BF_TRY(ensure_host(ctx, ctx->out.src, total_r * 8));
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.src.p, ev.out_src_rank, total_r * 8, hipMemcpyDeviceToHost, st));
     }
-    BF_HIP(ctx, hipStreamSynchronize(st));
     return BF_OK;
 }
 

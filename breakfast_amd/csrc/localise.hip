@@ -58,32 +58,55 @@ __global__ void __launch_bounds__(256) genome_pack_kernel(const uint8_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// encode_reads: thread (r, w) encodes read bases [64w, 64w+64) into planes[(p*W + w)*N + r],
-// p = 0 lo, 1 hi, 2 exception.  Reads longer than 64*W are left to the exact kernel.
-__global__ void __launch_bounds__(256) encode_reads_kernel(uint64_t n, int W,
-                                                           const uint8_t* __restrict__ seq,
+// encode_reads: one wave encodes 64 consecutive reads.  For read i and word w the 64 lanes load the
+// 64 bases [64w, 64w+64) (one coalesced 64-byte access), classify them, and three wave ballots ARE
+// the three plane words (bit k <-> base 64w+k); lane i keeps them, so after the loop lane i holds
+// read base+i and the plane stores are contiguous.  planes[(p*W + w)*n + r], p = 0 lo, 1 hi,
+// 2 exception.  Reads longer than 64*W get zero planes and are left to the exact kernel.
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int W>
+__global__ void __launch_bounds__(256) encode_reads_kernel(uint64_t n, const uint8_t* __restrict__ seq,
                                                            const uint64_t* __restrict__ seq_off,
                                                            uint64_t* __restrict__ planes) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int w = blockIdx.y;
-    if (r >= n) return;
-    const uint64_t o = seq_off[r];
-    const uint64_t L = seq_off[r + 1] - o;
-    uint64_t lo = 0, hi = 0, ex = 0;
-    if (L <= (uint64_t)64 * W && (uint64_t)64 * w < L) {
-        const int cnt = (int)min((uint64_t)64, L - (uint64_t)64 * w);
-        const uint8_t* p = seq + o + 64 * w;
-        for (int k = 0; k < cnt; k++) {
-            const uint8_t c = p[k];
-            const uint64_t code = (c >> 1) & 3;
-            lo |= (code & 1) << k;
-            hi |= (code >> 1) << k;
-            ex |= (uint64_t)(!is_acgt(c)) << k;
+    const int lane = threadIdx.x & 63;
+    const uint64_t base = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64;
+    if (base >= n) return;                                   // wave-uniform
+    const uint64_t r = base + lane;
+    uint64_t o = 0;
+    uint32_t L = 0;
+    if (r < n) { o = seq_off[r]; L = (uint32_t)(seq_off[r + 1] - o); }
+    uint64_t lo[W], hi[W], ex[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) lo[w] = hi[w] = ex[w] = 0;
+    if (L > 64u * W) L = 0;                                  // too long for the packed path: zero planes
+#pragma unroll 4
+    for (int i = 0; i < 64; i++) {                           // lanes past n carry L = 0
+        const uint64_t oi = readlane64(o, i);
+        const uint32_t Li = (uint32_t)__builtin_amdgcn_readlane((int)L, i);
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            const uint32_t pos = 64u * w + lane;
+            const bool in = pos < Li;
+            const uint32_t c = in ? seq[oi + pos] : (uint32_t)'A';
+            const uint32_t code = (c >> 1) & 3;              // A0 C1 T2 G3
+            const bool exc = c != ((0x47544341u >> (8 * code)) & 0xffu);   // not one of "ACGT"
+            const uint64_t blo = __ballot(in && (code & 1)), bhi = __ballot(in && (code >> 1)), bex = __ballot(exc);
+            if (lane == i) { lo[w] = blo; hi[w] = bhi; ex[w] = bex; }
         }
     }
-    planes[((uint64_t)(0 * W + w)) * n + r] = lo;
-    planes[((uint64_t)(1 * W + w)) * n + r] = hi;
-    planes[((uint64_t)(2 * W + w)) * n + r] = ex;
+    if (r < n) {
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            planes[((uint64_t)(0 * W + w)) * n + r] = lo[w];
+            planes[((uint64_t)(1 * W + w)) * n + r] = hi[w];
+            planes[((uint64_t)(2 * W + w)) * n + r] = ex[w];
+        }
+    }
 }
 
 // lengths + FNV-1a/64 with a final avalanche of the fragment id bytes
@@ -528,9 +551,13 @@ int run_localise(bf_ctx* ctx) {
 
     {
         Scope t(ctx, "encode_reads");
-        hipLaunchKernelGGL(encode_reads_kernel, dim3(grid_for(n, 256), W), dim3(256), 0, ctx->stream, n,
-                           (int)W, ctx->d_seq.as<uint8_t>(), ctx->d_seq_off.as<uint64_t>(),
-                           ctx->d_planes.as<uint64_t>());
+        const dim3 eg(grid_for(((n + 63) / 64) * 64, 256));
+        if (W == 2) hipLaunchKernelGGL(encode_reads_kernel<2>, eg, dim3(256), 0, ctx->stream, n, ctx->d_seq.as<uint8_t>(),
+                                       ctx->d_seq_off.as<uint64_t>(), ctx->d_planes.as<uint64_t>());
+        else if (W == 3) hipLaunchKernelGGL(encode_reads_kernel<3>, eg, dim3(256), 0, ctx->stream, n, ctx->d_seq.as<uint8_t>(),
+                                            ctx->d_seq_off.as<uint64_t>(), ctx->d_planes.as<uint64_t>());
+        else hipLaunchKernelGGL(encode_reads_kernel<4>, eg, dim3(256), 0, ctx->stream, n, ctx->d_seq.as<uint8_t>(),
+                                ctx->d_seq_off.as<uint64_t>(), ctx->d_planes.as<uint64_t>());
         hipLaunchKernelGGL(read_meta_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n,
                            ctx->d_seq_off.as<uint64_t>(), ctx->d_frag.as<uint8_t>(),
                            ctx->d_frag_off.as<uint64_t>(), ctx->d_len.as<uint16_t>(),

@@ -287,7 +287,7 @@ class Engine:
         self._check(self.lib.bf_clusterise(self.h, C.byref(r)))
         self._last = r
         res = self._wrap(r, copy)
-        if copy and r.n_reads:
+        if copy and r.n_reads and getattr(self, "n_ranks", 1) > 1:
             sr, si = C.c_void_p(), C.c_void_p()
             self._check(self.lib.bf_result_sources(self.h, C.byref(sr), C.byref(si)))
             res.src_rank = np.frombuffer((C.c_uint32 * r.n_reads).from_address(sr.value), np.uint32).copy()
