@@ -113,7 +113,7 @@ static OwnerView imported_view(bf_ctx* ctx) {
 }
 
 static void free_all(bf_ctx* ctx) {
-    DevBuf* all[] = {&ctx->g_blocks, &ctx->g_raw, &ctx->g_coarse, &ctx->g_contigs, &ctx->d_seq, &ctx->d_seq_off,
+    DevBuf* all[] = {&ctx->g_blocks, &ctx->g_raw, &ctx->g_coarse, &ctx->g_coarse2, &ctx->g_contigs, &ctx->d_seq, &ctx->d_seq_off,
         &ctx->d_frag, &ctx->d_frag_off, &ctx->d_hits, &ctx->d_planes, &ctx->d_len, &ctx->d_frag_len, &ctx->d_fhash,
         &ctx->d_key, &ctx->d_lpos, &ctx->d_rpos, &ctx->d_bp, &ctx->d_flags, &ctx->d_mask, &ctx->d_exact_list,
         &ctx->d_counters, &ctx->d_sigx, &ctx->d_sigx_slot, &ctx->d_send, &ctx->d_part_key, &ctx->d_part_idx,
@@ -216,15 +216,18 @@ int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, con
         off += (lens[i] + 63) & ~63ull;
     }
     const uint64_t total = (off + 4095) & ~4095ull;      // whole waves of 64 blocks
+    if (total / 64 >= 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "genome too large: %llu bases (limit 2^38)", (unsigned long long)total);
     ctx->genome_bases = total;
     const uint64_t n_blocks = total / 64;
     BF_TRY(ensure(ctx, ctx->g_raw, total + 4096));
     BF_TRY(ensure(ctx, ctx->g_blocks, (n_blocks + 16) * sizeof(GenomeBlock)));
     BF_TRY(ensure(ctx, ctx->g_coarse, (n_blocks / 64 + 4) * 8));
+    BF_TRY(ensure(ctx, ctx->g_coarse2, (n_blocks / 2048 + 4) * 4));
     BF_TRY(ensure(ctx, ctx->g_contigs, (size_t)n_contigs * sizeof(ContigDev)));
     BF_HIP(ctx, hipMemsetAsync(ctx->g_raw.p, 'A', total + 4096, ctx->stream));   // padding is never compared
     BF_HIP(ctx, hipMemsetAsync(ctx->g_blocks.p, 0, (n_blocks + 16) * sizeof(GenomeBlock), ctx->stream));
     BF_HIP(ctx, hipMemsetAsync(ctx->g_coarse.p, 0, (n_blocks / 64 + 4) * 8, ctx->stream));
+    BF_HIP(ctx, hipMemsetAsync(ctx->g_coarse2.p, 0, (n_blocks / 2048 + 4) * 4, ctx->stream));
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (uint32_t i = 0; i < n_contigs; i++)
         if (lens[i]) BF_HIP(ctx, hipMemcpy(ctx->g_raw.as<uint8_t>() + ctx->contig_host[i].goff, seqs[i], lens[i], hipMemcpyHostToDevice));

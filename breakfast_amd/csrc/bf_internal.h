@@ -118,7 +118,7 @@ struct bf_ctx {
     std::vector<uint32_t> contig_by_rank;       // rank -> id
     std::vector<bf::ContigDev> contig_host;
     uint64_t genome_bases = 0;                  // padded total (multiple of 64)
-    bf::DevBuf g_blocks, g_raw, g_coarse, g_contigs;
+    bf::DevBuf g_blocks, g_raw, g_coarse, g_coarse2, g_contigs;
 
     // source-side resident reads
     uint64_t n_reads = 0;

@@ -29,6 +29,7 @@ __device__ __forceinline__ bool is_acgt(uint8_t c) { return c == 'A' || c == 'C'
 __global__ void __launch_bounds__(256) genome_pack_kernel(const uint8_t* __restrict__ raw,
                                                           GenomeBlock* __restrict__ blocks,
                                                           uint64_t* __restrict__ coarse,
+                                                          uint32_t* __restrict__ coarse2,
                                                           uint64_t n_blocks /* multiple of 64 */) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_blocks) return;  // whole waves only: n_blocks and blockDim are multiples of 64
@@ -54,7 +55,11 @@ __global__ void __launch_bounds__(256) genome_pack_kernel(const uint8_t* __restr
     }
     blocks[t] = GenomeBlock{lo, hi};
     const uint64_t flags = __ballot(exc);
-    if ((threadIdx.x & 63) == 0) coarse[t >> 6] = flags;
+    if ((threadIdx.x & 63) == 0) {
+        coarse[t >> 6] = flags;
+        // second level: one bit per coarse word (4096 bases); zero-initialised, set bits are rare
+        if (flags) atomicOr(&coarse2[t >> 11], 1u << ((t >> 6) & 31));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -168,6 +173,48 @@ __device__ __forceinline__ void load_window(const GenomeBlock* __restrict__ bloc
     }
 }
 
+// Cooperative form of the same gather: the wave's 64 windows are fetched as 64*(W+1) 16-byte
+// pieces, piece p = block p%(W+1) of the window of lane p/(W+1), so the W+1 adjacent lanes that
+// fetch one window's consecutive blocks sit in ONE load instruction and coalesce into one or two
+// 64-byte requests (issued per lane, one block per instruction, the same line is requested W+1
+// times while its first miss is still in flight: rocprofv3 showed 5.0 128-byte requests per read
+// against the 3.4 the addresses need).  Pieces go through LDS rows of RS16*16 bytes
+// (48 B for W=2, 80 B otherwise: conflict-free for the ds_read_b128 lane groups).
+template <int W> struct CoopGeom {
+    static constexpr int NB = W + 1;
+    static constexpr int RS16 = (NB == 3) ? 3 : 5;
+    static constexpr int WAVE_U4 = 64 * RS16;              // uint4 per wave per window
+};
+
+template <int W>
+__device__ __forceinline__ void coop_fetch(const GenomeBlock* __restrict__ blocks, uint32_t first_block,
+                                           uint4* __restrict__ wlds, int lane) {
+    constexpr int NB = CoopGeom<W>::NB, RS16 = CoopGeom<W>::RS16;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const int p = 64 * k + lane;
+        const int ri = p / NB, bi = p - ri * NB;
+        const uint32_t src = (uint32_t)__shfl((int)first_block, ri);
+        wlds[ri * RS16 + bi] = ((const uint4*)blocks)[(uint64_t)src + bi];
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void coop_take(const uint4* __restrict__ wlds, int lane, int sh,
+                                          uint64_t (&lo)[W], uint64_t (&hi)[W]) {
+    constexpr int RS16 = CoopGeom<W>::RS16;
+    uint4 x[W + 1];
+#pragma unroll
+    for (int i = 0; i <= W; i++) x[i] = wlds[lane * RS16 + i];
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const uint64_t l0 = ((uint64_t)x[w].y << 32) | x[w].x, h0 = ((uint64_t)x[w].w << 32) | x[w].z;
+        const uint64_t l1 = ((uint64_t)x[w + 1].y << 32) | x[w + 1].x, h1 = ((uint64_t)x[w + 1].w << 32) | x[w + 1].z;
+        lo[w] = (l0 >> sh) | ((l1 << 1) << (63 - sh));
+        hi[w] = (h0 >> sh) | ((h1 << 1) << (63 - sh));
+    }
+}
+
 template <int W>
 __device__ __forceinline__ uint32_t extract8(const uint64_t (&p)[W], int off) {
     // bits [off, off+8) of the multi-word value (off + 8 <= 64W)
@@ -197,6 +244,7 @@ struct LocaliseArgs {
     const ContigDev* contigs;
     const GenomeBlock* blocks;
     const uint64_t* coarse;
+    const uint32_t* coarse2;
     uint64_t* key;
     int32_t* lpos;
     int32_t* rpos;
@@ -237,10 +285,13 @@ __device__ __forceinline__ uint64_t make_key(const Oriented& o, bool sigx, uint3
            ((uint64_t)sigx << kKeySigxBit) | sig;
 }
 
-template <int W>
+template <int W, bool COOP>
 __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n) return;
+    __shared__ uint4 lds[COOP ? 4 * 2 * CoopGeom<W>::WAVE_U4 : 1];
+    const uint64_t r_raw = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r_raw < a.n;
+    if (!COOP && !live) return;
+    const uint64_t r = live ? r_raw : a.n - 1;           // COOP: every lane of the wave takes part in the gather
     const int L = a.len[r];
     const int A = a.A;
     const bf_hit h = a.hits[r];
@@ -263,17 +314,41 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
         rex[w] = a.planes[((uint64_t)(2 * W + w)) * a.n + r];
     }
     uint64_t llo[W], lhi[W], qlo[W], qhi[W];
-    load_window<W>(a.blocks, lg, llo, lhi);
-    load_window<W>(a.blocks, rg, qlo, qhi);
+    if (COOP) {
+        const int lane = threadIdx.x & 63;
+        uint4* wl = lds + (threadIdx.x >> 6) * 2 * CoopGeom<W>::WAVE_U4;
+        uint4* wr = wl + CoopGeom<W>::WAVE_U4;
+        coop_fetch<W>(a.blocks, (uint32_t)(lg >> 6), wl, lane);
+        coop_fetch<W>(a.blocks, (uint32_t)(rg >> 6), wr, lane);
+        // LDS operations of one wave execute in order; only the compiler must not reorder them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        coop_take<W>(wl, lane, (int)(lg & 63), llo, lhi);
+        coop_take<W>(wr, lane, (int)(rg & 63), qlo, qhi);
+    } else {
+        load_window<W>(a.blocks, lg, llo, lhi);
+        load_window<W>(a.blocks, rg, qlo, qhi);
+    }
+    if (COOP && !live) return;
     {
-        const uint64_t lb = lg >> 6, rb = rg >> 6;
-        const int lnb = (int)(((lg + L - 1) >> 6) - lb) + 1, rnb = (int)(((rg + L - 1) >> 6) - rb) + 1;
-        const uint64_t c0 = a.coarse[lb >> 6], c1 = a.coarse[(lb >> 6) + 1];
-        const uint64_t d0 = a.coarse[rb >> 6], d1 = a.coarse[(rb >> 6) + 1];
-        const int ls_ = (int)(lb & 63), rs_ = (int)(rb & 63);
-        const uint64_t lbits = ((c0 >> ls_) | ((c1 << 1) << (63 - ls_))) & low_mask(lnb);
-        const uint64_t rbits = ((d0 >> rs_) | ((d1 << 1) << (63 - rs_))) & low_mask(rnb);
-        ok = ok && lbits == 0 && rbits == 0;
+        // exception test, two levels.  Level 2 (one bit per 4096 bases, ~100 KB for hg38, L2-resident)
+        // clears almost every window; only flagged ones read the per-64-base bitmap (6 MB for hg38:
+        // it does not fit a 4 MiB XCD L2, and probing it for every read cost 1.5 of the 5.0 memory
+        // requests per read that rocprofv3 counted).
+        const uint64_t lb = lg >> 6, rb = rg >> 6, le = (lg + L - 1) >> 6, re = (rg + L - 1) >> 6;
+        const uint32_t l0 = (uint32_t)(lb >> 6), l1 = (uint32_t)(le >> 6), r0 = (uint32_t)(rb >> 6), r1 = (uint32_t)(re >> 6);
+        const uint32_t hit2 = ((a.coarse2[l0 >> 5] >> (l0 & 31)) | (a.coarse2[l1 >> 5] >> (l1 & 31)) |
+                               (a.coarse2[r0 >> 5] >> (r0 & 31)) | (a.coarse2[r1 >> 5] >> (r1 & 31))) & 1u;
+        if (hit2) {
+            const int lnb = (int)(le - lb) + 1, rnb = (int)(re - rb) + 1;
+            const uint64_t c0 = a.coarse[lb >> 6], c1 = a.coarse[(lb >> 6) + 1];
+            const uint64_t d0 = a.coarse[rb >> 6], d1 = a.coarse[(rb >> 6) + 1];
+            const int ls_ = (int)(lb & 63), rs_ = (int)(rb & 63);
+            const uint64_t lbits = ((c0 >> ls_) | ((c1 << 1) << (63 - ls_))) & low_mask(lnb);
+            const uint64_t rbits = ((d0 >> rs_) | ((d1 << 1) << (63 - rs_))) & low_mask(rnb);
+            ok = ok && lbits == 0 && rbits == 0;
+        }
     }
     if (!ok) {
         const uint32_t slot = atomicAdd(&a.counters[0], 1u);
@@ -508,14 +583,17 @@ int genome_pack(bf_ctx* ctx) {
     Scope t(ctx, "genome_pack");
     hipLaunchKernelGGL(genome_pack_kernel, dim3(grid_for(n_blocks, 256)), dim3(256), 0, ctx->stream,
                        ctx->g_raw.as<uint8_t>(), ctx->g_blocks.as<GenomeBlock>(),
-                       ctx->g_coarse.as<uint64_t>(), n_blocks);
+                       ctx->g_coarse.as<uint64_t>(), ctx->g_coarse2.as<uint32_t>(), n_blocks);
     BF_HIP(ctx, hipGetLastError());
     return BF_OK;
 }
 
 template <int W>
 static void launch_fast(bf_ctx* ctx, const LocaliseArgs& a) {
-    hipLaunchKernelGGL(localise_fast_kernel<W>, dim3(grid_for(a.n, 256)), dim3(256), 0, ctx->stream, a);
+    if (ctx->cfg.flags & BF_FLAG_PER_LANE_GATHER)
+        hipLaunchKernelGGL((localise_fast_kernel<W, false>), dim3(grid_for(a.n, 256)), dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((localise_fast_kernel<W, true>), dim3(grid_for(a.n, 256)), dim3(256), 0, ctx->stream, a);
 }
 
 int run_localise(bf_ctx* ctx) {
@@ -570,6 +648,7 @@ int run_localise(bf_ctx* ctx) {
     a.hits = ctx->d_hits.as<bf_hit>(); a.len = ctx->d_len.as<uint16_t>();
     a.planes = ctx->d_planes.as<uint64_t>(); a.contigs = ctx->g_contigs.as<ContigDev>();
     a.blocks = ctx->g_blocks.as<GenomeBlock>(); a.coarse = ctx->g_coarse.as<uint64_t>();
+    a.coarse2 = ctx->g_coarse2.as<uint32_t>();
     a.key = ctx->d_key.as<uint64_t>(); a.lpos = ctx->d_lpos.as<int32_t>(); a.rpos = ctx->d_rpos.as<int32_t>();
     a.bp = ctx->d_bp.as<uint16_t>(); a.flags = ctx->d_flags.as<uint16_t>(); a.mask = ctx->d_mask.as<uint64_t>();
     a.exact_list = ctx->d_exact_list.as<uint32_t>(); a.counters = ctx->d_counters.as<uint32_t>();

@@ -10,7 +10,7 @@ import oracle_lib as ol
 from conftest import golden_names, load_golden
 
 from breakfast_amd import engine, synth
-from breakfast_amd.engine import BF_FLAG_FORCE_EXACT, BF_FLAG_KEEP_EVIDENCE
+from breakfast_amd.engine import BF_FLAG_FORCE_EXACT, BF_FLAG_KEEP_EVIDENCE, BF_FLAG_PER_LANE_GATHER
 
 pytestmark = pytest.mark.gpu
 
@@ -86,6 +86,15 @@ def test_scaled_baseline_config(cfg, scale, gscale):
     b = synth.make_reads(g, spec)
     res, ref = check_against_oracle(g, b, spec.anchor_len)
     assert ref.n_clusters > 0
+
+
+@pytest.mark.parametrize("cfg,scale,gscale", [(0, 0.05, 0.02), (1, 0.004, 0.002), (4, 0.002, 0.002)])
+def test_scaled_baseline_config_per_lane_gather(cfg, scale, gscale):
+    # the A/B variant of the localise kernel (per-lane window loads) must give the same answers
+    contigs, gk, spec = synth.config(cfg, scale=scale, genome_scale=gscale)
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    check_against_oracle(g, b, spec.anchor_len, flags=BF_FLAG_PER_LANE_GATHER)
 
 
 def test_scaled_config_exact_kernel_only():
