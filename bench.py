@@ -57,7 +57,9 @@ def main():
     ap.add_argument("--config", type=int, default=1, help="index into BASELINE.json configs (default 1)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink reads AND genome (smoke runs only)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads in the CPU baseline sample (0 = skip)")
-    ap.add_argument("--per-lane-gather", action="store_true", help="A/B: per-lane flank loads instead of the cooperative gather")
+    ap.add_argument("--variant", choices=["fused", "separate", "coop"], default="fused",
+                    help="A/B of the localise stage: fused encode+localise (shipped), separate encode kernel, "
+                         "separate encode + cooperative LDS-staged gather")
     ap.add_argument("--check", action="store_true", help="also compare the GPU .sv with the oracle's on the sample")
     args = ap.parse_args()
 
@@ -85,7 +87,7 @@ def main():
     log(rank, "reads: %d x %d bp per rank in %.1fs" % (n_local, L, time.time() - t1))
 
     # ---- resident inputs -------------------------------------------------------------------------
-    eng = engine.Engine(A, 5000, 2, device=local, flags=engine.BF_FLAG_PER_LANE_GATHER if args.per_lane_gather else 0)
+    eng = engine.Engine(A, 5000, 2, device=local, flags={"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER}[args.variant])
     t2 = time.time()
     eng.set_genome(genome.names, genome.seqs)
     log(rank, "genome packed into HBM in %.1fs" % (time.time() - t2))

@@ -234,13 +234,73 @@ __device__ __forceinline__ uint64_t low_mask(int nbits) {   // nbits in [0, 64]
     return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// In-register encoding of one read (fused path): the lane loads its own ASCII bases as 16-byte groups
+// (4-byte aligned; every fetched line is fully used by this lane and its neighbours) and turns each
+// dword of 4 bases into three 4-bit nibbles (low code bit, high code bit, "not ACGT") with SWAR
+// arithmetic: code = (c >> 1) & 3 (A0 C1 T2 G3); a byte is ACGT iff it equals
+// 0x41 + 2*c0 + 0x13*c1 - 0x0F*(c0 & c1) = 'A','C','T','G' for codes 0..3.
+struct __attribute__((aligned(4))) U4A { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ uint32_t gather4(uint32_t v) {   // bits 0,8,16,24 -> bits 0..3
+    const uint32_t a = v | (v >> 7);
+    return (a | (a >> 14)) & 0xfu;
+}
+
+template <int W>
+__device__ __forceinline__ void encode_ascii(const uint8_t* __restrict__ seq, uint64_t o, int L,
+                                             uint64_t (&lo)[W], uint64_t (&hi)[W], uint64_t (&ex)[W]) {
+    constexpr int ND = 16 * W;                              // dwords of 4 bases
+    const uint32_t sh8 = (uint32_t)(o & 3);
+    const U4A* __restrict__ src = (const U4A*)(seq + (o - sh8));
+    const int need = (int)((sh8 + (uint32_t)L + 3u) >> 2);  // aligned dwords holding the read
+    uint32_t d[ND + 4];
+#pragma unroll
+    for (int g = 0; g <= ND / 4; g++) {
+        U4A v{0, 0, 0, 0};
+        if (4 * g < need) v = src[g];
+        d[4 * g] = v.x; d[4 * g + 1] = v.y; d[4 * g + 2] = v.z; d[4 * g + 3] = v.w;
+    }
+    uint32_t plo[2 * W], phi[2 * W], pex[2 * W];
+#pragma unroll
+    for (int i = 0; i < 2 * W; i++) plo[i] = phi[i] = pex[i] = 0;
+#pragma unroll
+    for (int g = 0; g < ND / 4; g++) {
+        if (__any(4 * g < need)) {                          // wave-uniform skip of the unused tail
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int j = 4 * g + q;
+                const uint32_t x = __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh8);
+                const uint32_t c0 = (x >> 1) & 0x01010101u, c1 = (x >> 2) & 0x01010101u;
+                const uint32_t expect = 0x41414141u + (c0 << 1) + c1 * 0x13u - (c0 & c1) * 0x0fu;
+                const uint32_t e = x ^ expect;
+                const uint32_t nz = ((((e & 0x7f7f7f7fu) + 0x7f7f7f7fu) | e) >> 7) & 0x01010101u;
+                const int slot = j >> 3, bit = 4 * (j & 7);
+                plo[slot] |= gather4(c0) << bit;
+                phi[slot] |= gather4(c1) << bit;
+                pex[slot] |= gather4(nz) << bit;
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const uint64_t vm = low_mask(min(max(L - 64 * w, 0), 64));
+        lo[w] = (((uint64_t)plo[2 * w + 1] << 32) | plo[2 * w]) & vm;
+        hi[w] = (((uint64_t)phi[2 * w + 1] << 32) | phi[2 * w]) & vm;
+        ex[w] = (((uint64_t)pex[2 * w + 1] << 32) | pex[2 * w]) & vm;
+    }
+}
+
 struct LocaliseArgs {
     uint64_t n;
     int A;
     uint32_t force_exact;
     const bf_hit* hits;
-    const uint16_t* len;
-    const uint64_t* planes;
+    const uint16_t* len;          // separate-encode variant: read lengths (input)
+    uint16_t* len_out;            // fused variant: read lengths (output)
+    const uint64_t* planes;       // separate-encode variant
+    const uint8_t* seq;           // fused variant: ASCII reads
+    const uint64_t* seq_off;
     const ContigDev* contigs;
     const GenomeBlock* blocks;
     const uint64_t* coarse;
@@ -285,14 +345,22 @@ __device__ __forceinline__ uint64_t make_key(const Oriented& o, bool sigx, uint3
            ((uint64_t)sigx << kKeySigxBit) | sig;
 }
 
-template <int W, bool COOP>
+template <int W, bool COOP, bool FUSED>
 __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a) {
     __shared__ uint4 lds[COOP ? 4 * 2 * CoopGeom<W>::WAVE_U4 : 1];
     const uint64_t r_raw = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r_raw < a.n;
     if (!COOP && !live) return;
     const uint64_t r = live ? r_raw : a.n - 1;           // COOP: every lane of the wave takes part in the gather
-    const int L = a.len[r];
+    uint64_t so = 0;
+    int L;
+    if (FUSED) {
+        so = a.seq_off[r];
+        L = (int)(a.seq_off[r + 1] - so);
+        a.len_out[r] = (uint16_t)L;
+    } else {
+        L = a.len[r];
+    }
     const int A = a.A;
     const bf_hit h = a.hits[r];
     const Oriented o = orient(h, a.contigs);
@@ -305,13 +373,23 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
     const uint64_t lg = o.c.goff + (uint64_t)(ok ? ls : 0);
     const uint64_t rg = o.mc.goff + (uint64_t)(ok ? rs : 0);
 
-    // issue every load before the first use: planes (coalesced), windows + coarse bits (gathers)
     uint64_t rlo[W], rhi[W], rex[W];
+    if (FUSED) {
+        // read bases are requested first and the flank windows right after, so the encode arithmetic
+        // runs while the window gathers are still in flight (vmcnt retires in issue order)
+        if (L <= 64 * W) {
+            encode_ascii<W>(a.seq, so, L, rlo, rhi, rex);
+        } else {
 #pragma unroll
-    for (int w = 0; w < W; w++) {
-        rlo[w] = a.planes[((uint64_t)(0 * W + w)) * a.n + r];
-        rhi[w] = a.planes[((uint64_t)(1 * W + w)) * a.n + r];
-        rex[w] = a.planes[((uint64_t)(2 * W + w)) * a.n + r];
+            for (int w = 0; w < W; w++) rlo[w] = rhi[w] = rex[w] = 0;
+        }
+    } else {
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            rlo[w] = a.planes[((uint64_t)(0 * W + w)) * a.n + r];
+            rhi[w] = a.planes[((uint64_t)(1 * W + w)) * a.n + r];
+            rex[w] = a.planes[((uint64_t)(2 * W + w)) * a.n + r];
+        }
     }
     uint64_t llo[W], lhi[W], qlo[W], qhi[W];
     if (COOP) {
@@ -590,10 +668,13 @@ int genome_pack(bf_ctx* ctx) {
 
 template <int W>
 static void launch_fast(bf_ctx* ctx, const LocaliseArgs& a) {
-    if (ctx->cfg.flags & BF_FLAG_PER_LANE_GATHER)
-        hipLaunchKernelGGL((localise_fast_kernel<W, false>), dim3(grid_for(a.n, 256)), dim3(256), 0, ctx->stream, a);
+    const dim3 g(grid_for(a.n, 256)), b(256);
+    if (ctx->cfg.flags & BF_FLAG_COOP_GATHER)
+        hipLaunchKernelGGL((localise_fast_kernel<W, true, false>), g, b, 0, ctx->stream, a);
+    else if (ctx->cfg.flags & BF_FLAG_SEPARATE_ENCODE)
+        hipLaunchKernelGGL((localise_fast_kernel<W, false, false>), g, b, 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL((localise_fast_kernel<W, true>), dim3(grid_for(a.n, 256)), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL((localise_fast_kernel<W, false, true>), g, b, 0, ctx->stream, a);
 }
 
 int run_localise(bf_ctx* ctx) {
@@ -611,7 +692,6 @@ int run_localise(bf_ctx* ctx) {
     ctx->plane_words = W;
     ctx->mask_words = Wm;
 
-    BF_TRY(ensure(ctx, ctx->d_planes, (size_t)3 * W * n * 8));
     BF_TRY(ensure(ctx, ctx->d_len, n * 2));
     BF_TRY(ensure(ctx, ctx->d_frag_len, n * 2));
     BF_TRY(ensure(ctx, ctx->d_fhash, n * 8));
@@ -627,7 +707,9 @@ int run_localise(bf_ctx* ctx) {
     BF_HIP(ctx, hipMemsetAsync(ctx->d_counters.p, 0, 64, ctx->stream));
     if (Wm > W) BF_HIP(ctx, hipMemsetAsync(ctx->d_mask.p, 0, (size_t)Wm * n * 8, ctx->stream));
 
-    {
+    const bool separate = (ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE)) != 0;
+    if (separate) {
+        BF_TRY(ensure(ctx, ctx->d_planes, (size_t)3 * W * n * 8));
         Scope t(ctx, "encode_reads");
         const dim3 eg(grid_for(((n + 63) / 64) * 64, 256));
         if (W == 2) hipLaunchKernelGGL(encode_reads_kernel<2>, eg, dim3(256), 0, ctx->stream, n, ctx->d_seq.as<uint8_t>(),
@@ -636,6 +718,9 @@ int run_localise(bf_ctx* ctx) {
                                             ctx->d_seq_off.as<uint64_t>(), ctx->d_planes.as<uint64_t>());
         else hipLaunchKernelGGL(encode_reads_kernel<4>, eg, dim3(256), 0, ctx->stream, n, ctx->d_seq.as<uint8_t>(),
                                 ctx->d_seq_off.as<uint64_t>(), ctx->d_planes.as<uint64_t>());
+    }
+    {
+        Scope t(ctx, "read_meta");
         hipLaunchKernelGGL(read_meta_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n,
                            ctx->d_seq_off.as<uint64_t>(), ctx->d_frag.as<uint8_t>(),
                            ctx->d_frag_off.as<uint64_t>(), ctx->d_len.as<uint16_t>(),
@@ -646,7 +731,8 @@ int run_localise(bf_ctx* ctx) {
     LocaliseArgs a{};
     a.n = n; a.A = (int)A; a.force_exact = (ctx->cfg.flags & BF_FLAG_FORCE_EXACT) ? 1u : 0u;
     a.hits = ctx->d_hits.as<bf_hit>(); a.len = ctx->d_len.as<uint16_t>();
-    a.planes = ctx->d_planes.as<uint64_t>(); a.contigs = ctx->g_contigs.as<ContigDev>();
+    a.planes = ctx->d_planes.as<uint64_t>(); a.len_out = ctx->d_len.as<uint16_t>();
+    a.seq = ctx->d_seq.as<uint8_t>(); a.seq_off = ctx->d_seq_off.as<uint64_t>(); a.contigs = ctx->g_contigs.as<ContigDev>();
     a.blocks = ctx->g_blocks.as<GenomeBlock>(); a.coarse = ctx->g_coarse.as<uint64_t>();
     a.coarse2 = ctx->g_coarse2.as<uint32_t>();
     a.key = ctx->d_key.as<uint64_t>(); a.lpos = ctx->d_lpos.as<int32_t>(); a.rpos = ctx->d_rpos.as<int32_t>();

@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libbreakfast_hip.so")
 
 BF_FLAG_KEEP_EVIDENCE = 1
 BF_FLAG_FORCE_EXACT = 2
-BF_FLAG_PER_LANE_GATHER = 4
+BF_FLAG_COOP_GATHER = 4
+BF_FLAG_SEPARATE_ENCODE = 8
 BF_EV_STRAND, BF_EV_MSTRAND, BF_EV_SWAPPED, BF_EV_EXACT, BF_EV_SIGX = 1, 2, 4, 8, 16
 
 HIT_DTYPE = np.dtype([("pos5", "<u4"), ("pos3", "<u4"), ("contig5", "<u2"), ("contig3", "<u2"),

@@ -59,7 +59,8 @@ typedef struct {
 
 #define BF_FLAG_KEEP_EVIDENCE 1u   /* keep per-read evidence readable via bf_evidence_fetch (tests) */
 #define BF_FLAG_FORCE_EXACT   2u   /* route every read through the byte-exact kernel (tests)        */
-#define BF_FLAG_PER_LANE_GATHER 4u /* A/B: fetch flank windows per lane instead of cooperatively   */
+#define BF_FLAG_COOP_GATHER     4u /* A/B: separate encode kernel + cooperative (LDS-staged) flank gather */
+#define BF_FLAG_SEPARATE_ENCODE 8u /* A/B: separate encode kernel + per-lane flank gather               */
 
 /* One pair of anchor alignments = the fields the consume loop parses out of a `5p:`/`3p:` line
  * pair (detect.rs:94-103): bowtie's strand, contig and 1-based leftmost offset (-B1) of each anchor.

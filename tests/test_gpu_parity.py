@@ -10,7 +10,7 @@ import oracle_lib as ol
 from conftest import golden_names, load_golden
 
 from breakfast_amd import engine, synth
-from breakfast_amd.engine import BF_FLAG_FORCE_EXACT, BF_FLAG_KEEP_EVIDENCE, BF_FLAG_PER_LANE_GATHER
+from breakfast_amd.engine import BF_FLAG_COOP_GATHER, BF_FLAG_FORCE_EXACT, BF_FLAG_KEEP_EVIDENCE, BF_FLAG_SEPARATE_ENCODE
 
 pytestmark = pytest.mark.gpu
 
@@ -88,13 +88,15 @@ def test_scaled_baseline_config(cfg, scale, gscale):
     assert ref.n_clusters > 0
 
 
+@pytest.mark.parametrize("flag", [BF_FLAG_COOP_GATHER, BF_FLAG_SEPARATE_ENCODE])
 @pytest.mark.parametrize("cfg,scale,gscale", [(0, 0.05, 0.02), (1, 0.004, 0.002), (4, 0.002, 0.002)])
-def test_scaled_baseline_config_per_lane_gather(cfg, scale, gscale):
-    # the A/B variant of the localise kernel (per-lane window loads) must give the same answers
+def test_scaled_baseline_config_ab_variants(cfg, scale, gscale, flag):
+    # the A/B variants of the localise stage (separate encode kernel; cooperative gather) must give
+    # the same answers as the shipped fused kernel
     contigs, gk, spec = synth.config(cfg, scale=scale, genome_scale=gscale)
     g = synth.make_genome(contigs, **gk)
     b = synth.make_reads(g, spec)
-    check_against_oracle(g, b, spec.anchor_len, flags=BF_FLAG_PER_LANE_GATHER)
+    check_against_oracle(g, b, spec.anchor_len, flags=flag)
 
 
 def test_scaled_config_exact_kernel_only():
