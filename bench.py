@@ -140,7 +140,8 @@ def main():
     bpr = algorithmic_bytes_per_read(L)
     achieved = n_local * bpr / (loc_avg_ms * 1e-3) / 1e9 if loc_avg_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": "localise_fast_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": pmc_traffic(args, n_local, L),
                 "algorithmic_bytes_per_read": bpr, "reads_per_launch": n_local, "avg_launch_ms": round(loc_avg_ms, 4)}
     stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in ktimes.items()}
 
@@ -186,6 +187,24 @@ def main():
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(args, n_local, L):
+    """HBM bytes per launch of the localise kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.json, made by tools/pmc_traffic.py on this very workload and variant);
+    None when no pass matches the run's configuration."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            want = "config=%d reads=%d len=%d variant=%s" % (args.config, n_local, L, args.variant)
+            if want in d.get("workload", ""):
+                for k, v in d["kernels"].items():
+                    if "localise_fast_kernel" in k:
+                        return v["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
 
 
 def cpu_model():

@@ -327,9 +327,11 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
             BF_TRY(patch_reads(ctx, ctx->c_joff.as<uint64_t>(), nr));
             ctx->out.junction_size = total;
             BF_TRY(ensure_host(ctx, ctx->out.junction, total));
+            Scope t(ctx, "d2h_junctions");
             if (total) BF_HIP(ctx, hipMemcpyAsync(ctx->out.junction.p, ctx->c_jbytes.p, total, hipMemcpyDeviceToHost, ctx->stream));
         }
         BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
+        Scope t(ctx, "d2h_reads");
         BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
     }
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -175,3 +175,29 @@ def test_error_behaviour():
             eng.set_genome([b"x", b"x"], [b"ACGT" * 100, b"ACGT" * 100])
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("name", ["kat_survey", "hz_contig_order", "hz_ref_alphabet", "hz_pairing", "hz_wrapped_coords"])
+def test_cli_driver_reproduces_golden(name, tmp_path):
+    """`breakfast-hip detect` (the C++ host driver over the C ABI): same argv shape and stdout as the reference."""
+    import os
+    import subprocess
+    from conftest import GOLDEN, ROOT
+    exe = os.path.join(ROOT, "breakfast_amd", "csrc", "breakfast-hip")
+    assert os.path.exists(exe), "build the CLI driver first (__graft_entry__.build)"
+    fa, lines, (A, F, E), sv = load_golden(name)
+    prefix = os.path.join(GOLDEN, name)          # the driver opens <genome>.fa like detect.rs:48
+    p = subprocess.run([exe, "detect", "--anchor-len=%d" % A, "--max-frag-len=%d" % F, "--min-evidence=%d" % E,
+                        "--anchor-hits=%s.bowtie" % prefix, "unused.bam", prefix], capture_output=True, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()
+    assert p.stdout == sv
+    assert b"Found " in p.stderr and b"rearrangement supporting reads." in p.stderr
+
+
+def test_cli_driver_error_convention(tmp_path):
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "breakfast_amd", "csrc", "breakfast-hip")
+    p = subprocess.run([exe, "detect", "--anchor-hits=/dev/null", "x.bam", "/nonexistent/genome"], capture_output=True, timeout=120)
+    assert p.returncode == 255 and p.stderr.startswith(b"ERROR: ")      # common.rs:8-13: exit(-1)
