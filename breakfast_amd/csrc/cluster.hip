@@ -101,19 +101,27 @@ __device__ __forceinline__ bool rpos_far(int32_t rs, int32_t rp, int64_t F) {
     return (d < 0 ? -d : d) > F;
 }
 
-// The reference's sweep (detect.rs:203-227) inside one key segment; the lane at the segment head
-// walks it sequentially.  csize[p] = cluster size if p is a seed, else 0.
+// The reference's sweep (detect.rs:203-227) inside one key segment.  Segments of up to kBigSegment
+// evidence are walked sequentially by the lane at the segment head; longer ones (duplicate-heavy
+// libraries pile thousands of reads on one junction) are queued for sweep_big_kernel.
+// csize[p] = cluster size if p is a seed; csize is zero-initialised.
+constexpr uint32_t kBigSegment = 96;
+
 __global__ void __launch_bounds__(256) sweep_kernel(const SweepView v, uint8_t* __restrict__ reported,
-                                                    uint32_t* __restrict__ csize) {
+                                                    uint32_t* __restrict__ csize, uint32_t* __restrict__ big_list,
+                                                    uint32_t* __restrict__ big_count) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.n) return;
     const uint64_t key = v.skey[i];
     if (i > 0 && v.skey[i - 1] == key) return;
-    for (uint64_t p = i; p < v.n && v.skey[p] == key; p++) {
-        if (reported[p]) { csize[p] = 0; continue; }
+    uint64_t e = i + 1;
+    while (e < v.n && e - i <= kBigSegment && v.skey[e] == key) e++;
+    if (e - i > kBigSegment) { big_list[atomicAdd(big_count, 1u)] = (uint32_t)i; return; }
+    for (uint64_t p = i; p < e; p++) {
+        if (reported[p]) continue;
         const int32_t lp = v.slpos[p], rp = v.srpos[p];
         uint32_t cnt = 1;
-        for (uint64_t s = p + 1; s < v.n && v.skey[s] == key; s++) {
+        for (uint64_t s = p + 1; s < e; s++) {
             if (beyond(v.slpos[s], lp, v.F)) break;
             if (rpos_far(v.srpos[s], rp, v.F)) continue;
             if (!same_sigx(v, key, p, s)) continue;
@@ -121,6 +129,48 @@ __global__ void __launch_bounds__(256) sweep_kernel(const SweepView v, uint8_t* 
             reported[s] = 1;
         }
         csize[p] = cnt;
+    }
+}
+
+// One wave per long segment: seeds are still taken in order (the sweep is sequential in the seeds),
+// but finding the next unreported read and testing a seed's window run 64 reads at a time.
+__global__ void __launch_bounds__(256) sweep_big_kernel(const SweepView v, uint8_t* reported, uint32_t* __restrict__ csize,
+                                                        const uint32_t* __restrict__ big_list, uint32_t n_big) {
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (b >= n_big) return;
+    const uint64_t i = big_list[b];
+    const uint64_t key = v.skey[i];
+    uint64_t e = i;                                          // segment end
+    for (;; e += 64) {
+        const uint64_t s = e + lane;
+        const uint64_t same = __ballot(s < v.n && v.skey[s] == key);
+        if (same != ~0ull) { e += __popcll(same); break; }   // the key is constant over a prefix
+    }
+    uint64_t cursor = i;
+    while (cursor < e) {
+        // next unreported read at or after the cursor = the next seed
+        uint64_t p = ~0ull;
+        for (uint64_t c0 = cursor; c0 < e; c0 += 64) {
+            const uint64_t s = c0 + lane;
+            const uint64_t open = __ballot(s < e && reported[s] == 0);
+            if (open) { p = c0 + __builtin_ctzll(open); break; }
+        }
+        if (p == ~0ull) break;
+        const int32_t lp = v.slpos[p], rp = v.srpos[p];
+        uint32_t cnt = 1;
+        for (uint64_t s0 = p + 1;; s0 += 64) {
+            const uint64_t s = s0 + lane;
+            const bool live = s < e && !beyond(v.slpos[s], lp, v.F);
+            const bool take = live && !rpos_far(v.srpos[s], rp, v.F) && same_sigx(v, key, p, s);
+            if (take) reported[s] = 1;
+            cnt += (uint32_t)__popcll(__ballot(take));
+            if (__ballot(live) != ~0ull) break;
+        }
+        if (lane == 0) csize[p] = cnt;
+        // the marks written above are read back by other lanes of this wave in the next round
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        cursor = p + 1;
     }
 }
 
@@ -142,7 +192,7 @@ __global__ void compact_index_kernel(const uint32_t* __restrict__ flag, const ui
 struct MemberView {
     const uint32_t* qseed; const uint64_t* qoff;
     uint32_t* members;      // sorted positions
-    uint64_t* mhash;        // fragment hash per member slot
+    uint64_t* mkey;         // (cluster number << 32) | low half of the fragment-id hash, per member slot
     uint32_t* mscore;       // longest-flank score per member slot (detect.rs:273-279)
     const uint64_t* fhash; const uint16_t* bp; const uint16_t* len;
 };
@@ -159,7 +209,7 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
     auto put = [&](uint64_t slot, uint64_t spos) {
         const uint32_t rec = v.perm[spos];
         m.members[slot] = (uint32_t)spos;
-        m.mhash[slot] = m.fhash[rec];
+        m.mkey[slot] = (q << 32) | (uint32_t)m.fhash[rec];
         const uint32_t l = m.bp[rec], r = (uint32_t)m.len[rec] - l;
         m.mscore[slot] = min(l, r) * 10000u + max(l, r);
     };
@@ -189,53 +239,47 @@ __device__ __forceinline__ bool same_frag(const FragView& f, uint32_t ra, uint32
     return true;
 }
 
-// leader[i] = first member of i's fragment-id group (redundant_with, detect.rs:249-261).
-// Hash equality is only a filter: groups are decided by comparing the id bytes.
-__global__ void __launch_bounds__(256) leader_kernel(const MemberView m, const FragView f, const uint32_t* __restrict__ qsize,
-                                                     uint32_t* __restrict__ leader, uint64_t nq) {
-    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (q >= nq) return;
+// Fragment-id groups (remove_frag_id_duplicates, detect.rs:247-287) without the reference's O(c^2):
+// member slots are radix-sorted by (cluster, 32 hash bits); a run of equal sort keys holds every
+// member of each of its fragment ids (equal ids hash equally), in cluster order because the sort is
+// stable.  The lane at the head of a run applies the reference's own loop to the run -- first
+// unassigned member leads, later members with the same id BYTES join it, best score wins with
+// "first maximum" (strict >, :280) -- so hash collisions only lengthen a run, never change a group.
+// rep[leader slot] = representative (index inside the cluster); kNone elsewhere.
+__global__ void __launch_bounds__(256) dedup_runs_kernel(uint64_t total_m, const uint64_t* __restrict__ skey,
+                                                         const uint32_t* __restrict__ sslot, const MemberView m,
+                                                         const FragView f, uint32_t* __restrict__ leader,
+                                                         uint32_t* __restrict__ rep, uint32_t* __restrict__ qnrep) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total_m) return;
+    const uint64_t key = skey[j];
+    if (j > 0 && skey[j - 1] == key) return;
+    const uint32_t q = (uint32_t)(key >> 32);
     const uint64_t base = m.qoff[q];
-    const uint32_t c = qsize[q];
-    for (uint32_t i = lane; i < c; i += 64) {
-        const uint64_t h = m.mhash[base + i];
-        uint32_t lead = i;
-        for (uint32_t j = 0; j < i; j++) {
-            if (m.mhash[base + j] == h &&
-                same_frag(f, f.perm[m.members[base + i]], f.perm[m.members[base + j]])) { lead = j; break; }
-        }
-        leader[base + i] = lead;
+    if (j + 1 >= total_m || skey[j + 1] != key) {          // the common case: a fragment seen once
+        const uint32_t sa = sslot[j];
+        rep[sa] = (uint32_t)(sa - base);
+        atomicAdd(&qnrep[q], 1u);
+        return;
     }
-}
-
-// rep[i] for group leaders = the member with the best score, first maximum wins (detect.rs:268-284);
-// kNone for non-leaders.  qnrep[q] = number of groups = cluster size after dedup.
-__global__ void __launch_bounds__(256) best_kernel(const MemberView m, const uint32_t* __restrict__ qsize,
-                                                   const uint32_t* __restrict__ leader, uint32_t* __restrict__ rep,
-                                                   uint32_t* __restrict__ qnrep, uint64_t nq) {
-    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (q >= nq) return;
-    const uint64_t base = m.qoff[q];
-    const uint32_t c = qsize[q];
     uint32_t groups = 0;
-    for (uint32_t i0 = 0; i0 < c; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        bool lead = false;
-        if (i < c) {
-            lead = leader[base + i] == i;
-            uint32_t best = i, best_score = m.mscore[base + i];
-            if (lead) {
-                for (uint32_t k = i + 1; k < c; k++) {
-                    if (leader[base + k] == i && m.mscore[base + k] > best_score) { best = k; best_score = m.mscore[base + k]; }
-                }
-            }
-            rep[base + i] = lead ? best : kNone;
+    for (uint64_t a = j; a < total_m && skey[a] == key; a++) {
+        const uint32_t sa = sslot[a];
+        if (leader[sa] != kNone) continue;
+        leader[sa] = sa;
+        const uint32_t ra = f.perm[m.members[sa]];
+        uint32_t best = sa, best_score = m.mscore[sa];
+        for (uint64_t b = a + 1; b < total_m && skey[b] == key; b++) {
+            const uint32_t sb = sslot[b];
+            if (leader[sb] != kNone) continue;
+            if (!same_frag(f, ra, f.perm[m.members[sb]])) continue;
+            leader[sb] = sa;
+            if (m.mscore[sb] > best_score) { best = sb; best_score = m.mscore[sb]; }
         }
-        groups += (uint32_t)__popcll(__ballot(lead));
+        rep[sa] = (uint32_t)(best - base);
+        groups++;
     }
-    if (lane == 0) qnrep[q] = groups;
+    atomicAdd(&qnrep[q], groups);
 }
 
 struct OrderView {
@@ -359,9 +403,19 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     uint64_t nq = 0;
     {
         Scope t(ctx, "sweep");
+        BF_TRY(ensure(ctx, ctx->c_big, (n / kBigSegment + 2) * 4));
         BF_HIP(ctx, hipMemsetAsync(ctx->c_reported.p, 0, n, st));
+        BF_HIP(ctx, hipMemsetAsync(ctx->c_csize.p, 0, n * 4, st));
+        BF_HIP(ctx, hipMemsetAsync(ctx->c_big.p, 0, 4, st));
+        uint32_t* big_count = ctx->c_big.as<uint32_t>(); uint32_t* big_list = big_count + 1;
         hipLaunchKernelGGL(sweep_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, sv, ctx->c_reported.as<uint8_t>(),
-                           ctx->c_csize.as<uint32_t>());
+                           ctx->c_csize.as<uint32_t>(), big_list, big_count);
+        uint32_t n_big = 0;
+        BF_HIP(ctx, hipMemcpyAsync(&n_big, big_count, 4, hipMemcpyDeviceToHost, st));
+        BF_HIP(ctx, hipStreamSynchronize(st));
+        if (n_big)
+            hipLaunchKernelGGL(sweep_big_kernel, dim3(grid_for((uint64_t)n_big * 64, B)), dim3(B), 0, st, sv,
+                               ctx->c_reported.as<uint8_t>(), ctx->c_csize.as<uint32_t>(), big_list, n_big);
         hipLaunchKernelGGL(flag_ge_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
                            ctx->c_csize.as<uint32_t>(), ctx->cfg.min_evidence, n);
         BF_TRY(scan_u32_to_u64(ctx, ctx->c_flag.as<uint32_t>(), ctx->c_scan.as<uint64_t>(), n));
@@ -378,21 +432,28 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
                        ctx->c_qsize.as<uint32_t>(), n);
     BF_TRY(scan_u32_to_u64(ctx, ctx->c_qsize.as<uint32_t>(), ctx->c_qoff.as<uint64_t>(), nq));
     BF_TRY(fetch_u64(ctx, ctx->c_qoff.as<uint64_t>() + nq, &total_m));
+    if (total_m > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "cluster membership list too long (%llu)", (unsigned long long)total_m);
     BF_TRY(ensure(ctx, ctx->c_members, total_m * 4)); BF_TRY(ensure(ctx, ctx->c_k64a, std::max(total_m, n) * 8, false));
+    BF_TRY(ensure(ctx, ctx->c_mkey_s, total_m * 8)); BF_TRY(ensure(ctx, ctx->c_slot, total_m * 4 * 2));
     BF_TRY(ensure(ctx, ctx->c_d32, total_m * 4));
     BF_TRY(ensure(ctx, ctx->c_leader, total_m * 4)); BF_TRY(ensure(ctx, ctx->c_rep, total_m * 4));
     MemberView mv{};
     mv.qseed = ctx->c_qseed.as<uint32_t>(); mv.qoff = ctx->c_qoff.as<uint64_t>();
-    mv.members = ctx->c_members.as<uint32_t>(); mv.mhash = ctx->c_k64a.as<uint64_t>(); mv.mscore = ctx->c_d32.as<uint32_t>();
+    mv.members = ctx->c_members.as<uint32_t>(); mv.mkey = ctx->c_k64a.as<uint64_t>(); mv.mscore = ctx->c_d32.as<uint32_t>();
     mv.fhash = v.fhash; mv.bp = v.bp; mv.len = v.len;
     FragView fv{perm, v.frag, v.frag_off, v.frag_len};
     {
         Scope t(ctx, "dedup");
         hipLaunchKernelGGL(fill_members_kernel, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, sv, mv, nq);
-        hipLaunchKernelGGL(leader_kernel, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, mv, fv, ctx->c_qsize.as<uint32_t>(),
-                           ctx->c_leader.as<uint32_t>(), nq);
-        hipLaunchKernelGGL(best_kernel, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, mv, ctx->c_qsize.as<uint32_t>(),
-                           ctx->c_leader.as<uint32_t>(), ctx->c_rep.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>(), nq);
+        uint32_t* slot_in = ctx->c_slot.as<uint32_t>(); uint32_t* slot_s = slot_in + total_m;
+        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(total_m, B)), dim3(B), 0, st, slot_in, total_m);
+        unsigned qbits = 1; while ((1ull << qbits) < nq) qbits++;
+        BF_TRY(sort_pairs<uint64_t>(ctx, mv.mkey, ctx->c_mkey_s.as<uint64_t>(), slot_in, slot_s, total_m, 0, 32 + qbits));
+        BF_HIP(ctx, hipMemsetAsync(ctx->c_leader.p, 0xff, total_m * 4, st));
+        BF_HIP(ctx, hipMemsetAsync(ctx->c_rep.p, 0xff, total_m * 4, st));
+        BF_HIP(ctx, hipMemsetAsync(ctx->c_qnrep.p, 0, nq * 4, st));
+        hipLaunchKernelGGL(dedup_runs_kernel, dim3(grid_for(total_m, B)), dim3(B), 0, st, total_m, ctx->c_mkey_s.as<uint64_t>(),
+                           slot_s, mv, fv, ctx->c_leader.as<uint32_t>(), ctx->c_rep.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>());
     }
     BF_HIP(ctx, hipGetLastError());
 

@@ -201,3 +201,46 @@ def test_cli_driver_error_convention(tmp_path):
     exe = os.path.join(ROOT, "breakfast_amd", "csrc", "breakfast-hip")
     p = subprocess.run([exe, "detect", "--anchor-hits=/dev/null", "x.bam", "/nonexistent/genome"], capture_output=True, timeout=120)
     assert p.returncode == 255 and p.stderr.startswith(b"ERROR: ")      # common.rs:8-13: exit(-1)
+
+
+def _frag_hash32(b: bytes) -> int:
+    """low 32 bits of read_meta_kernel's fragment-id hash (FNV-1a/64 + avalanche)."""
+    M = (1 << 64) - 1
+    h = 0xcbf29ce484222325
+    for c in b:
+        h = ((h ^ c) * 0x100000001b3) & M
+    h ^= h >> 32
+    h = (h * 0xd6e8feb86659fd93) & M
+    h ^= h >> 32
+    return h & 0xffffffff
+
+
+def test_dedup_survives_hash_collisions():
+    """Two DIFFERENT fragment ids whose 32 sort-key hash bits collide must stay two fragments (groups are
+    decided on the id bytes, detect.rs:257), while equal ids still collapse."""
+    seen = {}
+    pair = None
+    i = 0
+    while pair is None:
+        name = b"frag%d" % i
+        h = _frag_hash32(name)
+        if h in seen:
+            pair = (seen[h], name)
+        seen[h] = name
+        i += 1
+    a_id, b_id = pair
+    assert a_id != b_id and _frag_hash32(a_id) == _frag_hash32(b_id)
+    import random
+    sys_path_golden = __import__("os").path.join(__import__("conftest").GOLDEN)
+    import sys
+    sys.path.insert(0, sys_path_golden)
+    import make_golden as mg
+    g, _ = mg.base_genome(77)
+    f = mg.Fixture("tmp_collision", g, (10, 5000, 2))
+    # one junction: a_id twice (collapses to its best), b_id twice (collapses), c once -> 3 reads survive
+    for frag, b in ((a_id, 20), (b_id, 22), (a_id, 30), (b"other", 26), (b_id, 28)):
+        f.add(frag, *mg.split_read(g, b"chr1", 300, True, b"chr2", 200, True, 60, b, 10))
+    expected = f.run()
+    assert expected.count(b";") == 2
+    text = b"".join(l + b"\n" for l in f.lines)
+    assert run_gpu_text(f.fasta(), text, 10, 5000, 2) == expected
