@@ -195,6 +195,8 @@ int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, con
     if (ctx->n_reads) return fail(ctx, BF_ERR_STATE, "bf_genome_set with resident reads; call bf_reset first");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     ctx->n_contigs = n_contigs;
+    ctx->contig_bits = 1;
+    while ((1u << ctx->contig_bits) < n_contigs) ctx->contig_bits++;
     ctx->contig_names.assign(names, names + n_contigs);
     // rank by byte-wise name order (Rust String Ord == memcmp order); names must be unique
     std::vector<uint32_t> order(n_contigs);
@@ -462,16 +464,16 @@ int bf_evidence_fetch(bf_ctx* ctx, bf_evidence_view* v) {
     ctx->ev_key.resize(n); ctx->ev_lpos.resize(n); ctx->ev_rpos.resize(n); ctx->ev_bp.resize(n); ctx->ev_flags.resize(n);
     ctx->ev_mask.assign(n * W, 0);
     if (n) {
-        std::vector<uint64_t> tmp(n * W);
+        std::vector<uint64_t> tmp(n * (W + 1));
         BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         BF_HIP(ctx, hipMemcpy(ctx->ev_key.data(), ctx->d_key.p, n * 8, hipMemcpyDeviceToHost));
         BF_HIP(ctx, hipMemcpy(ctx->ev_lpos.data(), ctx->d_lpos.p, n * 4, hipMemcpyDeviceToHost));
         BF_HIP(ctx, hipMemcpy(ctx->ev_rpos.data(), ctx->d_rpos.p, n * 4, hipMemcpyDeviceToHost));
         BF_HIP(ctx, hipMemcpy(ctx->ev_bp.data(), ctx->d_bp.p, n * 2, hipMemcpyDeviceToHost));
         BF_HIP(ctx, hipMemcpy(ctx->ev_flags.data(), ctx->d_flags.p, n * 2, hipMemcpyDeviceToHost));
-        BF_HIP(ctx, hipMemcpy(tmp.data(), ctx->d_mask.p, n * W * 8, hipMemcpyDeviceToHost));
-        for (uint32_t w = 0; w < W; w++)
-            for (uint64_t r = 0; r < n; r++) ctx->ev_mask[r * W + w] = tmp[(uint64_t)w * n + r];
+        BF_HIP(ctx, hipMemcpy(tmp.data(), ctx->d_mask.p, n * (W + 1) * 8, hipMemcpyDeviceToHost));
+        for (uint64_t r = 0; r < n; r++)
+            for (uint32_t w = 0; w < W; w++) ctx->ev_mask[r * W + w] = tmp[r * (W + 1) + w];
     }
     v->n = n; v->mask_words = W;
     v->class_key = ctx->ev_key.data(); v->lpos = ctx->ev_lpos.data(); v->rpos = ctx->ev_rpos.data();

@@ -33,8 +33,10 @@ constexpr int kKeySigxBit = 32;                 // signature holds a non-ACGT by
 constexpr int kKeyMstrandBit = 33;
 constexpr int kKeyStrandBit = 34;
 constexpr int kKeyMrankShift = 35;
-constexpr int kKeyRankShift = 35 + kContigBits; // 49
-constexpr int kKeyBits = kKeyRankShift + kContigBits;  // 63
+// The two contig ranks sit above bit 35 and take `cb` bits each, cb = ceil(log2(n_contigs)) chosen
+// per genome (5 for the 25 hg38 contigs), so the radix sort only walks bits that can differ.
+__host__ __device__ inline int key_rank_shift(int cb) { return kKeyMrankShift + cb; }
+__host__ __device__ inline int key_bits(int cb) { return kKeyMrankShift + 2 * cb; }
 
 // evidence flags (low bits mirror BF_EV_*)
 constexpr uint32_t kEvStrand = 1, kEvMstrand = 2, kEvSwapped = 4, kEvExact = 8, kEvSigx = 16;
@@ -113,6 +115,7 @@ struct bf_ctx {
 
     // genome
     uint32_t n_contigs = 0;
+    int contig_bits = 1;                        // bits per contig rank in the class key
     std::vector<std::string> contig_names;
     std::vector<uint32_t> contig_rank;          // by id
     std::vector<uint32_t> contig_by_rank;       // rank -> id

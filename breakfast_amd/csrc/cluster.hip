@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(256) dedup_runs_kernel(uint64_t total_m, const
 
 struct OrderView {
     const uint32_t* qseed; const uint64_t* skey; const int32_t* slpos; const uint32_t* perm;
-    const uint32_t* src_rank; const uint32_t* src_idx;
+    const uint32_t* src_rank; const uint32_t* src_idx; int cb;
 };
 // sort keys of surviving clusters: (contig rank, lpos as sorted, input order of the seed)
 __global__ void cluster_keys_kernel(const OrderView o, const uint32_t* __restrict__ sel, uint64_t* kpos, uint64_t* kidx, uint64_t ns) {
@@ -292,7 +292,7 @@ __global__ void cluster_keys_kernel(const OrderView o, const uint32_t* __restric
     if (k >= ns) return;
     const uint32_t p = o.qseed[sel[k]];
     const uint32_t rec = o.perm[p];
-    kpos[k] = ((o.skey[p] >> kKeyRankShift) << 32) | (uint32_t)o.slpos[p];
+    kpos[k] = ((o.skey[p] >> key_rank_shift(o.cb)) << 32) | (uint32_t)o.slpos[p];
     const uint64_t sr = o.src_rank ? o.src_rank[rec] : 0, si = o.src_idx ? o.src_idx[rec] : rec;
     kidx[k] = (sr << 32) | si;
 }
@@ -309,7 +309,7 @@ struct EmitView {
     const uint64_t* skey; const int32_t* slpos; const int32_t* srpos; const uint32_t* perm;
     const uint32_t* src_rank; const uint32_t* src_idx; const uint64_t* src_base;
     const uint16_t* bp; const uint16_t* flags;
-    const uint32_t* rank2id;
+    const uint32_t* rank2id; int cb;
     bf_cluster* clusters; bf_read* reads; uint32_t* out_src_rank; uint32_t* out_src_idx; uint32_t* out_rec;
 };
 
@@ -335,8 +335,8 @@ __global__ void __launch_bounds__(256) emit_kernel(const EmitView e, uint64_t ns
         cl.lpos = e.slpos[p]; cl.rpos = e.srpos[p];
         cl.seed_index = e.src_base[sr] + si;
         cl.read_begin = rbase; cl.read_end = e.roff[k + 1];
-        cl.contig = e.rank2id[(key >> kKeyRankShift) & ((1u << kContigBits) - 1)];
-        cl.mcontig = e.rank2id[(key >> kKeyMrankShift) & ((1u << kContigBits) - 1)];
+        cl.contig = e.rank2id[(key >> key_rank_shift(e.cb)) & ((1u << e.cb) - 1)];
+        cl.mcontig = e.rank2id[(key >> kKeyMrankShift) & ((1u << e.cb) - 1)];
         cl.strand = (key >> kKeyStrandBit) & 1; cl.mstrand = (key >> kKeyMstrandBit) & 1;
         e.clusters[k] = cl;
     }
@@ -386,7 +386,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
         hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_k64a.as<uint64_t>(), v.key,
                            ctx->c_c32.as<uint32_t>(), n);
         BF_TRY(sort_pairs<uint64_t>(ctx, ctx->c_k64a.as<uint64_t>(), ctx->c_k64b.as<uint64_t>(), ctx->c_c32.as<uint32_t>(),
-                                    perm, n, 0, kKeyBits));
+                                    perm, n, 0, key_bits(ctx->contig_bits)));
         hipLaunchKernelGGL(gather_pos_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_slpos.as<int32_t>(),
                            ctx->c_srpos.as<int32_t>(), v.lpos, v.rpos, perm, n);
     }
@@ -473,7 +473,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
         BF_TRY(ensure(ctx, ctx->c_misc, ns * 8 * 4));
         uint64_t* kpos = ctx->c_misc.as<uint64_t>();
         uint64_t* kidx = kpos + ns; uint64_t* kpos2 = kidx + ns; uint64_t* kidx2 = kpos2 + ns;
-        OrderView ov{ctx->c_qseed.as<uint32_t>(), sv.skey, sv.slpos, perm, v.src_rank, v.src_idx};
+        OrderView ov{ctx->c_qseed.as<uint32_t>(), sv.skey, sv.slpos, perm, v.src_rank, v.src_idx, ctx->contig_bits};
         hipLaunchKernelGGL(cluster_keys_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, ov, ctx->c_sel.as<uint32_t>(), kpos, kidx, ns);
         // LSD: input order first, then (contig rank, lpos).  values = positions in sel
         BF_TRY(ensure(ctx, ctx->c_b32, std::max(n, ns) * 4, false)); BF_TRY(ensure(ctx, ctx->c_c32, std::max(n, ns) * 4, false));
@@ -481,7 +481,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
         hipLaunchKernelGGL(iota_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, va, ns);
         BF_TRY(sort_pairs<uint64_t>(ctx, kidx, kidx2, va, vb, ns, 0, 64));
         hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, kpos2, kpos, vb, ns);
-        BF_TRY(sort_pairs<uint64_t>(ctx, kpos2, kidx2, vb, va, ns, 0, 32 + kContigBits));
+        BF_TRY(sort_pairs<uint64_t>(ctx, kpos2, kidx2, vb, va, ns, 0, 32 + ctx->contig_bits));
         // ord[k] = sel[va[k]]; nrep in output order -> read offsets
         hipLaunchKernelGGL(gather_u32_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, ctx->c_ord.as<uint32_t>(),
                            ctx->c_sel.as<uint32_t>(), va, ns);
@@ -507,7 +507,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     ev.members = ctx->c_members.as<uint32_t>(); ev.rep = ctx->c_rep.as<uint32_t>();
     ev.skey = sv.skey; ev.slpos = sv.slpos; ev.srpos = sv.srpos; ev.perm = perm;
     ev.src_rank = v.src_rank; ev.src_idx = v.src_idx; ev.src_base = (const uint64_t*)ctx->c_tables.p;
-    ev.bp = v.bp; ev.flags = v.flags; ev.rank2id = d_rank2id;
+    ev.bp = v.bp; ev.flags = v.flags; ev.rank2id = d_rank2id; ev.cb = ctx->contig_bits;
     ev.clusters = ctx->c_clusters.as<bf_cluster>(); ev.reads = ctx->c_reads.as<bf_read>();
     ev.out_src_rank = ctx->c_rsrc.as<uint32_t>(); ev.out_src_idx = ev.out_src_rank + total_r;
     ev.out_rec = ev.out_src_idx + total_r;

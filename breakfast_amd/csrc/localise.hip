@@ -294,6 +294,7 @@ __device__ __forceinline__ void encode_ascii(const uint8_t* __restrict__ seq, ui
 struct LocaliseArgs {
     uint64_t n;
     int A;
+    int cb;                  // bits per contig rank in the class key
     uint32_t force_exact;
     const bf_hit* hits;
     const uint16_t* len;          // separate-encode variant: read lengths (input)
@@ -310,7 +311,8 @@ struct LocaliseArgs {
     int32_t* rpos;
     uint16_t* bp;
     uint16_t* flags;
-    uint64_t* mask;          // [mask_words][n]
+    uint64_t* meta;          // render record per read: mask_words mask words + {bp, flags, len}
+    int meta_stride;         // u64 per record = mask_words + 1
     uint32_t* exact_list;
     uint32_t* counters;      // [0] = number of reads routed to the exact kernel
 };
@@ -339,8 +341,8 @@ __device__ __forceinline__ Oriented orient(const bf_hit& h, const ContigDev* __r
     return o;
 }
 
-__device__ __forceinline__ uint64_t make_key(const Oriented& o, bool sigx, uint32_t sig) {
-    return ((uint64_t)o.c.rank << kKeyRankShift) | ((uint64_t)o.mc.rank << kKeyMrankShift) |
+__device__ __forceinline__ uint64_t make_key(const Oriented& o, bool sigx, uint32_t sig, int cb) {
+    return ((uint64_t)o.c.rank << key_rank_shift(cb)) | ((uint64_t)o.mc.rank << kKeyMrankShift) |
            ((uint64_t)o.strand << kKeyStrandBit) | ((uint64_t)o.mstrand << kKeyMstrandBit) |
            ((uint64_t)sigx << kKeySigxBit) | sig;
 }
@@ -492,17 +494,20 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
     const int64_t lp = o.strand ? o.pos + bp - 1 : o.pos + A - bp;
     const int64_t rp = o.mstrand ? o.mpos + A - (L - bp) : o.mpos + (L - bp);
 
-    a.key[r] = make_key(o, false, sig);
+    a.key[r] = make_key(o, false, sig, a.cb);
     a.lpos[r] = (int32_t)lp;
     a.rpos[r] = (int32_t)rp;
     a.bp[r] = (uint16_t)bp;
-    a.flags[r] = (uint16_t)((o.strand ? kEvStrand : 0) | (o.mstrand ? kEvMstrand : 0) |
-                            (o.swapped ? kEvSwapped : 0));
+    const uint16_t fl = (uint16_t)((o.strand ? kEvStrand : 0) | (o.mstrand ? kEvMstrand : 0) | (o.swapped ? kEvSwapped : 0));
+    uint64_t* rec = a.meta + r * (uint64_t)a.meta_stride;
 #pragma unroll
     for (int w = 0; w < W; w++) {
         const uint64_t lowB = low_mask(min(max(bp - 64 * w, 0), 64));
-        a.mask[(uint64_t)w * a.n + r] = (ml[w] & lowB) | (mr[w] & ~lowB);
+        rec[w] = (ml[w] & lowB) | (mr[w] & ~lowB);
     }
+    for (int w = W; w < a.meta_stride - 1; w++) rec[w] = 0;
+    rec[a.meta_stride - 1] = (uint64_t)(uint16_t)bp | ((uint64_t)fl << 16) | ((uint64_t)(uint16_t)L << 32);
+    a.flags[r] = fl;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -512,6 +517,7 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
 struct ExactArgs {
     uint64_t n_total;
     int A;
+    int cb;
     const uint32_t* exact_list;
     const uint32_t* counters;
     const bf_hit* hits;
@@ -524,8 +530,8 @@ struct ExactArgs {
     int32_t* rpos;
     uint16_t* bp;
     uint16_t* flags;
-    uint64_t* mask;
-    int mask_words;
+    uint64_t* meta;
+    int mask_words;          // record stride = mask_words + 1
     uint8_t* sigx;           // 16 bytes per slot
     uint32_t* sigx_slot;     // read -> slot
 };
@@ -583,7 +589,7 @@ __global__ void __launch_bounds__(64) localise_exact_kernel(const ExactArgs a) {
             const bool mis = k < bp ? c != x.left(k) : c != x.right(k);
             m |= (uint64_t)mis << (k & 63);
         }
-        a.mask[(uint64_t)w * a.n_total + r] = m;
+        a.meta[(uint64_t)r * (a.mask_words + 1) + w] = m;
     }
     uint8_t sigb[16];
     bool plain = true;
@@ -604,12 +610,15 @@ __global__ void __launch_bounds__(64) localise_exact_kernel(const ExactArgs a) {
     }
     const int64_t lp = o.strand ? o.pos + bp - 1 : o.pos + A - bp;
     const int64_t rp = o.mstrand ? o.mpos + A - (L - bp) : o.mpos + (L - bp);
-    a.key[r] = make_key(o, !plain, sig);
+    a.key[r] = make_key(o, !plain, sig, a.cb);
     a.lpos[r] = (int32_t)lp;
     a.rpos[r] = (int32_t)rp;
     a.bp[r] = (uint16_t)bp;
-    a.flags[r] = (uint16_t)((o.strand ? kEvStrand : 0) | (o.mstrand ? kEvMstrand : 0) |
-                            (o.swapped ? kEvSwapped : 0) | kEvExact | (plain ? 0 : kEvSigx));
+    const uint16_t fl = (uint16_t)((o.strand ? kEvStrand : 0) | (o.mstrand ? kEvMstrand : 0) |
+                                   (o.swapped ? kEvSwapped : 0) | kEvExact | (plain ? 0 : kEvSigx));
+    a.flags[r] = fl;
+    a.meta[(uint64_t)r * (a.mask_words + 1) + a.mask_words] =
+        (uint64_t)(uint16_t)bp | ((uint64_t)fl << 16) | ((uint64_t)(uint16_t)L << 32);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -621,34 +630,34 @@ __global__ void __launch_bounds__(256) render_len_kernel(uint64_t n, const uint3
     if (i < n) out_len[i] = (uint32_t)len[idx[i]] + 1;
 }
 
-__global__ void __launch_bounds__(256) render_kernel(uint64_t n, uint64_t n_total,
-                                                     const uint32_t* __restrict__ idx,
+// 16 lanes per surviving read, 4 reads per wave: everything a read needs besides its bases sits in
+// ONE render record (mask words + bp/flags/len), so a read costs one record line, one offset line
+// and its own sequence lines (the first version gathered nine separate 128-byte lines per read and
+// was latency-bound at one read per wave).
+__global__ void __launch_bounds__(256) render_kernel(uint64_t n, const uint32_t* __restrict__ idx,
                                                      const uint64_t* __restrict__ joff,
                                                      const uint8_t* __restrict__ seq,
                                                      const uint64_t* __restrict__ seq_off,
-                                                     const uint16_t* __restrict__ bp_,
-                                                     const uint16_t* __restrict__ flags,
-                                                     const uint64_t* __restrict__ mask,
+                                                     const uint64_t* __restrict__ meta, int meta_stride,
                                                      uint8_t* __restrict__ out) {
-    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l16 = threadIdx.x & 15;
     if (i >= n) return;
     const uint32_t r = idx[i];
     const uint64_t o = seq_off[r];
-    const int L = (int)(seq_off[r + 1] - o);
-    const int bp = bp_[r];
-    const bool swapped = (flags[r] & kEvSwapped) != 0;
+    const uint64_t* rec = meta + (uint64_t)r * meta_stride;
+    const uint64_t tail = rec[meta_stride - 1];
+    const int bp = (int)(tail & 0xffff), L = (int)((tail >> 32) & 0xffff);
+    const bool swapped = ((tail >> 16) & kEvSwapped) != 0;
     uint8_t* dst = out + joff[i];
-    for (int k0 = 0; k0 < L; k0 += 64) {
-        const uint64_t m = mask[(uint64_t)(k0 >> 6) * n_total + r];
-        const int k = k0 + lane;
-        if (k < L) {
-            uint8_t c = swapped ? comp_byte(seq[o + L - 1 - k]) : seq[o + k];
-            if (((m >> lane) & 1) && c >= 'A' && c <= 'Z') c += 32;   // to_ascii_lowercase, :157,161
-            dst[k < bp ? k : k + 1] = c;
-        }
+#pragma unroll 4
+    for (int k = l16; k < L; k += 16) {
+        const uint64_t m = rec[k >> 6];
+        uint8_t c = swapped ? comp_byte(seq[o + L - 1 - k]) : seq[o + k];
+        if (((m >> (k & 63)) & 1) && c >= 'A' && c <= 'Z') c += 32;       // to_ascii_lowercase, :157,161
+        dst[k < bp ? k : k + 1] = c;
     }
-    if (lane == 0) dst[bp] = '|';
+    if (l16 == 0) dst[bp] = '|';
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -700,12 +709,11 @@ int run_localise(bf_ctx* ctx) {
     BF_TRY(ensure(ctx, ctx->d_rpos, n * 4));
     BF_TRY(ensure(ctx, ctx->d_bp, n * 2));
     BF_TRY(ensure(ctx, ctx->d_flags, n * 2));
-    BF_TRY(ensure(ctx, ctx->d_mask, (size_t)Wm * n * 8));
+    BF_TRY(ensure(ctx, ctx->d_mask, (size_t)(Wm + 1) * n * 8));
     BF_TRY(ensure(ctx, ctx->d_exact_list, n * 4));
     BF_TRY(ensure(ctx, ctx->d_sigx_slot, n * 4));
     BF_TRY(ensure(ctx, ctx->d_counters, 64));
     BF_HIP(ctx, hipMemsetAsync(ctx->d_counters.p, 0, 64, ctx->stream));
-    if (Wm > W) BF_HIP(ctx, hipMemsetAsync(ctx->d_mask.p, 0, (size_t)Wm * n * 8, ctx->stream));
 
     const bool separate = (ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE)) != 0;
     if (separate) {
@@ -729,14 +737,15 @@ int run_localise(bf_ctx* ctx) {
     BF_HIP(ctx, hipGetLastError());
 
     LocaliseArgs a{};
-    a.n = n; a.A = (int)A; a.force_exact = (ctx->cfg.flags & BF_FLAG_FORCE_EXACT) ? 1u : 0u;
+    a.n = n; a.A = (int)A; a.cb = ctx->contig_bits; a.force_exact = (ctx->cfg.flags & BF_FLAG_FORCE_EXACT) ? 1u : 0u;
     a.hits = ctx->d_hits.as<bf_hit>(); a.len = ctx->d_len.as<uint16_t>();
     a.planes = ctx->d_planes.as<uint64_t>(); a.len_out = ctx->d_len.as<uint16_t>();
     a.seq = ctx->d_seq.as<uint8_t>(); a.seq_off = ctx->d_seq_off.as<uint64_t>(); a.contigs = ctx->g_contigs.as<ContigDev>();
     a.blocks = ctx->g_blocks.as<GenomeBlock>(); a.coarse = ctx->g_coarse.as<uint64_t>();
     a.coarse2 = ctx->g_coarse2.as<uint32_t>();
     a.key = ctx->d_key.as<uint64_t>(); a.lpos = ctx->d_lpos.as<int32_t>(); a.rpos = ctx->d_rpos.as<int32_t>();
-    a.bp = ctx->d_bp.as<uint16_t>(); a.flags = ctx->d_flags.as<uint16_t>(); a.mask = ctx->d_mask.as<uint64_t>();
+    a.bp = ctx->d_bp.as<uint16_t>(); a.flags = ctx->d_flags.as<uint16_t>(); a.meta = ctx->d_mask.as<uint64_t>();
+    a.meta_stride = (int)Wm + 1;
     a.exact_list = ctx->d_exact_list.as<uint32_t>(); a.counters = ctx->d_counters.as<uint32_t>();
     {
         Scope t(ctx, "localise");
@@ -753,10 +762,10 @@ int run_localise(bf_ctx* ctx) {
     if (n_exact) {
         BF_TRY(ensure(ctx, ctx->d_sigx, (size_t)n_exact * 16));
         ExactArgs e{};
-        e.n_total = n; e.A = (int)A; e.exact_list = a.exact_list; e.counters = a.counters; e.hits = a.hits;
+        e.n_total = n; e.A = (int)A; e.cb = ctx->contig_bits; e.exact_list = a.exact_list; e.counters = a.counters; e.hits = a.hits;
         e.seq = ctx->d_seq.as<uint8_t>(); e.seq_off = ctx->d_seq_off.as<uint64_t>();
         e.contigs = a.contigs; e.raw = ctx->g_raw.as<uint8_t>();
-        e.key = a.key; e.lpos = a.lpos; e.rpos = a.rpos; e.bp = a.bp; e.flags = a.flags; e.mask = a.mask;
+        e.key = a.key; e.lpos = a.lpos; e.rpos = a.rpos; e.bp = a.bp; e.flags = a.flags; e.meta = a.meta;
         e.mask_words = (int)Wm; e.sigx = ctx->d_sigx.as<uint8_t>(); e.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
         Scope t(ctx, "localise_exact");
         hipLaunchKernelGGL(localise_exact_kernel, dim3(grid_for(n_exact, 64)), dim3(64), 0, ctx->stream, e);
@@ -783,10 +792,9 @@ int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_o
     BF_HIP(ctx, hipMemcpyAsync(&total, d_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     BF_TRY(ensure(ctx, d_bytes, total ? total : 1));
-    hipLaunchKernelGGL(render_kernel, dim3(grid_for(n * 64, 256)), dim3(256), 0, ctx->stream, n, ctx->n_reads,
-                       d_local_idx, d_off.as<uint64_t>(), ctx->d_seq.as<uint8_t>(), ctx->d_seq_off.as<uint64_t>(),
-                       ctx->d_bp.as<uint16_t>(), ctx->d_flags.as<uint16_t>(), ctx->d_mask.as<uint64_t>(),
-                       d_bytes.as<uint8_t>());
+    hipLaunchKernelGGL(render_kernel, dim3(grid_for(n * 16, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
+                       d_off.as<uint64_t>(), ctx->d_seq.as<uint8_t>(), ctx->d_seq_off.as<uint64_t>(),
+                       ctx->d_mask.as<uint64_t>(), (int)ctx->mask_words + 1, d_bytes.as<uint8_t>());
     BF_HIP(ctx, hipGetLastError());
     *total_bytes = total;
     return BF_OK;
