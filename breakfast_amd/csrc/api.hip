@@ -166,6 +166,9 @@ int bf_ctx_create(const bf_config* cfg, bf_ctx** out) {
         delete ctx;
         return fail(nullptr, BF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    bool ok = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    for (auto& e2 : ctx->ev) ok = ok && hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { bf_ctx_destroy(ctx); return fail(nullptr, BF_ERR_HIP, "could not create the copy stream / events"); }
     *out = ctx;
     return BF_OK;
 }
@@ -174,8 +177,11 @@ void bf_ctx_destroy(bf_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     drop_pending(ctx);
     free_all(ctx);
+    for (auto& e2 : ctx->ev) if (e2) (void)hipEventDestroy(e2);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->stream);
     delete reinterpret_cast<std::vector<PendingEvent>*>(ctx->timing_pending);
     delete ctx;
@@ -321,20 +327,38 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     BF_TRY(run_cluster(ctx, v));
     const uint64_t nr = ctx->out.n_reads;
     if (nr) {
+        BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
         if (!ctx->imported) {
-            // single rank: the surviving reads are local, render their junction strings now
+            // single rank: the surviving reads are local.  Their junction strings are rendered chunk by
+            // chunk; every finished chunk (and the read table) goes to pinned host memory on the copy
+            // stream while the next chunk renders.
             const uint32_t* d_idx = ctx->c_rsrc.as<uint32_t>() + nr;      // out_src_idx
-            uint64_t total = 0;
-            BF_TRY(run_render(ctx, nr, d_idx, ctx->c_joff, ctx->c_jbytes, &total));
+            constexpr int kMaxChunks = 8;
+            const int nc = nr >= (1u << 16) ? kMaxChunks : 1;
+            uint64_t off[kMaxChunks + 1];
+            BF_TRY(render_prepare(ctx, nr, d_idx, ctx->c_joff, nc, off));
+            const uint64_t total = off[nc];
             BF_TRY(patch_reads(ctx, ctx->c_joff.as<uint64_t>(), nr));
+            BF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+            BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[0], 0));
+            BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->copy_stream));
             ctx->out.junction_size = total;
             BF_TRY(ensure_host(ctx, ctx->out.junction, total));
-            Scope t(ctx, "d2h_junctions");
-            if (total) BF_HIP(ctx, hipMemcpyAsync(ctx->out.junction.p, ctx->c_jbytes.p, total, hipMemcpyDeviceToHost, ctx->stream));
+            BF_TRY(ensure(ctx, ctx->c_jbytes, total ? total : 1));
+            for (int c = 0; c < nc; c++) {
+                BF_TRY(render_range(ctx, nr * (uint64_t)c / nc, nr * (uint64_t)(c + 1) / nc, d_idx, ctx->c_joff, ctx->c_jbytes));
+                if (off[c + 1] > off[c]) {
+                    BF_HIP(ctx, hipEventRecord(ctx->ev[1 + c], ctx->stream));
+                    BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[1 + c], 0));
+                    BF_HIP(ctx, hipMemcpyAsync(ctx->out.junction.as<uint8_t>() + off[c], ctx->c_jbytes.as<uint8_t>() + off[c],
+                                               off[c + 1] - off[c], hipMemcpyDeviceToHost, ctx->copy_stream));
+                }
+            }
+            BF_HIP(ctx, hipEventRecord(ctx->ev[10], ctx->copy_stream));
+            BF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[10], 0));
+        } else {
+            BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
         }
-        BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
-        Scope t(ctx, "d2h_reads");
-        BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
     }
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     out->n_evidence = ctx->n_evidence;

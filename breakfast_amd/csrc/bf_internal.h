@@ -111,6 +111,8 @@ struct bf_ctx {
     bf_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;          // result D2H, overlapped with the render kernel
+    hipEvent_t ev[12] = {};                     // untimed events chaining the two streams
     std::string err;
 
     // genome
@@ -198,6 +200,8 @@ struct Scope {
 // localise.hip ----------------------------------------------------------------------------------
 int genome_pack(bf_ctx* ctx);                       // raw image -> blocks + coarse bitmap
 int run_localise(bf_ctx* ctx);                      // encode + hash + fast + exact kernels
+int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, int n_chunks, uint64_t* chunk_off);
+int render_range(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const DevBuf& d_off, DevBuf& d_bytes);
 int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, DevBuf& d_bytes,
                uint64_t* total_bytes);              // junction strings for local reads
 

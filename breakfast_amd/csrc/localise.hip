@@ -775,29 +775,46 @@ int run_localise(bf_ctx* ctx) {
     return BF_OK;
 }
 
-int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, DevBuf& d_bytes,
-               uint64_t* total_bytes) {
-    *total_bytes = 0;
+// Junction offsets of n surviving reads (exclusive scan of len+1).  chunk_off[c] = byte offset of
+// read n*c/n_chunks, so that the caller can render and copy out the text chunk by chunk.
+int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, int n_chunks,
+                   uint64_t* chunk_off) {
+    for (int c = 0; c <= n_chunks; c++) chunk_off[c] = 0;
     BF_TRY(ensure(ctx, d_off, (n + 1) * 8));
     if (n == 0) {
         BF_HIP(ctx, hipMemsetAsync(d_off.p, 0, 8, ctx->stream));
         return BF_OK;
     }
     BF_TRY(ensure(ctx, ctx->c_misc, n * 4));
-    Scope t(ctx, "render");
+    Scope t(ctx, "render_offsets");
     hipLaunchKernelGGL(render_len_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
                        ctx->d_len.as<uint16_t>(), ctx->c_misc.as<uint32_t>());
     BF_TRY(scan_u32_to_u64(ctx, ctx->c_misc.as<uint32_t>(), d_off.as<uint64_t>(), n));
-    uint64_t total = 0;
-    BF_HIP(ctx, hipMemcpyAsync(&total, d_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    for (int c = 0; c <= n_chunks; c++)
+        BF_HIP(ctx, hipMemcpyAsync(&chunk_off[c], d_off.as<uint64_t>() + n * (uint64_t)c / n_chunks, 8,
+                                   hipMemcpyDeviceToHost, ctx->stream));
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    BF_TRY(ensure(ctx, d_bytes, total ? total : 1));
-    hipLaunchKernelGGL(render_kernel, dim3(grid_for(n * 16, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
-                       d_off.as<uint64_t>(), ctx->d_seq.as<uint8_t>(), ctx->d_seq_off.as<uint64_t>(),
+    return BF_OK;
+}
+
+// Renders reads [a, b) of the list into d_bytes (offsets are absolute).
+int render_range(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const DevBuf& d_off, DevBuf& d_bytes) {
+    if (b <= a) return BF_OK;
+    Scope t(ctx, "render");
+    hipLaunchKernelGGL(render_kernel, dim3(grid_for((b - a) * 16, 256)), dim3(256), 0, ctx->stream, b - a, d_local_idx + a,
+                       d_off.as<uint64_t>() + a, ctx->d_seq.as<uint8_t>(), ctx->d_seq_off.as<uint64_t>(),
                        ctx->d_mask.as<uint64_t>(), (int)ctx->mask_words + 1, d_bytes.as<uint8_t>());
     BF_HIP(ctx, hipGetLastError());
-    *total_bytes = total;
     return BF_OK;
+}
+
+int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, DevBuf& d_bytes,
+               uint64_t* total_bytes) {
+    uint64_t off[2];
+    BF_TRY(render_prepare(ctx, n, d_local_idx, d_off, 1, off));
+    *total_bytes = off[1];
+    BF_TRY(ensure(ctx, d_bytes, off[1] ? off[1] : 1));
+    return render_range(ctx, 0, n, d_local_idx, d_off, d_bytes);
 }
 
 }  // namespace bf
