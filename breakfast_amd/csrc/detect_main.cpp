@@ -8,21 +8,44 @@
 //     --anchor-len=N --anchor-mm=N --max-frag-len=N --min-evidence=N     (as the reference)
 //     --anchor-hits=FILE   read bowtie's output (the 4-column `--suppress 5,6,7,8` lines) from FILE
 //                          ("-" = stdin) instead of spawning bowtie on <bam_file>.
+//     --threads=N          BGZF inflate workers of the BAM front-end [default: 4]
+//   breakfast-hip anchors [--anchor-len=N] <bam_file>
+//     prints the anchor FASTA that detect feeds to bowtie (detect.rs:290-338); needs no GPU.
+//
+// Without --anchor-hits the driver does what detect.rs:58-70 does: spawn
+// `bowtie -f -p1 -v0 -m1 -B1 --suppress 5,6,7,8 <genome> -`, feed it from a producer thread that
+// scans the BAM, and consume its stdout.  A parser thread turns lines into batches while the main
+// thread hands finished batches to the GPU library.
 //
 // Errors follow src/common.rs:8-13: "ERROR: <msg>" on stderr, exit status -1.
 
+#include <algorithm>
 #include <cerrno>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
+#include <fcntl.h>
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include "../../include/breakfast_hip.h"
+#include "bam_reader.h"
+
+extern char** environ;
 
 [[noreturn]] static void error(const char* fmt, ...) {
     va_list ap;
@@ -87,21 +110,39 @@ static Fasta read_fasta(const std::string& path) {
     return fa;
 }
 
-struct Batcher {
-    bf_ctx* ctx;
+struct Batch {                          // one bf_batch worth of parsed anchor-hit pairs
     std::string seq, frag;
     std::vector<uint64_t> seq_off{0}, frag_off{0};
     std::vector<bf_hit> hits;
-    void flush() {
-        if (hits.empty()) return;
-        bf_batch b;
-        b.n_reads = hits.size();
-        b.seq_bytes = (const uint8_t*)seq.data(); b.seq_off = seq_off.data();
-        b.frag_bytes = (const uint8_t*)frag.data(); b.frag_off = frag_off.data();
-        b.hits = hits.data();
-        if (bf_submit(ctx, &b) != BF_OK) error("%s", bf_last_error(ctx));
-        seq.clear(); frag.clear(); hits.clear();
-        seq_off.assign(1, 0); frag_off.assign(1, 0);
+};
+
+// parser thread -> main thread hand-over (at most two batches in flight)
+struct BatchQueue {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<Batch>> q;
+    bool closed = false;
+    std::string error;
+    void push(std::unique_ptr<Batch> b) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return q.size() < 2; });
+        q.push_back(std::move(b));
+        cv.notify_all();
+    }
+    void close(const std::string& err = "") {
+        std::lock_guard<std::mutex> g(mu);
+        closed = true;
+        if (error.empty()) error = err;
+        cv.notify_all();
+    }
+    std::unique_ptr<Batch> pop() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !q.empty() || closed; });
+        if (q.empty()) return nullptr;
+        auto b = std::move(q.front());
+        q.pop_front();
+        cv.notify_all();
+        return b;
     }
 };
 
@@ -126,16 +167,97 @@ static bool field(std::string_view s, char d, int n, std::string_view& out) {
     }
 }
 
+struct ParseError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// the consume loop, detect.rs:76-103: pair 5p/3p lines by read number, extract the fields
+static void parse_hits(FILE* in, const std::unordered_map<std::string, uint32_t>& contig_id, const std::string& genome_path,
+                       BatchQueue& out) {
+    const size_t kBatch = 1u << 20;
+    auto cur = std::make_unique<Batch>();
+    std::string prev;
+    uint64_t prev_read_num = 0;
+    char* lineb = nullptr;
+    size_t cap = 0;
+    ssize_t n;
+    auto bad = [&](const char* what, std::string_view line) { throw ParseError(std::string(what) + ": " + std::string(line)); };
+    while ((n = getline(&lineb, &cap, in)) >= 0) {
+        size_t len = (size_t)n;
+        if (len && lineb[len - 1] == '\n') len--;
+        if (len && lineb[len - 1] == '\r') len--;
+        std::string_view line(lineb, len);
+        std::string_view f1;
+        uint64_t read_num;
+        if (!field(line, ':', 1, f1) || !parse_u64(f1, read_num)) bad("Malformed anchor alignment line", line);
+        if (line.substr(0, 3) == "5p:") { prev.assign(line); prev_read_num = read_num; continue; }
+        else if (line.substr(0, 3) == "3p:" && read_num != prev_read_num) continue;
+        std::string_view frag, seq, st, mst, chr, mchr, p, mp;
+        if (!field(line, ':', 2, frag) || !field(line, ':', 3, seq)) bad("Malformed anchor alignment line", line);
+        std::string_view pv(prev);
+        if (!field(pv, '\t', 1, st) || !field(pv, '\t', 2, chr) || !field(pv, '\t', 3, p) ||
+            !field(line, '\t', 1, mst) || !field(line, '\t', 2, mchr) || !field(line, '\t', 3, mp))
+            bad("Malformed anchor alignment line", line);
+        uint64_t pos5, pos3;
+        if (!parse_u64(p, pos5) || !parse_u64(mp, pos3)) bad("Malformed anchor offset", line);
+        auto c5 = contig_id.find(std::string(chr)), c3 = contig_id.find(std::string(mchr));
+        if (c5 == contig_id.end() || c3 == contig_id.end())
+            throw ParseError("Anchor aligned to a contig that " + genome_path + ".fa does not contain (the reference panics here, detect.rs:115).");
+        if (pos5 >= 0x80000000ull || pos3 >= 0x80000000ull) throw ParseError("Anchor offset beyond 2^31.");
+        bf_hit h;
+        memset(&h, 0, sizeof h);
+        h.pos5 = (uint32_t)pos5; h.pos3 = (uint32_t)pos3;
+        h.contig5 = (uint16_t)c5->second; h.contig3 = (uint16_t)c3->second;
+        h.strands = (uint8_t)((st == "+" ? 1 : 0) | (mst == "+" ? 2 : 0));
+        cur->hits.push_back(h);
+        cur->seq.append(seq); cur->seq_off.push_back(cur->seq.size());
+        cur->frag.append(frag); cur->frag_off.push_back(cur->frag.size());
+        if (cur->hits.size() >= kBatch) { out.push(std::move(cur)); cur = std::make_unique<Batch>(); }
+    }
+    free(lineb);
+    if (!cur->hits.empty()) out.push(std::move(cur));
+}
+
+struct Child { pid_t pid = -1; int to_child = -1, from_child = -1; };
+
+// Command::new("bowtie").args(...).stdin(piped).stdout(piped).spawn(), detect.rs:60-63
+static Child spawn_bowtie(const std::string& genome_path) {
+    int in_pipe[2], out_pipe[2];
+    if (pipe2(in_pipe, O_CLOEXEC) != 0 || pipe2(out_pipe, O_CLOEXEC) != 0) error("Could not start Bowtie process.");
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_adddup2(&fa, in_pipe[0], 0);
+    posix_spawn_file_actions_adddup2(&fa, out_pipe[1], 1);
+    std::string g = genome_path;
+    const char* argv[] = {"bowtie", "-f", "-p1", "-v0", "-m1", "-B1", "--suppress", "5,6,7,8", g.c_str(), "-", nullptr};
+    Child c;
+    const int rc = posix_spawnp(&c.pid, "bowtie", &fa, nullptr, (char* const*)argv, environ);
+    posix_spawn_file_actions_destroy(&fa);
+    close(in_pipe[0]); close(out_pipe[1]);
+    if (rc != 0) { close(in_pipe[1]); close(out_pipe[0]); error("Could not start Bowtie process."); }
+    c.to_child = in_pipe[1]; c.from_child = out_pipe[0];
+    return c;
+}
+
+static std::unique_ptr<bam::Reader> open_bam(const std::string& path, int threads) {
+    try {
+        return std::make_unique<bam::Reader>(path, threads);
+    } catch (const std::exception& e) {
+        if (path == "-") error("Failed to read BAM file from standard input.");          // detect.rs:293-294
+        error("Could not open BAM file '%s'", path.c_str());                              // detect.rs:296-297
+    }
+}
+
 int main(int argc, char** argv) {
-    if (argc < 2 || strcmp(argv[1], "detect") != 0) {
+    const bool anchors_only = argc >= 2 && strcmp(argv[1], "anchors") == 0;
+    if (argc < 2 || (strcmp(argv[1], "detect") != 0 && !anchors_only)) {
         fputs("\nBreakfast is a software for detecting chromosomal rearrangements in DNA/RNA sequencing data.\n\n"
-              "Usage:\n  breakfast-hip detect [options] <bam_file> <genome>\n", stderr);
+              "Usage:\n  breakfast-hip detect [options] <bam_file> <genome>\n  breakfast-hip anchors [--anchor-len=N] <bam_file>\n", stderr);
         return -1;
     }
     bf_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.anchor_len = 30; cfg.max_frag_len = 5000; cfg.min_evidence = 2; cfg.device = -1;
     std::string hits_path;
+    int threads = 4;
     std::vector<std::string> pos;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
@@ -150,12 +272,47 @@ int main(int argc, char** argv) {
         else if (val("--anchor-mm=", v)) {}                       // parsed and ignored, detect.rs:44
         else if (val("--max-frag-len=", v)) cfg.max_frag_len = (uint32_t)std::min<uint64_t>(v, 0xffffffffu);
         else if (val("--min-evidence=", v)) cfg.min_evidence = (uint32_t)std::min<uint64_t>(v, 0xffffffffu);
+        else if (val("--threads=", v)) threads = (int)std::min<uint64_t>(std::max<uint64_t>(v, 1), 64);
         else if (a.compare(0, 14, "--anchor-hits=") == 0) hits_path = a.substr(14);
         else if (a.size() > 1 && a[0] == '-' && a != "-") error("Invalid arguments.\n%s", USAGE);
         else pos.push_back(a);
     }
+    if (anchors_only) {
+        if (pos.size() != 1) error("Invalid arguments.\nUsage:\n  breakfast-hip anchors [--anchor-len=N] <bam_file>");
+        auto bam = open_bam(pos[0], threads);
+        try {
+            bam::dispatch_reads(*bam, stdout, cfg.anchor_len);
+        } catch (const std::exception& e) { error("Failed reading BAM record: %s", e.what()); }   // common.rs:64
+        fflush(stdout);
+        return 0;
+    }
     if (pos.size() != 2) error("Invalid arguments.\n%s", USAGE);
-    const std::string genome_path = pos[1];
+    const std::string sam_path = pos[0], genome_path = pos[1];
+
+    // Bowtie and the BAM producer start BEFORE the GPU is touched (the child must be spawned from a
+    // process that has not initialised the device); the pipes simply fill until we start consuming.
+    FILE* in = nullptr;
+    Child child;
+    std::thread producer;
+    std::unique_ptr<bam::Reader> bam_reader;
+    if (hits_path.empty()) {
+        bam_reader = open_bam(sam_path, threads);
+        child = spawn_bowtie(genome_path);
+        const uint32_t A = cfg.anchor_len;
+        const int wfd = child.to_child;
+        bam::Reader* rd = bam_reader.get();
+        producer = std::thread([rd, wfd, A] {                      // thread::spawn(...), detect.rs:68-70
+            FILE* w = fdopen(wfd, "w");
+            try {
+                bam::dispatch_reads(*rd, w, A);
+            } catch (const std::exception& e) { error("Failed reading BAM record: %s", e.what()); }
+            fclose(w);
+        });
+        in = fdopen(child.from_child, "r");
+    } else {
+        in = hits_path == "-" ? stdin : fopen(hits_path.c_str(), "rb");
+        if (!in) error("Cannot open file %s for reading.", hits_path.c_str());
+    }
 
     bf_ctx* ctx = nullptr;
     if (bf_ctx_create(&cfg, &ctx) != BF_OK) error("%s", bf_last_error(nullptr));
@@ -178,55 +335,25 @@ int main(int argc, char** argv) {
     for (auto& s : fa.seqs) std::string().swap(s);             // the genome now lives in HBM
 
     fprintf(stderr, "Splitting unaligned reads into %u bp anchors and aligning against the genome...\n", cfg.anchor_len);
-    if (hits_path.empty())
-        error("The BAM front-end (detect.rs:290-338) and the Bowtie child process (detect.rs:60-70) are not part of "
-              "this build yet: pass Bowtie's output with --anchor-hits=FILE.");
-    FILE* in = hits_path == "-" ? stdin : fopen(hits_path.c_str(), "rb");
-    if (!in) error("Cannot open file %s for reading.", hits_path.c_str());
 
-    // the consume loop, detect.rs:76-103
-    Batcher bt{ctx};
-    std::string prev;
-    uint64_t prev_read_num = 0;
-    char* lineb = nullptr;
-    size_t cap = 0;
-    ssize_t n;
-    const size_t kBatch = 1u << 20;
-    while ((n = getline(&lineb, &cap, in)) >= 0) {
-        size_t len = (size_t)n;
-        if (len && lineb[len - 1] == '\n') len--;
-        if (len && lineb[len - 1] == '\r') len--;
-        std::string_view line(lineb, len);
-        std::string_view f1;
-        uint64_t read_num;
-        if (!field(line, ':', 1, f1) || !parse_u64(f1, read_num)) error("Malformed anchor alignment line: %.*s", (int)len, lineb);
-        if (line.substr(0, 3) == "5p:") { prev.assign(line); prev_read_num = read_num; continue; }
-        else if (line.substr(0, 3) == "3p:" && read_num != prev_read_num) continue;
-        std::string_view frag, seq, st, mst, chr, mchr, p, mp;
-        if (!field(line, ':', 2, frag) || !field(line, ':', 3, seq)) error("Malformed anchor alignment line: %.*s", (int)len, lineb);
-        std::string_view pv(prev);
-        if (!field(pv, '\t', 1, st) || !field(pv, '\t', 2, chr) || !field(pv, '\t', 3, p) ||
-            !field(line, '\t', 1, mst) || !field(line, '\t', 2, mchr) || !field(line, '\t', 3, mp))
-            error("Malformed anchor alignment line: %.*s", (int)len, lineb);
-        uint64_t pos5, pos3;
-        if (!parse_u64(p, pos5) || !parse_u64(mp, pos3)) error("Malformed anchor offset: %.*s", (int)len, lineb);
-        auto c5 = contig_id.find(std::string(chr)), c3 = contig_id.find(std::string(mchr));
-        if (c5 == contig_id.end() || c3 == contig_id.end())
-            error("Anchor aligned to a contig that %s.fa does not contain (the reference panics here, detect.rs:115).", genome_path.c_str());
-        if (pos5 >= 0x80000000ull || pos3 >= 0x80000000ull) error("Anchor offset beyond 2^31.");
-        bf_hit h;
-        memset(&h, 0, sizeof h);
-        h.pos5 = (uint32_t)pos5; h.pos3 = (uint32_t)pos3;
-        h.contig5 = (uint16_t)c5->second; h.contig3 = (uint16_t)c3->second;
-        h.strands = (uint8_t)((st == "+" ? 1 : 0) | (mst == "+" ? 2 : 0));
-        bt.hits.push_back(h);
-        bt.seq.append(seq); bt.seq_off.push_back(bt.seq.size());
-        bt.frag.append(frag); bt.frag_off.push_back(bt.frag.size());
-        if (bt.hits.size() >= kBatch) bt.flush();
+    BatchQueue queue;
+    std::thread parser([&] {
+        try { parse_hits(in, contig_id, genome_path, queue); queue.close(); }
+        catch (const std::exception& e) { queue.close(e.what()); }
+    });
+    while (auto b = queue.pop()) {
+        bf_batch bb;
+        bb.n_reads = b->hits.size();
+        bb.seq_bytes = (const uint8_t*)b->seq.data(); bb.seq_off = b->seq_off.data();
+        bb.frag_bytes = (const uint8_t*)b->frag.data(); bb.frag_off = b->frag_off.data();
+        bb.hits = b->hits.data();
+        if (bf_submit(ctx, &bb) != BF_OK) error("%s", bf_last_error(ctx));
     }
-    free(lineb);
+    parser.join();
+    if (!queue.error.empty()) error("%s", queue.error.c_str());
     if (in != stdin) fclose(in);
-    bt.flush();
+    if (producer.joinable()) producer.join();
+    if (child.pid > 0) { int st = 0; waitpid(child.pid, &st, 0); }     // the reference never checks it either
 
     bf_result res;
     if (bf_localise(ctx) != BF_OK) error("%s", bf_last_error(ctx));
