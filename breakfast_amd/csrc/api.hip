@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <numeric>
+#include <thread>
 
 static thread_local std::string g_create_error;
 
@@ -378,33 +379,86 @@ int bf_finish(bf_ctx* ctx, bf_result* out) {
     return bf_clusterise(ctx, out);
 }
 
-static void put_u64(std::string& s, uint64_t v) {
-    char buf[24]; int n = snprintf(buf, sizeof buf, "%llu", (unsigned long long)v); s.append(buf, (size_t)n);
+static inline unsigned dec_len(uint64_t v) { unsigned n = 1; while (v >= 10) { v /= 10; n++; } return n; }
+static inline char* put_dec(char* p, uint64_t v) {
+    char tmp[24]; int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
 }
 
+static const char kSvHeader[] = "CHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tCHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\t"
+                                "SUPPORTING READS\tSIGNATURE\tNOTES\n";                 // detect.rs:201
+
+// Row c of the .sv (detect.rs:233-240): size first, then the bytes.  Rows are independent, so the
+// text is laid out by a prefix sum of row sizes and filled by several host threads.
 int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t cap) {
     if (!ctx || !r) return BF_ERR_INVALID;
-    std::string out;
-    out.reserve(256 + r->junction_size + r->n_clusters * 64 + r->n_reads);
-    out += "CHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tCHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\t"
-           "SUPPORTING READS\tSIGNATURE\tNOTES\n";                                   // detect.rs:201
-    for (uint64_t c = 0; c < r->n_clusters; c++) {
+    const uint64_t nc = r->n_clusters;
+    if (nc && (!r->clusters || (r->n_reads && !r->reads))) return BF_ERR_INVALID;
+    std::vector<uint64_t> off(nc + 1);
+    const size_t hdr = sizeof(kSvHeader) - 1;
+    uint64_t total = hdr;
+    for (uint64_t c = 0; c < nc; c++) {
         const bf_cluster& cl = r->clusters[c];
         if (cl.contig >= ctx->n_contigs || cl.mcontig >= ctx->n_contigs) return BF_ERR_INVALID;
-        out += ctx->contig_names[cl.contig]; out += '\t'; out += cl.strand ? '+' : '-'; out += '\t';
-        put_u64(out, (uint64_t)cl.lpos); out += "\t\t";
-        out += ctx->contig_names[cl.mcontig]; out += '\t'; out += cl.mstrand ? '+' : '-'; out += '\t';
-        put_u64(out, (uint64_t)cl.rpos); out += "\t\t";                               // detect.rs:233-235
-        for (uint64_t k = cl.read_begin; k < cl.read_end; k++) {
-            if (k > cl.read_begin) out += ';';
-            const bf_read& rd = r->reads[k];
+        if (cl.read_end < cl.read_begin || cl.read_end > r->n_reads) return BF_ERR_INVALID;
+        off[c] = total;
+        uint64_t sz = ctx->contig_names[cl.contig].size() + ctx->contig_names[cl.mcontig].size() +
+                      dec_len((uint64_t)cl.lpos) + dec_len((uint64_t)cl.rpos) + 13;   // 10 tabs, 2 strands, newline
+        const uint64_t k = cl.read_end - cl.read_begin;
+        if (k) sz += k - 1;                                                             // ';' separators
+        for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
+            const bf_read& rd = r->reads[i];
             if (rd.junction_off + rd.junction_len > r->junction_size) return BF_ERR_INVALID;
-            out.append((const char*)r->junction_bytes + rd.junction_off, rd.junction_len);
+            sz += rd.junction_len;
         }
-        out += "\t\t\n";                                                              // detect.rs:240
+        total += sz;
     }
-    if (buf) memcpy(buf, out.data(), (size_t)std::min<uint64_t>(cap, out.size()));
-    return (int64_t)out.size();
+    off[nc] = total;
+    if (!buf) return (int64_t)total;
+    if (cap < total) {                                   // truncated copy, as documented: size is still returned
+        std::string tmp((size_t)total, '\0');
+        const int64_t n = bf_format_sv(ctx, r, tmp.data(), total);
+        if (n < 0) return n;
+        memcpy(buf, tmp.data(), (size_t)cap);
+        return (int64_t)total;
+    }
+    memcpy(buf, kSvHeader, hdr);
+    auto fill = [&](uint64_t c0, uint64_t c1) {
+        for (uint64_t c = c0; c < c1; c++) {
+            const bf_cluster& cl = r->clusters[c];
+            char* p = buf + off[c];
+            const std::string& n1 = ctx->contig_names[cl.contig];
+            const std::string& n2 = ctx->contig_names[cl.mcontig];
+            memcpy(p, n1.data(), n1.size()); p += n1.size();
+            *p++ = '\t'; *p++ = cl.strand ? '+' : '-'; *p++ = '\t';
+            p = put_dec(p, (uint64_t)cl.lpos); *p++ = '\t'; *p++ = '\t';
+            memcpy(p, n2.data(), n2.size()); p += n2.size();
+            *p++ = '\t'; *p++ = cl.mstrand ? '+' : '-'; *p++ = '\t';
+            p = put_dec(p, (uint64_t)cl.rpos); *p++ = '\t'; *p++ = '\t';                // detect.rs:233-235
+            for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
+                if (i > cl.read_begin) *p++ = ';';
+                const bf_read& rd = r->reads[i];
+                memcpy(p, r->junction_bytes + rd.junction_off, rd.junction_len); p += rd.junction_len;
+            }
+            *p++ = '\t'; *p++ = '\t'; *p++ = '\n';                                      // detect.rs:240
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const uint64_t nt = total < (8u << 20) ? 1 : std::min<uint64_t>(std::max(1u, std::min(hw, 8u)), nc);
+    if (nt <= 1) { fill(0, nc); return (int64_t)total; }
+    std::vector<std::thread> pool;
+    uint64_t c0 = 0;
+    for (uint64_t t = 0; t < nt; t++) {                  // equal bytes per thread
+        const uint64_t want = hdr + (total - hdr) * (t + 1) / nt;
+        uint64_t c1 = t + 1 == nt ? nc : (uint64_t)(std::upper_bound(off.begin(), off.end(), want) - off.begin());
+        c1 = std::min(std::max(c1, c0), nc);
+        pool.emplace_back(fill, c0, c1);
+        c0 = c1;
+    }
+    for (auto& th : pool) th.join();
+    return (int64_t)total;
 }
 
 // ---- multi-GPU stage calls -------------------------------------------------------------------

@@ -8,28 +8,31 @@
 //     --anchor-len=N --anchor-mm=N --max-frag-len=N --min-evidence=N     (as the reference)
 //     --anchor-hits=FILE   read bowtie's output (the 4-column `--suppress 5,6,7,8` lines) from FILE
 //                          ("-" = stdin) instead of spawning bowtie on <bam_file>.
-//     --threads=N          BGZF inflate workers of the BAM front-end [default: 4]
+//     --threads=N          host worker threads: BGZF inflate, FASTA load, anchor-hit parsing [default: 8]
+//     --timing             print the wall time of every host/GPU stage on stderr (TIMING lines)
+//   breakfast-hip hits [--threads=N] [--block-bytes=N] <hits_file> <genome>
+//     parses bowtie's output like detect does and prints one line per paired read; needs no GPU.
 //   breakfast-hip anchors [--anchor-len=N] <bam_file>
 //     prints the anchor FASTA that detect feeds to bowtie (detect.rs:290-338); needs no GPU.
 //
 // Without --anchor-hits the driver does what detect.rs:58-70 does: spawn
 // `bowtie -f -p1 -v0 -m1 -B1 --suppress 5,6,7,8 <genome> -`, feed it from a producer thread that
-// scans the BAM, and consume its stdout.  A parser thread turns lines into batches while the main
-// thread hands finished batches to the GPU library.
+// scans the BAM, and consume its stdout.  The stream is parsed by a pool of threads (hits_parser.cpp)
+// while the main thread hands finished batches, in input order, to the GPU library.
 //
 // Errors follow src/common.rs:8-13: "ERROR: <msg>" on stderr, exit status -1.
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
-#include <condition_variable>
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <deque>
+#include <functional>
 #include <memory>
-#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <string_view>
@@ -39,11 +42,14 @@
 
 #include <fcntl.h>
 #include <spawn.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
 #include "../../include/breakfast_hip.h"
 #include "bam_reader.h"
+#include "hits_parser.h"
 
 extern char** environ;
 
@@ -63,157 +69,147 @@ static const char* USAGE =
     "  --anchor-mm=N        Mismatches allowed in anchor alignments [default: 0]\n"
     "  --max-frag-len=N     Maximum fragment length [default: 5000]\n"
     "  --min-evidence=N     Minimum number of supporting DNA fragments [default: 2]\n"
-    "  --anchor-hits=FILE   Read Bowtie's anchor alignments from FILE instead of running Bowtie\n";
+    "  --anchor-hits=FILE   Read Bowtie's anchor alignments from FILE instead of running Bowtie\n"
+    "  --threads=N          Host worker threads [default: 8]\n"
+    "  --timing             Print stage wall times on stderr\n";
+
+struct Timing {
+    bool on = false;
+    std::vector<std::pair<std::string, double>> rows;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    void lap(const char* name) {
+        const auto now = std::chrono::steady_clock::now();
+        rows.emplace_back(name, std::chrono::duration<double>(now - last).count());
+        last = now;
+    }
+    void add(const char* name, double s) { rows.emplace_back(name, s); }
+    void print() const {
+        if (!on) return;
+        for (auto& r : rows) fprintf(stderr, "TIMING\t%s\t%.6f\n", r.first.c_str(), r.second);
+        fprintf(stderr, "TIMING\ttotal\t%.6f\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
+static void parallel_for(size_t n, int threads, const std::function<void(size_t)>& fn) {
+    const int t = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n));
+    if (t == 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (int k = 0; k < t; k++)
+        pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) fn(i); });
+    for (auto& th : pool) th.join();
+}
 
 struct Fasta {
     std::vector<std::string> names;
-    std::vector<std::string> seqs;
+    std::vector<std::unique_ptr<char[]>> seqs;      // uninitialised storage: no 3 GB zero-fill
+    std::vector<uint64_t> lens;
 };
 
 static bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; }
 
 // bio::io::fasta::Reader semantics (detect.rs:48-56): id = header up to the first whitespace, sequence
-// lines right-trimmed and concatenated, case preserved; a repeated id replaces the earlier record.
-static Fasta read_fasta(const std::string& path) {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) error("Genome FASTA file %s could not be read.", path.c_str());
+// lines right-trimmed and concatenated, case preserved; a repeated id replaces the earlier record
+// (HashMap::insert).  The file is mapped and cut into pieces at line boundaries; the pieces are
+// measured, then copied, by `threads` workers.
+static Fasta read_fasta(const std::string& path, int threads) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) error("Genome FASTA file %s could not be read.", path.c_str());
+    struct stat st;
+    if (fstat(fd, &st) != 0) error("Genome FASTA file %s could not be read.", path.c_str());
     Fasta fa;
-    std::unordered_map<std::string, size_t> index;
-    char* line = nullptr;
-    size_t cap = 0;
-    ssize_t n;
-    long cur = -1;
-    while ((n = getline(&line, &cap, f)) >= 0) {
-        size_t len = (size_t)n;
-        const bool header = len > 0 && line[0] == '>';
-        while (len > 0 && is_space(line[len - 1])) len--;
-        if (header) {
-            size_t e = 1;
-            while (e < len && !is_space(line[e])) e++;
-            std::string id(line + 1, e - 1);
-            auto it = index.find(id);
-            if (it == index.end()) {
-                index[id] = fa.names.size();
-                fa.names.push_back(id);
-                fa.seqs.emplace_back();
-                cur = (long)fa.names.size() - 1;
-            } else {
-                cur = (long)it->second;
-                fa.seqs[cur].clear();
+    const size_t size = (size_t)st.st_size;
+    if (size == 0) { close(fd); return fa; }
+    std::string fallback;
+    const char* data = nullptr;
+    void* map = S_ISREG(st.st_mode) ? mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+    size_t n = size;
+    if (map != MAP_FAILED) {
+        data = (const char*)map;
+        (void)madvise(map, size, MADV_WILLNEED);
+    } else {                                            // not mappable (a pipe): read it whole
+        char buf[1 << 16];
+        ssize_t r;
+        while ((r = read(fd, buf, sizeof buf)) > 0) fallback.append(buf, (size_t)r);
+        data = fallback.data(); n = fallback.size();
+    }
+    // record starts: '>' at the beginning of a line
+    struct Rec { size_t head, body, end; };
+    std::vector<Rec> recs;
+    for (const char* p = data; p < data + n;) {
+        const char* q = (const char*)memchr(p, '>', (size_t)(data + n - p));
+        if (!q) break;
+        if (q == data || q[-1] == '\n') {
+            if (!recs.empty()) recs.back().end = (size_t)(q - data);
+            const char* eol = (const char*)memchr(q, '\n', (size_t)(data + n - q));
+            recs.push_back(Rec{(size_t)(q - data), eol ? (size_t)(eol - data) + 1 : n, n});
+        }
+        p = q + 1;
+    }
+    // pieces of record bodies, cut at line boundaries
+    struct Piece { size_t rec, a, b, out; uint64_t len; };
+    std::vector<Piece> pieces;
+    const size_t kPiece = 16u << 20;
+    for (size_t r = 0; r < recs.size(); r++) {
+        size_t a = recs[r].body;
+        while (a < recs[r].end) {
+            size_t b = std::min(recs[r].end, a + kPiece);
+            if (b < recs[r].end) {
+                const char* nl = (const char*)memchr(data + b, '\n', recs[r].end - b);
+                b = nl ? (size_t)(nl - data) + 1 : recs[r].end;
             }
-        } else if (cur >= 0) {
-            fa.seqs[cur].append(line, len);
+            pieces.push_back(Piece{r, a, b, 0, 0});
+            a = b;
         }
     }
-    free(line);
-    fclose(f);
+    auto each_line = [&](const Piece& pc, auto&& fn) {
+        const char* s = data + pc.a;
+        const char* end = data + pc.b;
+        while (s < end) {
+            const char* nl = (const char*)memchr(s, '\n', (size_t)(end - s));
+            const char* e = nl ? nl : end;
+            while (e > s && is_space(e[-1])) e--;
+            fn(s, (size_t)(e - s));
+            s = nl ? nl + 1 : end;
+        }
+    };
+    parallel_for(pieces.size(), threads, [&](size_t i) {
+        uint64_t len = 0;
+        each_line(pieces[i], [&](const char*, size_t l) { len += l; });
+        pieces[i].len = len;
+    });
+    std::vector<uint64_t> rec_len(recs.size(), 0);
+    for (auto& pc : pieces) { pc.out = rec_len[pc.rec]; rec_len[pc.rec] += pc.len; }
+    // ids; a repeated id keeps its first slot and takes the later record's sequence
+    std::unordered_map<std::string, size_t> index;
+    std::vector<size_t> slot_rec;                        // slot -> record that supplies the sequence
+    for (size_t r = 0; r < recs.size(); r++) {
+        const char* h = data + recs[r].head + 1;
+        const char* hend = data + (recs[r].body > recs[r].head ? recs[r].body : n);
+        const char* e = h;
+        while (e < hend && !is_space(*e)) e++;
+        std::string id(h, (size_t)(e - h));
+        auto it = index.find(id);
+        if (it == index.end()) { index[id] = fa.names.size(); fa.names.push_back(id); slot_rec.push_back(r); }
+        else slot_rec[it->second] = r;
+    }
+    std::vector<long> rec_slot(recs.size(), -1);
+    for (size_t sl = 0; sl < slot_rec.size(); sl++) rec_slot[slot_rec[sl]] = (long)sl;
+    fa.seqs.resize(fa.names.size());
+    fa.lens.resize(fa.names.size());
+    for (size_t sl = 0; sl < slot_rec.size(); sl++) {
+        fa.lens[sl] = rec_len[slot_rec[sl]];
+        fa.seqs[sl].reset(new char[std::max<uint64_t>(fa.lens[sl], 1)]);
+    }
+    parallel_for(pieces.size(), threads, [&](size_t i) {
+        const long sl = rec_slot[pieces[i].rec];
+        if (sl < 0) return;                              // superseded by a later record of the same id
+        char* out = fa.seqs[(size_t)sl].get() + pieces[i].out;
+        each_line(pieces[i], [&](const char* s, size_t l) { memcpy(out, s, l); out += l; });
+    });
+    if (map != MAP_FAILED) munmap(map, size);
+    close(fd);
     return fa;
-}
-
-struct Batch {                          // one bf_batch worth of parsed anchor-hit pairs
-    std::string seq, frag;
-    std::vector<uint64_t> seq_off{0}, frag_off{0};
-    std::vector<bf_hit> hits;
-};
-
-// parser thread -> main thread hand-over (at most two batches in flight)
-struct BatchQueue {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<std::unique_ptr<Batch>> q;
-    bool closed = false;
-    std::string error;
-    void push(std::unique_ptr<Batch> b) {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return q.size() < 2; });
-        q.push_back(std::move(b));
-        cv.notify_all();
-    }
-    void close(const std::string& err = "") {
-        std::lock_guard<std::mutex> g(mu);
-        closed = true;
-        if (error.empty()) error = err;
-        cv.notify_all();
-    }
-    std::unique_ptr<Batch> pop() {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return !q.empty() || closed; });
-        if (q.empty()) return nullptr;
-        auto b = std::move(q.front());
-        q.pop_front();
-        cv.notify_all();
-        return b;
-    }
-};
-
-static bool parse_u64(std::string_view s, uint64_t& v) {
-    if (s.empty()) return false;
-    v = 0;
-    for (char c : s) {
-        if (c < '0' || c > '9') return false;
-        v = v * 10 + (uint64_t)(c - '0');
-    }
-    return true;
-}
-
-// nth field (0-based) of `s` split on `d`, like Rust's split(d).nth(n)
-static bool field(std::string_view s, char d, int n, std::string_view& out) {
-    size_t a = 0;
-    for (int i = 0;; i++) {
-        size_t b = s.find(d, a);
-        if (i == n) { out = s.substr(a, b == std::string_view::npos ? std::string_view::npos : b - a); return true; }
-        if (b == std::string_view::npos) return false;
-        a = b + 1;
-    }
-}
-
-struct ParseError : std::runtime_error { using std::runtime_error::runtime_error; };
-
-// the consume loop, detect.rs:76-103: pair 5p/3p lines by read number, extract the fields
-static void parse_hits(FILE* in, const std::unordered_map<std::string, uint32_t>& contig_id, const std::string& genome_path,
-                       BatchQueue& out) {
-    const size_t kBatch = 1u << 20;
-    auto cur = std::make_unique<Batch>();
-    std::string prev;
-    uint64_t prev_read_num = 0;
-    char* lineb = nullptr;
-    size_t cap = 0;
-    ssize_t n;
-    auto bad = [&](const char* what, std::string_view line) { throw ParseError(std::string(what) + ": " + std::string(line)); };
-    while ((n = getline(&lineb, &cap, in)) >= 0) {
-        size_t len = (size_t)n;
-        if (len && lineb[len - 1] == '\n') len--;
-        if (len && lineb[len - 1] == '\r') len--;
-        std::string_view line(lineb, len);
-        std::string_view f1;
-        uint64_t read_num;
-        if (!field(line, ':', 1, f1) || !parse_u64(f1, read_num)) bad("Malformed anchor alignment line", line);
-        if (line.substr(0, 3) == "5p:") { prev.assign(line); prev_read_num = read_num; continue; }
-        else if (line.substr(0, 3) == "3p:" && read_num != prev_read_num) continue;
-        std::string_view frag, seq, st, mst, chr, mchr, p, mp;
-        if (!field(line, ':', 2, frag) || !field(line, ':', 3, seq)) bad("Malformed anchor alignment line", line);
-        std::string_view pv(prev);
-        if (!field(pv, '\t', 1, st) || !field(pv, '\t', 2, chr) || !field(pv, '\t', 3, p) ||
-            !field(line, '\t', 1, mst) || !field(line, '\t', 2, mchr) || !field(line, '\t', 3, mp))
-            bad("Malformed anchor alignment line", line);
-        uint64_t pos5, pos3;
-        if (!parse_u64(p, pos5) || !parse_u64(mp, pos3)) bad("Malformed anchor offset", line);
-        auto c5 = contig_id.find(std::string(chr)), c3 = contig_id.find(std::string(mchr));
-        if (c5 == contig_id.end() || c3 == contig_id.end())
-            throw ParseError("Anchor aligned to a contig that " + genome_path + ".fa does not contain (the reference panics here, detect.rs:115).");
-        if (pos5 >= 0x80000000ull || pos3 >= 0x80000000ull) throw ParseError("Anchor offset beyond 2^31.");
-        bf_hit h;
-        memset(&h, 0, sizeof h);
-        h.pos5 = (uint32_t)pos5; h.pos3 = (uint32_t)pos3;
-        h.contig5 = (uint16_t)c5->second; h.contig3 = (uint16_t)c3->second;
-        h.strands = (uint8_t)((st == "+" ? 1 : 0) | (mst == "+" ? 2 : 0));
-        cur->hits.push_back(h);
-        cur->seq.append(seq); cur->seq_off.push_back(cur->seq.size());
-        cur->frag.append(frag); cur->frag_off.push_back(cur->frag.size());
-        if (cur->hits.size() >= kBatch) { out.push(std::move(cur)); cur = std::make_unique<Batch>(); }
-    }
-    free(lineb);
-    if (!cur->hits.empty()) out.push(std::move(cur));
 }
 
 struct Child { pid_t pid = -1; int to_child = -1, from_child = -1; };
@@ -246,18 +242,40 @@ static std::unique_ptr<bam::Reader> open_bam(const std::string& path, int thread
     }
 }
 
+static bool parse_u64(std::string_view s, uint64_t& v) {
+    if (s.empty()) return false;
+    v = 0;
+    for (char c : s) {
+        if (c < '0' || c > '9') return false;
+        v = v * 10 + (uint64_t)(c - '0');
+    }
+    return true;
+}
+
+static void write_all(int fd, const char* p, size_t n) {
+    while (n) {
+        const ssize_t w = write(fd, p, std::min<size_t>(n, 1u << 30));
+        if (w < 0) { if (errno == EINTR) continue; error("Could not write the output: %s", strerror(errno)); }
+        p += w; n -= (size_t)w;
+    }
+}
+
 int main(int argc, char** argv) {
     const bool anchors_only = argc >= 2 && strcmp(argv[1], "anchors") == 0;
-    if (argc < 2 || (strcmp(argv[1], "detect") != 0 && !anchors_only)) {
+    const bool hits_only = argc >= 2 && strcmp(argv[1], "hits") == 0;
+    if (argc < 2 || (strcmp(argv[1], "detect") != 0 && !anchors_only && !hits_only)) {
         fputs("\nBreakfast is a software for detecting chromosomal rearrangements in DNA/RNA sequencing data.\n\n"
-              "Usage:\n  breakfast-hip detect [options] <bam_file> <genome>\n  breakfast-hip anchors [--anchor-len=N] <bam_file>\n", stderr);
+              "Usage:\n  breakfast-hip detect [options] <bam_file> <genome>\n  breakfast-hip anchors [--anchor-len=N] <bam_file>\n"
+              "  breakfast-hip hits [--threads=N] [--block-bytes=N] <hits_file> <genome>\n", stderr);
         return -1;
     }
     bf_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.anchor_len = 30; cfg.max_frag_len = 5000; cfg.min_evidence = 2; cfg.device = -1;
     std::string hits_path;
-    int threads = 4;
+    int threads = 8;
+    hits::Options popt;
+    Timing timing;
     std::vector<std::string> pos;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
@@ -273,10 +291,13 @@ int main(int argc, char** argv) {
         else if (val("--max-frag-len=", v)) cfg.max_frag_len = (uint32_t)std::min<uint64_t>(v, 0xffffffffu);
         else if (val("--min-evidence=", v)) cfg.min_evidence = (uint32_t)std::min<uint64_t>(v, 0xffffffffu);
         else if (val("--threads=", v)) threads = (int)std::min<uint64_t>(std::max<uint64_t>(v, 1), 64);
+        else if (val("--block-bytes=", v)) popt.block_bytes = (size_t)std::max<uint64_t>(v, 1);
+        else if (a == "--timing") timing.on = true;
         else if (a.compare(0, 14, "--anchor-hits=") == 0) hits_path = a.substr(14);
         else if (a.size() > 1 && a[0] == '-' && a != "-") error("Invalid arguments.\n%s", USAGE);
         else pos.push_back(a);
     }
+    popt.threads = threads;
     if (anchors_only) {
         if (pos.size() != 1) error("Invalid arguments.\nUsage:\n  breakfast-hip anchors [--anchor-len=N] <bam_file>");
         auto bam = open_bam(pos[0], threads);
@@ -286,12 +307,35 @@ int main(int argc, char** argv) {
         fflush(stdout);
         return 0;
     }
+    if (hits_only) {
+        // the consume loop's parsing half alone (detect.rs:76-103): one line per paired read
+        if (pos.size() != 2) error("Invalid arguments.\nUsage:\n  breakfast-hip hits [--threads=N] [--block-bytes=N] <hits_file> <genome>");
+        Fasta fa = read_fasta(pos[1] + ".fa", threads);
+        hits::ContigIndex contigs;
+        for (size_t i = 0; i < fa.names.size(); i++) contigs.add(fa.names[i], (uint32_t)i);
+        contigs.build();
+        const int fd = pos[0] == "-" ? 0 : open(pos[0].c_str(), O_RDONLY);
+        if (fd < 0) error("Cannot open file %s for reading.", pos[0].c_str());
+        try {
+            hits::parse_stream(fd, contigs, pos[1], popt, [&](hits::Batch& b) {
+                for (size_t i = 0; i < b.n(); i++) {
+                    const bf_hit& h = b.hits[i];
+                    fwrite(b.frag.data() + b.frag_off[i], 1, b.frag_off[i + 1] - b.frag_off[i], stdout);
+                    fputc('\t', stdout);
+                    fwrite(b.seq.data() + b.seq_off[i], 1, b.seq_off[i + 1] - b.seq_off[i], stdout);
+                    fprintf(stdout, "\t%u\t%u\t%u\t%u\t%u\n", h.strands, h.contig5, h.pos5, h.contig3, h.pos3);
+                }
+            });
+        } catch (const std::exception& e) { error("%s", e.what()); }
+        fflush(stdout);
+        return 0;
+    }
     if (pos.size() != 2) error("Invalid arguments.\n%s", USAGE);
     const std::string sam_path = pos[0], genome_path = pos[1];
 
     // Bowtie and the BAM producer start BEFORE the GPU is touched (the child must be spawned from a
     // process that has not initialised the device); the pipes simply fill until we start consuming.
-    FILE* in = nullptr;
+    int in_fd = -1;
     Child child;
     std::thread producer;
     std::unique_ptr<bam::Reader> bam_reader;
@@ -308,52 +352,56 @@ int main(int argc, char** argv) {
             } catch (const std::exception& e) { error("Failed reading BAM record: %s", e.what()); }
             fclose(w);
         });
-        in = fdopen(child.from_child, "r");
+        in_fd = child.from_child;
     } else {
-        in = hits_path == "-" ? stdin : fopen(hits_path.c_str(), "rb");
-        if (!in) error("Cannot open file %s for reading.", hits_path.c_str());
+        in_fd = hits_path == "-" ? 0 : open(hits_path.c_str(), O_RDONLY);
+        if (in_fd < 0) error("Cannot open file %s for reading.", hits_path.c_str());
     }
+    timing.lap("start_up");
 
     bf_ctx* ctx = nullptr;
     if (bf_ctx_create(&cfg, &ctx) != BF_OK) error("%s", bf_last_error(nullptr));
+    timing.lap("gpu_context");
 
-    Fasta fa = read_fasta(genome_path + ".fa");
+    Fasta fa = read_fasta(genome_path + ".fa", threads);
     fprintf(stderr, "Reading reference genome into memory...\n");
+    timing.lap("fasta_load");
+    hits::ContigIndex contigs;
     {
-        std::vector<const char*> names; std::vector<const uint8_t*> seqs; std::vector<uint64_t> lens;
+        std::vector<const char*> names; std::vector<const uint8_t*> seqs;
         for (size_t i = 0; i < fa.names.size(); i++) {
             names.push_back(fa.names[i].c_str());
-            seqs.push_back((const uint8_t*)fa.seqs[i].data());
-            lens.push_back(fa.seqs[i].size());
+            seqs.push_back((const uint8_t*)fa.seqs[i].get());
+            contigs.add(fa.names[i], (uint32_t)i);
         }
         if (names.empty()) error("Genome FASTA file %s.fa holds no sequences.", genome_path.c_str());
-        if (bf_genome_set(ctx, (uint32_t)names.size(), names.data(), seqs.data(), lens.data()) != BF_OK)
+        if (bf_genome_set(ctx, (uint32_t)names.size(), names.data(), seqs.data(), fa.lens.data()) != BF_OK)
             error("%s", bf_last_error(ctx));
+        contigs.build();
     }
-    std::unordered_map<std::string, uint32_t> contig_id;
-    for (size_t i = 0; i < fa.names.size(); i++) contig_id[fa.names[i]] = (uint32_t)i;
-    for (auto& s : fa.seqs) std::string().swap(s);             // the genome now lives in HBM
+    for (auto& s : fa.seqs) s.reset();                         // the genome now lives in HBM
+    timing.lap("genome_to_hbm");
 
     fprintf(stderr, "Splitting unaligned reads into %u bp anchors and aligning against the genome...\n", cfg.anchor_len);
 
-    BatchQueue queue;
-    std::thread parser([&] {
-        try { parse_hits(in, contig_id, genome_path, queue); queue.close(); }
-        catch (const std::exception& e) { queue.close(e.what()); }
-    });
-    while (auto b = queue.pop()) {
-        bf_batch bb;
-        bb.n_reads = b->hits.size();
-        bb.seq_bytes = (const uint8_t*)b->seq.data(); bb.seq_off = b->seq_off.data();
-        bb.frag_bytes = (const uint8_t*)b->frag.data(); bb.frag_off = b->frag_off.data();
-        bb.hits = b->hits.data();
-        if (bf_submit(ctx, &bb) != BF_OK) error("%s", bf_last_error(ctx));
-    }
-    parser.join();
-    if (!queue.error.empty()) error("%s", queue.error.c_str());
-    if (in != stdin) fclose(in);
+    double submit_s = 0;
+    try {
+        hits::parse_stream(in_fd, contigs, genome_path, popt, [&](hits::Batch& b) {
+            const auto t0 = std::chrono::steady_clock::now();
+            bf_batch bb;
+            bb.n_reads = b.n();
+            bb.seq_bytes = (const uint8_t*)b.seq.data(); bb.seq_off = b.seq_off.data();
+            bb.frag_bytes = (const uint8_t*)b.frag.data(); bb.frag_off = b.frag_off.data();
+            bb.hits = b.hits.data();
+            if (bf_submit(ctx, &bb) != BF_OK) error("%s", bf_last_error(ctx));
+            submit_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
+    } catch (const std::exception& e) { error("%s", e.what()); }
+    if (in_fd > 0) close(in_fd);
     if (producer.joinable()) producer.join();
     if (child.pid > 0) { int st = 0; waitpid(child.pid, &st, 0); }     // the reference never checks it either
+    timing.lap("parse_and_submit");
+    timing.add("  of_which_bf_submit", submit_s);
 
     bf_result res;
     if (bf_localise(ctx) != BF_OK) error("%s", bf_last_error(ctx));
@@ -363,12 +411,17 @@ int main(int argc, char** argv) {
     fprintf(stderr, "Sorting rearrangement supporting reads by position...\n");
     fprintf(stderr, "Identifying rearrangements based on clusters of discordant reads...\n");
     if (bf_clusterise(ctx, &res) != BF_OK) error("%s", bf_last_error(ctx));
+    timing.lap("gpu_localise_clusterise");
     const int64_t size = bf_format_sv(ctx, &res, nullptr, 0);
     if (size < 0) error("could not render the result");
-    std::string out((size_t)size, '\0');
-    bf_format_sv(ctx, &res, out.data(), (uint64_t)size);
-    fwrite(out.data(), 1, out.size(), stdout);
+    std::unique_ptr<char[]> out(new char[(size_t)size + 1]);
+    if (bf_format_sv(ctx, &res, out.get(), (uint64_t)size) != size) error("could not render the result");
+    timing.lap("format_sv");
     fflush(stdout);
+    write_all(1, out.get(), (size_t)size);
+    timing.lap("write_stdout");
     bf_ctx_destroy(ctx);
+    timing.lap("teardown");
+    timing.print();
     return 0;
 }

@@ -1,0 +1,347 @@
+// See hits_parser.h.  Reference semantics: src/detect.rs:76-103.
+
+#include "hits_parser.h"
+
+#include <algorithm>
+#include <cerrno>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace hits {
+
+void ContigIndex::build() {
+    map_.clear();
+    map_.reserve(names_.size() * 2);
+    for (size_t i = 0; i < names_.size(); i++) map_[std::string_view(names_[i])] = ids_[i];   // last record of a name wins
+    built_ = true;
+}
+
+int ContigIndex::find(std::string_view name) const {
+    auto it = map_.find(name);
+    return it == map_.end() ? -1 : (int)it->second;
+}
+
+namespace {
+
+bool parse_u64(std::string_view s, uint64_t& v) {
+    if (s.empty()) return false;
+    v = 0;
+    for (char c : s) {
+        if (c < '0' || c > '9') return false;
+        if (v > (0xffffffffffffffffull - (uint64_t)(c - '0')) / 10) return false;    // usize::parse overflows -> Err
+        v = v * 10 + (uint64_t)(c - '0');
+    }
+    return true;
+}
+
+// Fields of `s` split on `d`, like Rust's s.split(d): out[i] = i-th field for i < want; returns the
+// number of fields found (<= want).  The last requested field ends at the next delimiter or at the end.
+int split_fields(std::string_view s, char d, int want, std::string_view* out) {
+    const char* p = s.data();
+    const char* end = p + s.size();
+    int n = 0;
+    while (n < want) {
+        const char* q = (const char*)memchr(p, d, (size_t)(end - p));
+        out[n++] = std::string_view(p, (size_t)((q ? q : end) - p));
+        if (!q) break;
+        p = q + 1;
+    }
+    return n;
+}
+
+[[noreturn]] void bad(const char* what, std::string_view line) {
+    throw ParseError(std::string(what) + ": " + std::string(line.substr(0, 200)));
+}
+
+// `line.split(':').nth(1).unwrap().parse().unwrap()`, detect.rs:79
+uint64_t read_number(std::string_view line) {
+    std::string_view f[2];
+    uint64_t v;
+    if (split_fields(line, ':', 2, f) < 2 || !parse_u64(f[1], v)) bad("Malformed anchor alignment line", line);
+    return v;
+}
+
+struct PairParser {
+    const ContigIndex& contigs;
+    const std::string& genome_path;
+    int contig(std::string_view name) const {
+        const int id = contigs.find(name);
+        if (id < 0)
+            throw ParseError("Anchor aligned to a contig that " + genome_path +
+                             ".fa does not contain (the reference panics here, detect.rs:115).");
+        return id;
+    }
+
+    // detect.rs:89-103 for one (5p line, 3p line) pair
+    void operator()(std::string_view prev, std::string_view line, Batch& out) const {
+        std::string_view a[4], c[4], m[4];
+        if (split_fields(line, ':', 4, a) < 4) bad("Malformed anchor alignment line", line);   // nth(2), next()
+        if (split_fields(prev, '\t', 4, c) < 4 || split_fields(line, '\t', 4, m) < 4)
+            bad("Malformed anchor alignment line", line);
+        uint64_t pos5, pos3;
+        if (!parse_u64(c[3], pos5) || !parse_u64(m[3], pos3)) bad("Malformed anchor offset", line);
+        const int c5 = contig(c[2]), c3 = contig(m[2]);
+        if (pos5 >= 0x80000000ull || pos3 >= 0x80000000ull) throw ParseError("Anchor offset beyond 2^31.");
+        bf_hit h;
+        memset(&h, 0, sizeof h);
+        h.pos5 = (uint32_t)pos5; h.pos3 = (uint32_t)pos3;
+        h.contig5 = (uint16_t)c5; h.contig3 = (uint16_t)c3;
+        h.strands = (uint8_t)((c[1] == "+" ? 1 : 0) | (m[1] == "+" ? 2 : 0));
+        out.hits.push_back(h);
+        out.seq.append(a[3]); out.seq_off.push_back(out.seq.size());
+        out.frag.append(a[2]); out.frag_off.push_back(out.frag.size());
+    }
+};
+
+struct Block {
+    uint64_t seq = 0;
+    const char* p = nullptr;
+    size_t n = 0;
+    std::unique_ptr<char[]> own;          // empty for views into a mapping
+};
+
+struct Lead { std::string line; uint64_t read_num; bool is3p; };
+
+struct Parsed {
+    Batch batch;
+    std::vector<Lead> lead;               // lines before the block's first 5p line
+    bool has5 = false;
+    std::string last5;
+    uint64_t last5_num = 0;
+    std::string error;
+    uint64_t lines = 0, bytes = 0;
+};
+
+void parse_block(const Block& b, const PairParser& pair, Parsed& out) {
+    const char* s = b.p;
+    const char* end = b.p + b.n;
+    std::string_view prev;
+    uint64_t prev_num = 0;
+    out.bytes = b.n;
+    out.batch.seq.reserve(b.n * 3 / 4);
+    out.batch.frag.reserve(b.n / 8);
+    try {
+        while (s < end) {
+            const char* nl = (const char*)memchr(s, '\n', (size_t)(end - s));
+            const char* e = nl ? nl : end;
+            size_t len = (size_t)(e - s);
+            if (nl && len && s[len - 1] == '\r') len--;       // BufRead::lines strips "\n" or "\r\n"
+            const std::string_view line(s, len);
+            s = nl ? nl + 1 : end;
+            out.lines++;
+            const uint64_t num = read_number(line);
+            const bool is5 = line.substr(0, 3) == "5p:", is3 = line.substr(0, 3) == "3p:";
+            if (is5) { prev = line; prev_num = num; out.has5 = true; continue; }      // detect.rs:81-84
+            if (!out.has5) { out.lead.push_back(Lead{std::string(line), num, is3}); continue; }
+            if (is3 && num != prev_num) continue;                                      // detect.rs:85-87
+            pair(prev, line, out.batch);
+        }
+    } catch (const std::exception& ex) {
+        out.error = ex.what();
+    }
+    if (out.has5) { out.last5.assign(prev); out.last5_num = prev_num; }
+}
+
+struct Pipeline {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done, cv_room;
+    std::deque<Block> work;
+    std::map<uint64_t, std::unique_ptr<Parsed>> done;
+    uint64_t produced = 0, consumed = 0;
+    bool eof = false, abort = false;
+    std::string reader_error;
+    size_t max_in_flight = 4;
+};
+
+void push_block(Pipeline& pl, Block&& b) {
+    std::unique_lock<std::mutex> lk(pl.mu);
+    pl.cv_room.wait(lk, [&] { return pl.abort || pl.produced - pl.consumed < pl.max_in_flight; });
+    if (pl.abort) return;
+    b.seq = pl.produced++;
+    pl.work.push_back(std::move(b));
+    pl.cv_work.notify_one();
+}
+
+void read_mapped(Pipeline& pl, const char* base, size_t size, size_t block_bytes) {
+    size_t pos = 0;
+    while (pos < size) {
+        size_t end = std::min(size, pos + block_bytes);
+        if (end < size) {
+            const void* back = memrchr(base + pos, '\n', end - pos);
+            if (back) end = (size_t)((const char*)back - base) + 1;
+            else {
+                const void* fwd = memchr(base + end, '\n', size - end);
+                end = fwd ? (size_t)((const char*)fwd - base) + 1 : size;
+            }
+        }
+        Block b;
+        b.p = base + pos; b.n = end - pos;
+        push_block(pl, std::move(b));
+        pos = end;
+        { std::lock_guard<std::mutex> g(pl.mu); if (pl.abort) return; }
+    }
+}
+
+void read_stream(Pipeline& pl, int fd, size_t block_bytes) {
+    std::unique_ptr<char[]> carry;
+    size_t carry_n = 0;
+    bool at_eof = false;
+    while (!at_eof) {
+        size_t cap = std::max(block_bytes, carry_n * 2);
+        std::unique_ptr<char[]> buf(new char[cap]);
+        if (carry_n) memcpy(buf.get(), carry.get(), carry_n);
+        size_t n = carry_n;
+        carry_n = 0;
+        const void* last_nl = nullptr;
+        for (;;) {
+            while (n < cap) {
+                const ssize_t r = read(fd, buf.get() + n, cap - n);
+                if (r < 0) { if (errno == EINTR) continue; throw std::runtime_error(std::string("read failed: ") + strerror(errno)); }
+                if (r == 0) { at_eof = true; break; }
+                n += (size_t)r;
+            }
+            last_nl = at_eof ? nullptr : memrchr(buf.get(), '\n', n);
+            if (at_eof || last_nl) break;
+            std::unique_ptr<char[]> bigger(new char[cap * 2]);       // one line longer than the block
+            memcpy(bigger.get(), buf.get(), n);
+            buf = std::move(bigger);
+            cap *= 2;
+        }
+        size_t take = n;
+        if (!at_eof) {
+            take = (size_t)((const char*)last_nl - buf.get()) + 1;
+            carry_n = n - take;
+            if (carry_n) { carry.reset(new char[carry_n]); memcpy(carry.get(), buf.get() + take, carry_n); }
+        }
+        if (take) {
+            Block b;
+            b.p = buf.get(); b.n = take; b.own = std::move(buf);
+            push_block(pl, std::move(b));
+        }
+        { std::lock_guard<std::mutex> g(pl.mu); if (pl.abort) return; }
+    }
+}
+
+}  // namespace
+
+Stats parse_stream(int fd, const ContigIndex& contigs, const std::string& genome_path, const Options& opt,
+                   const std::function<void(Batch&)>& sink) {
+    const int n_workers = std::max(1, opt.threads);
+    const size_t block_bytes = std::max<size_t>(opt.block_bytes, 1);
+    Pipeline pl;
+    pl.max_in_flight = (size_t)n_workers * 2 + 2;
+
+    // a regular file is mapped: blocks are views, nothing is copied before the parse
+    const char* map_base = nullptr;
+    size_t map_size = 0;
+    struct stat st;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && lseek(fd, 0, SEEK_CUR) == 0) {
+        void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            map_base = (const char*)m; map_size = (size_t)st.st_size;
+            (void)madvise(m, map_size, MADV_SEQUENTIAL);
+        }
+    }
+
+    std::thread reader([&] {
+        try {
+            if (map_base) read_mapped(pl, map_base, map_size, block_bytes);
+            else read_stream(pl, fd, block_bytes);
+        } catch (const std::exception& ex) {
+            std::lock_guard<std::mutex> g(pl.mu);
+            pl.reader_error = ex.what();
+        }
+        std::lock_guard<std::mutex> g(pl.mu);
+        pl.eof = true;
+        pl.cv_work.notify_all();
+        pl.cv_done.notify_all();
+    });
+
+    const PairParser proto{contigs, genome_path};
+    std::vector<std::thread> workers;
+    for (int w = 0; w < n_workers; w++) {
+        workers.emplace_back([&] {
+            PairParser pair{contigs, genome_path};
+            for (;;) {
+                Block b;
+                {
+                    std::unique_lock<std::mutex> lk(pl.mu);
+                    pl.cv_work.wait(lk, [&] { return pl.abort || !pl.work.empty() || pl.eof; });
+                    if (pl.abort || pl.work.empty()) return;
+                    b = std::move(pl.work.front());
+                    pl.work.pop_front();
+                }
+                auto out = std::make_unique<Parsed>();
+                parse_block(b, pair, *out);
+                std::lock_guard<std::mutex> g(pl.mu);
+                pl.done[b.seq] = std::move(out);
+                pl.cv_done.notify_all();
+            }
+        });
+    }
+
+    auto shut_down = [&](bool abort) {
+        {
+            std::lock_guard<std::mutex> g(pl.mu);
+            if (abort) pl.abort = true;
+            pl.cv_work.notify_all(); pl.cv_room.notify_all(); pl.cv_done.notify_all();
+        }
+        if (reader.joinable()) reader.join();
+        for (auto& t : workers) if (t.joinable()) t.join();
+        if (map_base) munmap((void*)map_base, map_size);
+    };
+
+    Stats stats;
+    std::string prev;                      // the most recent 5p line of the stream so far (detect.rs:73)
+    uint64_t prev_num = 0;                 // detect.rs:74
+    Batch lead_batch;
+    try {
+        for (;;) {
+            std::unique_ptr<Parsed> p;
+            {
+                std::unique_lock<std::mutex> lk(pl.mu);
+                pl.cv_done.wait(lk, [&] { return pl.done.count(pl.consumed) || (pl.eof && pl.consumed == pl.produced); });
+                auto it = pl.done.find(pl.consumed);
+                if (it == pl.done.end()) {
+                    if (!pl.reader_error.empty()) throw ParseError(pl.reader_error);
+                    break;
+                }
+                p = std::move(it->second);
+                pl.done.erase(it);
+            }
+            // the block's lines before its first 5p line, against the stream's state (detect.rs:85-103)
+            lead_batch.clear();
+            for (const Lead& l : p->lead) {
+                if (l.is3p && l.read_num != prev_num) continue;
+                proto(prev, l.line, lead_batch);
+            }
+            if (!p->error.empty()) throw ParseError(p->error);
+            if (lead_batch.n()) { stats.pairs += lead_batch.n(); sink(lead_batch); }
+            if (p->batch.n()) { stats.pairs += p->batch.n(); sink(p->batch); }
+            if (p->has5) { prev = std::move(p->last5); prev_num = p->last5_num; }
+            stats.bytes += p->bytes; stats.lines += p->lines; stats.blocks++;
+            p.reset();
+            {
+                std::lock_guard<std::mutex> g(pl.mu);
+                pl.consumed++;
+                pl.cv_room.notify_all();
+            }
+        }
+    } catch (...) {
+        shut_down(true);
+        throw;
+    }
+    shut_down(false);
+    return stats;
+}
+
+}  // namespace hits

@@ -1,0 +1,61 @@
+// Multi-threaded consumer of Bowtie's stdout = the line-pairing half of the consume loop
+// (src/detect.rs:76-103): pairs `5p:`/`3p:` lines by read number and extracts fragment id, read
+// sequence and the two (strand, contig, offset) triples into structure-of-arrays batches for
+// bf_submit.  Host code only (SURVEY.md section 8f "next" row 2, SURVEY H8: the text side of the
+// boundary is what bounds the end-to-end rate).
+//
+// The reference's loop is sequential: its only state is the most recent `5p:` line.  Here the
+// stream is cut into blocks at line boundaries and the blocks are parsed concurrently; a block's
+// lines that precede its first `5p:` line are the only ones whose fate depends on an earlier block,
+// and they are resolved in stream order by the consuming thread.  Batches reach the sink in input
+// order, so read indices are the reference's.
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/breakfast_hip.h"
+
+namespace hits {
+
+struct Batch {                           // one bf_batch worth of parsed anchor-hit pairs
+    std::string seq, frag;
+    std::vector<uint64_t> seq_off{0}, frag_off{0};
+    std::vector<bf_hit> hits;
+    size_t n() const { return hits.size(); }
+    void clear() { seq.clear(); frag.clear(); seq_off.assign(1, 0); frag_off.assign(1, 0); hits.clear(); }
+};
+
+struct ParseError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+class ContigIndex {                      // contig name -> id (index in the arrays given to bf_genome_set)
+public:
+    void add(const std::string& name, uint32_t id) { names_.push_back(name); ids_.push_back(id); built_ = false; }
+    void build();
+    int find(std::string_view name) const;          // -1 when absent
+private:
+    std::vector<std::string> names_;
+    std::vector<uint32_t> ids_;
+    std::unordered_map<std::string_view, uint32_t> map_;
+    bool built_ = false;
+};
+
+struct Options {
+    int threads = 8;                     // parser workers (>= 1)
+    size_t block_bytes = 32u << 20;      // nominal block size; blocks end on a line boundary
+};
+
+struct Stats { uint64_t bytes = 0, lines = 0, pairs = 0, blocks = 0; };
+
+// Reads `fd` to its end (a regular file is memory-mapped, anything else is read()), parses it and
+// calls sink(batch) on the calling thread, batch after batch in input order.  Throws ParseError for
+// what makes the reference panic (malformed line, unknown contig); the message names the line.
+Stats parse_stream(int fd, const ContigIndex& contigs, const std::string& genome_path, const Options& opt,
+                   const std::function<void(Batch&)>& sink);
+
+}  // namespace hits

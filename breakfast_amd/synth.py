@@ -48,8 +48,14 @@ class Genome:
         out = []
         for n, s in zip(self.names, self.seqs):
             out.append(b">" + n + b"\n")
-            b = s.tobytes()
-            out.extend(b[i:i + width] + b"\n" for i in range(0, len(b), width))
+            full = (s.shape[0] // width) * width
+            if full:
+                rows = np.empty((full // width, width + 1), np.uint8)
+                rows[:, :width] = s[:full].reshape(-1, width)
+                rows[:, width] = 10
+                out.append(rows.tobytes())
+            if s.shape[0] > full:
+                out.append(s[full:].tobytes() + b"\n")
         return b"".join(out)
 
 
@@ -241,8 +247,9 @@ def make_reads(genome: Genome, spec: ReadSpec) -> Batch:
                  frag.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(width + 1), hits)
 
 
-def bowtie_lines(batch: Batch, contig_names: Sequence[bytes], first_read_num: int = 1) -> bytes:
-    """The batch as bowtie's stdout (detect.rs:61 flags: `--suppress 5,6,7,8`): two lines per read."""
+def bowtie_lines_slow(batch: Batch, contig_names: Sequence[bytes], first_read_num: int = 1) -> bytes:
+    """The batch as bowtie's stdout (detect.rs:61 flags: `--suppress 5,6,7,8`): two lines per read.
+    Plain loop; bowtie_lines() is the vectorised form used for large batches."""
     out = []
     for i in range(batch.n):
         h = batch.hits[i]
@@ -252,6 +259,51 @@ def bowtie_lines(batch: Batch, contig_names: Sequence[bytes], first_read_num: in
         out.append(b"3p:%d:%s:%s:\t%s\t%s\t%d\n" % (num, batch.frag(i), batch.seq(i),
                                                      b"+" if h["strands"] & 2 else b"-",
                                                      contig_names[int(h["contig3"])], int(h["pos3"])))
+    return b"".join(out)
+
+
+def _decimal_cols(v: np.ndarray) -> np.ndarray:
+    """Non-negative ints -> (n, 20) ASCII digits with the leading zeros replaced by NUL bytes."""
+    d = _digits(v, 20)
+    lead = np.cumsum(d != 48, axis=1) == 0
+    lead[:, -1] = False
+    d[lead] = 0
+    return d
+
+
+def bowtie_lines(batch: Batch, contig_names: Sequence[bytes], first_read_num: int = 1, chunk: int = 1 << 17) -> bytes:
+    """Vectorised bowtie_lines_slow for batches whose reads (and fragment ids) all have one length:
+    every line is laid out in a fixed-width row padded with NUL bytes, and the NULs are dropped."""
+    n = batch.n
+    if n == 0:
+        return b""
+    sl = np.diff(batch.seq_off.astype(np.int64))
+    fl = np.diff(batch.frag_off.astype(np.int64))
+    if sl.min() != sl.max() or fl.min() != fl.max():
+        return bowtie_lines_slow(batch, contig_names, first_read_num)
+    L, F = int(sl[0]), int(fl[0])
+    wn = max(len(c) for c in contig_names)
+    names = np.zeros((len(contig_names), wn), np.uint8)
+    for i, c in enumerate(contig_names):
+        names[i, :len(c)] = np.frombuffer(c, np.uint8)
+    seq = batch.seq_bytes.reshape(n, L)
+    frag = batch.frag_bytes.reshape(n, F)
+    lit = lambda b, m: np.broadcast_to(np.frombuffer(b, np.uint8), (m, len(b)))
+    out = []
+    for a in range(0, n, chunk):
+        e = min(n, a + chunk)
+        m = e - a
+        h = batch.hits[a:e]
+        num = _decimal_cols(np.arange(first_read_num + a, first_read_num + e, dtype=np.int64))
+        st5 = np.where(h["strands"] & 1, 43, 45).astype(np.uint8)[:, None]
+        st3 = np.where(h["strands"] & 2, 43, 45).astype(np.uint8)[:, None]
+        row = np.concatenate([
+            lit(b"5p:", m), num, lit(b":\t", m), st5, lit(b"\t", m), names[h["contig5"]], lit(b"\t", m),
+            _decimal_cols(h["pos5"].astype(np.int64)), lit(b"\n", m),
+            lit(b"3p:", m), num, lit(b":", m), frag[a:e], lit(b":", m), seq[a:e], lit(b":\t", m), st3, lit(b"\t", m),
+            names[h["contig3"]], lit(b"\t", m), _decimal_cols(h["pos3"].astype(np.int64)), lit(b"\n", m)], axis=1)
+        flat = row.reshape(-1)
+        out.append(flat[flat != 0].tobytes())
     return b"".join(out)
 
 

@@ -1,0 +1,131 @@
+"""CPU tests of the multi-threaded anchor-hit parser (`breakfast-hip hits`, hits_parser.cpp = the line
+pairing half of the consume loop, detect.rs:76-103) against the sequential Python mirror of the same
+loop (engine.parse_bowtie_lines, itself checked against the oracle in test_host.py).  Tiny block sizes
+put a block boundary between every pair of lines, so the cross-block pairing rule is exercised."""
+import os
+import random
+import subprocess
+
+import pytest
+
+from conftest import load_golden
+from breakfast_amd import engine, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "breakfast_amd", "csrc", "breakfast-hip")
+
+
+def run_hits(tmp_path, fasta: bytes, text: bytes, block=None, threads=3, stdin=False):
+    (tmp_path / "g.fa").write_bytes(fasta)
+    (tmp_path / "hits.txt").write_bytes(text)
+    cmd = [EXE, "hits", "--threads=%d" % threads]
+    if block:
+        cmd.append("--block-bytes=%d" % block)
+    if stdin:
+        p = subprocess.run(cmd + ["-", str(tmp_path / "g")], input=text, capture_output=True, timeout=120)
+    else:
+        p = subprocess.run(cmd + [str(tmp_path / "hits.txt"), str(tmp_path / "g")], capture_output=True, timeout=120)
+    return p
+
+
+def expected(text: bytes, names) -> bytes:
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines = lines[:-1]
+    b = engine.parse_bowtie_lines(lines, {n: i for i, n in enumerate(names)})
+    out = []
+    for i in range(b.n):
+        h = b.hits[i]
+        out.append(b"%s\t%s\t%d\t%d\t%d\t%d\t%d\n" % (b.frag(i), b.seq(i), int(h["strands"]), int(h["contig5"]),
+                                                     int(h["pos5"]), int(h["contig3"]), int(h["pos3"])))
+    return b"".join(out)
+
+
+def fasta_names(fa: bytes):
+    return [l[1:].split()[0] for l in fa.split(b"\n") if l.startswith(b">")]
+
+
+@pytest.mark.parametrize("name", ["kat_survey", "hz_pairing", "hz_mixed_lengths"])
+@pytest.mark.parametrize("block", [1, 7, 50, 1000, None])
+@pytest.mark.parametrize("stdin", [False, True])
+def test_golden_hits_any_block_size(tmp_path, name, block, stdin):
+    fa, text, _, _ = load_golden(name)
+    p = run_hits(tmp_path, fa, text, block=block, stdin=stdin)
+    assert p.returncode == 0, p.stderr.decode()
+    assert p.stdout == expected(text, fasta_names(fa))
+
+
+def lossy_text(seed: int, n_reads: int = 3000):
+    """Synthetic hits with lines dropped the way bowtie drops unaligned anchors, plus repeated and
+    out-of-order read numbers."""
+    contigs, gk, spec = synth.config(1, scale=n_reads / 10_000_000, genome_scale=0.0005)
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    lines = synth.bowtie_lines(b, g.names).split(b"\n")[:-1]
+    rng = random.Random(seed)
+    kept = []
+    for ln in lines:
+        r = rng.random()
+        if r < 0.15:
+            continue                        # anchor did not align: no line
+        kept.append(ln)
+        if r > 0.97:
+            kept.append(ln)                 # duplicated line
+    for _ in range(20):                     # a few lines moved far away from their partner
+        i, j = rng.randrange(len(kept)), rng.randrange(len(kept))
+        kept[i], kept[j] = kept[j], kept[i]
+    return g, b"\n".join(kept) + b"\n"
+
+
+@pytest.mark.parametrize("block,threads", [(1, 4), (97, 4), (4096, 8), (1 << 16, 2), (None, 8)])
+def test_lossy_stream_matches_sequential_loop(tmp_path, block, threads):
+    g, text = lossy_text(7)
+    want = expected(text, g.names)
+    assert want.count(b"\n") > 1000
+    for stdin in (False, True):
+        p = run_hits(tmp_path, g.fasta(), text, block=block, threads=threads, stdin=stdin)
+        assert p.returncode == 0, p.stderr.decode()
+        assert p.stdout == want
+
+
+def test_no_trailing_newline_and_crlf(tmp_path):
+    fa, text, _, _ = load_golden("kat_survey")
+    names = fasta_names(fa)
+    p = run_hits(tmp_path, fa, text[:-1], block=16)
+    assert p.returncode == 0 and p.stdout == expected(text, names)
+    crlf = text.replace(b"\n", b"\r\n")
+    p = run_hits(tmp_path, fa, crlf, block=16)
+    assert p.returncode == 0 and p.stdout == expected(text, names)
+
+
+def test_empty_input(tmp_path):
+    fa, _, _, _ = load_golden("kat_survey")
+    for stdin in (False, True):
+        p = run_hits(tmp_path, fa, b"", stdin=stdin)
+        assert p.returncode == 0 and p.stdout == b""
+
+
+@pytest.mark.parametrize("bad", [
+    b"garbage without colon\n",                       # split(':').nth(1).unwrap() panics, detect.rs:79
+    b"5p:x:\t+\tchr1\t27\n",                          # read number does not parse
+    b"5p:1:\t+\tchr1\t27\n3p:1:f:ACGT:\t+\tchr2\n",   # offset column missing
+    b"5p:1:\t+\tchr1\t27\n3p:1:f:ACGT:\t+\tchrUn\t5\n",  # contig the FASTA lacks, detect.rs:115
+    b"3p:0:f:ACGT:\t+\tchr1\t5\n",                    # read number 0 pairs with the empty initial `prev`
+])
+@pytest.mark.parametrize("block", [1, None])
+def test_what_panics_in_the_reference_is_an_error(tmp_path, bad, block):
+    fa, text, _, _ = load_golden("kat_survey")
+    stream = bad if bad.startswith(b"3p:0:") else text + bad     # the last case needs the initial state
+    p = run_hits(tmp_path, fa, stream, block=block)
+    assert p.returncode == 255
+    assert p.stderr.startswith(b"ERROR: ")
+
+
+def test_fasta_loader_semantics(tmp_path):
+    """ids end at the first whitespace, lines are right-trimmed, a repeated id keeps its slot and takes
+    the later record (HashMap::insert, detect.rs:55)."""
+    fa = b">chr1 first\nACGT  \r\nAC\n>chr2\tx\nGGGG\n\n>chr1 again\nTTTTTTTT\nTT"
+    text = b"5p:1:\t+\tchr2\t1\n3p:1:f:ACGTACGT:\t-\tchr1\t3\n"
+    p = run_hits(tmp_path, fa, text)
+    assert p.returncode == 0, p.stderr.decode()
+    assert p.stdout == b"f\tACGTACGT\t1\t1\t1\t0\t3\n"
