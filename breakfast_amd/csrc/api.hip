@@ -251,7 +251,7 @@ int bf_reset(bf_ctx* ctx) {
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_reads = 0; ctx->seq_bytes = 0; ctx->frag_bytes = 0;
     ctx->max_len = 0; ctx->min_len = 0xffffffffu; ctx->max_frag = 0;
-    ctx->localised = false; ctx->imported = false; ctx->n_imported = 0; ctx->n_exact = 0;
+    ctx->localised = false; ctx->imported = false; ctx->clustered = false; ctx->n_imported = 0; ctx->n_exact = 0;
     ctx->out.n_clusters = ctx->out.n_reads = ctx->out.junction_size = 0;
     return BF_OK;
 }
@@ -325,7 +325,9 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     if (ctx->n_ranks > 1 && !ctx->imported) return fail(ctx, BF_ERR_STATE, "bf_clusterise on a multi-rank ctx before bf_exchange_import");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     const OwnerView v = ctx->imported ? imported_view(ctx) : local_view(ctx);
+    ctx->clustered = false;
     BF_TRY(run_cluster(ctx, v));
+    ctx->clustered = true;
     const uint64_t nr = ctx->out.n_reads;
     if (nr) {
         BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
@@ -529,6 +531,64 @@ int bf_render_junctions(bf_ctx* ctx, uint64_t n, const uint32_t* local_index, co
     if (total) BF_HIP(ctx, hipMemcpyAsync(ctx->render_bytes_host.data(), ctx->r_bytes.p, total, hipMemcpyDeviceToHost, ctx->stream));
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out_bytes = ctx->render_bytes_host.data(); *out_off = ctx->render_off_host.data();
+    return BF_OK;
+}
+
+// ---- device-resident junction routing (multi-GPU; every pointer below is device memory) ------
+
+int bf_result_sources_dev(bf_ctx* ctx, uint32_t* dev_src_rank, uint32_t* dev_src_index) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!ctx->imported || !ctx->clustered)
+        return fail(ctx, BF_ERR_STATE, "bf_result_sources_dev is only meaningful after bf_exchange_import + bf_clusterise");
+    const uint64_t nr = ctx->out.n_reads;
+    if (nr == 0) return BF_OK;
+    if (!dev_src_rank || !dev_src_index) return fail(ctx, BF_ERR_INVALID, "bf_result_sources_dev: null output");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t* src = ctx->c_rsrc.as<uint32_t>();                  // out_src_rank[nr], out_src_idx[nr]
+    BF_HIP(ctx, hipMemcpyAsync(dev_src_rank, src, nr * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    BF_HIP(ctx, hipMemcpyAsync(dev_src_index, src + nr, nr * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BF_OK;
+}
+
+int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_index, uint64_t* dev_off,
+                            uint8_t* dev_bytes, uint64_t dev_bytes_cap, uint64_t* total) {
+    if (!ctx || !total) return BF_ERR_INVALID;
+    if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_render_junctions_dev before bf_localise");
+    if (!dev_off || (n && !dev_local_index)) return fail(ctx, BF_ERR_INVALID, "bf_render_junctions_dev: null argument");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    return render_dev(ctx, n, dev_local_index, dev_off, dev_bytes, dev_bytes_cap, total);
+}
+
+int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const uint32_t* dev_jlen,
+                                   const uint8_t* dev_bytes, uint64_t size, bf_result* out) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!out) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junctions_dev: null result");
+    if (!ctx->imported || !ctx->clustered)
+        return fail(ctx, BF_ERR_STATE, "bf_result_attach_junctions_dev is only meaningful after bf_exchange_import + bf_clusterise");
+    const uint64_t nr = ctx->out.n_reads;
+    if (nr && (!dev_joff || !dev_jlen)) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junctions_dev: null offsets");
+    if (size && !dev_bytes) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junctions_dev: null junction bytes");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    if (nr) {
+        BF_TRY(patch_reads_len(ctx, dev_joff, dev_jlen, nr));
+        BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ctx->out.junction_size = size;
+    if (size) {
+        BF_TRY(ensure_host(ctx, ctx->out.junction, size));
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.junction.p, dev_bytes, size, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memset(out, 0, sizeof *out);
+    out->n_evidence = ctx->n_evidence;
+    out->n_clusters = ctx->out.n_clusters;
+    out->n_reads = nr;
+    out->clusters = ctx->out.clusters.as<bf_cluster>();
+    out->reads = ctx->out.reads.as<bf_read>();
+    out->junction_bytes = ctx->out.junction.as<uint8_t>();
+    out->junction_size = size;
     return BF_OK;
 }
 

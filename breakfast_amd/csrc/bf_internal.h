@@ -143,6 +143,7 @@ struct bf_ctx {
     uint64_t index_base = 0;
     std::vector<uint64_t> src_index_base;
     bool imported = false;
+    bool clustered = false;                     // ctx->out / c_rsrc describe the last bf_clusterise
     uint32_t wire_frag_stride = 0, wire_has_sigx = 0, wire_rec_bytes = 0;
     uint64_t n_imported = 0;
     bf::DevBuf d_send, d_part_key, d_part_idx, d_part_tmp;
@@ -205,6 +206,9 @@ int render_range(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_id
 int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, DevBuf& d_bytes,
                uint64_t* total_bytes);              // junction strings for local reads
 
+int render_dev(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint64_t* d_off, uint8_t* d_bytes,
+               uint64_t d_bytes_cap, uint64_t* total);
+
 // cluster.hip -----------------------------------------------------------------------------------
 int run_cluster(bf_ctx* ctx, const OwnerView& v);   // fills ctx->out (without junction text)
 int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint64_t dev_send_bytes, uint64_t* counts,
@@ -212,5 +216,6 @@ int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint
 int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts);
 int scan_u32_to_u64(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n);  // exclusive, out has n+1
 int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
+int patch_reads_len(bf_ctx* ctx, const uint64_t* d_joff, const uint32_t* d_jlen, uint64_t n);
 
 }  // namespace bf

@@ -686,6 +686,16 @@ __global__ void patch_reads_kernel(bf_read* reads, const uint64_t* __restrict__ 
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { reads[i].junction_off = joff[i]; reads[i].junction_len = (uint32_t)(joff[i + 1] - joff[i]); }
 }
+__global__ void patch_reads_len_kernel(bf_read* reads, const uint64_t* __restrict__ joff, const uint32_t* __restrict__ jlen, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { reads[i].junction_off = joff[i]; reads[i].junction_len = jlen[i]; }
+}
+int patch_reads_len(bf_ctx* ctx, const uint64_t* d_joff, const uint32_t* d_jlen, uint64_t n) {
+    if (n) hipLaunchKernelGGL(patch_reads_len_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
+                              ctx->c_reads.as<bf_read>(), d_joff, d_jlen, n);
+    BF_HIP(ctx, hipGetLastError());
+    return BF_OK;
+}
 int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n) {
     if (n) hipLaunchKernelGGL(patch_reads_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
                               ctx->c_reads.as<bf_read>(), d_joff, n);

@@ -630,6 +630,18 @@ __global__ void __launch_bounds__(256) render_len_kernel(uint64_t n, const uint3
     if (i < n) out_len[i] = (uint32_t)len[idx[i]] + 1;
 }
 
+// lengths for a caller-supplied (device) index list: an index outside the resident reads is counted,
+// not dereferenced
+__global__ void __launch_bounds__(256) render_len_checked_kernel(uint64_t n, const uint32_t* __restrict__ idx,
+                                                                 const uint16_t* __restrict__ len, uint64_t n_reads,
+                                                                 uint32_t* __restrict__ out_len, uint32_t* __restrict__ bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = idx[i];
+    if (r >= n_reads) { out_len[i] = 0; atomicAdd(bad, 1u); return; }
+    out_len[i] = (uint32_t)len[r] + 1;
+}
+
 // 16 lanes per surviving read, 4 reads per wave: everything a read needs besides its bases sits in
 // ONE render record (mask words + bp/flags/len), so a read costs one record line, one offset line
 // and its own sequence lines (the first version gathered nine separate 128-byte lines per read and
@@ -805,6 +817,48 @@ int render_range(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_id
                        d_off.as<uint64_t>() + a, ctx->d_seq.as<uint8_t>(), ctx->d_seq_off.as<uint64_t>(),
                        ctx->d_mask.as<uint64_t>(), (int)ctx->mask_words + 1, d_bytes.as<uint8_t>());
     BF_HIP(ctx, hipGetLastError());
+    return BF_OK;
+}
+
+// Junction strings for a DEVICE list of local read indices into caller-owned device memory (the
+// multi-GPU route: nothing crosses PCIe here).  d_off receives n+1 offsets; when d_bytes is null only
+// the offsets and *total are produced.
+int render_dev(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint64_t* d_off, uint8_t* d_bytes,
+               uint64_t d_bytes_cap, uint64_t* total) {
+    *total = 0;
+    if (n == 0) {
+        BF_HIP(ctx, hipMemsetAsync(d_off, 0, 8, ctx->stream));
+        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return BF_OK;
+    }
+    BF_TRY(ensure(ctx, ctx->r_idx, n * 4 + 16));                      // lengths + the bad-index counter
+    uint32_t* d_len = ctx->r_idx.as<uint32_t>();
+    uint32_t* d_bad = d_len + n;
+    BF_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    {
+        Scope t(ctx, "render_offsets");
+        hipLaunchKernelGGL(render_len_checked_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
+                           ctx->d_len.as<uint16_t>(), ctx->n_reads, d_len, d_bad);
+        BF_TRY(scan_u32_to_u64(ctx, d_len, d_off, n));
+    }
+    uint32_t bad = 0;
+    BF_HIP(ctx, hipMemcpyAsync(total, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BF_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad) return fail(ctx, BF_ERR_INVALID, "bf_render_junctions_dev: %u of %llu indices are outside the %llu resident reads",
+                         bad, (unsigned long long)n, (unsigned long long)ctx->n_reads);
+    if (!d_bytes) return BF_OK;
+    if (d_bytes_cap < *total)
+        return fail(ctx, BF_ERR_INVALID, "bf_render_junctions_dev: buffer of %llu bytes, %llu needed",
+                    (unsigned long long)d_bytes_cap, (unsigned long long)*total);
+    {
+        Scope t(ctx, "render");
+        hipLaunchKernelGGL(render_kernel, dim3(grid_for(n * 16, 256)), dim3(256), 0, ctx->stream, n, d_local_idx, d_off,
+                           ctx->d_seq.as<uint8_t>(), ctx->d_seq_off.as<uint64_t>(), ctx->d_mask.as<uint64_t>(),
+                           (int)ctx->mask_words + 1, d_bytes);
+    }
+    BF_HIP(ctx, hipGetLastError());
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BF_OK;
 }
 

@@ -41,11 +41,18 @@ def init_from_env(backend: Optional[str] = None):
 
 
 class HipStageEngine:
-    """Adapts breakfast_amd.Engine (device pointers) to torch tensors for the exchange."""
+    """Adapts breakfast_amd.Engine (device pointers) to torch tensors for the exchange.
+
+    The library works on its own HIP stream and every entry point returns after its GPU work has
+    completed; tensors produced by torch (collectives included) are made visible to it by
+    synchronising torch's current stream before the call (`_torch_done`)."""
 
     def __init__(self, eng: Engine, device: torch.device):
         self.eng, self.device = eng, device
         self._send = None
+
+    def _torch_done(self):
+        torch.cuda.current_stream(self.device).synchronize()
 
     def localise(self):
         self.eng.localise()
@@ -60,6 +67,7 @@ class HipStageEngine:
         rec = Engine.wire_record_bytes(max_frag, has_sigx)
         n = self.n_local()
         send = torch.empty(max(n * rec, 1), dtype=torch.uint8, device=self.device)
+        self._torch_done()
         counts, _, rec2 = self.eng.exchange_pack(max_frag, has_sigx, world, send.data_ptr(), send.numel())
         assert rec2 == rec
         return send[:n * rec], counts.astype(np.int64), rec
@@ -67,16 +75,48 @@ class HipStageEngine:
     def exchange_import_tensor(self, recv: torch.Tensor, src_counts: np.ndarray, bases: np.ndarray):
         if recv.device != self.device:
             recv = recv.to(self.device)
-        self._recv = recv      # keep alive until imported (import copies out of it)
+        self._torch_done()     # the all-to-all that filled `recv` ran on torch's stream, not the library's
         self.eng.exchange_import(recv.data_ptr() if recv.numel() else 0, src_counts.astype(np.uint64),
                                  bases.astype(np.uint64))
-        self._recv = None
 
     def clusterise(self) -> Result:
-        return self.eng.clusterise()
+        return self.eng.clusterise(copy=False)
 
     def render_junctions(self, local_index: np.ndarray):
         return self.eng.render_junctions(local_index)
+
+    # ---- device-resident junction routing (no PCIe round trips) ----
+    def result_sources_tensors(self, res: Result):
+        nr = int(res.reads.shape[0])
+        sr = torch.empty(nr, dtype=torch.int32, device=self.device)
+        si = torch.empty(nr, dtype=torch.int32, device=self.device)
+        if nr:
+            self._torch_done()
+            self.eng.result_sources_dev(sr.data_ptr(), si.data_ptr())
+        return sr, si
+
+    def render_junctions_tensor(self, idx: torch.Tensor):
+        """idx: int32 device tensor of local read indices -> (uint8 text, int64 offsets[n+1]) on the device."""
+        idx = idx.to(self.device, torch.int32).contiguous()
+        n = int(idx.numel())
+        off = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+        self._torch_done()
+        total = self.eng.render_junctions_dev(n, idx.data_ptr() if n else 0, off.data_ptr())
+        by = torch.empty(total, dtype=torch.uint8, device=self.device)
+        if total:
+            self._torch_done()
+            self.eng.render_junctions_dev(n, idx.data_ptr(), off.data_ptr(), by.data_ptr(), total)
+        return by, off
+
+    def attach_junctions(self, res: Result, joff: torch.Tensor, jlen: torch.Tensor, text: torch.Tensor) -> Result:
+        joff = joff.to(self.device, torch.int64).contiguous()
+        jlen = jlen.to(self.device, torch.int32).contiguous()
+        text = text.to(self.device).contiguous()
+        self._torch_done()
+        out = self.eng.attach_junctions_dev(joff.data_ptr() if joff.numel() else 0, jlen.data_ptr() if jlen.numel() else 0,
+                                            text.data_ptr() if text.numel() else 0, int(text.numel()))
+        out.src_rank, out.src_index = res.src_rank, res.src_index
+        return out
 
 
 def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits: Sequence[int], in_splits: Sequence[int], group=None):
@@ -165,47 +205,69 @@ class DistributedDetect:
         st.exchange_import_tensor(recv, recv_counts, self.bases)
         res = st.clusterise()
         self.stats = StepStats(int(counts.sum()), int(recv_counts.sum()), rec, int(counts.sum()) * rec)
-        self._route_junctions(res)
+        return self._route_junctions(res)
+
+    # Stage hooks with host fall-backs, so that stand-in engines (tests) only need the numpy calls.
+    def _sources(self, res: Result, dev):
+        if hasattr(self.stage, "result_sources_tensors"):
+            return self.stage.result_sources_tensors(res)
+        nr = res.reads.shape[0]
+        sr = res.src_rank if nr else np.zeros(0, np.uint32)
+        si = res.src_index if nr else np.zeros(0, np.uint32)
+        return torch.from_numpy(sr.astype(np.int32)).to(dev), torch.from_numpy(si.astype(np.int32)).to(dev)
+
+    def _render(self, got: torch.Tensor, dev):
+        if hasattr(self.stage, "render_junctions_tensor"):
+            return self.stage.render_junctions_tensor(got)
+        by, off = self.stage.render_junctions(got.cpu().numpy().astype(np.uint32))
+        return torch.from_numpy(by).to(dev), torch.from_numpy(off.astype(np.int64)).to(dev)
+
+    def _attach(self, res: Result, joff: torch.Tensor, jlen: torch.Tensor, text: torch.Tensor) -> Result:
+        if hasattr(self.stage, "attach_junctions"):
+            return self.stage.attach_junctions(res, joff, jlen, text)
+        res.reads = res.reads.copy()
+        res.reads["junction_off"] = joff.cpu().numpy().astype(np.uint64)
+        res.reads["junction_len"] = jlen.cpu().numpy().astype(np.uint32)
+        res.junction_bytes = text.cpu().numpy()
         return res
 
-    def _route_junctions(self, res: Result) -> None:
-        """Owners request the junction strings of their surviving reads from the source ranks."""
+    def _route_junctions(self, res: Result) -> Result:
+        """Owners request the junction strings of their surviving reads from the source ranks.  All
+        bulk data (index lists, lengths, text) stays in device tensors; only per-rank counts visit the
+        host.  Sequences and mismatch masks never leave their source rank."""
         W = self.world
-        nr = res.reads.shape[0]
-        src_rank = res.src_rank if nr else np.zeros(0, np.uint32)
-        src_index = res.src_index if nr else np.zeros(0, np.uint32)
-        order = np.argsort(src_rank, kind="stable")                  # requests grouped by source rank
-        req_counts = np.bincount(src_rank, minlength=W).astype(np.int64)
+        nccl = dist.get_backend(self.group) == "nccl"
+        src_rank, src_index = self._sources(res, self.device if nccl else torch.device("cpu"))
+        dev = src_rank.device
+        nr = int(src_rank.numel())
+        order = torch.argsort(src_rank, stable=True)                # requests grouped by source rank
+        req_counts = torch.bincount(src_rank, minlength=W).cpu().numpy().astype(np.int64)
         got_counts = self._exchange_counts(req_counts)              # how many each rank asks of me
-        dev = self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
-        req = torch.from_numpy(src_index[order].astype(np.int32)).to(dev)
+        req = src_index[order].contiguous()
         got = torch.empty(int(got_counts.sum()), dtype=torch.int32, device=dev)
         _a2a(got, req, [int(c) for c in got_counts], [int(c) for c in req_counts], self.group)
         # render what the others (and I) asked for, in request order
-        by, off = self.stage.render_junctions(got.cpu().numpy().astype(np.uint32))
-        off = off.astype(np.int64)
-        bounds = np.concatenate([[0], np.cumsum(got_counts)]).astype(np.int64)
-        out_bytes = [int(off[bounds[r + 1]] - off[bounds[r]]) for r in range(W)]
+        by, off = self._render(got, dev)
+        bounds = torch.from_numpy(np.concatenate([[0], np.cumsum(got_counts)]).astype(np.int64)).to(off.device)
+        ob = off[bounds].cpu().numpy()
+        out_bytes = [int(ob[r + 1] - ob[r]) for r in range(W)]
         # lengths are sent explicitly (4 B per read): the owner then needs no knowledge of read lengths
-        lens = torch.from_numpy((off[1:] - off[:-1]).astype(np.int32)).to(dev)
-        my_lens = torch.empty(nr, dtype=torch.int32, device=dev)
+        lens = (off[1:] - off[:-1]).to(torch.int32)
+        my_lens = torch.empty(nr, dtype=torch.int32, device=lens.device)
         _a2a(my_lens, lens, [int(c) for c in req_counts], [int(c) for c in got_counts], self.group)
-        my_lens_np = my_lens.cpu().numpy().astype(np.int64)
-        rb = np.concatenate([[0], np.cumsum(req_counts)]).astype(np.int64)
-        csum = np.concatenate([[0], np.cumsum(my_lens_np)]).astype(np.int64)
-        in_bytes = [int(csum[rb[r + 1]] - csum[rb[r]]) for r in range(W)]
-        payload = torch.from_numpy(by).to(dev) if by.size else torch.empty(0, dtype=torch.uint8, device=dev)
-        mine = torch.empty(int(csum[-1]), dtype=torch.uint8, device=dev)
-        _a2a(mine, payload, in_bytes, out_bytes, self.group)
-        # scatter back to result order
-        joff = np.zeros(nr, np.uint64)
-        jlen = np.zeros(nr, np.uint32)
-        joff[order] = csum[:-1].astype(np.uint64)
-        jlen[order] = my_lens_np.astype(np.uint32)
-        res.reads = res.reads.copy()
-        res.reads["junction_off"] = joff
-        res.reads["junction_len"] = jlen
-        res.junction_bytes = mine.cpu().numpy()
+        csum = torch.zeros(nr + 1, dtype=torch.int64, device=my_lens.device)
+        torch.cumsum(my_lens, 0, out=csum[1:])
+        rb = torch.from_numpy(np.concatenate([[0], np.cumsum(req_counts)]).astype(np.int64)).to(csum.device)
+        ib = csum[rb].cpu().numpy()
+        in_bytes = [int(ib[r + 1] - ib[r]) for r in range(W)]
+        mine = torch.empty(int(ib[-1]), dtype=torch.uint8, device=by.device)
+        _a2a(mine, by, in_bytes, out_bytes, self.group)
+        # back to result order
+        joff = torch.empty(nr, dtype=torch.int64, device=csum.device)
+        jlen = torch.empty(nr, dtype=torch.int32, device=csum.device)
+        joff[order] = csum[:-1]
+        jlen[order] = my_lens
+        return self._attach(res, joff, jlen, mine)
 
     # ---- output formatting (not part of the timed path) ----
     def gather_result(self, res: Result, contig_names: Sequence[bytes]) -> Optional[Result]:

@@ -68,7 +68,8 @@ ABI_SYMBOLS = [
     "bf_abi_version", "bf_ctx_create", "bf_ctx_destroy", "bf_last_error", "bf_genome_set", "bf_submit",
     "bf_localise", "bf_clusterise", "bf_finish", "bf_reset", "bf_sync", "bf_format_sv", "bf_set_rank",
     "bf_exchange_local", "bf_exchange_pack", "bf_exchange_import", "bf_result_sources",
-    "bf_render_junctions", "bf_evidence_fetch", "bf_kernel_times", "bf_stats",
+    "bf_render_junctions", "bf_result_sources_dev", "bf_render_junctions_dev", "bf_result_attach_junctions_dev",
+    "bf_evidence_fetch", "bf_kernel_times", "bf_stats",
 ]
 
 _lib = None
@@ -121,6 +122,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_exchange_import.argtypes = [vp, vp, u64p, u64p]
     lib.bf_result_sources.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.bf_render_junctions.argtypes = [vp, C.c_uint64, vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.bf_result_sources_dev.argtypes = [vp, vp, vp]
+    lib.bf_render_junctions_dev.argtypes = [vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]
+    lib.bf_result_attach_junctions_dev.argtypes = [vp, vp, vp, vp, C.c_uint64, C.POINTER(BfResult)]
     lib.bf_evidence_fetch.argtypes = [vp, C.POINTER(BfEvidenceView)]
     lib.bf_kernel_times.argtypes = [vp, C.POINTER(C.POINTER(BfKernelTime)), C.POINTER(C.c_uint32)]
     lib.bf_stats.argtypes = [vp, u64p, u64p]
@@ -367,6 +371,24 @@ class Engine:
         by = (np.frombuffer((C.c_uint8 * total).from_address(pb.value), np.uint8).copy() if total
               else np.zeros(0, np.uint8))
         return by, off
+
+    # device-resident routing: arguments are raw device pointers (e.g. torch tensors' data_ptr())
+    def result_sources_dev(self, dev_src_rank: int, dev_src_index: int) -> None:
+        self._check(self.lib.bf_result_sources_dev(self.h, C.c_void_p(dev_src_rank or None), C.c_void_p(dev_src_index or None)))
+
+    def render_junctions_dev(self, n: int, dev_index: int, dev_off: int, dev_bytes: int = 0, cap: int = 0) -> int:
+        """-> total bytes; with dev_bytes == 0 only the n+1 offsets are written (size query)."""
+        total = C.c_uint64()
+        self._check(self.lib.bf_render_junctions_dev(self.h, n, C.c_void_p(dev_index or None), C.c_void_p(dev_off),
+                                                     C.c_void_p(dev_bytes or None), cap, C.byref(total)))
+        return int(total.value)
+
+    def attach_junctions_dev(self, dev_joff: int, dev_jlen: int, dev_bytes: int, size: int, copy: bool = False) -> Result:
+        r = BfResult()
+        self._check(self.lib.bf_result_attach_junctions_dev(self.h, C.c_void_p(dev_joff or None), C.c_void_p(dev_jlen or None),
+                                                            C.c_void_p(dev_bytes or None), size, C.byref(r)))
+        self._last = r
+        return self._wrap(r, copy)
 
     # -- introspection --
     def evidence(self) -> Dict[str, np.ndarray]:

@@ -203,6 +203,30 @@ int bf_result_sources(bf_ctx* ctx, const uint32_t** src_rank, const uint32_t** s
 int bf_render_junctions(bf_ctx* ctx, uint64_t n, const uint32_t* local_index,
                         const uint8_t** out_bytes, const uint64_t** out_off);
 
+/* Device-resident form of the two calls above, for callers whose transport moves device memory
+ * (RCCL): nothing but a few counters crosses PCIe until the final result lands in host memory.
+ * Every pointer named dev_* is device memory owned by the caller; each call returns after its GPU
+ * work has completed (the ctx runs on its own stream).  No counterpart in the reference: detect.rs
+ * is one process.
+ *
+ * bf_result_sources_dev: copies (source rank, source-local index) of the result.n_reads supporting
+ * reads of the last bf_clusterise into two caller arrays of n_reads uint32 each. */
+int bf_result_sources_dev(bf_ctx* ctx, uint32_t* dev_src_rank, uint32_t* dev_src_index);
+
+/* On a source rank: junction strings (detect.rs:155-162) of n local reads given as a device index
+ * list.  dev_off receives n+1 byte offsets, *total their sum.  With dev_bytes == NULL only offsets
+ * and *total are produced (size query); otherwise dev_bytes (capacity dev_bytes_cap >= *total)
+ * receives the text.  An index outside the resident reads is an error, never dereferenced. */
+int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_index, uint64_t* dev_off,
+                            uint8_t* dev_bytes, uint64_t dev_bytes_cap, uint64_t* total);
+
+/* On an owner rank, after the junction text of its supporting reads has arrived in device memory:
+ * dev_joff[i]/dev_jlen[i] locate read i's string inside dev_bytes (size bytes).  Patches the read
+ * table, copies table and text to the ctx's pinned host memory and fills *out with the complete
+ * result, laid out exactly as bf_finish returns it on one GPU. */
+int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const uint32_t* dev_jlen,
+                                   const uint8_t* dev_bytes, uint64_t size, bf_result* out);
+
 /* ---- introspection (tests, bench) ---------------------------------------------------------- */
 
 /* Per-read evidence in input order (needs BF_FLAG_KEEP_EVIDENCE): arrays of n entries each, any

@@ -61,3 +61,28 @@ def test_sharded_hip_detect_matches_oracle(tmp_path, world):
     out = str(tmp_path / "out.sv")
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert open(out, "rb").read() == ref.sv
+
+
+def test_device_render_matches_host_render_and_rejects_bad_indices():
+    """bf_render_junctions_dev (device index list -> device text) against bf_render_junctions."""
+    g, b, A, F, E = make_case()
+    eng = engine.Engine(A, F, E, device=0)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        eng.submit(b)
+        eng.localise()
+        dev = torch.device("cuda", 0)
+        stage = HipStageEngine(eng, dev)
+        rng = np.random.default_rng(5)
+        for n in (0, 1, 777, 5000):
+            idx = rng.integers(0, b.n, size=n).astype(np.uint32)
+            by_h, off_h = eng.render_junctions(idx)
+            by_d, off_d = stage.render_junctions_tensor(torch.from_numpy(idx.astype(np.int32)).to(dev))
+            assert np.array_equal(off_d.cpu().numpy().astype(np.uint64), off_h)
+            assert np.array_equal(by_d.cpu().numpy(), by_h)
+        bad = torch.tensor([0, b.n, 3], dtype=torch.int32, device=dev)
+        with pytest.raises(engine.BreakfastError) as ei:
+            stage.render_junctions_tensor(bad)
+        assert ei.value.code == -1
+    finally:
+        eng.close()
