@@ -49,7 +49,17 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def claim_stdout():
+    """Keeps stdout for the ONE JSON line: file descriptor 1 is pointed at stderr for everything else
+    (RCCL prints a version banner on stdout when a communicator is created)."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(keep, "w")
+
+
 def main():
+    json_out = claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -60,10 +70,21 @@ def main():
     ap.add_argument("--variant", choices=["fused", "separate", "coop"], default="fused",
                     help="A/B of the localise stage: fused encode+localise (shipped), separate encode kernel, "
                          "separate encode + cooperative LDS-staged gather")
+    ap.add_argument("--exchange", action="store_true",
+                    help="with one GPU: run the sharded code path anyway (pack -> RCCL all-to-all with itself -> import -> "
+                         "device junction routing), to time what the exchange adds per rank")
+    ap.add_argument("--phases", action="store_true", help="sharded path: synchronise after every phase and report phase_ms "
+                                                           "(diagnostic: the extra synchronisation slows the step)")
     ap.add_argument("--check", action="store_true", help="also compare the GPU .sv with the oracle's on the sample")
     args = ap.parse_args()
 
     rank, world, local = init_from_env()
+    forced = args.exchange and world == 1
+    if forced:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
     if world != args.gpus:
         log(rank, "note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -87,12 +108,13 @@ def main():
     log(rank, "reads: %d x %d bp per rank in %.1fs" % (n_local, L, time.time() - t1))
 
     # ---- resident inputs -------------------------------------------------------------------------
-    eng = engine.Engine(A, 5000, 2, device=local, flags={"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER}[args.variant])
+    routing = engine.BF_FLAG_DEVICE_ROUTING if (world > 1 or forced) else 0
+    eng = engine.Engine(A, 5000, 2, device=local, flags=routing | {"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER}[args.variant])
     t2 = time.time()
     eng.set_genome(genome.names, genome.seqs)
     log(rank, "genome packed into HBM in %.1fs" % (time.time() - t2))
     t3 = time.time()
-    if world > 1:
+    if world > 1 or forced:
         eng.set_rank(rank, world, rank * n_local)
     chunk = 1 << 21
     for a in range(0, n_local, chunk):
@@ -100,21 +122,26 @@ def main():
     log(rank, "reads resident in HBM in %.1fs (host->device rate %.2f GB/s incl. pageable staging)" %
         (time.time() - t3, (batch.seq_bytes.nbytes + batch.frag_bytes.nbytes) / 1e9 / max(time.time() - t3, 1e-9)))
 
-    if world > 1:
+    if world > 1 or forced:
         dd = DistributedDetect(HipStageEngine(eng, dev), rank, world, rank * n_local, n_local, dev)
+        dd.profile = args.phases
         step = dd.step
     else:
         step = eng.finish_raw
 
+    sharded_run = world > 1 or forced
+
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
         eng.sync()
 
     for _ in range(args.warmup):
         step()
     eng.kernel_times()                                # drop warm-up timings
+    if sharded_run:
+        dd.phase_ms = {}
     barrier()
     t_start = time.perf_counter()
     last = None
@@ -127,8 +154,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ktimes = eng.kernel_times()
-    n_clusters = int(last.n_clusters) if world == 1 else int(last.clusters.shape[0])
-    n_support = int(last.n_reads) if world == 1 else int(last.reads.shape[0])
+    sharded = world > 1 or forced
+    n_clusters = int(last.clusters.shape[0]) if sharded else int(last.n_clusters)
+    n_support = int(last.reads.shape[0]) if sharded else int(last.n_reads)
+    if world > 1:                                      # totals over all owner ranks
+        t = torch.tensor([n_clusters, n_support], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        n_clusters, n_support = (int(v) for v in t.tolist())
 
     total_reads = n_local * world
     ms_per_step = elapsed / args.steps * 1e3
@@ -178,14 +210,16 @@ def main():
             "config": {"workload": "configs[%d]: %d unaligned 2x%d bp reads per GPU with anchor hits on a %.2f Gb genome, anchor length %d"
                        % (args.config, n_local, L, sum(l for _, l in contigs) / 1e9, A),
                        "reads_per_gpu": n_local, "read_len": L, "anchor_len": A, "max_frag_len": 5000, "min_evidence": 2,
-                       "parallelism": "shard%d+alltoall" % world if world > 1 else "single"},
+                       "parallelism": "shard%d+alltoall" % world if sharded else "single"},
             "result": {"clusters": n_clusters, "supporting_reads": n_support},
             "stage_ms": stages, "roofline": roofline, "cpu_baseline": cpu,
+            **({"phase_ms": {k: round(v / args.steps, 3) for k, v in dd.phase_ms.items()}} if sharded_run and args.phases else {}),
             "published_reference": "~40M BAM reads/min/core whole-file scan (README.md:6), a different stage",
         }
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     eng.close()
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 

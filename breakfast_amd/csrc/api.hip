@@ -359,7 +359,7 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
             }
             BF_HIP(ctx, hipEventRecord(ctx->ev[10], ctx->copy_stream));
             BF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[10], 0));
-        } else {
+        } else if (!(ctx->cfg.flags & BF_FLAG_DEVICE_ROUTING)) {
             BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
         }
     }
@@ -368,7 +368,7 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     out->n_clusters = ctx->out.n_clusters;
     out->n_reads = nr;
     out->clusters = ctx->out.clusters.as<bf_cluster>();
-    out->reads = ctx->out.reads.as<bf_read>();
+    out->reads = (ctx->imported && (ctx->cfg.flags & BF_FLAG_DEVICE_ROUTING)) ? nullptr : ctx->out.reads.as<bf_read>();
     out->junction_bytes = ctx->out.junction.as<uint8_t>();
     out->junction_size = ctx->out.junction_size;
     return BF_OK;
@@ -556,6 +556,8 @@ int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_i
     if (!ctx || !total) return BF_ERR_INVALID;
     if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_render_junctions_dev before bf_localise");
     if (!dev_off || (n && !dev_local_index)) return fail(ctx, BF_ERR_INVALID, "bf_render_junctions_dev: null argument");
+    if (((uintptr_t)dev_bytes & 3) || ((uintptr_t)dev_off & 7) || ((uintptr_t)dev_local_index & 3))
+        return fail(ctx, BF_ERR_INVALID, "bf_render_junctions_dev: dev_bytes/dev_local_index must be 4-byte and dev_off 8-byte aligned");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     return render_dev(ctx, n, dev_local_index, dev_off, dev_bytes, dev_bytes_cap, total);
 }

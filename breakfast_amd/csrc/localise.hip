@@ -642,34 +642,88 @@ __global__ void __launch_bounds__(256) render_len_checked_kernel(uint64_t n, con
     out_len[i] = (uint32_t)len[r] + 1;
 }
 
-// 16 lanes per surviving read, 4 reads per wave: everything a read needs besides its bases sits in
-// ONE render record (mask words + bp/flags/len), so a read costs one record line, one offset line
-// and its own sequence lines (the first version gathered nine separate 128-byte lines per read and
-// was latency-bound at one read per wave).
+// render: 16 lanes per surviving read, 4 reads per wave, 16 reads per block.  The junction string is
+// produced in tiles of 64 ALIGNED output dwords: the group stages the source bytes the tile needs
+// (aligned dword loads of the read, forwards or backwards) and the mask words in LDS, then every
+// lane assembles whole output dwords from LDS bytes -- complement when the read was reoriented
+// (detect.rs:112), lower case where the mask says mismatch (:157,161), '|' at the breakpoint -- and
+// stores them with one dword store; only the first and last dword of a string, which it shares with
+// its neighbours in the output, are stored bytewise.  Everything a read needs besides its bases sits
+// in ONE render record (mask words + bp/flags/len).
+constexpr int kRenderTileDw = 64;                            // output dwords per tile
+constexpr int kRenderStageDw = kRenderTileDw + 4;            // source dwords a tile can touch
+constexpr int kRenderMaskW = (4 * kRenderTileDw) / 64 + 2;   // mask words a tile can touch
+
 __global__ void __launch_bounds__(256) render_kernel(uint64_t n, const uint32_t* __restrict__ idx,
                                                      const uint64_t* __restrict__ joff,
                                                      const uint8_t* __restrict__ seq,
                                                      const uint64_t* __restrict__ seq_off,
                                                      const uint64_t* __restrict__ meta, int meta_stride,
                                                      uint8_t* __restrict__ out) {
-    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int l16 = threadIdx.x & 15;
+    __shared__ uint8_t comp[256];
+    __shared__ uint32_t stage[16][kRenderStageDw];
+    __shared__ uint64_t smask[16][kRenderMaskW];
+    comp[threadIdx.x] = kComp[threadIdx.x];
+    __syncthreads();
+    const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    const uint64_t i = (uint64_t)blockIdx.x * 16 + g;
     if (i >= n) return;
     const uint32_t r = idx[i];
     const uint64_t o = seq_off[r];
     const uint64_t* rec = meta + (uint64_t)r * meta_stride;
     const uint64_t tail = rec[meta_stride - 1];
-    const int bp = (int)(tail & 0xffff), L = (int)((tail >> 32) & 0xffff);
+    const int64_t bp = (int64_t)(tail & 0xffff), L = (int64_t)((tail >> 32) & 0xffff);
     const bool swapped = ((tail >> 16) & kEvSwapped) != 0;
-    uint8_t* dst = out + joff[i];
-#pragma unroll 4
-    for (int k = l16; k < L; k += 16) {
-        const uint64_t m = rec[k >> 6];
-        uint8_t c = swapped ? comp_byte(seq[o + L - 1 - k]) : seq[o + k];
-        if (((m >> (k & 63)) & 1) && c >= 'A' && c <= 'Z') c += 32;       // to_ascii_lowercase, :157,161
-        dst[k < bp ? k : k + 1] = c;
+    const int64_t dst0 = (int64_t)joff[i], out_len = L + 1;
+    const int64_t first_dw = dst0 >> 2, last_dw = (dst0 + out_len - 1) >> 2;
+    const uint8_t* sbytes = (const uint8_t*)stage[g];
+    for (int64_t t0 = first_dw; t0 <= last_dw; t0 += kRenderTileDw) {
+        // output positions [q_lo, q_hi) of this tile need read bases [k_lo, k_hi)
+        const int64_t q_lo = max((int64_t)0, 4 * t0 - dst0), q_hi = min(out_len, 4 * (t0 + kRenderTileDw) - dst0);
+        const int64_t k_lo = max((int64_t)0, q_lo - 1), k_hi = min(L, q_hi);
+        const int64_t src_lo = (int64_t)o + (swapped ? L - k_hi : k_lo), src_hi = (int64_t)o + (swapped ? L - k_lo : k_hi);
+        const int64_t base_dw = src_lo >> 2;
+        const int n_dw = (int)(((src_hi + 3) >> 2) - base_dw);
+        for (int d = l16; d < n_dw; d += 16) stage[g][d] = ((const uint32_t*)seq)[base_dw + d];
+        const int64_t w_lo = k_lo >> 6;
+        const int n_w = k_hi > k_lo ? (int)(((k_hi - 1) >> 6) - w_lo) + 1 : 0;
+        if (l16 < n_w) smask[g][l16] = rec[w_lo + l16];
+        // LDS operations of one wave execute in order; only the compiler must not reorder them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int w = l16; w < kRenderTileDw; w += 16) {
+            const int64_t dw = t0 + w;
+            if (dw > last_dw) break;
+            uint32_t val = 0, valid = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int64_t q = 4 * dw + b - dst0;
+                if (q < 0 || q >= out_len) continue;
+                uint32_t c = '|';
+                if (q != bp) {
+                    const int64_t k = q < bp ? q : q - 1;
+                    const int64_t sa = (int64_t)o + (swapped ? L - 1 - k : k);
+                    c = sbytes[sa - 4 * base_dw];
+                    if (swapped) c = comp[c];
+                    const uint64_t m = smask[g][(k >> 6) - w_lo];
+                    if (((m >> (k & 63)) & 1) && c >= 'A' && c <= 'Z') c += 32;       // to_ascii_lowercase
+                }
+                val |= c << (8 * b);
+                valid |= 1u << b;
+            }
+            if (valid == 0xfu) {
+                ((uint32_t*)out)[dw] = val;
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    if (valid & (1u << b)) out[4 * dw + b] = (uint8_t)(val >> (8 * b));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (l16 == 0) dst[bp] = '|';
 }
 
 // ---------------------------------------------------------------------------------------------

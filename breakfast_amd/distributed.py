@@ -87,7 +87,7 @@ class HipStageEngine:
 
     # ---- device-resident junction routing (no PCIe round trips) ----
     def result_sources_tensors(self, res: Result):
-        nr = int(res.reads.shape[0])
+        nr = res.n_reads if res.n_reads >= 0 else int(res.reads.shape[0])
         sr = torch.empty(nr, dtype=torch.int32, device=self.device)
         si = torch.empty(nr, dtype=torch.int32, device=self.device)
         if nr:
@@ -179,6 +179,22 @@ class DistributedDetect:
         else:
             self.bases = np.array([index_base], np.uint64)
         self.stats = StepStats()
+        self.profile = False            # True: synchronise after every phase and accumulate wall ms in phase_ms
+        self.phase_ms = {}
+        self._t = None
+
+    def _phase(self, name: Optional[str]):
+        """Closes the running phase (if profiling) and opens `name`."""
+        if not self.profile:
+            return
+        import time
+        if torch.cuda.is_available() and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        now = time.perf_counter()
+        if self._t is not None:
+            k, t0 = self._t
+            self.phase_ms[k] = self.phase_ms.get(k, 0.0) + (now - t0) * 1e3
+        self._t = (name, now) if name else None
 
     def _ctl(self, values: List[int]) -> torch.Tensor:
         dev = self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
@@ -193,19 +209,28 @@ class DistributedDetect:
 
     def step(self) -> Result:
         st, W = self.stage, self.world
+        self._phase("localise")
         st.localise()
+        self._phase("agree")
         mf, sx = st.exchange_local()
         agreed = self._ctl([mf, sx])
         dist.all_reduce(agreed, op=dist.ReduceOp.MAX, group=self.group)
         mf, sx = (int(v) for v in agreed.cpu().tolist())
+        self._phase("pack")
         send, counts, rec = st.exchange_pack_tensor(mf, sx, W)
+        self._phase("alltoall_records")
         recv_counts = self._exchange_counts(counts)
         recv = torch.empty(int(recv_counts.sum()) * rec, dtype=torch.uint8, device=send.device)
         _a2a(recv, send, [int(c) * rec for c in recv_counts], [int(c) * rec for c in counts], self.group)
+        self._phase("import")
         st.exchange_import_tensor(recv, recv_counts, self.bases)
+        del recv, send
+        self._phase("clusterise")
         res = st.clusterise()
         self.stats = StepStats(int(counts.sum()), int(recv_counts.sum()), rec, int(counts.sum()) * rec)
-        return self._route_junctions(res)
+        out = self._route_junctions(res)
+        self._phase(None)
+        return out
 
     # Stage hooks with host fall-backs, so that stand-in engines (tests) only need the numpy calls.
     def _sources(self, res: Result, dev):
@@ -237,6 +262,7 @@ class DistributedDetect:
         host.  Sequences and mismatch masks never leave their source rank."""
         W = self.world
         nccl = dist.get_backend(self.group) == "nccl"
+        self._phase("route_requests")
         src_rank, src_index = self._sources(res, self.device if nccl else torch.device("cpu"))
         dev = src_rank.device
         nr = int(src_rank.numel())
@@ -247,7 +273,9 @@ class DistributedDetect:
         got = torch.empty(int(got_counts.sum()), dtype=torch.int32, device=dev)
         _a2a(got, req, [int(c) for c in got_counts], [int(c) for c in req_counts], self.group)
         # render what the others (and I) asked for, in request order
+        self._phase("render")
         by, off = self._render(got, dev)
+        self._phase("alltoall_junctions")
         bounds = torch.from_numpy(np.concatenate([[0], np.cumsum(got_counts)]).astype(np.int64)).to(off.device)
         ob = off[bounds].cpu().numpy()
         out_bytes = [int(ob[r + 1] - ob[r]) for r in range(W)]
@@ -263,6 +291,7 @@ class DistributedDetect:
         mine = torch.empty(int(ib[-1]), dtype=torch.uint8, device=by.device)
         _a2a(mine, by, in_bytes, out_bytes, self.group)
         # back to result order
+        self._phase("attach_to_host")
         joff = torch.empty(nr, dtype=torch.int64, device=csum.device)
         jlen = torch.empty(nr, dtype=torch.int32, device=csum.device)
         joff[order] = csum[:-1]

@@ -21,6 +21,7 @@ BF_FLAG_KEEP_EVIDENCE = 1
 BF_FLAG_FORCE_EXACT = 2
 BF_FLAG_COOP_GATHER = 4
 BF_FLAG_SEPARATE_ENCODE = 8
+BF_FLAG_DEVICE_ROUTING = 16
 BF_EV_STRAND, BF_EV_MSTRAND, BF_EV_SWAPPED, BF_EV_EXACT, BF_EV_SIGX = 1, 2, 4, 8, 16
 
 HIT_DTYPE = np.dtype([("pos5", "<u4"), ("pos3", "<u4"), ("contig5", "<u2"), ("contig3", "<u2"),
@@ -167,6 +168,7 @@ class Result:
     junction_bytes: np.ndarray
     src_rank: Optional[np.ndarray] = None
     src_index: Optional[np.ndarray] = None
+    n_reads: int = -1         # supporting reads (== reads.shape[0] unless the table is still on the device)
 
     def junction(self, k: int) -> bytes:
         r = self.reads[k]
@@ -286,7 +288,7 @@ class Engine:
             return a.copy() if copy else a
         return Result(int(r.n_evidence), arr(r.clusters, r.n_clusters, CLUSTER_DTYPE),
                       arr(r.reads, r.n_reads, READ_DTYPE),
-                      arr(r.junction_bytes, r.junction_size, np.dtype("u1")))
+                      arr(r.junction_bytes, r.junction_size, np.dtype("u1")), n_reads=int(r.n_reads))
 
     def clusterise(self, copy: bool = True) -> Result:
         r = BfResult()

@@ -61,6 +61,9 @@ typedef struct {
 #define BF_FLAG_FORCE_EXACT   2u   /* route every read through the byte-exact kernel (tests)        */
 #define BF_FLAG_COOP_GATHER     4u /* A/B: separate encode kernel + cooperative (LDS-staged) flank gather */
 #define BF_FLAG_SEPARATE_ENCODE 8u /* A/B: separate encode kernel + per-lane flank gather               */
+#define BF_FLAG_DEVICE_ROUTING 16u /* multi-rank: bf_clusterise leaves the read table on the device (result.reads
+                                      is NULL, n_reads is set) until bf_result_attach_junctions_dev copies the
+                                      finished table out once */
 
 /* One pair of anchor alignments = the fields the consume loop parses out of a `5p:`/`3p:` line
  * pair (detect.rs:94-103): bowtie's strand, contig and 1-based leftmost offset (-B1) of each anchor.
@@ -216,7 +219,8 @@ int bf_result_sources_dev(bf_ctx* ctx, uint32_t* dev_src_rank, uint32_t* dev_src
 /* On a source rank: junction strings (detect.rs:155-162) of n local reads given as a device index
  * list.  dev_off receives n+1 byte offsets, *total their sum.  With dev_bytes == NULL only offsets
  * and *total are produced (size query); otherwise dev_bytes (capacity dev_bytes_cap >= *total)
- * receives the text.  An index outside the resident reads is an error, never dereferenced. */
+ * receives the text.  An index outside the resident reads is an error, never dereferenced.
+ * dev_bytes and dev_local_index must be 4-byte aligned, dev_off 8-byte aligned. */
 int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_index, uint64_t* dev_off,
                             uint8_t* dev_bytes, uint64_t dev_bytes_cap, uint64_t* total);
 

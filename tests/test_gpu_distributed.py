@@ -25,7 +25,7 @@ def make_case():
     return g, synth.make_reads(g, spec), 20, 5000, 2
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, flags=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,7 +34,7 @@ def _worker(rank, world, port, out_path):
         cuts = [0, b.n // 3, b.n] if world == 2 else [0, b.n // 4, b.n // 2, b.n]
         lo, hi = cuts[rank], cuts[rank + 1]
         dev = torch.device("cuda", 0)
-        eng = engine.Engine(A, F, E, device=0)
+        eng = engine.Engine(A, F, E, device=0, flags=flags)
         eng.set_genome(g.names, g.seqs)
         eng.set_rank(rank, world, lo)
         eng.submit(b.slice(lo, hi))
@@ -53,13 +53,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_hip_detect_matches_oracle(tmp_path, world):
+@pytest.mark.parametrize("world,flags", [(2, 0), (3, 0), (2, engine.BF_FLAG_DEVICE_ROUTING)])
+def test_sharded_hip_detect_matches_oracle(tmp_path, world, flags):
     g, b, A, F, E = make_case()
     ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, A, F, E)
     assert ref.n_clusters > 50
     out = str(tmp_path / "out.sv")
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, flags), nprocs=world, join=True)
     assert open(out, "rb").read() == ref.sv
 
 

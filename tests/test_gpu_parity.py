@@ -244,3 +244,40 @@ def test_dedup_survives_hash_collisions():
     assert expected.count(b";") == 2
     text = b"".join(l + b"\n" for l in f.lines)
     assert run_gpu_text(f.fasta(), text, 10, 5000, 2) == expected
+
+
+def test_long_reads_render_in_several_tiles():
+    # reads longer than one render tile (256 output bytes) and than the packed path (exact kernel)
+    contigs = [("c%d" % i, 120000) for i in range(3)]
+    g = synth.make_genome(contigs, seed=19)
+    for L in (257, 700, 1100):
+        spec = synth.ReadSpec(n_reads=900, read_len=L, anchor_len=25, n_events=15, singleton_frac=0.3, seed=200 + L,
+                              margin=1300, subst_rate=0.02)
+        b = synth.make_reads(g, spec)
+        check_against_oracle(g, b, 25)
+
+
+def test_full_size_headline_config_is_byte_identical():
+    """BASELINE.json configs[1] at FULL size (10M reads x 150 bp, 3.09 Gb genome): the whole .sv
+    (about 600 MB) against the C++ oracle, plus idempotence of a second pass on the resident reads."""
+    import hashlib
+    contigs, gk, spec = synth.config(1)
+    spec.margin = 10000 + 2 * spec.read_len + 128
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    eng = engine.Engine(spec.anchor_len, 5000, 2)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        for a in range(0, b.n, 1 << 21):
+            eng.submit(b.slice(a, min(b.n, a + (1 << 21))))
+        res = eng.finish(copy=False)
+        sv = eng.format_sv(res)
+        h1 = hashlib.sha256(sv).hexdigest()
+        n_clusters = res.clusters.shape[0]
+        res2 = eng.finish(copy=False)
+        assert hashlib.sha256(eng.format_sv(res2)).hexdigest() == h1
+    finally:
+        eng.close()
+    ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, spec.anchor_len, 5000, 2)
+    assert n_clusters == ref.n_clusters > 100000
+    assert len(sv) == len(ref.sv) and sv == ref.sv
