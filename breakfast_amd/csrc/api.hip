@@ -225,16 +225,16 @@ int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, con
         off += (lens[i] + 63) & ~63ull;
     }
     const uint64_t total = (off + 4095) & ~4095ull;      // whole waves of 64 blocks
-    if (total / 64 >= 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "genome too large: %llu bases (limit 2^38)", (unsigned long long)total);
+    if (total / 64 >= 0x7ffffff0ull) return fail(ctx, BF_ERR_RANGE, "genome too large: %llu bases (limit 2^37)", (unsigned long long)total);
     ctx->genome_bases = total;
     const uint64_t n_blocks = total / 64;
     BF_TRY(ensure(ctx, ctx->g_raw, total + 4096));
-    BF_TRY(ensure(ctx, ctx->g_blocks, (n_blocks + 16) * sizeof(GenomeBlock)));
+    BF_TRY(ensure(ctx, ctx->g_blocks, block_image_slots(n_blocks) * sizeof(GenomeBlock)));
     BF_TRY(ensure(ctx, ctx->g_coarse, (n_blocks / 64 + 4) * 8));
     BF_TRY(ensure(ctx, ctx->g_coarse2, (n_blocks / 2048 + 4) * 4));
     BF_TRY(ensure(ctx, ctx->g_contigs, (size_t)n_contigs * sizeof(ContigDev)));
     BF_HIP(ctx, hipMemsetAsync(ctx->g_raw.p, 'A', total + 4096, ctx->stream));   // padding is never compared
-    BF_HIP(ctx, hipMemsetAsync(ctx->g_blocks.p, 0, (n_blocks + 16) * sizeof(GenomeBlock), ctx->stream));
+    BF_HIP(ctx, hipMemsetAsync(ctx->g_blocks.p, 0, block_image_slots(n_blocks) * sizeof(GenomeBlock), ctx->stream));
     BF_HIP(ctx, hipMemsetAsync(ctx->g_coarse.p, 0, (n_blocks / 64 + 4) * 8, ctx->stream));
     BF_HIP(ctx, hipMemsetAsync(ctx->g_coarse2.p, 0, (n_blocks / 2048 + 4) * 4, ctx->stream));
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));

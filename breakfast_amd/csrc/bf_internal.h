@@ -21,6 +21,15 @@ namespace bf {
 // which reads the raw image.  Every contig starts on a block boundary.
 struct GenomeBlock { uint64_t lo, hi; };
 
+// The block image is stored as OVERLAPPING 128-byte lines: line j holds blocks 4j .. 4j+7, so every
+// block lives twice (in line b/4 and, as its upper half, in line b/4 - 1) and any run of up to 5
+// consecutive blocks -- a flank window of up to 256 bases at any offset -- lies inside ONE line.
+// A window gather therefore costs one 128-byte memory request instead of 1.375 on average
+// (a 64-byte run at 16-byte granularity straddles a line boundary 3 times in 8).  Twice the 2-bit
+// image (1.5 GB for hg38) is nothing against 288 GB of HBM.
+__host__ __device__ inline uint64_t block_slot(uint64_t b) { return ((b >> 2) << 3) + (b & 3); }
+__host__ __device__ inline uint64_t block_image_slots(uint64_t n_blocks) { return ((n_blocks >> 2) + 2) << 3; }
+
 struct ContigDev {      // 16 B, indexed by contig id
     uint64_t goff;      // global base offset of the contig's first base (multiple of 64)
     uint32_t len;

@@ -53,7 +53,9 @@ __global__ void __launch_bounds__(256) genome_pack_kernel(const uint8_t* __restr
             }
         }
     }
-    blocks[t] = GenomeBlock{lo, hi};
+    // overlapping lines: block t is the lower-half slot t%4 of line t/4 and the upper-half slot of line t/4 - 1
+    blocks[block_slot(t)] = GenomeBlock{lo, hi};
+    if (t >= 4) blocks[block_slot(t - 4) + 4] = GenomeBlock{lo, hi};
     const uint64_t flags = __ballot(exc);
     if ((threadIdx.x & 63) == 0) {
         coarse[t >> 6] = flags;
@@ -161,11 +163,11 @@ template <int W>
 __device__ __forceinline__ void load_window(const GenomeBlock* __restrict__ blocks, uint64_t g,
                                             uint64_t (&lo)[W], uint64_t (&hi)[W]) {
     // bits of bases [g, g + 64W): W+1 consecutive 16-byte blocks, funnel-shifted by g % 64
-    const uint64_t b = g >> 6;
+    const GenomeBlock* __restrict__ p = blocks + block_slot(g >> 6);   // W+1 <= 5 blocks: inside one 128-byte line
     const int sh = (int)(g & 63);
     GenomeBlock x[W + 1];
 #pragma unroll
-    for (int i = 0; i <= W; i++) x[i] = blocks[b + i];
+    for (int i = 0; i <= W; i++) x[i] = p[i];
 #pragma unroll
     for (int w = 0; w < W; w++) {
         lo[w] = (x[w].lo >> sh) | ((x[w + 1].lo << 1) << (63 - sh));
@@ -398,8 +400,8 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
         const int lane = threadIdx.x & 63;
         uint4* wl = lds + (threadIdx.x >> 6) * 2 * CoopGeom<W>::WAVE_U4;
         uint4* wr = wl + CoopGeom<W>::WAVE_U4;
-        coop_fetch<W>(a.blocks, (uint32_t)(lg >> 6), wl, lane);
-        coop_fetch<W>(a.blocks, (uint32_t)(rg >> 6), wr, lane);
+        coop_fetch<W>(a.blocks, (uint32_t)block_slot(lg >> 6), wl, lane);
+        coop_fetch<W>(a.blocks, (uint32_t)block_slot(rg >> 6), wr, lane);
         // LDS operations of one wave execute in order; only the compiler must not reorder them
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
