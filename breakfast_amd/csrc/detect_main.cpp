@@ -53,6 +53,9 @@
 
 extern char** environ;
 
+int filter_main(int argc, char** argv);      // text_tools.cpp: src/filter.rs
+int annotate_main(int argc, char** argv);    // text_tools.cpp: src/annotate.rs
+
 [[noreturn]] static void error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -261,11 +264,14 @@ static void write_all(int fd, const char* p, size_t n) {
 }
 
 int main(int argc, char** argv) {
+    if (argc >= 2 && strcmp(argv[1], "filter") == 0) return filter_main(argc, argv);        // main.rs:26
+    if (argc >= 2 && strcmp(argv[1], "annotate") == 0) return annotate_main(argc, argv);    // main.rs:27
     const bool anchors_only = argc >= 2 && strcmp(argv[1], "anchors") == 0;
     const bool hits_only = argc >= 2 && strcmp(argv[1], "hits") == 0;
     if (argc < 2 || (strcmp(argv[1], "detect") != 0 && !anchors_only && !hits_only)) {
         fputs("\nBreakfast is a software for detecting chromosomal rearrangements in DNA/RNA sequencing data.\n\n"
-              "Usage:\n  breakfast-hip detect [options] <bam_file> <genome>\n  breakfast-hip anchors [--anchor-len=N] <bam_file>\n"
+              "Usage:\n  breakfast-hip detect [options] <bam_file> <genome>\n  breakfast-hip filter [options] <sample_sheet>\n"
+              "  breakfast-hip annotate <sv_path> <bed_path>\n  breakfast-hip anchors [--anchor-len=N] <bam_file>\n"
               "  breakfast-hip hits [--threads=N] [--block-bytes=N] <hits_file> <genome>\n", stderr);
         return -1;
     }
