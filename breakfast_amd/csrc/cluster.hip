@@ -65,10 +65,17 @@ __global__ void gather_key_kernel(uint64_t* out, const uint64_t* __restrict__ in
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[idx[i]];
 }
-__global__ void gather_pos_kernel(int32_t* slpos, int32_t* srpos, const int32_t* __restrict__ lpos,
-                                  const int32_t* __restrict__ rpos, const uint32_t* __restrict__ perm, uint64_t n) {
+// identity permutation + the two positions of a record side by side, so that the gather by sort
+// permutation below costs one random 8-byte access per record instead of two 4-byte ones
+__global__ void iota_zip_kernel(uint32_t* idx, int2* pos2, const int32_t* __restrict__ lpos,
+                                const int32_t* __restrict__ rpos, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const uint32_t r = perm[i]; slpos[i] = lpos[r]; srpos[i] = rpos[r]; }
+    if (i < n) { idx[i] = (uint32_t)i; pos2[i] = make_int2(lpos[i], rpos[i]); }
+}
+__global__ void gather_pos_kernel(int32_t* slpos, int32_t* srpos, const int2* __restrict__ pos2,
+                                  const uint32_t* __restrict__ perm, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int2 p = pos2[perm[i]]; slpos[i] = p.x; srpos[i] = p.y; }
 }
 
 struct SweepView {
@@ -101,22 +108,60 @@ __device__ __forceinline__ bool rpos_far(int32_t rs, int32_t rp, int64_t F) {
     return (d < 0 ? -d : d) > F;
 }
 
-// The reference's sweep (detect.rs:203-227) inside one key segment.  Segments of up to kBigSegment
-// evidence are walked sequentially by the lane at the segment head; longer ones (duplicate-heavy
-// libraries pile thousands of reads on one junction) are queued for sweep_big_kernel.
+// The reference's sweep (detect.rs:203-227) inside one key segment.
+//
+// Fast path.  The first seed of a segment is its first record h.  If EVERY other record of the segment
+// passes the seed's tests (left position within max_frag_len -- the break test, monotone in sorted
+// order --, right position within max_frag_len, identical signature bytes), the sweep adds them all to
+// h's cluster and marks them reported, so the segment is exactly one cluster of its own size and no
+// walk is needed.  That is decided for all records at once: head index by a max-scan, one "covered"
+// flag per record, a prefix sum of the flags, and one lane per segment TAIL compares the covered count
+// with the segment length.  Only segments that fail (two junctions sharing a class, mates far apart)
+// are walked: by one lane when short, by one wave when longer than kBigSegment (duplicate-heavy
+// libraries pile thousands of reads on one junction).
 // csize[p] = cluster size if p is a seed; csize is zero-initialised.
 constexpr uint32_t kBigSegment = 96;
 
-__global__ void __launch_bounds__(256) sweep_kernel(const SweepView v, uint8_t* __restrict__ reported,
-                                                    uint32_t* __restrict__ csize, uint32_t* __restrict__ big_list,
-                                                    uint32_t* __restrict__ big_count) {
+__global__ void __launch_bounds__(256) head_mark_kernel(const uint64_t* __restrict__ skey, uint32_t* __restrict__ head, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || skey[i - 1] != skey[i]) ? (uint32_t)i : 0u;
+}
+
+__global__ void __launch_bounds__(256) covered_kernel(const SweepView v, const uint32_t* __restrict__ head,
+                                                      uint32_t* __restrict__ covered) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.n) return;
+    const uint64_t h = head[i];
+    bool ok = false;
+    if (i != h)
+        ok = !beyond(v.slpos[i], v.slpos[h], v.F) && !rpos_far(v.srpos[i], v.srpos[h], v.F) && same_sigx(v, v.skey[i], h, i);
+    covered[i] = ok ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) tails_kernel(const SweepView v, const uint32_t* __restrict__ head,
+                                                    const uint64_t* __restrict__ cov_scan /* exclusive, n+1 */,
+                                                    uint32_t* __restrict__ csize, uint32_t* __restrict__ small_list,
+                                                    uint32_t* __restrict__ big_list, uint32_t* __restrict__ counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.n) return;
+    if (i + 1 < v.n && v.skey[i + 1] == v.skey[i]) return;          // not the last record of its segment
+    const uint64_t h = head[i];
+    const uint64_t others = i - h, cov = cov_scan[i + 1] - cov_scan[h];
+    if (cov == others) { csize[h] = (uint32_t)(others + 1); return; }
+    if (others + 1 > kBigSegment) big_list[atomicAdd(&counts[1], 1u)] = (uint32_t)h;
+    else small_list[atomicAdd(&counts[0], 1u)] = (uint32_t)h;
+}
+
+// one lane per listed short segment: the reference's two loops as they are
+__global__ void __launch_bounds__(64) sweep_list_kernel(const SweepView v, uint8_t* __restrict__ reported,
+                                                        uint32_t* __restrict__ csize, const uint32_t* __restrict__ small_list,
+                                                        uint32_t n_small) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_small) return;
+    const uint64_t i = small_list[k];
     const uint64_t key = v.skey[i];
-    if (i > 0 && v.skey[i - 1] == key) return;
     uint64_t e = i + 1;
-    while (e < v.n && e - i <= kBigSegment && v.skey[e] == key) e++;
-    if (e - i > kBigSegment) { big_list[atomicAdd(big_count, 1u)] = (uint32_t)i; return; }
+    while (e < v.n && v.skey[e] == key) e++;
     for (uint64_t p = i; p < e; p++) {
         if (reported[p]) continue;
         const int32_t lp = v.slpos[p], rp = v.srpos[p];
@@ -377,10 +422,12 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     BF_TRY(ensure(ctx, ctx->c_c32, n * 4));
     BF_TRY(ensure(ctx, ctx->c_k64a, n * 8)); BF_TRY(ensure(ctx, ctx->c_k64b, n * 8));
     BF_TRY(ensure(ctx, ctx->c_slpos, n * 4)); BF_TRY(ensure(ctx, ctx->c_srpos, n * 4));
+    BF_TRY(ensure(ctx, ctx->c_pos2, n * 8));
     uint32_t* perm = ctx->c_a32.as<uint32_t>();
     {
         Scope t(ctx, "sort");
-        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_a32.as<uint32_t>(), n);
+        hipLaunchKernelGGL(iota_zip_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_a32.as<uint32_t>(), ctx->c_pos2.as<int2>(),
+                           v.lpos, v.rpos, n);
         BF_TRY(sort_pairs<uint32_t>(ctx, (const uint32_t*)v.lpos, ctx->c_b32.as<uint32_t>(), ctx->c_a32.as<uint32_t>(),
                                     ctx->c_c32.as<uint32_t>(), n, 0, 32));
         hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_k64a.as<uint64_t>(), v.key,
@@ -388,7 +435,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
         BF_TRY(sort_pairs<uint64_t>(ctx, ctx->c_k64a.as<uint64_t>(), ctx->c_k64b.as<uint64_t>(), ctx->c_c32.as<uint32_t>(),
                                     perm, n, 0, key_bits(ctx->contig_bits)));
         hipLaunchKernelGGL(gather_pos_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_slpos.as<int32_t>(),
-                           ctx->c_srpos.as<int32_t>(), v.lpos, v.rpos, perm, n);
+                           ctx->c_srpos.as<int32_t>(), ctx->c_pos2.as<int2>(), perm, n);
     }
     BF_HIP(ctx, hipGetLastError());
 
@@ -403,19 +450,35 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     uint64_t nq = 0;
     {
         Scope t(ctx, "sweep");
-        BF_TRY(ensure(ctx, ctx->c_big, (n / kBigSegment + 2) * 4));
+        // lists of segments that need a walk: counts[0] short ones, counts[1] long ones
+        BF_TRY(ensure(ctx, ctx->c_big, (n + n / kBigSegment + 8) * 4));
         BF_HIP(ctx, hipMemsetAsync(ctx->c_reported.p, 0, n, st));
         BF_HIP(ctx, hipMemsetAsync(ctx->c_csize.p, 0, n * 4, st));
-        BF_HIP(ctx, hipMemsetAsync(ctx->c_big.p, 0, 4, st));
-        uint32_t* big_count = ctx->c_big.as<uint32_t>(); uint32_t* big_list = big_count + 1;
-        hipLaunchKernelGGL(sweep_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, sv, ctx->c_reported.as<uint8_t>(),
-                           ctx->c_csize.as<uint32_t>(), big_list, big_count);
-        uint32_t n_big = 0;
-        BF_HIP(ctx, hipMemcpyAsync(&n_big, big_count, 4, hipMemcpyDeviceToHost, st));
+        BF_HIP(ctx, hipMemsetAsync(ctx->c_big.p, 0, 8, st));
+        uint32_t* counts = ctx->c_big.as<uint32_t>();
+        uint32_t* big_list = counts + 2; uint32_t* small_list = big_list + n / kBigSegment + 2;
+        uint32_t* head = ctx->c_flag.as<uint32_t>();          // reused for the min_evidence flags below
+        uint32_t* covered = ctx->c_b32.as<uint32_t>();        // free since the sort
+        hipLaunchKernelGGL(head_mark_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, sv.skey, head, n);
+        {
+            size_t bytes = 0;
+            BF_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes, head, head, n, rocprim::maximum<uint32_t>(), st));
+            BF_TRY(ensure(ctx, ctx->c_tmp, bytes ? bytes : 1, false));
+            BF_HIP(ctx, rocprim::inclusive_scan(ctx->c_tmp.p, bytes, head, head, n, rocprim::maximum<uint32_t>(), st));
+        }
+        hipLaunchKernelGGL(covered_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, sv, head, covered);
+        BF_TRY(scan_u32_to_u64(ctx, covered, ctx->c_scan.as<uint64_t>(), n));
+        hipLaunchKernelGGL(tails_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, sv, head, ctx->c_scan.as<uint64_t>(),
+                           ctx->c_csize.as<uint32_t>(), small_list, big_list, counts);
+        uint32_t n_walk[2] = {0, 0};
+        BF_HIP(ctx, hipMemcpyAsync(n_walk, counts, 8, hipMemcpyDeviceToHost, st));
         BF_HIP(ctx, hipStreamSynchronize(st));
-        if (n_big)
-            hipLaunchKernelGGL(sweep_big_kernel, dim3(grid_for((uint64_t)n_big * 64, B)), dim3(B), 0, st, sv,
-                               ctx->c_reported.as<uint8_t>(), ctx->c_csize.as<uint32_t>(), big_list, n_big);
+        if (n_walk[0])
+            hipLaunchKernelGGL(sweep_list_kernel, dim3(grid_for(n_walk[0], 64)), dim3(64), 0, st, sv,
+                               ctx->c_reported.as<uint8_t>(), ctx->c_csize.as<uint32_t>(), small_list, n_walk[0]);
+        if (n_walk[1])
+            hipLaunchKernelGGL(sweep_big_kernel, dim3(grid_for((uint64_t)n_walk[1] * 64, B)), dim3(B), 0, st, sv,
+                               ctx->c_reported.as<uint8_t>(), ctx->c_csize.as<uint32_t>(), big_list, n_walk[1]);
         hipLaunchKernelGGL(flag_ge_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
                            ctx->c_csize.as<uint32_t>(), ctx->cfg.min_evidence, n);
         BF_TRY(scan_u32_to_u64(ctx, ctx->c_flag.as<uint32_t>(), ctx->c_scan.as<uint64_t>(), n));

@@ -281,3 +281,50 @@ def test_full_size_headline_config_is_byte_identical():
     ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, spec.anchor_len, 5000, 2)
     assert n_clusters == ref.n_clusters > 100000
     assert len(sv) == len(ref.sv) and sv == ref.sv
+
+
+def test_segments_that_need_a_walk():
+    """Several junctions sharing ONE breakpoint class (same contigs, strands and 8+8 signature bases, made by
+    copying the flanks around the genome): the sweep's fast path (whole segment = one cluster) must not
+    fire; short segments take the one-lane walk, long ones the one-wave walk; left positions within
+    max_frag_len with right positions far apart exercise the `continue` branch and reads that join a
+    later seed's cluster although an earlier seed already reported them (detect.rs:215-226)."""
+    rng = np.random.Generator(np.random.PCG64(123))
+    A, L = 20, 100
+    g = synth.make_genome([("c0", 400000), ("c1", 300000)], seed=31)
+    s0 = g.seqs[0]
+    seqs, frags, hits = [], [], []
+
+    def plant(src, dsts, contig):
+        for d in dsts:
+            g.seqs[contig][d - 300:d + 300] = g.seqs[contig][src - 300:src + 300]
+
+    def add_reads(x1, y1, c2, count, tag):
+        for i in range(count):
+            b = int(rng.integers(A, L - A))
+            read = np.concatenate([g.seqs[0][x1 - b + 1:x1 + 1], g.seqs[c2][y1:y1 + L - b]]).copy()
+            if rng.random() < 0.3:                                   # a substitution outside the anchors
+                k = int(rng.integers(A, L - A))
+                read[k] = ord("A") if read[k] != ord("A") else ord("C")
+            seqs.append(read.tobytes())
+            frags.append(b"%s_%d" % (tag, i // 2 if i % 5 == 0 else 100000 + i))
+            hits.append((x1 - b + 2, y1 + L - A - b + 1, 0, c2, 3))
+
+    # class 1 (long segment): left copies 20 kb apart (beyond -> separate clusters), 400 reads each
+    plant(50000, [70000, 90000], 0); plant(250000, [270000, 290000], 0)
+    for k in range(3):
+        add_reads(50000 + 20000 * k, 250000 + 20000 * k, 0, 400, b"big%d" % k)
+    # class 2 (short segment): left copies 150 bases apart (within max_frag_len), right copies 30 kb apart
+    plant(120000, [120150, 120300], 0); plant(100000, [130000, 160000], 1)
+    for k in range(3):
+        add_reads(120000 + 150 * k, 100000 + 30000 * k, 1, 12, b"small%d" % k)
+    # class 3: same left copies, right copies 2 kb apart: everything within the seed's windows -> fast path
+    plant(200000, [202000], 1)
+    for k in range(2):
+        add_reads(120000 + 150 * k + 7, 200000 + 2000 * k, 1, 20, b"fast%d" % k)
+    order = rng.permutation(len(seqs))
+    b = engine.make_batch([seqs[i] for i in order], [frags[i] for i in order], [hits[i] for i in order])
+    res, ref = check_against_oracle(g, b, A)
+    assert ref.n_clusters >= 7
+    # a smaller window turns the 150-base neighbours into separate clusters as well
+    check_against_oracle(g, b, A, F=100)
