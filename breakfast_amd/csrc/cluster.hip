@@ -634,6 +634,52 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackView v) {
     }
 }
 
+// Same records, staged through LDS: every lane assembles its record as 8-byte words in the block's LDS
+// tile, then the tile (256 consecutive records = one contiguous piece of the send buffer) is written
+// with fully coalesced stores.  The plain kernel above stores 56-byte records lane by lane, bytewise
+// for the fragment id: 1.28 ms per 10M records against 0.3 ms here.  Used when a record is at most
+// kWireLdsMaxRecord bytes (fragment ids of up to 200 bytes), i.e. practically always.
+constexpr uint32_t kWireLdsMaxRecord = 256;
+
+__global__ void __launch_bounds__(256) pack_lds_kernel(const PackView v) {
+    extern __shared__ uint64_t tile[];
+    const uint32_t words = v.rec_bytes >> 3, fwords = v.frag_stride >> 3;
+    const uint64_t j0 = (uint64_t)blockIdx.x * 256, j = j0 + threadIdx.x;
+    if (j < v.n) {
+        const uint32_t i = v.order[j];
+        uint64_t* rec = tile + (uint64_t)threadIdx.x * words;
+        const uint64_t key = v.key[i];
+        const uint32_t fl = v.frag_len[i];
+        rec[0] = key;
+        rec[1] = (uint64_t)(uint32_t)v.lpos[i] | ((uint64_t)(uint32_t)v.rpos[i] << 32);
+        rec[2] = v.fhash[i];
+        rec[3] = (uint64_t)i | ((uint64_t)v.bp[i] << 32) | ((uint64_t)v.len[i] << 48);
+        rec[4] = (uint64_t)(uint16_t)fl | ((uint64_t)v.flags[i] << 16);
+        const uint8_t* f = v.frag + v.frag_off[i];
+        for (uint32_t w = 0; w < fwords; w++) {
+            uint64_t x = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 8; b++) {
+                const uint32_t k = 8 * w + b;
+                if (k < fl) x |= (uint64_t)f[k] << (8 * b);
+            }
+            rec[5 + w] = x;
+        }
+        if (v.has_sigx) {
+            uint64_t s0 = 0, s1 = 0;
+            if ((key >> kKeySigxBit) & 1) {
+                const uint8_t* src = v.sigx + (uint64_t)v.sigx_slot[i] * 16;
+                for (int b = 0; b < 8; b++) { s0 |= (uint64_t)src[b] << (8 * b); s1 |= (uint64_t)src[8 + b] << (8 * b); }
+            }
+            rec[5 + fwords] = s0; rec[6 + fwords] = s1;
+        }
+    }
+    __syncthreads();
+    const uint64_t in_tile = min((uint64_t)256, v.n - j0) * words;
+    uint64_t* out = (uint64_t*)v.out + j0 * words;
+    for (uint64_t t = threadIdx.x; t < in_tile; t += 256) out[t] = tile[t];
+}
+
 struct ImportView {
     uint64_t n; uint32_t rec_bytes, frag_stride, has_sigx, n_ranks;
     const uint8_t* in; const uint64_t* src_start;   // n_ranks+1 prefix of src_counts
@@ -655,6 +701,31 @@ __global__ void __launch_bounds__(256) import_kernel(const ImportView v) {
     uint32_t r = 0;
     while (r + 1 < v.n_ranks && j >= v.src_start[r + 1]) r++;
     v.src_rank[j] = r; v.src_idx[j] = h.src_idx;
+}
+
+__global__ void __launch_bounds__(256) import_lds_kernel(const ImportView v) {
+    extern __shared__ uint64_t tile[];
+    const uint32_t words = v.rec_bytes >> 3, fwords = v.frag_stride >> 3;
+    const uint64_t j0 = (uint64_t)blockIdx.x * 256, j = j0 + threadIdx.x;
+    const uint64_t in_tile = min((uint64_t)256, v.n - j0) * words;
+    const uint64_t* in = (const uint64_t*)v.in + j0 * words;
+    for (uint64_t t = threadIdx.x; t < in_tile; t += 256) tile[t] = in[t];
+    __syncthreads();
+    if (j >= v.n) return;
+    const uint64_t* rec = tile + (uint64_t)threadIdx.x * words;
+    v.key[j] = rec[0];
+    v.lpos[j] = (int32_t)(uint32_t)rec[1]; v.rpos[j] = (int32_t)(uint32_t)(rec[1] >> 32);
+    v.fhash[j] = rec[2];
+    v.src_idx[j] = (uint32_t)rec[3]; v.bp[j] = (uint16_t)(rec[3] >> 32); v.len[j] = (uint16_t)(rec[3] >> 48);
+    v.frag_len[j] = (uint16_t)rec[4]; v.flags[j] = (uint16_t)(rec[4] >> 16);
+    v.frag_off[j] = j * v.frag_stride;
+    uint64_t* fdst = (uint64_t*)(v.frag + j * v.frag_stride);
+    for (uint32_t w = 0; w < fwords; w++) fdst[w] = rec[5 + w];
+    v.sigx_slot[j] = (uint32_t)j;
+    if (v.has_sigx) { uint64_t* sd = (uint64_t*)(v.sigx + j * 16); sd[0] = rec[5 + fwords]; sd[1] = rec[6 + fwords]; }
+    uint32_t r = 0;
+    while (r + 1 < v.n_ranks && j >= v.src_start[r + 1]) r++;
+    v.src_rank[j] = r;
 }
 
 int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint64_t dev_send_bytes, uint64_t* counts,
@@ -697,7 +768,10 @@ int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint
     pv.flags = ctx->d_flags.as<uint16_t>(); pv.frag = ctx->d_frag.as<uint8_t>(); pv.frag_off = ctx->d_frag_off.as<uint64_t>();
     pv.frag_len = ctx->d_frag_len.as<uint16_t>(); pv.sigx = ctx->d_sigx.as<uint8_t>(); pv.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
     pv.out = (uint8_t*)*dev_out;
-    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, pv);
+    if (rec <= kWireLdsMaxRecord && ((uintptr_t)pv.out & 7) == 0)
+        hipLaunchKernelGGL(pack_lds_kernel, dim3(grid_for(n, 256)), dim3(256), 256 * rec, st, pv);
+    else
+        hipLaunchKernelGGL(pack_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, pv);
     BF_HIP(ctx, hipGetLastError());
     BF_HIP(ctx, hipMemcpyAsync(start.data(), ctx->d_part_tmp.p, (size_t)(R + 1) * 8, hipMemcpyDeviceToHost, st));
     BF_HIP(ctx, hipStreamSynchronize(st));
@@ -738,7 +812,10 @@ int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts) {
     v.frag_len = ctx->i_frag_len.as<uint16_t>(); v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
     v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>();
     Scope t(ctx, "exchange_import");
-    hipLaunchKernelGGL(import_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, v);
+    if (v.rec_bytes <= kWireLdsMaxRecord && ((uintptr_t)v.in & 7) == 0)
+        hipLaunchKernelGGL(import_lds_kernel, dim3(grid_for(n, 256)), dim3(256), 256 * v.rec_bytes, st, v);
+    else
+        hipLaunchKernelGGL(import_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, v);
     BF_HIP(ctx, hipGetLastError());
     BF_HIP(ctx, hipStreamSynchronize(st));   // dev_recv may be released by the caller on return
     return BF_OK;
