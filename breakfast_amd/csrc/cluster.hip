@@ -234,10 +234,15 @@ __global__ void compact_index_kernel(const uint32_t* __restrict__ flag, const ui
     if (i < n && flag[i]) out[scan[i]] = (uint32_t)i;
 }
 
+// Hash bits in the member sort key: enough to keep runs of equal keys short (a cluster rarely holds
+// more than a few hundred fragments), few enough to save two radix passes over 32 bits.  A collision
+// only lengthens a run; groups are decided on the id bytes.
+constexpr int kMemberHashBits = 16;
+
 struct MemberView {
     const uint32_t* qseed; const uint64_t* qoff;
     uint32_t* members;      // sorted positions
-    uint64_t* mkey;         // (cluster number << 32) | low half of the fragment-id hash, per member slot
+    uint64_t* mkey;         // (cluster number << kMemberHashBits) | low bits of the fragment-id hash, per member slot
     uint32_t* mscore;       // longest-flank score per member slot (detect.rs:273-279)
     const uint64_t* fhash; const uint16_t* bp; const uint16_t* len;
 };
@@ -254,7 +259,7 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
     auto put = [&](uint64_t slot, uint64_t spos) {
         const uint32_t rec = v.perm[spos];
         m.members[slot] = (uint32_t)spos;
-        m.mkey[slot] = (q << 32) | (uint32_t)m.fhash[rec];
+        m.mkey[slot] = (q << kMemberHashBits) | (m.fhash[rec] & ((1ull << kMemberHashBits) - 1));
         const uint32_t l = m.bp[rec], r = (uint32_t)m.len[rec] - l;
         m.mscore[slot] = min(l, r) * 10000u + max(l, r);
     };
@@ -294,20 +299,18 @@ __device__ __forceinline__ bool same_frag(const FragView& f, uint32_t ra, uint32
 __global__ void __launch_bounds__(256) dedup_runs_kernel(uint64_t total_m, const uint64_t* __restrict__ skey,
                                                          const uint32_t* __restrict__ sslot, const MemberView m,
                                                          const FragView f, uint32_t* __restrict__ leader,
-                                                         uint32_t* __restrict__ rep, uint32_t* __restrict__ qnrep) {
+                                                         uint32_t* __restrict__ rep) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= total_m) return;
     const uint64_t key = skey[j];
     if (j > 0 && skey[j - 1] == key) return;
-    const uint32_t q = (uint32_t)(key >> 32);
+    const uint32_t q = (uint32_t)(key >> kMemberHashBits);
     const uint64_t base = m.qoff[q];
     if (j + 1 >= total_m || skey[j + 1] != key) {          // the common case: a fragment seen once
         const uint32_t sa = sslot[j];
         rep[sa] = (uint32_t)(sa - base);
-        atomicAdd(&qnrep[q], 1u);
         return;
     }
-    uint32_t groups = 0;
     for (uint64_t a = j; a < total_m && skey[a] == key; a++) {
         const uint32_t sa = sslot[a];
         if (leader[sa] != kNone) continue;
@@ -322,9 +325,20 @@ __global__ void __launch_bounds__(256) dedup_runs_kernel(uint64_t total_m, const
             if (m.mscore[sb] > best_score) { best = sb; best_score = m.mscore[sb]; }
         }
         rep[sa] = (uint32_t)(best - base);
-        groups++;
     }
-    atomicAdd(&qnrep[q], groups);
+}
+
+// qnrep[q] = fragment-id groups of cluster q = member slots that lead a group (one wave per cluster)
+__global__ void __launch_bounds__(256) count_groups_kernel(uint64_t nq, const uint64_t* __restrict__ qoff,
+                                                           const uint32_t* __restrict__ rep, uint32_t* __restrict__ qnrep) {
+    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const uint64_t a = qoff[q], b = qoff[q + 1];
+    uint32_t cnt = 0;
+    for (uint64_t s = a + lane; s < b; s += 64) cnt += rep[s] != kNone;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if (lane == 0) qnrep[q] = cnt;
 }
 
 struct OrderView {
@@ -511,12 +525,13 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
         uint32_t* slot_in = ctx->c_slot.as<uint32_t>(); uint32_t* slot_s = slot_in + total_m;
         hipLaunchKernelGGL(iota_kernel, dim3(grid_for(total_m, B)), dim3(B), 0, st, slot_in, total_m);
         unsigned qbits = 1; while ((1ull << qbits) < nq) qbits++;
-        BF_TRY(sort_pairs<uint64_t>(ctx, mv.mkey, ctx->c_mkey_s.as<uint64_t>(), slot_in, slot_s, total_m, 0, 32 + qbits));
+        BF_TRY(sort_pairs<uint64_t>(ctx, mv.mkey, ctx->c_mkey_s.as<uint64_t>(), slot_in, slot_s, total_m, 0, kMemberHashBits + qbits));
         BF_HIP(ctx, hipMemsetAsync(ctx->c_leader.p, 0xff, total_m * 4, st));
         BF_HIP(ctx, hipMemsetAsync(ctx->c_rep.p, 0xff, total_m * 4, st));
-        BF_HIP(ctx, hipMemsetAsync(ctx->c_qnrep.p, 0, nq * 4, st));
         hipLaunchKernelGGL(dedup_runs_kernel, dim3(grid_for(total_m, B)), dim3(B), 0, st, total_m, ctx->c_mkey_s.as<uint64_t>(),
-                           slot_s, mv, fv, ctx->c_leader.as<uint32_t>(), ctx->c_rep.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>());
+                           slot_s, mv, fv, ctx->c_leader.as<uint32_t>(), ctx->c_rep.as<uint32_t>());
+        hipLaunchKernelGGL(count_groups_kernel, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, nq, ctx->c_qoff.as<uint64_t>(),
+                           ctx->c_rep.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>());
     }
     BF_HIP(ctx, hipGetLastError());
 
