@@ -15,7 +15,7 @@ from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbreakfast_hip.so")
+LIB_PATH = os.environ.get("BREAKFAST_HIP_LIB") or os.path.join(_HERE, "csrc", "libbreakfast_hip.so")   # override: kernel A/B builds
 
 BF_FLAG_KEEP_EVIDENCE = 1
 BF_FLAG_FORCE_EXACT = 2
