@@ -85,3 +85,17 @@ def test_error_conventions(tmp_path):
     trunc.write_bytes(raw[:len(raw) // 2])
     p = subprocess.run([EXE, "anchors", str(trunc)], capture_output=True)
     assert p.returncode == 255 and p.stderr.startswith(b"ERROR: ")
+
+
+def test_corrupt_block_is_an_error(tmp_path):
+    rng = random.Random(3)
+    reads = [dict(qname=b"r%d" % i, flag=4, seq=rseq(rng, 80)) for i in range(400)]
+    path = str(tmp_path / "c.bam")
+    raw = bytearray(bamtools.write_bam(path, [("c", 10)], reads, block_bytes=5000))
+    assert run_anchors(path, 20).count(b">5p:") == 400
+    for pos in (len(raw) // 2, len(raw) // 3):              # a flipped bit in some block's deflate data or trailer
+        bad = bytearray(raw)
+        bad[pos] ^= 0x10
+        (tmp_path / "bad.bam").write_bytes(bytes(bad))
+        p = subprocess.run([EXE, "anchors", "--anchor-len=20", str(tmp_path / "bad.bam")], capture_output=True, timeout=60)
+        assert p.returncode == 255 and b"ERROR: " in p.stderr
