@@ -86,3 +86,75 @@ def test_device_render_matches_host_render_and_rejects_bad_indices():
         assert ei.value.code == -1
     finally:
         eng.close()
+
+
+def _worker_nccl_single(rank, world, port, out_path):
+    """World size 1 over the nccl (RCCL) backend: the collectives move device tensors and run on torch's
+    stream, as they do on a multi-GPU node (one GPU cannot host two RCCL ranks)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        g, b, A, F, E = make_case()
+        dev = torch.device("cuda", 0)
+        eng = engine.Engine(A, F, E, device=0, flags=engine.BF_FLAG_DEVICE_ROUTING)
+        eng.set_genome(g.names, g.seqs)
+        eng.set_rank(0, 1, 0)
+        eng.submit(b)
+        dd = DistributedDetect(HipStageEngine(eng, dev), 0, 1, 0, b.n, dev)
+        for _ in range(3):
+            res = dd.step()
+        merged = dd.gather_result(res, g.names)
+        open(out_path, "wb").write(format_sv(merged, g.names))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_path_over_rccl_with_one_rank(tmp_path):
+    g, b, A, F, E = make_case()
+    ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, A, F, E)
+    out = str(tmp_path / "out.sv")
+    mp.spawn(_worker_nccl_single, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert open(out, "rb").read() == ref.sv
+
+
+def _worker_scaled(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g, b, A = scaled_case()
+        n = b.n
+        cuts = [0, (2 * n) // 5, n]
+        lo, hi = cuts[rank], cuts[rank + 1]
+        dev = torch.device("cuda", 0)
+        eng = engine.Engine(A, 5000, 2, device=0, flags=engine.BF_FLAG_DEVICE_ROUTING)
+        eng.set_genome(g.names, g.seqs)
+        eng.set_rank(rank, world, lo)
+        eng.submit(b.slice(lo, hi))
+        dd = DistributedDetect(HipStageEngine(eng, dev), rank, world, lo, hi - lo, dev)
+        res = dd.step()
+        merged = dd.gather_result(res, g.names)
+        if rank == 0:
+            open(out_path, "wb").write(format_sv(merged, g.names))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def scaled_case():
+    contigs, gk, spec = synth.config(1, scale=0.05, genome_scale=0.05)      # 500k reads, 154 Mb genome, 25 contigs
+    spec.margin = 10000 + 2 * spec.read_len + 128
+    g = synth.make_genome(contigs, **gk)
+    return g, synth.make_reads(g, spec), spec.anchor_len
+
+
+def test_two_ranks_at_half_a_million_reads(tmp_path):
+    g, b, A = scaled_case()
+    ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, A, 5000, 2)
+    assert ref.n_clusters > 3000
+    out = str(tmp_path / "out.sv")
+    mp.spawn(_worker_scaled, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out, "rb").read() == ref.sv
