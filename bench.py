@@ -34,7 +34,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from breakfast_amd import engine, synth  # noqa: E402
-from breakfast_amd.distributed import DistributedDetect, HipStageEngine, init_from_env  # noqa: E402
+from breakfast_amd.distributed import DistributedDetect, HipStageEngine, bind_to_gpu_numa_node, init_from_env  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -91,6 +91,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    node = bind_to_gpu_numa_node(local) if world > 1 else None
+    if node is not None:
+        print("[bench] rank %d: GPU %d, CPUs of NUMA node %d" % (rank, local, node), file=sys.stderr, flush=True)
 
     # ---- synthetic workload ----------------------------------------------------------------------
     t0 = time.time()

@@ -40,6 +40,30 @@ def init_from_env(backend: Optional[str] = None):
     return rank, world, local
 
 
+def bind_to_gpu_numa_node(local_rank: int) -> Optional[int]:
+    """Pins this process (and the pinned result buffers it allocates afterwards) to the CPUs of the NUMA
+    node its GPU hangs off, so that eight ranks copying 0.7 GB of results per step to host memory do not
+    all write through one socket.  Returns the node, or None when the machine does not say (then nothing
+    changes).  One process per GPU is what makes this possible at all."""
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        allowed = cpus & os.sched_getaffinity(0)
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return node
+    except Exception:
+        return None
+
+
 class HipStageEngine:
     """Adapts breakfast_amd.Engine (device pointers) to torch tensors for the exchange.
 
