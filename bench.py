@@ -75,6 +75,9 @@ def main():
                          "device junction routing), to time what the exchange adds per rank")
     ap.add_argument("--phases", action="store_true", help="sharded path: synchronise after every phase and report phase_ms "
                                                            "(diagnostic: the extra synchronisation slows the step)")
+    ap.add_argument("--soft-mask", type=float, default=0.0,
+                    help="fraction of the genome in lowercase (soft-masked repeats, as in UCSC hg38.fa), in runs of 300-30000 "
+                         "bases; 0 = the all-uppercase genome of BASELINE's config (diagnostic for the byte-exact path)")
     ap.add_argument("--check", action="store_true", help="also compare the GPU .sv with the oracle's on the sample")
     args = ap.parse_args()
 
@@ -102,11 +105,23 @@ def main():
     if args.scale >= 0.05:
         spec.margin = 10000 + 2 * L + 128            # junctions clear of the 10 kb N runs at contig ends
     genome = synth.make_genome(contigs, **gk)
+    if args.soft_mask > 0:
+        mrng = np.random.Generator(np.random.PCG64(spec.seed + 99))
+        for sq in genome.seqs:
+            n_runs = max(1, int(sq.shape[0] * args.soft_mask / 3000))
+            st = mrng.integers(0, max(sq.shape[0] - 30000, 1), size=n_runs)
+            ln = (300 * np.exp(mrng.random(n_runs) * np.log(100))).astype(np.int64)      # 300 .. 30000, log-uniform
+            mask = np.zeros(sq.shape[0] + 1, np.int32)
+            np.add.at(mask, st, 1)
+            np.add.at(mask, np.minimum(st + ln, sq.shape[0]), -1)
+            sq[np.cumsum(mask[:-1]) > 0] |= 0x20
     log(rank, "genome: %d contigs, %.3f Gb in %.1fs" % (len(contigs), sum(l for _, l in contigs) / 1e9, time.time() - t0))
     t1 = time.time()
     spec.read_seed = spec.seed * 1000 + rank          # same junctions on every rank, different reads
     spec.frag_base = rank * spec.n_reads
     batch = synth.make_reads(genome, spec)
+    if args.soft_mask > 0:
+        batch.seq_bytes &= np.uint8(0xDF)              # sequencer reads are upper case whatever the reference's case
     n_local = batch.n
     log(rank, "reads: %d x %d bp per rank in %.1fs" % (n_local, L, time.time() - t1))
 

@@ -114,7 +114,7 @@ static OwnerView imported_view(bf_ctx* ctx) {
 }
 
 static void free_all(bf_ctx* ctx) {
-    DevBuf* all[] = {&ctx->g_blocks, &ctx->g_raw, &ctx->g_coarse, &ctx->g_coarse2, &ctx->g_contigs, &ctx->d_seq, &ctx->d_seq_off,
+    DevBuf* all[] = {&ctx->g_blocks, &ctx->g_exc, &ctx->g_raw, &ctx->g_coarse, &ctx->g_coarse2, &ctx->g_contigs, &ctx->d_seq, &ctx->d_seq_off,
         &ctx->d_frag, &ctx->d_frag_off, &ctx->d_hits, &ctx->d_planes, &ctx->d_len, &ctx->d_frag_len, &ctx->d_fhash,
         &ctx->d_key, &ctx->d_lpos, &ctx->d_rpos, &ctx->d_bp, &ctx->d_flags, &ctx->d_mask, &ctx->d_exact_list,
         &ctx->d_counters, &ctx->d_sigx, &ctx->d_sigx_slot, &ctx->d_send, &ctx->d_part_key, &ctx->d_part_idx,
@@ -230,11 +230,13 @@ int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, con
     const uint64_t n_blocks = total / 64;
     BF_TRY(ensure(ctx, ctx->g_raw, total + 4096));
     BF_TRY(ensure(ctx, ctx->g_blocks, block_image_slots(n_blocks) * sizeof(GenomeBlock)));
+    BF_TRY(ensure(ctx, ctx->g_exc, exc_image_slots(n_blocks) * 8));
     BF_TRY(ensure(ctx, ctx->g_coarse, (n_blocks / 64 + 4) * 8));
     BF_TRY(ensure(ctx, ctx->g_coarse2, (n_blocks / 2048 + 4) * 4));
     BF_TRY(ensure(ctx, ctx->g_contigs, (size_t)n_contigs * sizeof(ContigDev)));
     BF_HIP(ctx, hipMemsetAsync(ctx->g_raw.p, 'A', total + 4096, ctx->stream));   // padding is never compared
     BF_HIP(ctx, hipMemsetAsync(ctx->g_blocks.p, 0, block_image_slots(n_blocks) * sizeof(GenomeBlock), ctx->stream));
+    BF_HIP(ctx, hipMemsetAsync(ctx->g_exc.p, 0, exc_image_slots(n_blocks) * 8, ctx->stream));
     BF_HIP(ctx, hipMemsetAsync(ctx->g_coarse.p, 0, (n_blocks / 64 + 4) * 8, ctx->stream));
     BF_HIP(ctx, hipMemsetAsync(ctx->g_coarse2.p, 0, (n_blocks / 2048 + 4) * 4, ctx->stream));
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -478,13 +480,7 @@ int bf_exchange_local(bf_ctx* ctx, bf_wire_local* out) {
     if (!ctx || !out) return BF_ERR_INVALID;
     if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_exchange_local before bf_localise");
     out->max_frag_len_bytes = ctx->max_frag;
-    out->has_exact_sig = 0;
-    if (ctx->n_exact) {
-        // any evidence with a non-ACGT signature?  flags live on the device; n_exact is small
-        std::vector<uint16_t> fl(ctx->n_reads);
-        BF_HIP(ctx, hipMemcpy(fl.data(), ctx->d_flags.p, ctx->n_reads * 2, hipMemcpyDeviceToHost));
-        for (uint16_t f : fl) if (f & kEvSigx) { out->has_exact_sig = 1; break; }
-    }
+    out->has_exact_sig = ctx->n_sigx ? 1 : 0;
     return BF_OK;
 }
 

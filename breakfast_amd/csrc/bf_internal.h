@@ -30,6 +30,13 @@ struct GenomeBlock { uint64_t lo, hi; };
 __host__ __device__ inline uint64_t block_slot(uint64_t b) { return ((b >> 2) << 3) + (b & 3); }
 __host__ __device__ inline uint64_t block_image_slots(uint64_t n_blocks) { return ((n_blocks >> 2) + 2) << 3; }
 
+// Exception plane: one 64-bit word per 64-base block, bit k = "base k is not one of ACGT" (N, soft-masked
+// lowercase, IUPAC).  Stored the same way as overlapping 128-byte lines (line j = words 8j .. 8j+15), so
+// the up to five consecutive words of a window are one memory request.  Only windows that the coarse
+// bitmaps flag ever read it.
+__host__ __device__ inline uint64_t exc_slot(uint64_t b) { return ((b >> 3) << 4) + (b & 7); }
+__host__ __device__ inline uint64_t exc_image_slots(uint64_t n_blocks) { return ((n_blocks >> 3) + 2) << 4; }
+
 struct ContigDev {      // 16 B, indexed by contig id
     uint64_t goff;      // global base offset of the contig's first base (multiple of 64)
     uint32_t len;
@@ -132,7 +139,7 @@ struct bf_ctx {
     std::vector<uint32_t> contig_by_rank;       // rank -> id
     std::vector<bf::ContigDev> contig_host;
     uint64_t genome_bases = 0;                  // padded total (multiple of 64)
-    bf::DevBuf g_blocks, g_raw, g_coarse, g_coarse2, g_contigs;
+    bf::DevBuf g_blocks, g_exc, g_raw, g_coarse, g_coarse2, g_contigs;
 
     // source-side resident reads
     uint64_t n_reads = 0;
@@ -143,6 +150,7 @@ struct bf_ctx {
     bool localised = false;
     uint32_t plane_words = 0, mask_words = 0;
     uint64_t n_exact = 0;
+    uint64_t n_sigx = 0;                        // evidence whose signature holds a non-ACGT byte
     bf::DevBuf d_planes, d_len, d_frag_len, d_fhash;
     bf::DevBuf d_key, d_lpos, d_rpos, d_bp, d_flags, d_mask;
     bf::DevBuf d_exact_list, d_counters, d_sigx, d_sigx_slot;

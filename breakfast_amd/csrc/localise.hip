@@ -28,14 +28,14 @@ __device__ __forceinline__ bool is_acgt(uint8_t c) { return c == 'A' || c == 'C'
 // of the coarse bitmap (ballot), so block t's flag is bit t%64 of coarse[t/64].
 __global__ void __launch_bounds__(256) genome_pack_kernel(const uint8_t* __restrict__ raw,
                                                           GenomeBlock* __restrict__ blocks,
+                                                          uint64_t* __restrict__ exc_plane,
                                                           uint64_t* __restrict__ coarse,
                                                           uint32_t* __restrict__ coarse2,
                                                           uint64_t n_blocks /* multiple of 64 */) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_blocks) return;  // whole waves only: n_blocks and blockDim are multiples of 64
     const uint4* src = (const uint4*)(raw + t * 64);
-    uint64_t lo = 0, hi = 0;
-    bool exc = false;
+    uint64_t lo = 0, hi = 0, ex = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint4 v = src[q];
@@ -49,14 +49,18 @@ __global__ void __launch_bounds__(256) genome_pack_kernel(const uint8_t* __restr
                 const uint64_t code = (c >> 1) & 3;
                 lo |= (code & 1) << k;
                 hi |= (code >> 1) << k;
-                exc |= !is_acgt(c);
+                ex |= (uint64_t)!is_acgt(c) << k;
             }
         }
     }
     // overlapping lines: block t is the lower-half slot t%4 of line t/4 and the upper-half slot of line t/4 - 1
     blocks[block_slot(t)] = GenomeBlock{lo, hi};
     if (t >= 4) blocks[block_slot(t - 4) + 4] = GenomeBlock{lo, hi};
-    const uint64_t flags = __ballot(exc);
+    if (ex) {                                            // the plane is zero-initialised
+        exc_plane[exc_slot(t)] = ex;
+        if (t >= 8) exc_plane[exc_slot(t - 8) + 8] = ex;
+    }
+    const uint64_t flags = __ballot(ex != 0);
     if ((threadIdx.x & 63) == 0) {
         coarse[t >> 6] = flags;
         // second level: one bit per coarse word (4096 bases); zero-initialised, set bits are rare
@@ -173,6 +177,25 @@ __device__ __forceinline__ void load_window(const GenomeBlock* __restrict__ bloc
         lo[w] = (x[w].lo >> sh) | ((x[w + 1].lo << 1) << (63 - sh));
         hi[w] = (x[w].hi >> sh) | ((x[w + 1].hi << 1) << (63 - sh));
     }
+}
+
+template <int W>
+__device__ __forceinline__ void load_window_exc(const uint64_t* __restrict__ exc_plane, uint64_t g, uint64_t (&ex)[W]) {
+    const uint64_t* __restrict__ p = exc_plane + exc_slot(g >> 6);        // W+1 <= 5 words: inside one line
+    const int sh = (int)(g & 63);
+    uint64_t x[W + 1];
+#pragma unroll
+    for (int i = 0; i <= W; i++) x[i] = p[i];
+#pragma unroll
+    for (int w = 0; w < W; w++) ex[w] = (x[w] >> sh) | ((x[w + 1] << 1) << (63 - sh));
+}
+
+// 32-bit stand-in for a signature that holds a non-ACGT byte (the sweep compares the 16 raw bytes)
+__device__ __forceinline__ uint32_t sigx_hash(const uint8_t (&sb)[16]) {
+    uint32_t h = 0x811c9dc5u;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { h ^= sb[k]; h *= 0x01000193u; }
+    return h;
 }
 
 // Cooperative form of the same gather: the wave's 64 windows are fetched as 64*(W+1) 16-byte
@@ -321,6 +344,10 @@ struct LocaliseArgs {
     const GenomeBlock* blocks;
     const uint64_t* coarse;
     const uint32_t* coarse2;
+    const uint64_t* exc;          // exception plane (overlapping lines), read only by flagged windows
+    const uint8_t* raw;           // raw genome bytes, read only for signatures that hold a non-ACGT byte
+    uint8_t* sigx;                // 16 raw signature bytes per slot
+    uint32_t* sigx_slot;          // read -> slot
     uint64_t* key;
     int32_t* lpos;
     int32_t* rpos;
@@ -329,7 +356,7 @@ struct LocaliseArgs {
     uint64_t* meta;          // render record per read: mask_words mask words + {bp, flags, len}
     int meta_stride;         // u64 per record = mask_words + 1
     uint32_t* exact_list;
-    uint32_t* counters;      // [0] = number of reads routed to the exact kernel
+    uint32_t* counters;      // [0] = reads routed to the exact kernel, [1] = raw-signature slots handed out
 };
 
 struct Oriented {            // the read's two anchors after detect.rs:108-113
@@ -426,6 +453,7 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
         load_window<W>(a.blocks, rg, qlo, qhi);
     }
     if (COOP && !live) return;
+    bool flagged = false;        // a window touches a 64-base block that holds a byte outside ACGT
     {
         // exception test, two levels.  Level 2 (one bit per 4096 bases, ~100 KB for hg38, L2-resident)
         // clears almost every window; only flagged ones read the per-64-base bitmap (6 MB for hg38:
@@ -442,13 +470,24 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
             const int ls_ = (int)(lb & 63), rs_ = (int)(rb & 63);
             const uint64_t lbits = ((c0 >> ls_) | ((c1 << 1) << (63 - ls_))) & low_mask(lnb);
             const uint64_t rbits = ((d0 >> rs_) | ((d1 << 1) << (63 - rs_))) & low_mask(rnb);
-            ok = ok && lbits == 0 && rbits == 0;
+            flagged = (lbits | rbits) != 0;
         }
     }
     if (!ok) {
         const uint32_t slot = atomicAdd(&a.counters[0], 1u);
         a.exact_list[slot] = (uint32_t)r;
         return;
+    }
+    // Reference bytes outside ACGT (N, soft-masked lowercase -- half of UCSC's hg38.fa --, IUPAC) stay on
+    // this path: the comparison is on raw bytes (detect.rs:137-145), so such a base differs from every
+    // read base that IS one of ACGT, which is all the packed planes need to know.  Only a read base that is
+    // itself outside ACGT facing such a reference base (N against N) cannot be decided here.
+    uint64_t lex[W], qex[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) lex[w] = qex[w] = 0;
+    if (flagged) {
+        load_window_exc<W>(a.exc, lg, lex);
+        load_window_exc<W>(a.exc, rg, qex);
     }
 
     uint64_t vm[W];
@@ -470,13 +509,27 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
 #pragma unroll
         for (int w = 0; w < W; w++) qhi[w] ^= vm[w];
     }
+    if (flagged) {                // the complement of a byte outside ACGT is outside ACGT: only the order changes
+#pragma unroll
+        for (int w = 0; w < W; w++) { lex[w] &= vm[w]; qex[w] &= vm[w]; }      // bits of the bases after the window
+        if (!o.strand) reverse_bits<W>(lex, L);
+        if (!o.mstrand) reverse_bits<W>(qex, L);
+        uint64_t both = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) both |= rex[w] & (lex[w] | qex[w]);
+        if (both) {               // non-ACGT read base against non-ACGT reference base: bytes decide
+            const uint32_t slot = atomicAdd(&a.counters[0], 1u);
+            a.exact_list[slot] = (uint32_t)r;
+            return;
+        }
+    }
 
-    // mismatch masks: a read base outside "ACGT" differs from every packed reference base
+    // mismatch masks: a base outside "ACGT" on one side differs from every ACGT base on the other
     uint64_t ml[W], mr[W];
 #pragma unroll
     for (int w = 0; w < W; w++) {
-        ml[w] = ((rlo[w] ^ llo[w]) | (rhi[w] ^ lhi[w]) | rex[w]) & vm[w];
-        mr[w] = ((rlo[w] ^ qlo[w]) | (rhi[w] ^ qhi[w]) | rex[w]) & vm[w];
+        ml[w] = ((rlo[w] ^ llo[w]) | (rhi[w] ^ lhi[w]) | rex[w] | lex[w]) & vm[w];
+        mr[w] = ((rlo[w] ^ qlo[w]) | (rhi[w] ^ qhi[w]) | rex[w] | qex[w]) & vm[w];
     }
 
     // split scan, detect.rs:135-153: mm[A] by popcount, then the running sum; first minimum wins
@@ -501,19 +554,40 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
         }
     }
 
-    // signature, detect.rs:165-168: 8 reference bases left of bp and 8 right of it (all ACGT here)
-    const uint32_t sig = extract8<W>(llo, bp - 8) | (extract8<W>(lhi, bp - 8) << 8) |
-                         (extract8<W>(qlo, bp) << 16) | (extract8<W>(qhi, bp) << 24);
+    // signature, detect.rs:165-168: 8 reference bases left of bp and 8 right of it
+    uint32_t sig = extract8<W>(llo, bp - 8) | (extract8<W>(lhi, bp - 8) << 8) |
+                   (extract8<W>(qlo, bp) << 16) | (extract8<W>(qhi, bp) << 24);
+    const bool sigx = flagged && (extract8<W>(lex, bp - 8) | extract8<W>(qex, bp)) != 0;
+    if (sigx) {
+        // a signature byte outside ACGT: the class is decided on the 16 raw bytes (case-sensitive,
+        // detect.rs:223); the key carries their hash and the bytes are kept aside for the sweep
+        uint8_t sb[16];
+        const uint8_t* lraw = a.raw + o.c.goff;
+        const uint8_t* rraw = a.raw + o.mc.goff;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int kl = bp - 8 + k, kr = bp + k;
+            const uint8_t cl = o.strand ? lraw[o.pos - 1 + kl] : comp_byte(lraw[o.pos + A - 2 - kl]);          // detect.rs:118,121
+            const uint8_t cr = o.mstrand ? rraw[o.mpos + A - L - 1 + kr] : comp_byte(rraw[o.mpos + L - 2 - kr]);   // :127,130
+            sb[k] = cl; sb[8 + k] = cr;
+        }
+        sig = sigx_hash(sb);
+        const uint32_t slot = atomicAdd(&a.counters[1], 1u);
+#pragma unroll
+        for (int k = 0; k < 16; k++) a.sigx[(uint64_t)slot * 16 + k] = sb[k];
+        a.sigx_slot[r] = slot;
+    }
 
     // coordinates, detect.rs:172-181 (signed; a negative value is the reference's wrapped usize)
     const int64_t lp = o.strand ? o.pos + bp - 1 : o.pos + A - bp;
     const int64_t rp = o.mstrand ? o.mpos + A - (L - bp) : o.mpos + (L - bp);
 
-    a.key[r] = make_key(o, false, sig, a.cb);
+    a.key[r] = make_key(o, sigx, sig, a.cb);
     a.lpos[r] = (int32_t)lp;
     a.rpos[r] = (int32_t)rp;
     a.bp[r] = (uint16_t)bp;
-    const uint16_t fl = (uint16_t)((o.strand ? kEvStrand : 0) | (o.mstrand ? kEvMstrand : 0) | (o.swapped ? kEvSwapped : 0));
+    const uint16_t fl = (uint16_t)((o.strand ? kEvStrand : 0) | (o.mstrand ? kEvMstrand : 0) | (o.swapped ? kEvSwapped : 0) |
+                                   (sigx ? kEvSigx : 0));
     uint64_t* rec = a.meta + r * (uint64_t)a.meta_stride;
 #pragma unroll
     for (int w = 0; w < W; w++) {
@@ -534,7 +608,7 @@ struct ExactArgs {
     int A;
     int cb;
     const uint32_t* exact_list;
-    const uint32_t* counters;
+    uint32_t* counters;      // [0] = length of exact_list, [1] = raw-signature slots handed out
     const bf_hit* hits;
     const uint8_t* seq;
     const uint64_t* seq_off;
@@ -617,11 +691,10 @@ __global__ void __launch_bounds__(64) localise_exact_kernel(const ExactArgs a) {
         sig |= ((dl & 1) << k) | ((dl >> 1) << (8 + k)) | ((dr & 1) << (16 + k)) | ((dr >> 1) << (24 + k));
     }
     if (!plain) {
-        uint32_t hsh = 0x811c9dc5u;
-        for (int k = 0; k < 16; k++) { hsh ^= sigb[k]; hsh *= 0x01000193u; }
-        sig = hsh;
-        for (int k = 0; k < 16; k++) a.sigx[(uint64_t)slot * 16 + k] = sigb[k];
-        a.sigx_slot[r] = slot;
+        sig = sigx_hash(sigb);
+        const uint32_t xs = atomicAdd(&a.counters[1], 1u);
+        for (int k = 0; k < 16; k++) a.sigx[(uint64_t)xs * 16 + k] = sigb[k];
+        a.sigx_slot[r] = xs;
     }
     const int64_t lp = o.strand ? o.pos + bp - 1 : o.pos + A - bp;
     const int64_t rp = o.mstrand ? o.mpos + A - (L - bp) : o.mpos + (L - bp);
@@ -750,7 +823,7 @@ int genome_pack(bf_ctx* ctx) {
     const uint64_t n_blocks = ctx->genome_bases / 64;     // multiple of 64 by construction
     Scope t(ctx, "genome_pack");
     hipLaunchKernelGGL(genome_pack_kernel, dim3(grid_for(n_blocks, 256)), dim3(256), 0, ctx->stream,
-                       ctx->g_raw.as<uint8_t>(), ctx->g_blocks.as<GenomeBlock>(),
+                       ctx->g_raw.as<uint8_t>(), ctx->g_blocks.as<GenomeBlock>(), ctx->g_exc.as<uint64_t>(),
                        ctx->g_coarse.as<uint64_t>(), ctx->g_coarse2.as<uint32_t>(), n_blocks);
     BF_HIP(ctx, hipGetLastError());
     return BF_OK;
@@ -769,7 +842,7 @@ static void launch_fast(bf_ctx* ctx, const LocaliseArgs& a) {
 
 int run_localise(bf_ctx* ctx) {
     const uint64_t n = ctx->n_reads;
-    ctx->n_exact = 0;
+    ctx->n_exact = 0; ctx->n_sigx = 0;
     ctx->localised = false;
     if (n == 0) { ctx->localised = true; ctx->plane_words = 1; ctx->mask_words = 1; return BF_OK; }
     const uint32_t A = ctx->cfg.anchor_len;
@@ -824,6 +897,10 @@ int run_localise(bf_ctx* ctx) {
     a.seq = ctx->d_seq.as<uint8_t>(); a.seq_off = ctx->d_seq_off.as<uint64_t>(); a.contigs = ctx->g_contigs.as<ContigDev>();
     a.blocks = ctx->g_blocks.as<GenomeBlock>(); a.coarse = ctx->g_coarse.as<uint64_t>();
     a.coarse2 = ctx->g_coarse2.as<uint32_t>();
+    a.exc = ctx->g_exc.as<uint64_t>(); a.raw = ctx->g_raw.as<uint8_t>();
+    // raw signature bytes: one 16-byte slot per read at most (handed out with an atomic counter by both kernels)
+    BF_TRY(ensure(ctx, ctx->d_sigx, (size_t)n * 16));
+    a.sigx = ctx->d_sigx.as<uint8_t>(); a.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
     a.key = ctx->d_key.as<uint64_t>(); a.lpos = ctx->d_lpos.as<int32_t>(); a.rpos = ctx->d_rpos.as<int32_t>();
     a.bp = ctx->d_bp.as<uint16_t>(); a.flags = ctx->d_flags.as<uint16_t>(); a.meta = ctx->d_mask.as<uint64_t>();
     a.meta_stride = (int)Wm + 1;
@@ -836,12 +913,13 @@ int run_localise(bf_ctx* ctx) {
     }
     BF_HIP(ctx, hipGetLastError());
 
-    uint32_t n_exact = 0;
-    BF_HIP(ctx, hipMemcpyAsync(&n_exact, ctx->d_counters.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t cnt[2] = {0, 0};
+    BF_HIP(ctx, hipMemcpyAsync(cnt, ctx->d_counters.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t n_exact = cnt[0];
     ctx->n_exact = n_exact;
+    ctx->n_sigx = cnt[1];
     if (n_exact) {
-        BF_TRY(ensure(ctx, ctx->d_sigx, (size_t)n_exact * 16));
         ExactArgs e{};
         e.n_total = n; e.A = (int)A; e.cb = ctx->contig_bits; e.exact_list = a.exact_list; e.counters = a.counters; e.hits = a.hits;
         e.seq = ctx->d_seq.as<uint8_t>(); e.seq_off = ctx->d_seq_off.as<uint64_t>();
@@ -851,6 +929,9 @@ int run_localise(bf_ctx* ctx) {
         Scope t(ctx, "localise_exact");
         hipLaunchKernelGGL(localise_exact_kernel, dim3(grid_for(n_exact, 64)), dim3(64), 0, ctx->stream, e);
         BF_HIP(ctx, hipGetLastError());
+        BF_HIP(ctx, hipMemcpyAsync(cnt, ctx->d_counters.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->n_sigx = cnt[1];
     }
     ctx->localised = true;
     return BF_OK;

@@ -117,13 +117,47 @@ def test_packed_path_is_the_one_that_runs():
 
 
 def test_soft_masked_and_n_reference():
-    # lowercase + N runs under the junctions: routed to the exact kernel, same answers
+    # lowercase + N runs under the junctions (UCSC-style soft-masked genomes): the packed kernel keeps these
+    # reads (a reference byte outside ACGT differs from every ACGT read base) and builds raw-byte signatures
     contigs = [("chrA", 300000), ("chrB", 200000)]
     g = synth.make_genome(contigs, seed=5, n_runs=[(0, 50000, 3000), (1, 1000, 500)],
                           lower_runs=[(0, 100000, 100000), (1, 100000, 50000)])
-    spec = synth.ReadSpec(n_reads=6000, read_len=100, anchor_len=30, n_events=60, singleton_frac=0.3, seed=77)
+    spec = synth.ReadSpec(n_reads=6000, read_len=100, anchor_len=30, n_events=60, singleton_frac=0.3, seed=77, margin=400)
     b = synth.make_reads(g, spec)
+    upper = synth.Batch(b.seq_bytes & np.uint8(0xDF), b.seq_off, b.frag_bytes, b.frag_off, b.hits)   # BAM reads are upper case
+    # (a few generated reads come out of the N runs and carry N themselves: those need the bytes)
+    check_against_oracle(g, upper, 30, expect_exact=lambda x, n: x < n // 20)
+    # the generator's own reads copy the genome's case: a lowercase (or N) read base facing a masked
+    # reference base needs the bytes -> exact kernel
     check_against_oracle(g, b, 30, expect_exact=lambda x, n: 0 < x < n)
+    spec = synth.ReadSpec(n_reads=6000, read_len=100, anchor_len=30, n_events=60, singleton_frac=0.3, seed=78, n_rate=0.02, margin=400)
+    b = synth.make_reads(g, spec)
+    upper = synth.Batch(np.where(b.seq_bytes == ord("n"), b.seq_bytes, b.seq_bytes & np.uint8(0xDF)).astype(np.uint8), b.seq_off,
+                        b.frag_bytes, b.frag_off, b.hits)
+    check_against_oracle(g, upper, 30, expect_exact=lambda x, n: 0 < x < n // 2)
+
+
+def test_heavily_soft_masked_genome_every_variant():
+    # half of the genome in lowercase runs of 50..3000 bases, windows straddling run boundaries, every
+    # strand combination; shipped kernel and both A/B variants
+    rng = np.random.Generator(np.random.PCG64(17))
+    contigs = [("chr1", 250000), ("chr2", 150000), ("chrM", 40000)]
+    g = synth.make_genome(contigs, seed=15, end_n=500)
+    for sq in g.seqs:
+        for _ in range(sq.shape[0] // 2000):
+            a = int(rng.integers(0, sq.shape[0] - 3000))
+            sq[a:a + int(rng.integers(50, 3000))] |= 0x20
+    g.seqs[0][100000:100040] = np.frombuffer(b"RYKMSWBDHV" * 4, np.uint8)          # IUPAC codes in the reference
+    for L, A in ((100, 30), (151, 20), (250, 30)):
+        spec = synth.ReadSpec(n_reads=5000, read_len=L, anchor_len=A, n_events=80, singleton_frac=0.3, deletion_frac=0.3,
+                              seed=300 + L, margin=800, subst_rate=0.01)
+        b = synth.make_reads(g, spec)
+        b = synth.Batch(b.seq_bytes & np.uint8(0xDF), b.seq_off, b.frag_bytes, b.frag_off, b.hits)     # upper-case reads
+        # (reads drawn from the IUPAC stretch carry those codes themselves and go to the exact kernel)
+        res, ref = check_against_oracle(g, b, A, expect_exact=lambda x, n: x < n // 50)
+        assert ref.n_clusters > 20
+        for flag in (BF_FLAG_COOP_GATHER, BF_FLAG_SEPARATE_ENCODE):
+            check_against_oracle(g, b, A, flags=flag)
 
 
 def test_mixed_read_lengths_and_batches():
