@@ -362,3 +362,30 @@ def test_segments_that_need_a_walk():
     assert ref.n_clusters >= 7
     # a smaller window turns the 150-base neighbours into separate clusters as well
     check_against_oracle(g, b, A, F=100)
+
+
+def test_format_sv_size_query_truncation_and_threads():
+    """bf_format_sv: NULL buffer = size query; a short buffer receives a prefix and the full size is still
+    returned; a result large enough for the multi-threaded fill equals the oracle's text."""
+    import ctypes as C
+    contigs, gk, spec = synth.config(1, scale=0.02, genome_scale=0.01)          # ~12 MB of .sv: several fill threads
+    spec.margin = 10000 + 2 * spec.read_len + 128
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, spec.anchor_len, 5000, 2)
+    eng = engine.Engine(spec.anchor_len, 5000, 2)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        eng.submit(b)
+        eng.finish(copy=False)
+        r = eng._last
+        n = eng.lib.bf_format_sv(eng.h, C.byref(r), None, 0)
+        assert n == len(ref.sv) > (8 << 20)
+        full = C.create_string_buffer(n)
+        assert eng.lib.bf_format_sv(eng.h, C.byref(r), full, n) == n
+        assert full.raw == ref.sv
+        short = C.create_string_buffer(b"\xee" * 1000, 1000)
+        assert eng.lib.bf_format_sv(eng.h, C.byref(r), short, 777) == n
+        assert short.raw[:777] == ref.sv[:777] and short.raw[777:] == b"\xee" * 223
+    finally:
+        eng.close()
