@@ -67,9 +67,9 @@ def main():
     ap.add_argument("--config", type=int, default=1, help="index into BASELINE.json configs (default 1)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink reads AND genome (smoke runs only)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads in the CPU baseline sample (0 = skip)")
-    ap.add_argument("--variant", choices=["fused", "separate", "coop"], default="fused",
+    ap.add_argument("--variant", choices=["fused", "separate", "coop", "exact"], default="fused",
                     help="A/B of the localise stage: fused encode+localise (shipped), separate encode kernel, "
-                         "separate encode + cooperative LDS-staged gather")
+                         "separate encode + cooperative LDS-staged gather, every read through the byte-exact kernel")
     ap.add_argument("--exchange", action="store_true",
                     help="with one GPU: run the sharded code path anyway (pack -> RCCL all-to-all with itself -> import -> "
                          "device junction routing), to time what the exchange adds per rank")
@@ -127,7 +127,8 @@ def main():
 
     # ---- resident inputs -------------------------------------------------------------------------
     routing = engine.BF_FLAG_DEVICE_ROUTING if (world > 1 or forced) else 0
-    eng = engine.Engine(A, 5000, 2, device=local, flags=routing | {"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER}[args.variant])
+    eng = engine.Engine(A, 5000, 2, device=local, flags=routing | {"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER,
+                                                                               "exact": engine.BF_FLAG_FORCE_EXACT}[args.variant])
     t2 = time.time()
     eng.set_genome(genome.names, genome.seqs)
     log(rank, "genome packed into HBM in %.1fs" % (time.time() - t2))

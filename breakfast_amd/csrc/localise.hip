@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
 }
 
 // ---------------------------------------------------------------------------------------------
-// Byte-exact path: one lane per routed read, straight from the raw images.  Handles windows that
+// Byte-exact path: one wave per routed read, straight from the raw images.  Handles windows that
 // leave the contig (-> 'N', detect.rs:118-130), reference bytes outside ACGT (soft-masked, N,
 // IUPAC), and reads longer than the packed path's 64*W.
 struct ExactArgs {
@@ -644,9 +644,15 @@ struct ExactRead {
     }
 };
 
-__global__ void __launch_bounds__(64) localise_exact_kernel(const ExactArgs a) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= a.counters[0]) return;
+// One WAVE per routed read, any read length.  Lane l looks at base 64c + l of chunk c; a wave ballot of
+// "read byte != flank byte" IS the chunk's 64-bit mismatch word, so the arithmetic below is the packed
+// kernel's (popcounts for mm[A], prefix popcounts for the running sum, lowest k among the minima), only
+// with words that come from byte compares.  Three passes over the chunks (mm[A]; the scan; the combined
+// mask once bp is known): the bytes are cache-resident after the first.
+__global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) {
+    const uint32_t slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (slot >= a.counters[0]) return;                               // wave-uniform
     const uint32_t r = a.exact_list[slot];
     const bf_hit h = a.hits[r];
     const Oriented o = orient(h, a.contigs);
@@ -660,42 +666,75 @@ __global__ void __launch_bounds__(64) localise_exact_kernel(const ExactArgs a) {
     x.lbase = o.strand ? o.pos - 1 : o.pos + A - 2;                 // detect.rs:118,121
     x.rraw = a.raw + o.mc.goff; x.rlen = o.mc.len; x.rfwd = o.mstrand;
     x.rbase = o.mstrand ? o.mpos + A - L - 1 : o.mpos + L - 2;      // detect.rs:127,130
+    const int n_chunks = (L + 63) >> 6;
 
+    auto words = [&](int c, uint64_t& ml, uint64_t& mr) {            // mismatch words of chunk c (wave-uniform results)
+        const int k = 64 * c + lane;
+        bool dl = false, dr = false;
+        if (k < L) { const uint8_t sb = x.s(k); dl = sb != x.left(k); dr = sb != x.right(k); }
+        ml = __ballot(dl); mr = __ballot(dr);
+    };
+    auto low = [](int nbits) -> uint64_t { return nbits <= 0 ? 0ull : nbits >= 64 ? ~0ull : ((1ull << nbits) - 1); };
+
+    // mm[A] = mismatches of [0, A) against the left flank + of [A, L) against the right flank (detect.rs:137-146)
     int mm = 0;
-    for (int k = 0; k < A; k++) mm += x.s(k) != x.left(k);
-    for (int k = A; k < L; k++) mm += x.s(k) != x.right(k);
-    int best = mm, bp = A;
-    for (int k = A + 1; k < L - A; k++) {
-        const uint8_t c = x.s(k - 1);
-        mm += (int)(c != x.left(k - 1)) - (int)(c != x.right(k - 1));
-        if (mm < best) { best = mm; bp = k; }
+    for (int c = 0; c < n_chunks; c++) {
+        uint64_t ml, mr; words(c, ml, mr);
+        const uint64_t lowA = low(A - 64 * c);
+        mm += __popcll(ml & lowA) + __popcll(mr & ~lowA);
     }
-    for (int w = 0; w < a.mask_words; w++) {
-        uint64_t m = 0;
-        const int k1 = min(64 * w + 64, L);
-        for (int k = 64 * w; k < k1; k++) {
-            const uint8_t c = x.s(k);
-            const bool mis = k < bp ? c != x.left(k) : c != x.right(k);
-            m |= (uint64_t)mis << (k & 63);
+    // candidates k in [A+1, L-A): mm[k] = mm[k-1] + ml[k-1] - mr[k-1]; j = k-1 runs over [A, L-A-2]
+    uint64_t best = ((uint64_t)(uint32_t)mm << 32) | (uint32_t)A;    // (mm, k): lexicographic min = first minimum
+    for (int c = A >> 6; c < n_chunks && 64 * c <= L - A - 2; c++) {
+        uint64_t ml, mr; words(c, ml, mr);
+        const int j0 = max(A - 64 * c, 0), j1 = min(L - A - 1 - 64 * c, 64);     // [j0, j1) inside this chunk
+        if (j0 >= j1) continue;
+        const uint64_t range = low(j1) & ~low(j0);
+        const uint64_t upto = low(lane + 1) & range;                 // steps j0 .. lane of this chunk
+        uint64_t cand = ~0ull;
+        if (lane >= j0 && lane < j1) {
+            const int v = mm + __popcll(ml & upto) - __popcll(mr & upto);
+            cand = ((uint64_t)(uint32_t)v << 32) | (uint32_t)(64 * c + lane + 1);
         }
-        a.meta[(uint64_t)r * (a.mask_words + 1) + w] = m;
+        for (int d = 32; d > 0; d >>= 1) {
+            const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(cand >> 32), d) << 32) |
+                                   (uint32_t)__shfl_xor((int)(uint32_t)cand, d);
+            cand = min(cand, other);
+        }
+        best = min(best, cand);
+        mm += __popcll(ml & range) - __popcll(mr & range);
     }
-    uint8_t sigb[16];
-    bool plain = true;
-    uint32_t sig = 0;
-    for (int k = 0; k < 8; k++) {
-        const uint8_t cl = x.left(bp - 8 + k), cr = x.right(bp + k);
-        sigb[k] = cl; sigb[8 + k] = cr;
-        plain = plain && is_acgt(cl) && is_acgt(cr);
-        const uint32_t dl = (cl >> 1) & 3, dr = (cr >> 1) & 3;
-        sig |= ((dl & 1) << k) | ((dl >> 1) << (8 + k)) | ((dr & 1) << (16 + k)) | ((dr >> 1) << (24 + k));
+    const int bp = (int)(uint32_t)best;
+
+    // combined mask: left-flank mismatches below bp, right-flank mismatches from bp on (detect.rs:155-162)
+    for (int c = 0; c < a.mask_words; c++) {
+        uint64_t ml = 0, mr = 0;
+        if (c < n_chunks) words(c, ml, mr);
+        const uint64_t lowB = low(bp - 64 * c);
+        if (lane == 0) a.meta[(uint64_t)r * (a.mask_words + 1) + c] = (ml & lowB) | (mr & ~lowB);
     }
+
+    // signature (detect.rs:165-168): lanes 0..7 hold left[bp-8+k], lanes 8..15 right[bp+k-8]
+    uint8_t sc = 'A';
+    if (lane < 8) sc = x.left(bp - 8 + lane);
+    else if (lane < 16) sc = x.right(bp + lane - 8);
+    const bool plain = (__ballot(lane < 16 && !is_acgt(sc)) == 0);
+    const uint32_t code = (sc >> 1) & 3;
+    const uint64_t blo = __ballot(lane < 16 && (code & 1)), bhi = __ballot(lane < 16 && (code >> 1));
+    uint32_t sig = (uint32_t)(blo & 0xff) | ((uint32_t)(bhi & 0xff) << 8) | ((uint32_t)((blo >> 8) & 0xff) << 16) |
+                   ((uint32_t)((bhi >> 8) & 0xff) << 24);
     if (!plain) {
+        uint8_t sigb[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) sigb[k] = (uint8_t)__shfl((int)sc, k);
         sig = sigx_hash(sigb);
-        const uint32_t xs = atomicAdd(&a.counters[1], 1u);
-        for (int k = 0; k < 16; k++) a.sigx[(uint64_t)xs * 16 + k] = sigb[k];
-        a.sigx_slot[r] = xs;
+        uint32_t xs = 0;
+        if (lane == 0) xs = atomicAdd(&a.counters[1], 1u);
+        xs = (uint32_t)__shfl((int)xs, 0);
+        if (lane < 16) a.sigx[(uint64_t)xs * 16 + lane] = sc;
+        if (lane == 0) a.sigx_slot[r] = xs;
     }
+    if (lane != 0) return;
     const int64_t lp = o.strand ? o.pos + bp - 1 : o.pos + A - bp;
     const int64_t rp = o.mstrand ? o.mpos + A - (L - bp) : o.mpos + (L - bp);
     a.key[r] = make_key(o, !plain, sig, a.cb);
@@ -927,7 +966,7 @@ int run_localise(bf_ctx* ctx) {
         e.key = a.key; e.lpos = a.lpos; e.rpos = a.rpos; e.bp = a.bp; e.flags = a.flags; e.meta = a.meta;
         e.mask_words = (int)Wm; e.sigx = ctx->d_sigx.as<uint8_t>(); e.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
         Scope t(ctx, "localise_exact");
-        hipLaunchKernelGGL(localise_exact_kernel, dim3(grid_for(n_exact, 64)), dim3(64), 0, ctx->stream, e);
+        hipLaunchKernelGGL(localise_exact_kernel, dim3(grid_for((uint64_t)n_exact * 64, 256)), dim3(256), 0, ctx->stream, e);
         BF_HIP(ctx, hipGetLastError());
         BF_HIP(ctx, hipMemcpyAsync(cnt, ctx->d_counters.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
