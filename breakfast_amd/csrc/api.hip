@@ -130,6 +130,66 @@ static void free_all(bf_ctx* ctx) {
     for (HostBuf* h : hosts) { if (h->p) (void)hipHostFree(h->p); h->p = nullptr; h->cap = 0; }
 }
 
+// ---- junction records -> text (host) ----------------------------------------------------------
+// bit i of a byte -> byte i of a 64-bit word (value 1)
+static const uint64_t* spread_table() {
+    static uint64_t t[256];
+    static bool init = [] {
+        for (int v = 0; v < 256; v++) {
+            uint64_t x = 0;
+            for (int i = 0; i < 8; i++) x |= (uint64_t)((v >> i) & 1) << (8 * i);
+            t[v] = x;
+        }
+        return true;
+    }();
+    (void)init;
+    return t;
+}
+
+// Text of one junction record (include/breakfast_hip.h, "Junction records"): the read's bases, lower case
+// where they differ from the flank they were assigned to, with '|' at the breakpoint (detect.rs:155-162).
+// Returns len + 1, or -1 for a malformed record; writes only when `out` is given and cap suffices.
+int64_t junction_decode(const uint8_t* rec, uint64_t rec_len, uint8_t* out, uint64_t cap) {
+    if (!rec || rec_len < 6) return -1;
+    uint16_t h[3];
+    memcpy(h, rec, 6);
+    const uint32_t L = h[0], bp = h[1], nx = h[2];
+    if (bp > L) return -1;
+    const uint64_t text = (uint64_t)L + 1;
+    if (nx == kJunctionText) {
+        if (rec_len < 6 + text) return -1;
+        if (out && cap >= text) memcpy(out, rec + 6, text);
+        return (int64_t)text;
+    }
+    const uint32_t groups = (L + 31) >> 5;
+    if (rec_len < 8 + 12ull * groups + 4ull * nx) return -1;
+    const uint8_t* g = rec + 8;
+    for (uint32_t e = 0; e < nx; e++) {                      // validated in the size query too
+        uint16_t k; memcpy(&k, g + 12ull * groups + 4 * e, 2);
+        if (k >= L) return -1;
+    }
+    if (!out || cap < text) return (int64_t)text;
+    const uint64_t* S = spread_table();
+    uint8_t* dst = out + 1;                                  // bases land one to the right; the left part moves down below
+    for (uint32_t k = 0; k < L; k += 8) {
+        const uint8_t* grp = g + 12 * (k >> 5);
+        const uint32_t b = (k >> 3) & 3;
+        const uint8_t lo = grp[b], hi = grp[4 + b], cs = grp[8 + b];
+        // 'A' + 2*lo + 0x13*hi - 0x0f*(lo&hi) = A C T G for codes 0..3; + 0x20 = lower case
+        const uint64_t v = 0x4141414141414141ull + 2 * S[lo] + 0x13 * S[hi] - 0x0f * S[lo & hi] + 0x20 * S[cs];
+        const uint32_t take = L - k < 8 ? L - k : 8;
+        memcpy(dst + k, &v, take);
+    }
+    const uint8_t* xe = g + 12ull * groups;
+    for (uint32_t e = 0; e < nx; e++) {
+        uint16_t k; memcpy(&k, xe + 4 * e, 2);
+        dst[k] = xe[4 * e + 2];
+    }
+    memmove(out, out + 1, bp);
+    out[bp] = '|';
+    return (int64_t)text;
+}
+
 }  // namespace bf
 
 using namespace bf;
@@ -415,7 +475,9 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t 
         for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
             const bf_read& rd = r->reads[i];
             if (rd.junction_off + rd.junction_len > r->junction_size) return BF_ERR_INVALID;
-            sz += rd.junction_len;
+            const int64_t tl = junction_decode(r->junction_bytes + rd.junction_off, rd.junction_len, nullptr, 0);
+            if (tl < 0) return BF_ERR_INVALID;
+            sz += (uint64_t)tl;
         }
         total += sz;
     }
@@ -444,7 +506,7 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t 
             for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
                 if (i > cl.read_begin) *p++ = ';';
                 const bf_read& rd = r->reads[i];
-                memcpy(p, r->junction_bytes + rd.junction_off, rd.junction_len); p += rd.junction_len;
+                p += junction_decode(r->junction_bytes + rd.junction_off, rd.junction_len, (uint8_t*)p, ~0ull);
             }
             *p++ = '\t'; *p++ = '\t'; *p++ = '\n';                                      // detect.rs:240
         }
@@ -461,6 +523,38 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t 
         pool.emplace_back(fill, c0, c1);
         c0 = c1;
     }
+    for (auto& th : pool) th.join();
+    return (int64_t)total;
+}
+
+int64_t bf_junction_text(const uint8_t* record, uint64_t record_len, char* buf, uint64_t cap) {
+    const int64_t n = junction_decode(record, record_len, (uint8_t*)buf, buf ? cap : 0);
+    return n < 0 ? (int64_t)BF_ERR_INVALID : n;
+}
+
+int64_t bf_result_junction_text(const bf_result* r, uint8_t* text, uint64_t cap, uint64_t* text_off) {
+    if (!r || (r->n_reads && (!r->reads || !text_off))) return BF_ERR_INVALID;
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < r->n_reads; i++) {
+        const bf_read& rd = r->reads[i];
+        if (rd.junction_off + rd.junction_len > r->junction_size) return BF_ERR_INVALID;
+        const int64_t tl = junction_decode(r->junction_bytes + rd.junction_off, rd.junction_len, nullptr, 0);
+        if (tl < 0) return BF_ERR_INVALID;
+        text_off[i] = total;
+        total += (uint64_t)tl;
+    }
+    if (r->n_reads) text_off[r->n_reads] = total;
+    if (!text || cap < total) return (int64_t)total;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const uint64_t nt = total < (8u << 20) ? 1 : std::max(1u, std::min(hw, 8u));
+    auto fill = [&](uint64_t a, uint64_t b) {
+        for (uint64_t i = a; i < b; i++)
+            junction_decode(r->junction_bytes + r->reads[i].junction_off, r->reads[i].junction_len, text + text_off[i],
+                            text_off[i + 1] - text_off[i]);
+    };
+    if (nt <= 1) { fill(0, r->n_reads); return (int64_t)total; }
+    std::vector<std::thread> pool;
+    for (uint64_t t = 0; t < nt; t++) pool.emplace_back(fill, r->n_reads * t / nt, r->n_reads * (t + 1) / nt);
     for (auto& th : pool) th.join();
     return (int64_t)total;
 }
@@ -521,11 +615,22 @@ int bf_render_junctions(bf_ctx* ctx, uint64_t n, const uint32_t* local_index, co
     if (n) BF_HIP(ctx, hipMemcpyAsync(ctx->r_idx.p, local_index, n * 4, hipMemcpyHostToDevice, ctx->stream));
     uint64_t total = 0;
     BF_TRY(run_render(ctx, n, ctx->r_idx.as<uint32_t>(), ctx->r_off, ctx->r_bytes, &total));
-    ctx->render_off_host.resize(n + 1);
-    ctx->render_bytes_host.resize(total);
-    BF_HIP(ctx, hipMemcpyAsync(ctx->render_off_host.data(), ctx->r_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (total) BF_HIP(ctx, hipMemcpyAsync(ctx->render_bytes_host.data(), ctx->r_bytes.p, total, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<uint64_t> roff(n + 1);
+    std::vector<uint8_t> recs(total);
+    BF_HIP(ctx, hipMemcpyAsync(roff.data(), ctx->r_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (total) BF_HIP(ctx, hipMemcpyAsync(recs.data(), ctx->r_bytes.p, total, hipMemcpyDeviceToHost, ctx->stream));
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // this host-side call hands out TEXT (the device-side call hands out records): expand here
+    ctx->render_off_host.assign(n + 1, 0);
+    for (uint64_t i = 0; i < n; i++) {
+        const int64_t tl = junction_decode(recs.data() + roff[i], roff[i + 1] - roff[i], nullptr, 0);
+        if (tl < 0) return fail(ctx, BF_ERR_HIP, "bf_render_junctions: malformed junction record for list entry %llu", (unsigned long long)i);
+        ctx->render_off_host[i + 1] = ctx->render_off_host[i] + (uint64_t)tl;
+    }
+    ctx->render_bytes_host.resize(ctx->render_off_host[n]);
+    for (uint64_t i = 0; i < n; i++)
+        junction_decode(recs.data() + roff[i], roff[i + 1] - roff[i], ctx->render_bytes_host.data() + ctx->render_off_host[i],
+                        ctx->render_off_host[i + 1] - ctx->render_off_host[i]);
     *out_bytes = ctx->render_bytes_host.data(); *out_off = ctx->render_off_host.data();
     return BF_OK;
 }

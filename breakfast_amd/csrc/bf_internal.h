@@ -57,6 +57,18 @@ __host__ __device__ inline int key_bits(int cb) { return kKeyMrankShift + 2 * cb
 // evidence flags (low bits mirror BF_EV_*)
 constexpr uint32_t kEvStrand = 1, kEvMstrand = 2, kEvSwapped = 4, kEvExact = 8, kEvSigx = 16;
 
+// ---- junction records (include/breakfast_hip.h, "Junction records") ------------------------------
+// A surviving read's junction string crosses PCIe (and xGMI on the sharded path) as a self-describing
+// record: 3 bits per base instead of 8 when the read is (almost) plain ACGT.  `max_packed` = 64 * W of the
+// ctx's localise kernel; `n_exc` = read bases outside "ACGT" (saturating u16 from the render record).
+constexpr uint32_t kJunctionText = 0xffffu;
+__host__ __device__ inline bool junction_packable(uint32_t L, uint32_t n_exc, uint32_t max_packed) {
+    return L <= max_packed && 8u * n_exc <= L;
+}
+__host__ __device__ inline uint32_t junction_record_bytes(uint32_t L, uint32_t n_exc, uint32_t max_packed) {
+    return junction_packable(L, n_exc, max_packed) ? 8u + 12u * ((L + 31u) >> 5) + 4u * n_exc : (6u + L + 1u + 3u) & ~3u;
+}
+
 // ---- wire record of the multi-GPU exchange ---------------------------------------------------
 struct WireHeader {     // 40 B, followed by frag bytes (fixed stride) and optionally 16 raw sig bytes
     uint64_t key;
@@ -151,6 +163,7 @@ struct bf_ctx {
     uint32_t plane_words = 0, mask_words = 0;
     uint64_t n_exact = 0;
     uint64_t n_sigx = 0;                        // evidence whose signature holds a non-ACGT byte
+    uint64_t n_text_records = 0;                // resident reads whose junction record cannot be packed
     bf::DevBuf d_planes, d_len, d_frag_len, d_fhash;
     bf::DevBuf d_key, d_lpos, d_rpos, d_bp, d_flags, d_mask;
     bf::DevBuf d_exact_list, d_counters, d_sigx, d_sigx_slot;
@@ -219,6 +232,7 @@ struct Scope {
 int genome_pack(bf_ctx* ctx);                       // raw image -> blocks + coarse bitmap
 int run_localise(bf_ctx* ctx);                      // encode + hash + fast + exact kernels
 int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, int n_chunks, uint64_t* chunk_off);
+int64_t junction_decode(const uint8_t* rec, uint64_t rec_len, uint8_t* out, uint64_t cap);   // api.hip, host
 int render_range(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const DevBuf& d_off, DevBuf& d_bytes);
 int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, DevBuf& d_bytes,
                uint64_t* total_bytes);              // junction strings for local reads

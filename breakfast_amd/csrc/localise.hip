@@ -356,7 +356,8 @@ struct LocaliseArgs {
     uint64_t* meta;          // render record per read: mask_words mask words + {bp, flags, len}
     int meta_stride;         // u64 per record = mask_words + 1
     uint32_t* exact_list;
-    uint32_t* counters;      // [0] = reads routed to the exact kernel, [1] = raw-signature slots handed out
+    uint32_t* counters;      // [0] = reads routed to the exact kernel, [1] = raw-signature slots handed out,
+                             // [2] = reads whose junction record is text (not packable)
 };
 
 struct Oriented {            // the read's two anchors after detect.rs:108-113
@@ -597,7 +598,11 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
         rec[w] = (ml[w] & lowB) | (mr[w] & ~lowB);
     }
     for (int w = W; w < a.meta_stride - 1; w++) rec[w] = 0;
-    rec[a.meta_stride - 1] = (uint64_t)(uint16_t)bp | ((uint64_t)fl << 16) | ((uint64_t)(uint16_t)L << 32);
+    uint32_t n_exc = 0;          // read bases outside "ACGT": what the packed junction record lists one by one
+#pragma unroll
+    for (int w = 0; w < W; w++) n_exc += (uint32_t)__popcll(rex[w]);
+    if (!junction_packable((uint32_t)L, n_exc, 64u * W)) atomicAdd(&a.counters[2], 1u);
+    rec[a.meta_stride - 1] = (uint64_t)(uint16_t)bp | ((uint64_t)fl << 16) | ((uint64_t)(uint16_t)L << 32) | ((uint64_t)n_exc << 48);
     a.flags[r] = fl;
 }
 
@@ -623,6 +628,7 @@ struct ExactArgs {
     uint16_t* flags;
     uint64_t* meta;
     int mask_words;          // record stride = mask_words + 1
+    uint32_t max_packed;     // longest read a packed junction record can hold
     uint8_t* sigx;           // 16 bytes per slot
     uint32_t* sigx_slot;     // read -> slot
 };
@@ -680,11 +686,15 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
 
     // mm[A] = mismatches of [0, A) against the left flank + of [A, L) against the right flank (detect.rs:137-146)
     int mm = 0;
+    uint32_t n_exc = 0;                                              // read bases outside "ACGT" (junction record)
     for (int c = 0; c < n_chunks; c++) {
         uint64_t ml, mr; words(c, ml, mr);
         const uint64_t lowA = low(A - 64 * c);
         mm += __popcll(ml & lowA) + __popcll(mr & ~lowA);
+        const int k = 64 * c + lane;
+        n_exc += (uint32_t)__popcll(__ballot(k < L && !is_acgt(x.seq[k])));
     }
+    n_exc = min(n_exc, 0xffffu);
     // candidates k in [A+1, L-A): mm[k] = mm[k-1] + ml[k-1] - mr[k-1]; j = k-1 runs over [A, L-A-2]
     uint64_t best = ((uint64_t)(uint32_t)mm << 32) | (uint32_t)A;    // (mm, k): lexicographic min = first minimum
     for (int c = A >> 6; c < n_chunks && 64 * c <= L - A - 2; c++) {
@@ -746,29 +756,35 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
     const uint16_t fl = (uint16_t)((o.strand ? kEvStrand : 0) | (o.mstrand ? kEvMstrand : 0) |
                                    (o.swapped ? kEvSwapped : 0) | kEvExact | (plain ? 0 : kEvSigx));
     a.flags[r] = fl;
+    if (!junction_packable((uint32_t)L, n_exc, a.max_packed)) atomicAdd(&a.counters[2], 1u);
     a.meta[(uint64_t)r * (a.mask_words + 1) + a.mask_words] =
-        (uint64_t)(uint16_t)bp | ((uint64_t)fl << 16) | ((uint64_t)(uint16_t)L << 32);
+        (uint64_t)(uint16_t)bp | ((uint64_t)fl << 16) | ((uint64_t)(uint16_t)L << 32) | ((uint64_t)n_exc << 48);
 }
 
 // ---------------------------------------------------------------------------------------------
-// render: one wave per supporting read; lanes stride over the read's bases.
+// Junction records of surviving reads (format: include/breakfast_hip.h, "Junction records").
+// Record sizes from the render records' last word {bp, flags, len, n_exc}.
+__device__ __forceinline__ uint32_t record_bytes_of(uint64_t tail, uint32_t max_packed) {
+    return junction_record_bytes((uint32_t)((tail >> 32) & 0xffff), (uint32_t)(tail >> 48), max_packed);
+}
 __global__ void __launch_bounds__(256) render_len_kernel(uint64_t n, const uint32_t* __restrict__ idx,
-                                                         const uint16_t* __restrict__ len,
-                                                         uint32_t* __restrict__ out_len) {
+                                                         const uint64_t* __restrict__ meta, int meta_stride,
+                                                         uint32_t max_packed, uint32_t* __restrict__ out_len) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out_len[i] = (uint32_t)len[idx[i]] + 1;
+    if (i < n) out_len[i] = record_bytes_of(meta[(uint64_t)idx[i] * meta_stride + meta_stride - 1], max_packed);
 }
 
 // lengths for a caller-supplied (device) index list: an index outside the resident reads is counted,
 // not dereferenced
 __global__ void __launch_bounds__(256) render_len_checked_kernel(uint64_t n, const uint32_t* __restrict__ idx,
-                                                                 const uint16_t* __restrict__ len, uint64_t n_reads,
+                                                                 const uint64_t* __restrict__ meta, int meta_stride,
+                                                                 uint32_t max_packed, uint64_t n_reads,
                                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ bad) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t r = idx[i];
     if (r >= n_reads) { out_len[i] = 0; atomicAdd(bad, 1u); return; }
-    out_len[i] = (uint32_t)len[r] + 1;
+    out_len[i] = record_bytes_of(meta[(uint64_t)r * meta_stride + meta_stride - 1], max_packed);
 }
 
 // render: 16 lanes per surviving read, 4 reads per wave, 16 reads per block.  The junction string is
@@ -791,7 +807,7 @@ render_kernel(uint64_t n, const uint32_t* __restrict__ idx,
                                                      const uint8_t* __restrict__ seq,
                                                      const uint64_t* __restrict__ seq_off,
                                                      const uint64_t* __restrict__ meta, int meta_stride,
-                                                     uint8_t* __restrict__ out) {
+                                                     uint32_t max_packed, uint8_t* __restrict__ out) {
     __shared__ uint8_t comp[256];
     __shared__ uint32_t stage[16][kRenderStageDw];
     __shared__ uint64_t smask[16][kRenderMaskW];
@@ -806,7 +822,13 @@ render_kernel(uint64_t n, const uint32_t* __restrict__ idx,
     const uint64_t tail = rec[meta_stride - 1];
     const int64_t bp = (int64_t)(tail & 0xffff), L = (int64_t)((tail >> 32) & 0xffff);
     const bool swapped = ((tail >> 16) & kEvSwapped) != 0;
-    const int64_t dst0 = (int64_t)joff[i], out_len = L + 1;
+    if (junction_packable((uint32_t)L, (uint32_t)(tail >> 48), max_packed)) return;      // render_packed_kernel's
+    if (l16 == 0) {                                                      // text record: {len, bp, 0xffff} + the string
+        uint16_t* hd = (uint16_t*)(out + joff[i]);                       // records start on 4-byte boundaries
+        hd[0] = (uint16_t)L; hd[1] = (uint16_t)bp; hd[2] = (uint16_t)kJunctionText;
+        for (int64_t q = 6 + L + 1; q & 3; q++) out[joff[i] + q] = 0;    // padding
+    }
+    const int64_t dst0 = (int64_t)joff[i] + 6, out_len = L + 1;
     const int64_t first_dw = dst0 >> 2, last_dw = (dst0 + out_len - 1) >> 2;
     const uint8_t* sbytes = (const uint8_t*)stage[g];
     for (int64_t t0 = first_dw; t0 <= last_dw; t0 += kRenderTileDw) {
@@ -858,6 +880,70 @@ render_kernel(uint64_t n, const uint32_t* __restrict__ idx,
     }
 }
 
+// Packed junction records: one lane per surviving read whose record is packable (at most 64*W bases, few
+// bases outside ACGT).  The lane re-encodes its read from the ASCII bases exactly as the localise kernel did
+// (same function, so the exception count in the render record is the one found here), re-orients it when the
+// read was reverse-complemented (detect.rs:112), and writes
+//   {u16 len, u16 bp, u16 n_exc, u16 0}, then per 32 bases {u32 lo, u32 hi, u32 lower-case},
+//   then n_exc x {u16 position, u8 printed byte, u8 0}
+// -- 68 bytes for a 150-base read against 151 bytes of text: the result copy to the host is the longest
+// stage of a step, and the .sv formatter expands records at memcpy speed.
+template <int W>
+__global__ void __launch_bounds__(256) render_packed_kernel(uint64_t n, const uint32_t* __restrict__ idx,
+                                                            const uint64_t* __restrict__ joff,
+                                                            const uint8_t* __restrict__ seq,
+                                                            const uint64_t* __restrict__ seq_off,
+                                                            const uint64_t* __restrict__ meta, int meta_stride,
+                                                            uint8_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = idx[i];
+    const uint64_t* __restrict__ rec = meta + (uint64_t)r * meta_stride;
+    const uint64_t tail = rec[meta_stride - 1];
+    const int L = (int)((tail >> 32) & 0xffff), bp = (int)(tail & 0xffff);
+    const uint32_t n_exc = (uint32_t)(tail >> 48);
+    if (!junction_packable((uint32_t)L, n_exc, 64u * W)) return;         // text record: render_kernel's
+    const bool swapped = ((tail >> 16) & kEvSwapped) != 0;
+    const uint64_t so = seq_off[r];
+    uint64_t lo[W], hi[W], ex[W], cs[W];
+    encode_ascii<W>(seq, so, L, lo, hi, ex);
+#pragma unroll
+    for (int w = 0; w < W; w++) cs[w] = w < meta_stride - 1 ? rec[w] : 0ull;
+    if (swapped) {
+        reverse_bits<W>(lo, L); reverse_bits<W>(hi, L); reverse_bits<W>(ex, L);
+#pragma unroll
+        for (int w = 0; w < W; w++) hi[w] ^= low_mask(min(max(L - 64 * w, 0), 64));
+    }
+    uint32_t* __restrict__ o32 = (uint32_t*)(out + joff[i]);
+    o32[0] = (uint32_t)L | ((uint32_t)bp << 16);
+    o32[1] = n_exc;
+#pragma unroll
+    for (int g = 0; g < 2 * W; g++) {
+        if (32 * g < L) {
+            const int sh = 32 * (g & 1);
+            o32[2 + 3 * g] = (uint32_t)(lo[g >> 1] >> sh);
+            o32[3 + 3 * g] = (uint32_t)(hi[g >> 1] >> sh);
+            o32[4 + 3 * g] = (uint32_t)(cs[g >> 1] >> sh);
+        }
+    }
+    if (n_exc) {                                                         // rare: N and other IUPAC letters, as printed
+        uint32_t* __restrict__ xo = o32 + 2 + 3 * ((L + 31) >> 5);
+        uint32_t e = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            uint64_t m = ex[w];
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const int k = 64 * w + b;
+                uint32_t c = swapped ? comp_byte(seq[so + (uint64_t)(L - 1 - k)]) : seq[so + (uint64_t)k];
+                if (((cs[w] >> b) & 1) && c >= 'A' && c <= 'Z') c += 32;  // to_ascii_lowercase, detect.rs:157,161
+                xo[e++] = (uint32_t)k | (c << 16);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 
@@ -886,7 +972,7 @@ static void launch_fast(bf_ctx* ctx, const LocaliseArgs& a) {
 
 int run_localise(bf_ctx* ctx) {
     const uint64_t n = ctx->n_reads;
-    ctx->n_exact = 0; ctx->n_sigx = 0;
+    ctx->n_exact = 0; ctx->n_sigx = 0; ctx->n_text_records = 0;
     ctx->localised = false;
     if (n == 0) { ctx->localised = true; ctx->plane_words = 1; ctx->mask_words = 1; return BF_OK; }
     const uint32_t A = ctx->cfg.anchor_len;
@@ -957,25 +1043,27 @@ int run_localise(bf_ctx* ctx) {
     }
     BF_HIP(ctx, hipGetLastError());
 
-    uint32_t cnt[2] = {0, 0};
-    BF_HIP(ctx, hipMemcpyAsync(cnt, ctx->d_counters.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t cnt[3] = {0, 0, 0};
+    BF_HIP(ctx, hipMemcpyAsync(cnt, ctx->d_counters.p, 12, hipMemcpyDeviceToHost, ctx->stream));
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t n_exact = cnt[0];
     ctx->n_exact = n_exact;
     ctx->n_sigx = cnt[1];
+    ctx->n_text_records = cnt[2];
     if (n_exact) {
         ExactArgs e{};
         e.n_total = n; e.A = (int)A; e.cb = ctx->contig_bits; e.exact_list = a.exact_list; e.counters = a.counters; e.hits = a.hits;
         e.seq = ctx->d_seq.as<uint8_t>(); e.seq_off = ctx->d_seq_off.as<uint64_t>();
         e.contigs = a.contigs; e.raw = ctx->g_raw.as<uint8_t>();
         e.key = a.key; e.lpos = a.lpos; e.rpos = a.rpos; e.bp = a.bp; e.flags = a.flags; e.meta = a.meta;
-        e.mask_words = (int)Wm; e.sigx = ctx->d_sigx.as<uint8_t>(); e.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
+        e.mask_words = (int)Wm; e.max_packed = 64u * W; e.sigx = ctx->d_sigx.as<uint8_t>(); e.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
         Scope t(ctx, "localise_exact");
         hipLaunchKernelGGL(localise_exact_kernel, dim3(grid_for((uint64_t)n_exact * 64, 256)), dim3(256), 0, ctx->stream, e);
         BF_HIP(ctx, hipGetLastError());
-        BF_HIP(ctx, hipMemcpyAsync(cnt, ctx->d_counters.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        BF_HIP(ctx, hipMemcpyAsync(cnt, ctx->d_counters.p, 12, hipMemcpyDeviceToHost, ctx->stream));
         BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->n_sigx = cnt[1];
+        ctx->n_text_records = cnt[2];
     }
     ctx->localised = true;
     return BF_OK;
@@ -999,7 +1087,7 @@ int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf&
     BF_TRY(ensure(ctx, ctx->c_misc, n * 4 + 16 + 64 * 8));
     Scope t(ctx, "render_offsets");
     hipLaunchKernelGGL(render_len_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
-                       ctx->d_len.as<uint16_t>(), ctx->c_misc.as<uint32_t>());
+                       ctx->d_mask.as<uint64_t>(), (int)ctx->mask_words + 1, 64u * ctx->plane_words, ctx->c_misc.as<uint32_t>());
     BF_TRY(scan_u32_to_u64(ctx, ctx->c_misc.as<uint32_t>(), d_off.as<uint64_t>(), n));
     // the chunk boundaries in ONE small copy (nine separate 8-byte copies cost 30 us each)
     uint64_t* d_pick = (uint64_t*)(ctx->c_misc.as<uint8_t>() + ((n * 4 + 15) & ~(size_t)15));
@@ -1009,15 +1097,30 @@ int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf&
     return BF_OK;
 }
 
+// Junction records of n listed reads at the given (absolute) offsets: packed records by one kernel, the
+// text records of the reads that cannot be packed (too long, many bases outside ACGT) by the other.
+static int launch_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_idx, const uint64_t* d_off, uint8_t* d_bytes) {
+    const int stride = (int)ctx->mask_words + 1;
+    const uint32_t W = ctx->plane_words;
+    const dim3 g(grid_for(n, 256)), b(256);
+    const uint8_t* seq = ctx->d_seq.as<uint8_t>();
+    const uint64_t* so = ctx->d_seq_off.as<uint64_t>();
+    const uint64_t* meta = ctx->d_mask.as<uint64_t>();
+    if (W == 2) hipLaunchKernelGGL(render_packed_kernel<2>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes);
+    else if (W == 3) hipLaunchKernelGGL(render_packed_kernel<3>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes);
+    else hipLaunchKernelGGL(render_packed_kernel<4>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes);
+    if (ctx->n_text_records)
+        hipLaunchKernelGGL(render_kernel, dim3(grid_for(n * 16, 256)), dim3(256), 0, ctx->stream, n, d_idx, d_off, seq, so, meta,
+                           stride, 64u * W, d_bytes);
+    BF_HIP(ctx, hipGetLastError());
+    return BF_OK;
+}
+
 // Renders reads [a, b) of the list into d_bytes (offsets are absolute).
 int render_range(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const DevBuf& d_off, DevBuf& d_bytes) {
     if (b <= a) return BF_OK;
     Scope t(ctx, "render");
-    hipLaunchKernelGGL(render_kernel, dim3(grid_for((b - a) * 16, 256)), dim3(256), 0, ctx->stream, b - a, d_local_idx + a,
-                       d_off.as<uint64_t>() + a, ctx->d_seq.as<uint8_t>(), ctx->d_seq_off.as<uint64_t>(),
-                       ctx->d_mask.as<uint64_t>(), (int)ctx->mask_words + 1, d_bytes.as<uint8_t>());
-    BF_HIP(ctx, hipGetLastError());
-    return BF_OK;
+    return launch_render(ctx, b - a, d_local_idx + a, d_off.as<uint64_t>() + a, d_bytes.as<uint8_t>());
 }
 
 // Junction strings for a DEVICE list of local read indices into caller-owned device memory (the
@@ -1038,7 +1141,7 @@ int render_dev(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint64_t* d
     {
         Scope t(ctx, "render_offsets");
         hipLaunchKernelGGL(render_len_checked_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
-                           ctx->d_len.as<uint16_t>(), ctx->n_reads, d_len, d_bad);
+                           ctx->d_mask.as<uint64_t>(), (int)ctx->mask_words + 1, 64u * ctx->plane_words, ctx->n_reads, d_len, d_bad);
         BF_TRY(scan_u32_to_u64(ctx, d_len, d_off, n));
     }
     uint32_t bad = 0;
@@ -1053,11 +1156,8 @@ int render_dev(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint64_t* d
                     (unsigned long long)d_bytes_cap, (unsigned long long)*total);
     {
         Scope t(ctx, "render");
-        hipLaunchKernelGGL(render_kernel, dim3(grid_for(n * 16, 256)), dim3(256), 0, ctx->stream, n, d_local_idx, d_off,
-                           ctx->d_seq.as<uint8_t>(), ctx->d_seq_off.as<uint64_t>(), ctx->d_mask.as<uint64_t>(),
-                           (int)ctx->mask_words + 1, d_bytes);
+        BF_TRY(launch_render(ctx, n, d_local_idx, d_off, d_bytes));
     }
-    BF_HIP(ctx, hipGetLastError());
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BF_OK;
 }

@@ -372,12 +372,13 @@ def format_sv(res: Result, contig_names: Sequence[bytes]) -> bytes:
     """The print statements detect.rs:201,233-240 for a merged multi-rank result (pure formatting;
     single-GPU runs use the library's bf_format_sv)."""
     out = [SV_HEADER]
+    from .engine import junction_text
     jb = res.junction_bytes.tobytes()
     for c in res.clusters:
         out.append(b"%s\t%s\t%d\t\t%s\t%s\t%d\t\t" % (
             contig_names[int(c["contig"])], b"+" if c["strand"] else b"-", int(c["lpos"]) & ((1 << 64) - 1),
             contig_names[int(c["mcontig"])], b"+" if c["mstrand"] else b"-", int(c["rpos"]) & ((1 << 64) - 1)))
         rows = res.reads[int(c["read_begin"]):int(c["read_end"])]
-        out.append(b";".join(jb[int(r["junction_off"]):int(r["junction_off"]) + int(r["junction_len"])] for r in rows))
+        out.append(b";".join(junction_text(jb[int(r["junction_off"]):int(r["junction_off"]) + int(r["junction_len"])]) for r in rows))
         out.append(b"\t\t\n")
     return b"".join(out)

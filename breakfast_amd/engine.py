@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
     "bf_localise", "bf_clusterise", "bf_finish", "bf_reset", "bf_sync", "bf_format_sv", "bf_set_rank",
     "bf_exchange_local", "bf_exchange_pack", "bf_exchange_import", "bf_result_sources",
     "bf_render_junctions", "bf_result_sources_dev", "bf_render_junctions_dev", "bf_result_attach_junctions_dev",
-    "bf_evidence_fetch", "bf_kernel_times", "bf_stats",
+    "bf_evidence_fetch", "bf_kernel_times", "bf_stats", "bf_junction_text", "bf_result_junction_text",
 ]
 
 _lib = None
@@ -129,6 +129,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_evidence_fetch.argtypes = [vp, C.POINTER(BfEvidenceView)]
     lib.bf_kernel_times.argtypes = [vp, C.POINTER(C.POINTER(BfKernelTime)), C.POINTER(C.c_uint32)]
     lib.bf_stats.argtypes = [vp, u64p, u64p]
+    lib.bf_junction_text.argtypes = [vp, C.c_uint64, vp, C.c_uint64]
+    lib.bf_junction_text.restype = C.c_int64
+    lib.bf_result_junction_text.argtypes = [C.POINTER(BfResult), vp, C.c_uint64, vp]
+    lib.bf_result_junction_text.restype = C.c_int64
     if path is None:
         _lib = lib
     return lib
@@ -171,9 +175,54 @@ class Result:
     n_reads: int = -1         # supporting reads (== reads.shape[0] unless the table is still on the device)
 
     def junction(self, k: int) -> bytes:
+        """Junction string of supporting read k (detect.rs:155-162), expanded from its record."""
         r = self.reads[k]
         o, n = int(r["junction_off"]), int(r["junction_len"])
-        return self.junction_bytes[o:o + n].tobytes()
+        return junction_text(self.junction_bytes[o:o + n].tobytes())
+
+    def junction_texts(self) -> Tuple[np.ndarray, np.ndarray]:
+        """All junction strings, concatenated in read order -> (uint8 text, uint64 offsets[n+1])."""
+        lib = load_library()
+        rd = np.ascontiguousarray(self.reads, READ_DTYPE)
+        jb = np.ascontiguousarray(self.junction_bytes, np.uint8)
+        n = rd.shape[0]
+        r = BfResult(self.n_evidence, 0, n, None, _ptr(rd), _ptr(jb), jb.size)
+        off = np.zeros(n + 1, np.uint64)
+        total = lib.bf_result_junction_text(C.byref(r), None, 0, off.ctypes.data)
+        if total < 0:
+            raise BreakfastError(int(total), "malformed junction record")
+        text = np.zeros(int(total), np.uint8)
+        if total:
+            lib.bf_result_junction_text(C.byref(r), text.ctypes.data, int(total), off.ctypes.data)
+        return text, off
+
+
+def junction_text(record: bytes) -> bytes:
+    """Expands one junction record (include/breakfast_hip.h, "Junction records") with the library's own
+    host decoder."""
+    lib = load_library()
+    rec = np.frombuffer(record, np.uint8)
+    n = lib.bf_junction_text(rec.ctypes.data if rec.size else None, rec.size, None, 0)
+    if n < 0:
+        raise BreakfastError(int(n), "malformed junction record")
+    buf = C.create_string_buffer(int(n))
+    lib.bf_junction_text(rec.ctypes.data, rec.size, buf, n)
+    return buf.raw[:n]
+
+
+def text_records(text: np.ndarray, off: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Wraps junction strings as TEXT records {u16 len, u16 bp, u16 0xffff} + string, padded to 4 bytes
+    (what an engine without the packed renderer hands to the exchange) -> (records, offsets[n+1])."""
+    n = off.shape[0] - 1
+    out, ro = [], np.zeros(n + 1, np.uint64)
+    tb = np.ascontiguousarray(text, np.uint8).tobytes()
+    for i in range(n):
+        s = tb[int(off[i]):int(off[i + 1])]
+        rec = np.array([len(s) - 1, s.index(b"|"), 0xffff], "<u2").tobytes() + s
+        rec += b"\0" * (-len(rec) % 4)
+        out.append(rec)
+        ro[i + 1] = ro[i] + len(rec)
+    return np.frombuffer(b"".join(out), np.uint8).copy(), ro
 
 
 def _ptr(a: Optional[np.ndarray]) -> Optional[int]:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 1
+#define BF_ABI_VERSION 2
 
 enum {
     BF_OK = 0,
@@ -101,10 +101,26 @@ typedef struct {
     uint8_t  pad[6];
 } bf_cluster;
 
+/* Junction records.  A supporting read's case-marked sequence with '|' at the breakpoint (detect.rs:155-162)
+ * leaves the GPU as a self-describing record, because the result copy over PCIe is the longest stage of
+ * the path and 3 bits per base say what 8 bits of text say.  Records start on 4-byte boundaries; little endian:
+ *     u16 len      read length L
+ *     u16 bp       position of '|' in the string (0 <= bp <= L)
+ *     u16 n_exc    number of exception entries, or 0xFFFF = text record
+ *   text record (reads longer than the packed kernel's 256 bases, or with many bases outside ACGT):
+ *     L+1 bytes    the string itself, then zero padding to a multiple of 4 bytes
+ *   packed record:
+ *     u16 0
+ *     ceil(L/32) x { u32 lo, u32 hi, u32 lower }   bit j of group g = base k = 32g+j of the printed sequence:
+ *                  letter "ACTG"[lo + 2*hi], printed in lower case when `lower` is set
+ *     n_exc x { u16 k, u8 byte, u8 0 }             base k prints as `byte` (N and other IUPAC letters)
+ * bf_junction_text() expands one record, bf_result_junction_text() all records of a result, and
+ * bf_format_sv() expands them while it prints.  68 bytes instead of 151 for a 150-base read. */
+
 /* One supporting read that survived frag-id dedup (detect.rs:247-287), in printed order. */
 typedef struct {
     uint64_t index;          /* global input index (position in submit order, + ctx base)          */
-    uint64_t junction_off;   /* its case-marked sequence with '|' (detect.rs:155-162) is            */
+    uint64_t junction_off;   /* its junction record (see above) is                                  */
     uint32_t junction_len;   /*   junction_bytes[junction_off .. junction_off+junction_len)          */
     uint16_t bp;             /* breakpoint offset inside the (re-oriented) read (detect.rs:147-153) */
     uint8_t  swapped;        /* read was reverse-complemented by the reorient step (detect.rs:108)  */
@@ -166,6 +182,15 @@ int bf_sync(bf_ctx* ctx);
  * bytes.  Call with buf == NULL to query the size. */
 int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* result, char* buf, uint64_t cap);
 
+/* The string detect.rs:155-162 builds for one read, from its junction record: writes len+1 bytes (no
+ * terminator) when buf is given and cap suffices; returns len+1, or BF_ERR_INVALID for a malformed
+ * record.  Pure host code, needs no ctx. */
+int64_t bf_junction_text(const uint8_t* record, uint64_t record_len, char* buf, uint64_t cap);
+
+/* All junction strings of a result, concatenated in read order: text_off receives n_reads+1 offsets,
+ * text (capacity cap) the bytes when given and large enough.  Returns the total size or a negative error. */
+int64_t bf_result_junction_text(const bf_result* result, uint8_t* text, uint64_t cap, uint64_t* text_off);
+
 /* ---- multi-GPU stage calls (one ctx per GPU/process) ------------------ */
 /* The path shards by contiguous input ranges; rank r's reads have global indices
  * [index_base, index_base + n).  Evidence of one breakpoint class must meet on one rank, so after
@@ -201,8 +226,9 @@ int bf_exchange_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_co
  * Arrays of result.n_reads entries, owned by the ctx. */
 int bf_result_sources(bf_ctx* ctx, const uint32_t** src_rank, const uint32_t** src_index);
 
-/* On a source rank: renders the junction strings of the given local read indices (device work).
- * out_bytes/out_off (n+1 offsets) are owned by the ctx until the next call. */
+/* On a source rank: renders the junction strings of the given local read indices (device work) and
+ * expands them to TEXT on the host.  out_bytes/out_off (n+1 offsets) are owned by the ctx until the
+ * next call. */
 int bf_render_junctions(bf_ctx* ctx, uint64_t n, const uint32_t* local_index,
                         const uint8_t** out_bytes, const uint64_t** out_off);
 
@@ -216,8 +242,8 @@ int bf_render_junctions(bf_ctx* ctx, uint64_t n, const uint32_t* local_index,
  * reads of the last bf_clusterise into two caller arrays of n_reads uint32 each. */
 int bf_result_sources_dev(bf_ctx* ctx, uint32_t* dev_src_rank, uint32_t* dev_src_index);
 
-/* On a source rank: junction strings (detect.rs:155-162) of n local reads given as a device index
- * list.  dev_off receives n+1 byte offsets, *total their sum.  With dev_bytes == NULL only offsets
+/* On a source rank: junction RECORDS (detect.rs:155-162; format above) of n local reads given as a device
+ * index list.  dev_off receives n+1 byte offsets, *total their sum.  With dev_bytes == NULL only offsets
  * and *total are produced (size query); otherwise dev_bytes (capacity dev_bytes_cap >= *total)
  * receives the text.  An index outside the resident reads is an error, never dereferenced.
  * dev_bytes and dev_local_index must be 4-byte aligned, dev_off 8-byte aligned. */

@@ -21,7 +21,7 @@ import detect_oracle as po
 
 from breakfast_amd import synth
 from breakfast_amd.distributed import DistributedDetect, format_sv
-from breakfast_amd.engine import CLUSTER_DTYPE, READ_DTYPE, Result
+from breakfast_amd.engine import CLUSTER_DTYPE, READ_DTYPE, Result, text_records
 
 
 class OracleStage:
@@ -82,7 +82,8 @@ class OracleStage:
         js = [self.local[int(i)].sequence for i in local_index]
         off = np.zeros(len(js) + 1, np.uint64)
         off[1:] = np.cumsum([len(j) for j in js])
-        return np.frombuffer(b"".join(js), np.uint8).copy(), off
+        # junction strings travel as records (include/breakfast_hip.h); this stand-in has no packed renderer
+        return text_records(np.frombuffer(b"".join(js), np.uint8).copy(), off)
 
 
 def make_case(seed=0):

@@ -78,8 +78,11 @@ def test_device_render_matches_host_render_and_rejects_bad_indices():
             idx = rng.integers(0, b.n, size=n).astype(np.uint32)
             by_h, off_h = eng.render_junctions(idx)
             by_d, off_d = stage.render_junctions_tensor(torch.from_numpy(idx.astype(np.int32)).to(dev))
-            assert np.array_equal(off_d.cpu().numpy().astype(np.uint64), off_h)
-            assert np.array_equal(by_d.cpu().numpy(), by_h)
+            # the device call hands out junction RECORDS, the host call their text
+            rec, roff = by_d.cpu().numpy().tobytes(), off_d.cpu().numpy()
+            text = [engine.junction_text(rec[int(roff[i]):int(roff[i + 1])]) for i in range(n)]
+            assert [len(t) for t in text] == list(np.diff(off_h).astype(np.int64))
+            assert b"".join(text) == by_h.tobytes()
         bad = torch.tensor([0, b.n, 3], dtype=torch.int32, device=dev)
         with pytest.raises(engine.BreakfastError) as ei:
             stage.render_junctions_tensor(bad)

@@ -1,0 +1,92 @@
+"""Junction records (include/breakfast_hip.h, "Junction records"): the library's host decoder against
+records packed here in plain Python from junction strings -- packed form, exception entries, text form,
+breakpoint at either end, padding, malformed input.  No GPU involved."""
+import numpy as np
+import pytest
+
+from breakfast_amd import engine
+
+CODE = {ord("A"): 0, ord("C"): 1, ord("T"): 2, ord("G"): 3}
+
+
+def pack(junction: bytes) -> bytes:
+    """Reference packer: the record the GPU writes for this string."""
+    bp = junction.index(b"|")
+    seq = junction[:bp] + junction[bp + 1:]
+    L = len(seq)
+    groups = (L + 31) // 32
+    lo, hi, cs = [0] * groups, [0] * groups, [0] * groups
+    exc = []
+    for k, c in enumerate(seq):
+        up = c - 32 if 97 <= c <= 122 else c
+        if up in CODE:
+            lo[k >> 5] |= (CODE[up] & 1) << (k & 31)
+            hi[k >> 5] |= (CODE[up] >> 1) << (k & 31)
+            cs[k >> 5] |= (1 if c != up else 0) << (k & 31)
+        else:
+            exc.append((k, c))
+    out = np.array([L, bp, len(exc), 0], "<u2").tobytes()
+    for g in range(groups):
+        out += np.array([lo[g], hi[g], cs[g]], "<u4").tobytes()
+    for k, c in exc:
+        out += np.array([k], "<u2").tobytes() + bytes([c, 0])
+    return out
+
+
+def text_record(junction: bytes) -> bytes:
+    rec = np.array([len(junction) - 1, junction.index(b"|"), 0xffff], "<u2").tobytes() + junction
+    return rec + b"\0" * (-len(rec) % 4)
+
+
+def random_junction(rng, L, n_exc=0, lower=0.05):
+    seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=L)
+    seq = np.where(rng.random(L) < lower, seq | 0x20, seq).astype(np.uint8)
+    for k in rng.choice(L, size=min(n_exc, L), replace=False):
+        seq[k] = rng.choice(np.frombuffer(b"NnRYKM=", np.uint8))
+    bp = int(rng.integers(0, L + 1))
+    s = seq.tobytes()
+    return s[:bp] + b"|" + s[bp:]
+
+
+@pytest.mark.parametrize("L", [1, 7, 8, 31, 32, 33, 40, 64, 100, 150, 191, 192, 250, 256, 1000])
+def test_packed_records_expand_to_the_string(L):
+    rng = np.random.default_rng(L)
+    for n_exc in (0, 1, 3, L // 8):
+        for _ in range(20):
+            j = random_junction(rng, L, n_exc)
+            assert engine.junction_text(pack(j)) == j
+            assert engine.junction_text(text_record(j)) == j
+
+
+def test_breakpoint_at_either_end_and_known_answer():
+    assert engine.junction_text(pack(b"|ACGT")) == b"|ACGT"
+    assert engine.junction_text(pack(b"ACGT|")) == b"ACGT|"
+    # the survey's known-answer read 1
+    j = b"AGTTATCGGTGCCG|AAcTGATGGA"
+    rec = pack(j)
+    assert len(rec) == 8 + 12 and engine.junction_text(rec) == j
+
+
+def test_malformed_records_are_rejected():
+    good = pack(b"ACGTACGTAC|GTNACGTACGT")
+    for bad in (b"", good[:5], good[:12], good[:-1],
+                np.array([4, 9, 0, 0], "<u2").tobytes() + b"\0" * 12,            # bp > len
+                np.array([4, 1, 1, 0], "<u2").tobytes() + b"\0" * 12 + np.array([7], "<u2").tobytes() + b"N\0",   # exception past the end
+                np.array([10, 1, 0xffff], "<u2").tobytes() + b"A|CG"):            # text shorter than len+1
+        with pytest.raises(engine.BreakfastError):
+            engine.junction_text(bad)
+
+
+def test_result_junction_texts_batch():
+    rng = np.random.default_rng(7)
+    js = [random_junction(rng, int(rng.integers(40, 300)), int(rng.integers(0, 4))) for _ in range(500)]
+    recs = [pack(j) if i % 3 else text_record(j) for i, j in enumerate(js)]
+    rd = np.zeros(len(js), engine.READ_DTYPE)
+    off = 0
+    for i, r in enumerate(recs):
+        rd[i]["junction_off"], rd[i]["junction_len"] = off, len(r)
+        off += len(r)
+    res = engine.Result(len(js), np.zeros(0, engine.CLUSTER_DTYPE), rd, np.frombuffer(b"".join(recs), np.uint8))
+    text, toff = res.junction_texts()
+    assert [text[int(toff[i]):int(toff[i + 1])].tobytes() for i in range(len(js))] == js
+    assert res.junction(17) == js[17]
