@@ -50,7 +50,11 @@ int ensure(bf_ctx* ctx, DevBuf& b, size_t bytes, bool keep) {
 
 int ensure_host(bf_ctx* ctx, HostBuf& b, size_t bytes) {
     if (bytes <= b.cap && b.p) return BF_OK;
-    if (b.p) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+    if (b.p) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0;
+    }
     size_t cap = std::max<size_t>(bytes + bytes / 4, 4096);
     hipError_t e = hipHostMalloc(&b.p, cap, hipHostMallocDefault);
     if (e != hipSuccess) { b.p = nullptr; return fail(ctx, BF_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e)); }
@@ -110,6 +114,7 @@ static OwnerView imported_view(bf_ctx* ctx) {
     v.frag = ctx->i_frag.as<uint8_t>(); v.frag_off = ctx->i_frag_off.as<uint64_t>(); v.frag_len = ctx->i_frag_len.as<uint16_t>();
     v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
     v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>();
+    v.jrec = ctx->i_jrec.as<uint32_t>();
     return v;
 }
 
@@ -120,7 +125,7 @@ static void free_all(bf_ctx* ctx) {
         &ctx->d_counters, &ctx->d_sigx, &ctx->d_sigx_slot, &ctx->d_send, &ctx->d_part_key, &ctx->d_part_idx,
         &ctx->d_part_tmp, &ctx->i_key, &ctx->i_lpos, &ctx->i_rpos, &ctx->i_fhash, &ctx->i_bp, &ctx->i_len, &ctx->i_flags,
         &ctx->i_frag, &ctx->i_frag_off, &ctx->i_frag_len, &ctx->i_sigx, &ctx->i_sigx_slot, &ctx->i_src_rank,
-        &ctx->i_src_idx, &ctx->c_tmp, &ctx->c_a32, &ctx->c_b32, &ctx->c_c32, &ctx->c_d32, &ctx->c_k64a, &ctx->c_k64b,
+        &ctx->i_src_idx, &ctx->i_jrec, &ctx->c_tmp, &ctx->c_a32, &ctx->c_b32, &ctx->c_c32, &ctx->c_d32, &ctx->c_k64a, &ctx->c_k64b,
         &ctx->c_slpos, &ctx->c_srpos, &ctx->c_reported, &ctx->c_csize, &ctx->c_flag, &ctx->c_scan, &ctx->c_qseed,
         &ctx->c_qsize, &ctx->c_qoff, &ctx->c_members, &ctx->c_leader, &ctx->c_rep, &ctx->c_qnrep, &ctx->c_sel,
         &ctx->c_ord, &ctx->c_clusters, &ctx->c_reads, &ctx->c_misc, &ctx->c_joff, &ctx->c_jbytes, &ctx->c_rsrc,
@@ -387,7 +392,7 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     if (ctx->n_ranks > 1 && !ctx->imported) return fail(ctx, BF_ERR_STATE, "bf_clusterise on a multi-rank ctx before bf_exchange_import");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     const OwnerView v = ctx->imported ? imported_view(ctx) : local_view(ctx);
-    ctx->clustered = false;
+    ctx->clustered = false; ctx->table_attached = false; ctx->junction_attached = 0;
     BF_TRY(run_cluster(ctx, v));
     ctx->clustered = true;
     const uint64_t nr = ctx->out.n_reads;
@@ -693,6 +698,86 @@ int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const 
     out->junction_bytes = ctx->out.junction.as<uint8_t>();
     out->junction_size = size;
     return BF_OK;
+}
+
+// Pipelined form of bf_result_attach_junctions_dev.  The owner knows every supporting read's record size
+// from the exchange (bf_result_junction_sizes_dev), so it can lay out its junction buffer, send the read
+// table to the host while the records are still being requested, and then hand over the records piece by
+// piece as they arrive; the copies run on the ctx's copy stream behind the caller's next collective.
+int bf_result_junction_sizes_dev(bf_ctx* ctx, uint32_t* dev_len) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!ctx->imported || !ctx->clustered)
+        return fail(ctx, BF_ERR_STATE, "bf_result_junction_sizes_dev is only meaningful after bf_exchange_import + bf_clusterise");
+    const uint64_t nr = ctx->out.n_reads;
+    if (nr == 0) return BF_OK;
+    if (!dev_len) return fail(ctx, BF_ERR_INVALID, "bf_result_junction_sizes_dev: null output");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    BF_TRY(read_sizes(ctx, dev_len, nr));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BF_OK;
+}
+
+int bf_result_attach_offsets_dev(bf_ctx* ctx, const uint64_t* dev_joff) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!ctx->imported || !ctx->clustered)
+        return fail(ctx, BF_ERR_STATE, "bf_result_attach_offsets_dev is only meaningful after bf_exchange_import + bf_clusterise");
+    const uint64_t nr = ctx->out.n_reads;
+    if (nr && !dev_joff) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_offsets_dev: null offsets");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    if (nr) {
+        BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
+        BF_TRY(patch_reads_off(ctx, dev_joff, nr));
+        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));            // dev_joff may be released by the caller on return
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+    ctx->table_attached = true;
+    return BF_OK;
+}
+
+int bf_result_attach_junction_chunk_dev(bf_ctx* ctx, const uint8_t* dev_bytes, uint64_t size, uint64_t dst_off, uint64_t total_size) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!ctx->imported || !ctx->clustered)
+        return fail(ctx, BF_ERR_STATE, "bf_result_attach_junction_chunk_dev is only meaningful after bf_exchange_import + bf_clusterise");
+    if (dst_off + size > total_size) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junction_chunk_dev: chunk [%llu, +%llu) outside %llu bytes",
+                                                 (unsigned long long)dst_off, (unsigned long long)size, (unsigned long long)total_size);
+    if (size && !dev_bytes) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junction_chunk_dev: null chunk");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    if (total_size > ctx->out.junction.cap || !ctx->out.junction.p) {
+        if (ctx->junction_attached) return fail(ctx, BF_ERR_STATE, "bf_result_attach_junction_chunk_dev: total size changed between chunks");
+        BF_TRY(ensure_host(ctx, ctx->out.junction, total_size));
+    }
+    ctx->out.junction_size = total_size;
+    // the caller keeps dev_bytes alive until bf_result_attach_finish
+    if (size) BF_HIP(ctx, hipMemcpyAsync(ctx->out.junction.as<uint8_t>() + dst_off, dev_bytes, size, hipMemcpyDeviceToHost, ctx->copy_stream));
+    ctx->junction_attached += size;
+    return BF_OK;
+}
+
+int bf_result_attach_finish(bf_ctx* ctx, bf_result* out) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!out) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_finish: null result");
+    if (!ctx->imported || !ctx->clustered || !ctx->table_attached)
+        return fail(ctx, BF_ERR_STATE, "bf_result_attach_finish before bf_result_attach_offsets_dev");
+    BF_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->out.n_reads == 0) ctx->out.junction_size = 0;
+    if (ctx->junction_attached != ctx->out.junction_size)
+        return fail(ctx, BF_ERR_STATE, "bf_result_attach_finish: %llu of %llu junction bytes were attached",
+                    (unsigned long long)ctx->junction_attached, (unsigned long long)ctx->out.junction_size);
+    memset(out, 0, sizeof *out);
+    out->n_evidence = ctx->n_evidence;
+    out->n_clusters = ctx->out.n_clusters;
+    out->n_reads = ctx->out.n_reads;
+    out->clusters = ctx->out.clusters.as<bf_cluster>();
+    out->reads = ctx->out.reads.as<bf_read>();
+    out->junction_bytes = ctx->out.junction.as<uint8_t>();
+    out->junction_size = ctx->out.junction_size;
+    return BF_OK;
+}
+
+uint64_t bf_junction_record_bound(const bf_ctx* ctx) {
+    // packed: 8 + 12*ceil(L/32) + 4*(L/8) <= 7L/8 + 20; text: L + 10
+    return ctx ? (uint64_t)ctx->max_len + 24 : 0;
 }
 
 // ---- introspection ---------------------------------------------------------------------------

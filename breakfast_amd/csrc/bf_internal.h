@@ -77,7 +77,7 @@ struct WireHeader {     // 40 B, followed by frag bytes (fixed stride) and optio
     uint32_t src_idx;
     uint16_t bp, len;
     uint16_t frag_len, flags;
-    uint32_t pad1;
+    uint32_t jrec;       // bytes of the read's junction record: the owner lays out its result without asking
 };
 static_assert(sizeof(WireHeader) == 40, "wire header layout");
 
@@ -108,6 +108,7 @@ struct OwnerView {
     const uint32_t* sigx_slot = nullptr; // record -> slot (only read when the key's sigx bit is set)
     const uint32_t* src_rank = nullptr;  // nullptr = all from this rank
     const uint32_t* src_idx = nullptr;   // nullptr = identity
+    const uint32_t* jrec = nullptr;      // junction record bytes per record (imported views only)
 };
 
 struct HostBuf {                         // pinned host staging (hipHostMalloc): full-rate D2H copies
@@ -178,7 +179,9 @@ struct bf_ctx {
     uint64_t n_imported = 0;
     bf::DevBuf d_send, d_part_key, d_part_idx, d_part_tmp;
     bf::DevBuf i_key, i_lpos, i_rpos, i_fhash, i_bp, i_len, i_flags, i_frag, i_frag_off, i_frag_len, i_sigx,
-        i_sigx_slot, i_src_rank, i_src_idx;
+        i_sigx_slot, i_src_rank, i_src_idx, i_jrec;
+    bool table_attached = false;                // the read table of the last bf_clusterise is (being) copied to the host
+    uint64_t junction_attached = 0;             // junction bytes queued for the host so far
 
     // cluster stage scratch + results
     bf::DevBuf c_tmp, c_a32, c_b32, c_c32, c_d32, c_k64a, c_k64b, c_slpos, c_srpos, c_reported,
@@ -248,5 +251,7 @@ int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts);
 int scan_u32_to_u64(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n);  // exclusive, out has n+1
 int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
 int patch_reads_len(bf_ctx* ctx, const uint64_t* d_joff, const uint32_t* d_jlen, uint64_t n);
+int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
+int read_sizes(bf_ctx* ctx, uint32_t* d_out, uint64_t n);
 
 }  // namespace bf

@@ -367,7 +367,7 @@ struct EmitView {
     const uint32_t* members; const uint32_t* rep;
     const uint64_t* skey; const int32_t* slpos; const int32_t* srpos; const uint32_t* perm;
     const uint32_t* src_rank; const uint32_t* src_idx; const uint64_t* src_base;
-    const uint16_t* bp; const uint16_t* flags;
+    const uint16_t* bp; const uint16_t* flags; const uint32_t* jrec;
     const uint32_t* rank2id; int cb;
     bf_cluster* clusters; bf_read* reads; uint32_t* out_src_rank; uint32_t* out_src_idx; uint32_t* out_rec;
 };
@@ -414,6 +414,7 @@ __global__ void __launch_bounds__(256) emit_kernel(const EmitView e, uint64_t ns
             rd.index = e.src_base[sr] + si;
             rd.bp = e.bp[rec];
             rd.swapped = (e.flags[rec] & kEvSwapped) ? 1 : 0;
+            if (e.jrec) rd.junction_len = e.jrec[rec];
             e.reads[slot] = rd;
             e.out_src_rank[slot] = sr; e.out_src_idx[slot] = si; e.out_rec[slot] = rec;
         }
@@ -585,7 +586,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     ev.members = ctx->c_members.as<uint32_t>(); ev.rep = ctx->c_rep.as<uint32_t>();
     ev.skey = sv.skey; ev.slpos = sv.slpos; ev.srpos = sv.srpos; ev.perm = perm;
     ev.src_rank = v.src_rank; ev.src_idx = v.src_idx; ev.src_base = (const uint64_t*)ctx->c_tables.p;
-    ev.bp = v.bp; ev.flags = v.flags; ev.rank2id = d_rank2id; ev.cb = ctx->contig_bits;
+    ev.bp = v.bp; ev.flags = v.flags; ev.jrec = v.jrec; ev.rank2id = d_rank2id; ev.cb = ctx->contig_bits;
     ev.clusters = ctx->c_clusters.as<bf_cluster>(); ev.reads = ctx->c_reads.as<bf_read>();
     ev.out_src_rank = ctx->c_rsrc.as<uint32_t>(); ev.out_src_idx = ev.out_src_rank + total_r;
     ev.out_rec = ev.out_src_idx + total_r;
@@ -628,8 +629,13 @@ struct PackView {
     const uint16_t* bp; const uint16_t* len; const uint16_t* flags;
     const uint8_t* frag; const uint64_t* frag_off; const uint16_t* frag_len;
     const uint8_t* sigx; const uint32_t* sigx_slot;
+    const uint64_t* meta; int meta_stride; uint32_t max_packed;     // render records: {.., len, n_exc} -> junction record bytes
     uint8_t* out;
 };
+__device__ __forceinline__ uint32_t pack_jrec(const PackView& v, uint32_t i) {
+    const uint64_t tail = v.meta[(uint64_t)i * v.meta_stride + v.meta_stride - 1];
+    return junction_record_bytes((uint32_t)((tail >> 32) & 0xffff), (uint32_t)(tail >> 48), v.max_packed);
+}
 __global__ void __launch_bounds__(256) pack_kernel(const PackView v) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= v.n) return;
@@ -637,7 +643,7 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackView v) {
     uint8_t* dst = v.out + j * v.rec_bytes;
     WireHeader h;
     h.key = v.key[i]; h.lpos = v.lpos[i]; h.rpos = v.rpos[i]; h.fhash = v.fhash[i]; h.src_idx = i;
-    h.bp = v.bp[i]; h.len = v.len[i]; h.frag_len = v.frag_len[i]; h.flags = v.flags[i]; h.pad1 = 0;
+    h.bp = v.bp[i]; h.len = v.len[i]; h.frag_len = v.frag_len[i]; h.flags = v.flags[i]; h.jrec = pack_jrec(v, i);
     *(WireHeader*)dst = h;
     const uint8_t* f = v.frag + v.frag_off[i];
     for (uint32_t k = 0; k < v.frag_stride; k++) dst[sizeof(WireHeader) + k] = k < h.frag_len ? f[k] : 0;
@@ -669,7 +675,7 @@ __global__ void __launch_bounds__(256) pack_lds_kernel(const PackView v) {
         rec[1] = (uint64_t)(uint32_t)v.lpos[i] | ((uint64_t)(uint32_t)v.rpos[i] << 32);
         rec[2] = v.fhash[i];
         rec[3] = (uint64_t)i | ((uint64_t)v.bp[i] << 32) | ((uint64_t)v.len[i] << 48);
-        rec[4] = (uint64_t)(uint16_t)fl | ((uint64_t)v.flags[i] << 16);
+        rec[4] = (uint64_t)(uint16_t)fl | ((uint64_t)v.flags[i] << 16) | ((uint64_t)pack_jrec(v, i) << 32);
         const uint8_t* f = v.frag + v.frag_off[i];
         for (uint32_t w = 0; w < fwords; w++) {
             uint64_t x = 0;
@@ -700,7 +706,7 @@ struct ImportView {
     const uint8_t* in; const uint64_t* src_start;   // n_ranks+1 prefix of src_counts
     uint64_t* key; int32_t* lpos; int32_t* rpos; uint64_t* fhash; uint16_t* bp; uint16_t* len; uint16_t* flags;
     uint8_t* frag; uint64_t* frag_off; uint16_t* frag_len; uint8_t* sigx; uint32_t* sigx_slot;
-    uint32_t* src_rank; uint32_t* src_idx;
+    uint32_t* src_rank; uint32_t* src_idx; uint32_t* jrec;
 };
 __global__ void __launch_bounds__(256) import_kernel(const ImportView v) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -708,7 +714,7 @@ __global__ void __launch_bounds__(256) import_kernel(const ImportView v) {
     const uint8_t* src = v.in + j * v.rec_bytes;
     const WireHeader h = *(const WireHeader*)src;
     v.key[j] = h.key; v.lpos[j] = h.lpos; v.rpos[j] = h.rpos; v.fhash[j] = h.fhash;
-    v.bp[j] = h.bp; v.len[j] = h.len; v.flags[j] = h.flags; v.frag_len[j] = h.frag_len;
+    v.bp[j] = h.bp; v.len[j] = h.len; v.flags[j] = h.flags; v.frag_len[j] = h.frag_len; v.jrec[j] = h.jrec;
     v.frag_off[j] = j * v.frag_stride;
     for (uint32_t k = 0; k < v.frag_stride; k++) v.frag[j * v.frag_stride + k] = src[sizeof(WireHeader) + k];
     v.sigx_slot[j] = (uint32_t)j;
@@ -732,7 +738,7 @@ __global__ void __launch_bounds__(256) import_lds_kernel(const ImportView v) {
     v.lpos[j] = (int32_t)(uint32_t)rec[1]; v.rpos[j] = (int32_t)(uint32_t)(rec[1] >> 32);
     v.fhash[j] = rec[2];
     v.src_idx[j] = (uint32_t)rec[3]; v.bp[j] = (uint16_t)(rec[3] >> 32); v.len[j] = (uint16_t)(rec[3] >> 48);
-    v.frag_len[j] = (uint16_t)rec[4]; v.flags[j] = (uint16_t)(rec[4] >> 16);
+    v.frag_len[j] = (uint16_t)rec[4]; v.flags[j] = (uint16_t)(rec[4] >> 16); v.jrec[j] = (uint32_t)(rec[4] >> 32);
     v.frag_off[j] = j * v.frag_stride;
     uint64_t* fdst = (uint64_t*)(v.frag + j * v.frag_stride);
     for (uint32_t w = 0; w < fwords; w++) fdst[w] = rec[5 + w];
@@ -782,6 +788,7 @@ int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint
     pv.fhash = ctx->d_fhash.as<uint64_t>(); pv.bp = ctx->d_bp.as<uint16_t>(); pv.len = ctx->d_len.as<uint16_t>();
     pv.flags = ctx->d_flags.as<uint16_t>(); pv.frag = ctx->d_frag.as<uint8_t>(); pv.frag_off = ctx->d_frag_off.as<uint64_t>();
     pv.frag_len = ctx->d_frag_len.as<uint16_t>(); pv.sigx = ctx->d_sigx.as<uint8_t>(); pv.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
+    pv.meta = ctx->d_mask.as<uint64_t>(); pv.meta_stride = (int)ctx->mask_words + 1; pv.max_packed = 64u * ctx->plane_words;
     pv.out = (uint8_t*)*dev_out;
     if (rec <= kWireLdsMaxRecord && ((uintptr_t)pv.out & 7) == 0)
         hipLaunchKernelGGL(pack_lds_kernel, dim3(grid_for(n, 256)), dim3(256), 256 * rec, st, pv);
@@ -816,6 +823,7 @@ int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts) {
     BF_TRY(ensure(ctx, ctx->i_frag_off, n * 8)); BF_TRY(ensure(ctx, ctx->i_frag_len, n * 2));
     BF_TRY(ensure(ctx, ctx->i_sigx, n * 16)); BF_TRY(ensure(ctx, ctx->i_sigx_slot, n * 4));
     BF_TRY(ensure(ctx, ctx->i_src_rank, n * 4)); BF_TRY(ensure(ctx, ctx->i_src_idx, n * 4));
+    BF_TRY(ensure(ctx, ctx->i_jrec, n * 4));
     BF_TRY(ensure(ctx, ctx->d_part_tmp, (size_t)(R + 1) * 8));
     BF_HIP(ctx, hipMemcpyAsync(ctx->d_part_tmp.p, start.data(), (size_t)(R + 1) * 8, hipMemcpyHostToDevice, st));
     ImportView v{};
@@ -825,7 +833,7 @@ int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts) {
     v.fhash = ctx->i_fhash.as<uint64_t>(); v.bp = ctx->i_bp.as<uint16_t>(); v.len = ctx->i_len.as<uint16_t>();
     v.flags = ctx->i_flags.as<uint16_t>(); v.frag = ctx->i_frag.as<uint8_t>(); v.frag_off = ctx->i_frag_off.as<uint64_t>();
     v.frag_len = ctx->i_frag_len.as<uint16_t>(); v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
-    v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>();
+    v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>(); v.jrec = ctx->i_jrec.as<uint32_t>();
     Scope t(ctx, "exchange_import");
     if (v.rec_bytes <= kWireLdsMaxRecord && ((uintptr_t)v.in & 7) == 0)
         hipLaunchKernelGGL(import_lds_kernel, dim3(grid_for(n, 256)), dim3(256), 256 * v.rec_bytes, st, v);
@@ -844,6 +852,26 @@ __global__ void patch_reads_kernel(bf_read* reads, const uint64_t* __restrict__ 
 __global__ void patch_reads_len_kernel(bf_read* reads, const uint64_t* __restrict__ joff, const uint32_t* __restrict__ jlen, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { reads[i].junction_off = joff[i]; reads[i].junction_len = jlen[i]; }
+}
+__global__ void patch_reads_off_kernel(bf_read* reads, const uint64_t* __restrict__ joff, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) reads[i].junction_off = joff[i];
+}
+__global__ void read_sizes_kernel(const bf_read* __restrict__ reads, uint32_t* __restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = reads[i].junction_len;
+}
+int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n) {
+    if (n) hipLaunchKernelGGL(patch_reads_off_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
+                              ctx->c_reads.as<bf_read>(), d_joff, n);
+    BF_HIP(ctx, hipGetLastError());
+    return BF_OK;
+}
+int read_sizes(bf_ctx* ctx, uint32_t* d_out, uint64_t n) {
+    if (n) hipLaunchKernelGGL(read_sizes_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
+                              ctx->c_reads.as<bf_read>(), d_out, n);
+    BF_HIP(ctx, hipGetLastError());
+    return BF_OK;
 }
 int patch_reads_len(bf_ctx* ctx, const uint64_t* d_joff, const uint32_t* d_jlen, uint64_t n) {
     if (n) hipLaunchKernelGGL(patch_reads_len_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,

@@ -111,26 +111,28 @@ class HipStageEngine:
 
     # ---- device-resident junction routing (no PCIe round trips) ----
     def result_sources_tensors(self, res: Result):
+        """-> (source rank, source-local index, junction record bytes) of the supporting reads, int32 on the device"""
         nr = res.n_reads if res.n_reads >= 0 else int(res.reads.shape[0])
         sr = torch.empty(nr, dtype=torch.int32, device=self.device)
         si = torch.empty(nr, dtype=torch.int32, device=self.device)
+        jl = torch.empty(nr, dtype=torch.int32, device=self.device)
         if nr:
             self._torch_done()
             self.eng.result_sources_dev(sr.data_ptr(), si.data_ptr())
-        return sr, si
+            self.eng.result_junction_sizes_dev(jl.data_ptr())
+        return sr, si, jl
 
     def render_junctions_tensor(self, idx: torch.Tensor):
-        """idx: int32 device tensor of local read indices -> (uint8 text, int64 offsets[n+1]) on the device."""
+        """idx: int32 device tensor of local read indices -> (uint8 junction records, int64 offsets[n+1]) on the
+        device.  One library call: the buffer is sized by the per-record bound, not by a size query."""
         idx = idx.to(self.device, torch.int32).contiguous()
         n = int(idx.numel())
         off = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+        cap = n * self.eng.junction_record_bound()
+        by = torch.empty(max(cap, 4), dtype=torch.uint8, device=self.device)
         self._torch_done()
-        total = self.eng.render_junctions_dev(n, idx.data_ptr() if n else 0, off.data_ptr())
-        by = torch.empty(total, dtype=torch.uint8, device=self.device)
-        if total:
-            self._torch_done()
-            self.eng.render_junctions_dev(n, idx.data_ptr(), off.data_ptr(), by.data_ptr(), total)
-        return by, off
+        total = self.eng.render_junctions_dev(n, idx.data_ptr() if n else 0, off.data_ptr(), by.data_ptr(), cap)
+        return by[:total], off
 
     def attach_junctions(self, res: Result, joff: torch.Tensor, jlen: torch.Tensor, text: torch.Tensor) -> Result:
         joff = joff.to(self.device, torch.int64).contiguous()
@@ -139,6 +141,21 @@ class HipStageEngine:
         self._torch_done()
         out = self.eng.attach_junctions_dev(joff.data_ptr() if joff.numel() else 0, jlen.data_ptr() if jlen.numel() else 0,
                                             text.data_ptr() if text.numel() else 0, int(text.numel()))
+        out.src_rank, out.src_index = res.src_rank, res.src_index
+        return out
+
+    # pipelined attach: table first, records piece by piece (copies run on the library's copy stream)
+    def attach_offsets(self, res: Result, joff: torch.Tensor):
+        joff = joff.to(self.device, torch.int64).contiguous()
+        self._torch_done()
+        self.eng.attach_offsets_dev(joff.data_ptr() if joff.numel() else 0)
+
+    def attach_chunk(self, res: Result, piece: torch.Tensor, dst_off: int, total: int):
+        self._torch_done()      # the all-to-all that filled `piece` ran on torch's stream
+        self.eng.attach_junction_chunk_dev(piece.data_ptr() if piece.numel() else 0, int(piece.numel()), dst_off, total)
+
+    def attach_finish(self, res: Result) -> Result:
+        out = self.eng.attach_finish()
         out.src_rank, out.src_index = res.src_rank, res.src_index
         return out
 
@@ -203,6 +220,8 @@ class DistributedDetect:
         else:
             self.bases = np.array([index_base], np.uint64)
         self.stats = StepStats()
+        self.junction_chunks = 4        # pieces the junction records come in (each piece's host copy hides the next one's exchange)
+        self.chunk_threshold = 1 << 16  # fewer supporting reads than this: one piece
         self.profile = False            # True: synchronise after every phase and accumulate wall ms in phase_ms
         self.phase_ms = {}
         self._t = None
@@ -263,7 +282,9 @@ class DistributedDetect:
         nr = res.reads.shape[0]
         sr = res.src_rank if nr else np.zeros(0, np.uint32)
         si = res.src_index if nr else np.zeros(0, np.uint32)
-        return torch.from_numpy(sr.astype(np.int32)).to(dev), torch.from_numpy(si.astype(np.int32)).to(dev)
+        jl = res.reads["junction_len"] if nr else np.zeros(0, np.uint32)
+        return (torch.from_numpy(sr.astype(np.int32)).to(dev), torch.from_numpy(si.astype(np.int32)).to(dev),
+                torch.from_numpy(jl.astype(np.int32)).to(dev))
 
     def _render(self, got: torch.Tensor, dev):
         if hasattr(self.stage, "render_junctions_tensor"):
@@ -271,56 +292,87 @@ class DistributedDetect:
         by, off = self.stage.render_junctions(got.cpu().numpy().astype(np.uint32))
         return torch.from_numpy(by).to(dev), torch.from_numpy(off.astype(np.int64)).to(dev)
 
-    def _attach(self, res: Result, joff: torch.Tensor, jlen: torch.Tensor, text: torch.Tensor) -> Result:
-        if hasattr(self.stage, "attach_junctions"):
-            return self.stage.attach_junctions(res, joff, jlen, text)
+    def _attach_offsets(self, res: Result, joff: torch.Tensor, total: int):
+        if hasattr(self.stage, "attach_offsets"):
+            return self.stage.attach_offsets(res, joff)
         res.reads = res.reads.copy()
         res.reads["junction_off"] = joff.cpu().numpy().astype(np.uint64)
-        res.reads["junction_len"] = jlen.cpu().numpy().astype(np.uint32)
-        res.junction_bytes = text.cpu().numpy()
+        res.junction_bytes = np.zeros(total, np.uint8)
+
+    def _attach_chunk(self, res: Result, piece: torch.Tensor, dst_off: int, total: int):
+        if hasattr(self.stage, "attach_chunk"):
+            return self.stage.attach_chunk(res, piece, dst_off, total)
+        res.junction_bytes[dst_off:dst_off + int(piece.numel())] = piece.cpu().numpy()
+
+    def _attach_finish(self, res: Result) -> Result:
+        if hasattr(self.stage, "attach_finish"):
+            return self.stage.attach_finish(res)
         return res
 
     def _route_junctions(self, res: Result) -> Result:
-        """Owners request the junction strings of their surviving reads from the source ranks.  All
-        bulk data (index lists, lengths, text) stays in device tensors; only per-rank counts visit the
-        host.  Sequences and mismatch masks never leave their source rank."""
+        """Owners request the junction records of their surviving reads from the source ranks (sequences and
+        mismatch masks never leave their source rank).  All bulk data (index lists, records) stays in device
+        tensors; only per-rank counts and piece boundaries visit the host.
+
+        The owner knows every record's size (it travelled in the exchange record), so it lays out its junction
+        buffer first and sends the read table to the host at once; the records then come in K pieces --
+        piece c holds, from every source rank s, the c-th K-th of the owner's requests to s -- and each piece's
+        copy to host memory runs behind the rendering and the all-to-all of the next one."""
         W = self.world
         nccl = dist.get_backend(self.group) == "nccl"
         self._phase("route_requests")
-        src_rank, src_index = self._sources(res, self.device if nccl else torch.device("cpu"))
+        src_rank, src_index, jlen = self._sources(res, self.device if nccl else torch.device("cpu"))
         dev = src_rank.device
         nr = int(src_rank.numel())
-        order = torch.argsort(src_rank, stable=True)                # requests grouped by source rank
+        # requests grouped by source rank (one radix pass on byte keys when the ranks fit a byte)
+        order = torch.argsort(src_rank.to(torch.uint8) if W <= 256 else src_rank, stable=True)
         req_counts = torch.bincount(src_rank, minlength=W).cpu().numpy().astype(np.int64)
+        K = self.junction_chunks if nr >= self.chunk_threshold else 1
+        rb = np.concatenate([[0], np.cumsum(req_counts)]).astype(np.int64)
+        cut = np.array([[rb[s] + req_counts[s] * c // K for s in range(W)] for c in range(K + 1)], np.int64)   # (K+1, W)
+        seg_start, seg_len = cut[:-1].ravel(), (cut[1:] - cut[:-1]).ravel()      # piece (c, s) of the grouped list
+        out_start = np.cumsum(seg_len) - seg_len                                  # its place in chunk-major order
+        lens = jlen[order].to(torch.int64)
+        if K > 1:
+            shift = torch.from_numpy(seg_start - out_start).to(dev)
+            chunk_order = torch.arange(nr, device=dev) + torch.repeat_interleave(shift, torch.from_numpy(seg_len).to(dev),
+                                                                                 output_size=nr)
+            lens = lens[chunk_order]
+            place = order[chunk_order]
+        else:
+            place = order
+        csum = torch.zeros(nr + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(lens, 0, out=csum[1:])
+        joff = torch.empty(nr, dtype=torch.int64, device=dev)
+        joff[place] = csum[:-1]
+        pb = csum[torch.from_numpy(np.concatenate([out_start, [nr]])).to(dev)].cpu().numpy()   # byte bounds of the pieces
+        total = int(pb[-1])
+        self._attach_offsets(res, joff, total)                      # the read table leaves for the host now
         got_counts = self._exchange_counts(req_counts)              # how many each rank asks of me
         req = src_index[order].contiguous()
         got = torch.empty(int(got_counts.sum()), dtype=torch.int32, device=dev)
         _a2a(got, req, [int(c) for c in got_counts], [int(c) for c in req_counts], self.group)
-        # render what the others (and I) asked for, in request order
-        self._phase("render")
-        by, off = self._render(got, dev)
-        self._phase("alltoall_junctions")
-        bounds = torch.from_numpy(np.concatenate([[0], np.cumsum(got_counts)]).astype(np.int64)).to(off.device)
-        ob = off[bounds].cpu().numpy()
-        out_bytes = [int(ob[r + 1] - ob[r]) for r in range(W)]
-        # lengths are sent explicitly (4 B per read): the owner then needs no knowledge of read lengths
-        lens = (off[1:] - off[:-1]).to(torch.int32)
-        my_lens = torch.empty(nr, dtype=torch.int32, device=lens.device)
-        _a2a(my_lens, lens, [int(c) for c in req_counts], [int(c) for c in got_counts], self.group)
-        csum = torch.zeros(nr + 1, dtype=torch.int64, device=my_lens.device)
-        torch.cumsum(my_lens, 0, out=csum[1:])
-        rb = torch.from_numpy(np.concatenate([[0], np.cumsum(req_counts)]).astype(np.int64)).to(csum.device)
-        ib = csum[rb].cpu().numpy()
-        in_bytes = [int(ib[r + 1] - ib[r]) for r in range(W)]
-        mine = torch.empty(int(ib[-1]), dtype=torch.uint8, device=by.device)
-        _a2a(mine, by, in_bytes, out_bytes, self.group)
-        # back to result order
+        gb = np.concatenate([[0], np.cumsum(got_counts)]).astype(np.int64)
+        keep = []
+        for c in range(K):
+            self._phase("render")
+            lo = [int(gb[r] + got_counts[r] * c // K) for r in range(W)]
+            hi = [int(gb[r] + got_counts[r] * (c + 1) // K) for r in range(W)]
+            idx_c = got[lo[0]:hi[0]] if W == 1 else torch.cat([got[a:b] for a, b in zip(lo, hi)])
+            by, off = self._render(idx_c, dev)
+            self._phase("alltoall_junctions")
+            bounds = np.concatenate([[0], np.cumsum([b - a for a, b in zip(lo, hi)])]).astype(np.int64)
+            ob = off[torch.from_numpy(bounds).to(off.device)].cpu().numpy()
+            out_bytes = [int(ob[r + 1] - ob[r]) for r in range(W)]
+            in_bytes = [int(pb[c * W + s + 1] - pb[c * W + s]) for s in range(W)]
+            mine = torch.empty(sum(in_bytes), dtype=torch.uint8, device=by.device)
+            _a2a(mine, by[:int(ob[-1])], in_bytes, out_bytes, self.group)
+            self._attach_chunk(res, mine, int(pb[c * W]), total)
+            keep.append((mine, by))
         self._phase("attach_to_host")
-        joff = torch.empty(nr, dtype=torch.int64, device=csum.device)
-        jlen = torch.empty(nr, dtype=torch.int32, device=csum.device)
-        joff[order] = csum[:-1]
-        jlen[order] = my_lens
-        return self._attach(res, joff, jlen, mine)
+        out = self._attach_finish(res)
+        del keep
+        return out
 
     # ---- output formatting (not part of the timed path) ----
     def gather_result(self, res: Result, contig_names: Sequence[bytes]) -> Optional[Result]:

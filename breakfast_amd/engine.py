@@ -71,6 +71,8 @@ ABI_SYMBOLS = [
     "bf_exchange_local", "bf_exchange_pack", "bf_exchange_import", "bf_result_sources",
     "bf_render_junctions", "bf_result_sources_dev", "bf_render_junctions_dev", "bf_result_attach_junctions_dev",
     "bf_evidence_fetch", "bf_kernel_times", "bf_stats", "bf_junction_text", "bf_result_junction_text",
+    "bf_result_junction_sizes_dev", "bf_result_attach_offsets_dev", "bf_result_attach_junction_chunk_dev",
+    "bf_result_attach_finish", "bf_junction_record_bound",
 ]
 
 _lib = None
@@ -129,6 +131,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_evidence_fetch.argtypes = [vp, C.POINTER(BfEvidenceView)]
     lib.bf_kernel_times.argtypes = [vp, C.POINTER(C.POINTER(BfKernelTime)), C.POINTER(C.c_uint32)]
     lib.bf_stats.argtypes = [vp, u64p, u64p]
+    lib.bf_result_junction_sizes_dev.argtypes = [vp, vp]
+    lib.bf_result_attach_offsets_dev.argtypes = [vp, vp]
+    lib.bf_result_attach_junction_chunk_dev.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    lib.bf_result_attach_finish.argtypes = [vp, C.POINTER(BfResult)]
+    lib.bf_junction_record_bound.argtypes = [vp]
+    lib.bf_junction_record_bound.restype = C.c_uint64
     lib.bf_junction_text.argtypes = [vp, C.c_uint64, vp, C.c_uint64]
     lib.bf_junction_text.restype = C.c_int64
     lib.bf_result_junction_text.argtypes = [C.POINTER(BfResult), vp, C.c_uint64, vp]
@@ -440,6 +448,24 @@ class Engine:
                                                             C.c_void_p(dev_bytes or None), size, C.byref(r)))
         self._last = r
         return self._wrap(r, copy)
+
+    def result_junction_sizes_dev(self, dev_len: int) -> None:
+        self._check(self.lib.bf_result_junction_sizes_dev(self.h, C.c_void_p(dev_len or None)))
+
+    def attach_offsets_dev(self, dev_joff: int) -> None:
+        self._check(self.lib.bf_result_attach_offsets_dev(self.h, C.c_void_p(dev_joff or None)))
+
+    def attach_junction_chunk_dev(self, dev_bytes: int, size: int, dst_off: int, total_size: int) -> None:
+        self._check(self.lib.bf_result_attach_junction_chunk_dev(self.h, C.c_void_p(dev_bytes or None), size, dst_off, total_size))
+
+    def attach_finish(self, copy: bool = False) -> Result:
+        r = BfResult()
+        self._check(self.lib.bf_result_attach_finish(self.h, C.byref(r)))
+        self._last = r
+        return self._wrap(r, copy)
+
+    def junction_record_bound(self) -> int:
+        return int(self.lib.bf_junction_record_bound(self.h))
 
     # -- introspection --
     def evidence(self) -> Dict[str, np.ndarray]:

@@ -257,6 +257,26 @@ int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_i
 int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const uint32_t* dev_jlen,
                                    const uint8_t* dev_bytes, uint64_t size, bf_result* out);
 
+/* Pipelined form of bf_result_attach_junctions_dev (same state requirements, same finished result).  The
+ * exchange carries every read's junction record size, so an owner rank can lay out its junction buffer
+ * before any record has arrived:
+ *   bf_result_junction_sizes_dev   record bytes of the result.n_reads supporting reads -> dev_len[n_reads]
+ *   bf_result_attach_offsets_dev   sets reads[i].junction_off = dev_joff[i] and starts the copy of the read
+ *                                  table to pinned host memory on the ctx's copy stream
+ *   bf_result_attach_junction_chunk_dev   queues bytes [dst_off, dst_off+size) of the total_size-byte junction
+ *                                  buffer for the host (same copy stream; returns at once; the caller keeps
+ *                                  dev_bytes alive until bf_result_attach_finish)
+ *   bf_result_attach_finish        waits for the copies and fills *out
+ * so that table and record copies overlap the caller's remaining collectives.  No counterpart in the
+ * reference (one process). */
+int bf_result_junction_sizes_dev(bf_ctx* ctx, uint32_t* dev_len);
+int bf_result_attach_offsets_dev(bf_ctx* ctx, const uint64_t* dev_joff);
+int bf_result_attach_junction_chunk_dev(bf_ctx* ctx, const uint8_t* dev_bytes, uint64_t size, uint64_t dst_off,
+                                        uint64_t total_size);
+int bf_result_attach_finish(bf_ctx* ctx, bf_result* out);
+/* Upper bound of a resident read's junction record in bytes (sizing of bf_render_junctions_dev buffers). */
+uint64_t bf_junction_record_bound(const bf_ctx* ctx);
+
 /* ---- introspection (tests, bench) ---------------------------------------------------------- */
 
 /* Per-read evidence in input order (needs BF_FLAG_KEEP_EVIDENCE): arrays of n entries each, any

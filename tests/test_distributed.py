@@ -72,7 +72,8 @@ class OracleStage:
             cl[k]["contig"] = cid[seed.chr]; cl[k]["mcontig"] = cid[seed.mchr]
             cl[k]["strand"] = seed.strand; cl[k]["mstrand"] = seed.mstrand
             for m in members:
-                reads.append((m.read_num, 0, 0, m.bp, m.swapped, 0))
+                # the record size travels with the exchange record: a text record here (no packed renderer)
+                reads.append((m.read_num, 0, (6 + len(m.sequence) + 3) & ~3, m.bp, m.swapped, 0))
                 r = int(np.searchsorted(self.bases, m.read_num, side="right") - 1)
                 src_rank.append(r); src_index.append(m.read_num - int(self.bases[r]))
         rd = np.array(reads, READ_DTYPE) if reads else np.zeros(0, READ_DTYPE)
@@ -94,7 +95,7 @@ def make_case(seed=0):
     return g, synth.make_reads(g, spec), 20, 5000, 2
 
 
-def _worker(rank, world, port, out_path, uneven):
+def _worker(rank, world, port, out_path, uneven, chunks):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -107,6 +108,7 @@ def _worker(rank, world, port, out_path, uneven):
         lo, hi = cuts[rank], cuts[rank + 1]
         stage = OracleStage(g.as_dict(), g.names, b, lo, hi, A, F, E)
         dd = DistributedDetect(stage, rank, world, lo, hi - lo, torch.device("cpu"))
+        dd.junction_chunks, dd.chunk_threshold = chunks, 0
         res = dd.step()
         merged = dd.gather_result(res, g.names)
         if rank == 0:
@@ -119,13 +121,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("world,uneven", [(2, False), (2, True), (3, False)])
-def test_sharded_detect_matches_single_process(tmp_path, world, uneven):
+@pytest.mark.parametrize("world,uneven,chunks", [(2, False, 1), (2, True, 3), (3, False, 4), (2, False, 1000)])
+def test_sharded_detect_matches_single_process(tmp_path, world, uneven, chunks):
     g, b, A, F, E = make_case()
     expected = po.detect(g.fasta(), synth.bowtie_lines(b, g.names).split(b"\n")[:-1], A, F, E)
     assert expected.count(b"\n") > 5
     out = str(tmp_path / "out.sv")
-    mp.spawn(_worker, args=(world, _free_port(), out, uneven), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, uneven, chunks), nprocs=world, join=True)
     assert open(out, "rb").read() == expected
 
 

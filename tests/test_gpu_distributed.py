@@ -39,6 +39,7 @@ def _worker(rank, world, port, out_path, flags=0):
         eng.set_rank(rank, world, lo)
         eng.submit(b.slice(lo, hi))
         dd = DistributedDetect(HipStageEngine(eng, dev), rank, world, lo, hi - lo, dev)
+        dd.junction_chunks, dd.chunk_threshold = 3, 0       # junction records in three pieces even at this size
         for _ in range(2):                      # the step must be repeatable on resident reads
             res = dd.step()
         merged = dd.gather_result(res, g.names)
