@@ -248,7 +248,14 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v);   // fills ctx->out (without j
 int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint64_t dev_send_bytes, uint64_t* counts,
                   void** dev_out, uint32_t* record_bytes);
 int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts);
+// primitives.hip -------------------------------------------------------------------------------
+// stable LSD radix sort of (key, value) pairs on key bits [begin_bit, end_bit); result in kout/vout, inputs kept
+int radix_sort_pairs(bf_ctx* ctx, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n,
+                     unsigned begin_bit, unsigned end_bit);
+int radix_sort_pairs(bf_ctx* ctx, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n,
+                     unsigned begin_bit, unsigned end_bit);
 int scan_u32_to_u64(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n);  // exclusive, out has n+1
+int scan_max_u32_inplace(bf_ctx* ctx, uint32_t* data, uint64_t n);                // running maximum
 int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
 int patch_reads_len(bf_ctx* ctx, const uint64_t* d_joff, const uint32_t* d_jlen, uint64_t n);
 int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);

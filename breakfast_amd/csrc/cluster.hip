@@ -17,37 +17,17 @@
 
 #include "bf_internal.h"
 
-#include <rocprim/rocprim.hpp>
-
 namespace bf {
 
 constexpr uint32_t kNone = 0xffffffffu;
 
 static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
-// ---- rocPRIM wrappers --------------------------------------------------------------------------
+// stable LSD radix sort and the scans: primitives.hip
 template <class K>
 static int sort_pairs(bf_ctx* ctx, const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, uint64_t n,
                       unsigned begin_bit, unsigned end_bit) {
-    size_t bytes = 0;
-    BF_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, ctx->stream));
-    BF_TRY(ensure(ctx, ctx->c_tmp, bytes ? bytes : 1, false));
-    BF_HIP(ctx, rocprim::radix_sort_pairs(ctx->c_tmp.p, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, ctx->stream));
-    return BF_OK;
-}
-
-struct WidenU32 { __host__ __device__ uint64_t operator()(uint32_t x) const { return x; } };
-
-// exclusive scan with total: out[0] = 0, out[i+1] = in[0] + ... + in[i]
-int scan_u32_to_u64(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n) {
-    BF_HIP(ctx, hipMemsetAsync(out, 0, 8, ctx->stream));
-    if (n == 0) return BF_OK;
-    auto it = rocprim::make_transform_iterator(in, WidenU32());
-    size_t bytes = 0;
-    BF_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes, it, out + 1, n, rocprim::plus<uint64_t>(), ctx->stream));
-    BF_TRY(ensure(ctx, ctx->c_tmp, bytes ? bytes : 1, false));
-    BF_HIP(ctx, rocprim::inclusive_scan(ctx->c_tmp.p, bytes, it, out + 1, n, rocprim::plus<uint64_t>(), ctx->stream));
-    return BF_OK;
+    return radix_sort_pairs(ctx, kin, kout, vin, vout, n, begin_bit, end_bit);
 }
 
 static int fetch_u64(bf_ctx* ctx, const uint64_t* d, uint64_t* h) {
@@ -475,12 +455,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
         uint32_t* head = ctx->c_flag.as<uint32_t>();          // reused for the min_evidence flags below
         uint32_t* covered = ctx->c_b32.as<uint32_t>();        // free since the sort
         hipLaunchKernelGGL(head_mark_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, sv.skey, head, n);
-        {
-            size_t bytes = 0;
-            BF_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes, head, head, n, rocprim::maximum<uint32_t>(), st));
-            BF_TRY(ensure(ctx, ctx->c_tmp, bytes ? bytes : 1, false));
-            BF_HIP(ctx, rocprim::inclusive_scan(ctx->c_tmp.p, bytes, head, head, n, rocprim::maximum<uint32_t>(), st));
-        }
+        BF_TRY(scan_max_u32_inplace(ctx, head, n));
         hipLaunchKernelGGL(covered_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, sv, head, covered);
         BF_TRY(scan_u32_to_u64(ctx, covered, ctx->c_scan.as<uint64_t>(), n));
         hipLaunchKernelGGL(tails_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, sv, head, ctx->c_scan.as<uint64_t>(),
@@ -558,7 +533,11 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
         BF_TRY(ensure(ctx, ctx->c_b32, std::max(n, ns) * 4, false)); BF_TRY(ensure(ctx, ctx->c_c32, std::max(n, ns) * 4, false));
         uint32_t* va = ctx->c_b32.as<uint32_t>(); uint32_t* vb = ctx->c_c32.as<uint32_t>();
         hipLaunchKernelGGL(iota_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, va, ns);
-        BF_TRY(sort_pairs<uint64_t>(ctx, kidx, kidx2, va, vb, ns, 0, 64));
+        // significant bits of (source rank << 32 | source index): on one rank the index alone, below n
+        unsigned idx_bits = 64;
+        if (!v.src_rank) { idx_bits = 1; while (idx_bits < 32 && (1ull << idx_bits) < n) idx_bits++; }
+        else { unsigned rb = 1; while ((1u << rb) < ctx->n_ranks) rb++; idx_bits = 32 + rb; }
+        BF_TRY(sort_pairs<uint64_t>(ctx, kidx, kidx2, va, vb, ns, 0, idx_bits));
         hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, kpos2, kpos, vb, ns);
         BF_TRY(sort_pairs<uint64_t>(ctx, kpos2, kidx2, vb, va, ns, 0, 32 + ctx->contig_bits));
         // ord[k] = sel[va[k]]; nrep in output order -> read offsets
