@@ -167,26 +167,41 @@ int64_t junction_decode(const uint8_t* rec, uint64_t rec_len, uint8_t* out, uint
         return (int64_t)text;
     }
     const uint32_t groups = (L + 31) >> 5;
-    if (rec_len < 8 + 12ull * groups + 4ull * nx) return -1;
+    if (rec_len < 8) return -1;
+    uint16_t form;
+    memcpy(&form, rec + 6, 2);
+    const bool sparse = (form & kJunctionSparse) != 0;
+    const uint32_t n_lower = sparse ? (form & 0x7fffu) : 0u, gb = sparse ? 8u : 12u;
+    if (!sparse && form != 0) return -1;
+    if (rec_len < 8 + (uint64_t)gb * groups + 4ull * nx + 2ull * n_lower) return -1;
     const uint8_t* g = rec + 8;
+    const uint8_t* xe = g + (uint64_t)gb * groups;           // exception entries
+    const uint8_t* pl = xe + 4ull * nx;                      // lower-case positions (sparse form)
     for (uint32_t e = 0; e < nx; e++) {                      // validated in the size query too
-        uint16_t k; memcpy(&k, g + 12ull * groups + 4 * e, 2);
+        uint16_t k; memcpy(&k, xe + 4 * e, 2);
+        if (k >= L) return -1;
+    }
+    for (uint32_t e = 0; e < n_lower; e++) {
+        uint16_t k; memcpy(&k, pl + 2 * e, 2);
         if (k >= L) return -1;
     }
     if (!out || cap < text) return (int64_t)text;
     const uint64_t* S = spread_table();
     uint8_t* dst = out + 1;                                  // bases land one to the right; the left part moves down below
     for (uint32_t k = 0; k < L; k += 8) {
-        const uint8_t* grp = g + 12 * (k >> 5);
+        const uint8_t* grp = g + gb * (k >> 5);
         const uint32_t b = (k >> 3) & 3;
-        const uint8_t lo = grp[b], hi = grp[4 + b], cs = grp[8 + b];
+        const uint8_t lo = grp[b], hi = grp[4 + b], cs = sparse ? 0 : grp[8 + b];
         // 'A' + 2*lo + 0x13*hi - 0x0f*(lo&hi) = A C T G for codes 0..3; + 0x20 = lower case
         const uint64_t v = 0x4141414141414141ull + 2 * S[lo] + 0x13 * S[hi] - 0x0f * S[lo & hi] + 0x20 * S[cs];
         const uint32_t take = L - k < 8 ? L - k : 8;
         memcpy(dst + k, &v, take);
     }
-    const uint8_t* xe = g + 12ull * groups;
-    for (uint32_t e = 0; e < nx; e++) {
+    for (uint32_t e = 0; e < n_lower; e++) {                 // plain ACGT bases: lower case is + 0x20
+        uint16_t k; memcpy(&k, pl + 2 * e, 2);
+        dst[k] |= 0x20;
+    }
+    for (uint32_t e = 0; e < nx; e++) {                      // exceptions are stored as printed
         uint16_t k; memcpy(&k, xe + 4 * e, 2);
         dst[k] = xe[4 * e + 2];
     }

@@ -65,8 +65,29 @@ constexpr uint32_t kJunctionText = 0xffffu;
 __host__ __device__ inline bool junction_packable(uint32_t L, uint32_t n_exc, uint32_t max_packed) {
     return L <= max_packed && 8u * n_exc <= L;
 }
-__host__ __device__ inline uint32_t junction_record_bytes(uint32_t L, uint32_t n_exc, uint32_t max_packed) {
-    return junction_packable(L, n_exc, max_packed) ? 8u + 12u * ((L + 31u) >> 5) + 4u * n_exc : (6u + L + 1u + 3u) & ~3u;
+// Packed records come in two forms: with a lower-case (mismatch) bit per base, or -- most reads differ from
+// their flanks in a base or two -- with the lower-case positions listed after the two code planes.
+constexpr uint32_t kJunctionSparse = 0x8000u;        // flag in the header's fourth u16; its low 15 bits = listed positions
+__host__ __device__ inline bool junction_sparse(uint32_t L, uint32_t n_lower) {
+    return n_lower < 0x8000u && ((2u * n_lower + 3u) & ~3u) < 4u * ((L + 31u) >> 5);
+}
+__host__ __device__ inline uint32_t junction_record_bytes(uint32_t L, uint32_t n_exc, uint32_t n_lower, uint32_t max_packed) {
+    if (!junction_packable(L, n_exc, max_packed)) return (6u + L + 1u + 3u) & ~3u;
+    const uint32_t g = (L + 31u) >> 5;
+    return junction_sparse(L, n_lower) ? 8u + 8u * g + 4u * n_exc + ((2u * n_lower + 3u) & ~3u) : 8u + 12u * g + 4u * n_exc;
+}
+// from a render record: mask words + {bp, flags, len, n_exc}
+__host__ __device__ inline uint32_t junction_record_bytes_of(const uint64_t* rec, int stride, uint32_t max_packed) {
+    const uint64_t tail = rec[stride - 1];
+    uint32_t n_lower = 0;
+    for (int w = 0; w < stride - 1; w++) {
+#ifdef __HIP_DEVICE_COMPILE__
+        n_lower += (uint32_t)__popcll(rec[w]);
+#else
+        n_lower += (uint32_t)__builtin_popcountll(rec[w]);
+#endif
+    }
+    return junction_record_bytes((uint32_t)((tail >> 32) & 0xffff), (uint32_t)(tail >> 48), n_lower, max_packed);
 }
 
 // ---- wire record of the multi-GPU exchange ---------------------------------------------------

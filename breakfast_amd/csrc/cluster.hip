@@ -612,8 +612,7 @@ struct PackView {
     uint8_t* out;
 };
 __device__ __forceinline__ uint32_t pack_jrec(const PackView& v, uint32_t i) {
-    const uint64_t tail = v.meta[(uint64_t)i * v.meta_stride + v.meta_stride - 1];
-    return junction_record_bytes((uint32_t)((tail >> 32) & 0xffff), (uint32_t)(tail >> 48), v.max_packed);
+    return junction_record_bytes_of(v.meta + (uint64_t)i * v.meta_stride, v.meta_stride, v.max_packed);
 }
 __global__ void __launch_bounds__(256) pack_kernel(const PackView v) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -764,14 +764,11 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
 // ---------------------------------------------------------------------------------------------
 // Junction records of surviving reads (format: include/breakfast_hip.h, "Junction records").
 // Record sizes from the render records' last word {bp, flags, len, n_exc}.
-__device__ __forceinline__ uint32_t record_bytes_of(uint64_t tail, uint32_t max_packed) {
-    return junction_record_bytes((uint32_t)((tail >> 32) & 0xffff), (uint32_t)(tail >> 48), max_packed);
-}
 __global__ void __launch_bounds__(256) render_len_kernel(uint64_t n, const uint32_t* __restrict__ idx,
                                                          const uint64_t* __restrict__ meta, int meta_stride,
                                                          uint32_t max_packed, uint32_t* __restrict__ out_len) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out_len[i] = record_bytes_of(meta[(uint64_t)idx[i] * meta_stride + meta_stride - 1], max_packed);
+    if (i < n) out_len[i] = junction_record_bytes_of(meta + (uint64_t)idx[i] * meta_stride, meta_stride, max_packed);
 }
 
 // lengths for a caller-supplied (device) index list: an index outside the resident reads is counted,
@@ -784,7 +781,7 @@ __global__ void __launch_bounds__(256) render_len_checked_kernel(uint64_t n, con
     if (i >= n) return;
     const uint32_t r = idx[i];
     if (r >= n_reads) { out_len[i] = 0; atomicAdd(bad, 1u); return; }
-    out_len[i] = record_bytes_of(meta[(uint64_t)r * meta_stride + meta_stride - 1], max_packed);
+    out_len[i] = junction_record_bytes_of(meta + (uint64_t)r * meta_stride, meta_stride, max_packed);
 }
 
 // render: 16 lanes per surviving read, 4 reads per wave, 16 reads per block.  The junction string is
@@ -884,10 +881,12 @@ render_kernel(uint64_t n, const uint32_t* __restrict__ idx,
 // bases outside ACGT).  The lane re-encodes its read from the ASCII bases exactly as the localise kernel did
 // (same function, so the exception count in the render record is the one found here), re-orients it when the
 // read was reverse-complemented (detect.rs:112), and writes
-//   {u16 len, u16 bp, u16 n_exc, u16 0}, then per 32 bases {u32 lo, u32 hi, u32 lower-case},
+//   {u16 len, u16 bp, u16 n_exc, u16 form}, then per 32 bases {u32 lo, u32 hi, u32 lower-case},
 //   then n_exc x {u16 position, u8 printed byte, u8 0}
-// -- 68 bytes for a 150-base read against 151 bytes of text: the result copy to the host is the longest
-// stage of a step, and the .sv formatter expands records at memcpy speed.
+// or, when the lower-case bases are few (form = 0x8000 | their number): per 32 bases {u32 lo, u32 hi}, the
+// exception entries, then the lower-case positions as u16 (padded to 4 bytes)
+// -- 52 bytes for a 150-base read with one mismatch against 151 bytes of text: the result copy to the host
+// is the longest stage of a step, and the .sv formatter expands records at memcpy speed.
 template <int W>
 __global__ void __launch_bounds__(256) render_packed_kernel(uint64_t n, const uint32_t* __restrict__ idx,
                                                             const uint64_t* __restrict__ joff,
@@ -914,20 +913,40 @@ __global__ void __launch_bounds__(256) render_packed_kernel(uint64_t n, const ui
 #pragma unroll
         for (int w = 0; w < W; w++) hi[w] ^= low_mask(min(max(L - 64 * w, 0), 64));
     }
+    uint32_t n_lower = 0;
+#pragma unroll
+    for (int w = 0; w < W; w++) n_lower += (uint32_t)__popcll(cs[w]);
+    const bool sparse = junction_sparse((uint32_t)L, n_lower);
+    const int per_group = sparse ? 2 : 3;
     uint32_t* __restrict__ o32 = (uint32_t*)(out + joff[i]);
     o32[0] = (uint32_t)L | ((uint32_t)bp << 16);
-    o32[1] = n_exc;
+    o32[1] = n_exc | (sparse ? (kJunctionSparse | n_lower) << 16 : 0u);
 #pragma unroll
     for (int g = 0; g < 2 * W; g++) {
         if (32 * g < L) {
             const int sh = 32 * (g & 1);
-            o32[2 + 3 * g] = (uint32_t)(lo[g >> 1] >> sh);
-            o32[3 + 3 * g] = (uint32_t)(hi[g >> 1] >> sh);
-            o32[4 + 3 * g] = (uint32_t)(cs[g >> 1] >> sh);
+            o32[2 + per_group * g] = (uint32_t)(lo[g >> 1] >> sh);
+            o32[3 + per_group * g] = (uint32_t)(hi[g >> 1] >> sh);
+            if (!sparse) o32[4 + 3 * g] = (uint32_t)(cs[g >> 1] >> sh);
         }
     }
+    uint32_t* __restrict__ xo = o32 + 2 + per_group * ((L + 31) >> 5);
+    if (sparse && n_lower) {                                             // lower-case positions, two per dword
+        uint32_t* __restrict__ po = xo + n_exc;
+        uint32_t pend = 0, cnt = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            uint64_t m = cs[w];
+            while (m) {
+                const uint32_t k = 64u * w + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                if (cnt & 1) po[cnt >> 1] = pend | (k << 16); else pend = k;
+                cnt++;
+            }
+        }
+        if (cnt & 1) po[cnt >> 1] = pend;
+    }
     if (n_exc) {                                                         // rare: N and other IUPAC letters, as printed
-        uint32_t* __restrict__ xo = o32 + 2 + 3 * ((L + 31) >> 5);
         uint32_t e = 0;
 #pragma unroll
         for (int w = 0; w < W; w++) {

@@ -109,13 +109,18 @@ typedef struct {
  *     u16 n_exc    number of exception entries, or 0xFFFF = text record
  *   text record (reads longer than the packed kernel's 256 bases, or with many bases outside ACGT):
  *     L+1 bytes    the string itself, then zero padding to a multiple of 4 bytes
- *   packed record:
+ *   packed record, dense form:
  *     u16 0
  *     ceil(L/32) x { u32 lo, u32 hi, u32 lower }   bit j of group g = base k = 32g+j of the printed sequence:
  *                  letter "ACTG"[lo + 2*hi], printed in lower case when `lower` is set
  *     n_exc x { u16 k, u8 byte, u8 0 }             base k prints as `byte` (N and other IUPAC letters)
+ *   packed record, sparse form (few mismatches, the usual case):
+ *     u16 0x8000 | n_lower
+ *     ceil(L/32) x { u32 lo, u32 hi }
+ *     n_exc x { u16 k, u8 byte, u8 0 }
+ *     n_lower x u16 k                               base k prints in lower case; zero padding to 4 bytes
  * bf_junction_text() expands one record, bf_result_junction_text() all records of a result, and
- * bf_format_sv() expands them while it prints.  68 bytes instead of 151 for a 150-base read. */
+ * bf_format_sv() expands them while it prints.  52 bytes instead of 151 for a 150-base read with one mismatch. */
 
 /* One supporting read that survived frag-id dedup (detect.rs:247-287), in printed order. */
 typedef struct {

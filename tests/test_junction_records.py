@@ -9,27 +9,33 @@ from breakfast_amd import engine
 CODE = {ord("A"): 0, ord("C"): 1, ord("T"): 2, ord("G"): 3}
 
 
-def pack(junction: bytes) -> bytes:
-    """Reference packer: the record the GPU writes for this string."""
+def pack(junction: bytes, form: str = "auto") -> bytes:
+    """Reference packer: the record the GPU writes for this string (form "auto"), or a given packed form."""
     bp = junction.index(b"|")
     seq = junction[:bp] + junction[bp + 1:]
     L = len(seq)
     groups = (L + 31) // 32
     lo, hi, cs = [0] * groups, [0] * groups, [0] * groups
-    exc = []
+    exc, lower = [], []
     for k, c in enumerate(seq):
         up = c - 32 if 97 <= c <= 122 else c
         if up in CODE:
             lo[k >> 5] |= (CODE[up] & 1) << (k & 31)
             hi[k >> 5] |= (CODE[up] >> 1) << (k & 31)
-            cs[k >> 5] |= (1 if c != up else 0) << (k & 31)
+            if c != up:
+                cs[k >> 5] |= 1 << (k & 31)
+                lower.append(k)
         else:
             exc.append((k, c))
-    out = np.array([L, bp, len(exc), 0], "<u2").tobytes()
+    sparse = ((2 * len(lower) + 3) & ~3) < 4 * groups if form == "auto" else form == "sparse"
+    out = np.array([L, bp, len(exc), (0x8000 | len(lower)) if sparse else 0], "<u2").tobytes()
     for g in range(groups):
-        out += np.array([lo[g], hi[g], cs[g]], "<u4").tobytes()
+        out += np.array([lo[g], hi[g]] + ([] if sparse else [cs[g]]), "<u4").tobytes()
     for k, c in exc:
         out += np.array([k], "<u2").tobytes() + bytes([c, 0])
+    if sparse:
+        out += np.array(lower, "<u2").tobytes()
+        out += b"\0" * (-len(out) % 4)
     return out
 
 
@@ -55,6 +61,8 @@ def test_packed_records_expand_to_the_string(L):
         for _ in range(20):
             j = random_junction(rng, L, n_exc)
             assert engine.junction_text(pack(j)) == j
+            assert engine.junction_text(pack(j, "dense")) == j
+            assert engine.junction_text(pack(j, "sparse")) == j
             assert engine.junction_text(text_record(j)) == j
 
 
@@ -63,13 +71,17 @@ def test_breakpoint_at_either_end_and_known_answer():
     assert engine.junction_text(pack(b"ACGT|")) == b"ACGT|"
     # the survey's known-answer read 1
     j = b"AGTTATCGGTGCCG|AAcTGATGGA"
-    rec = pack(j)
-    assert len(rec) == 8 + 12 and engine.junction_text(rec) == j
+    rec = pack(j)                                   # one mismatch: sparse form, 8 + 8 + 4 bytes
+    assert len(rec) == 20 and engine.junction_text(rec) == j
+    assert len(pack(j, "dense")) == 20
 
 
 def test_malformed_records_are_rejected():
-    good = pack(b"ACGTACGTAC|GTNACGTACGT")
-    for bad in (b"", good[:5], good[:12], good[:-1],
+    good = pack(b"ACGTACGTAC|GTNACGTACGT", "dense")
+    sparse = pack(b"ACGTACgTAC|GTNACGTACGT", "sparse")
+    for bad in (b"", good[:5], good[:12], good[:-1], sparse[:-4],
+                sparse[:-4] + np.array([99, 0], "<u2").tobytes(),                  # lower-case position past the end
+                good[:6] + b"\x01\x00" + good[8:],                               # unknown form
                 np.array([4, 9, 0, 0], "<u2").tobytes() + b"\0" * 12,            # bp > len
                 np.array([4, 1, 1, 0], "<u2").tobytes() + b"\0" * 12 + np.array([7], "<u2").tobytes() + b"N\0",   # exception past the end
                 np.array([10, 1, 0xffff], "<u2").tobytes() + b"A|CG"):            # text shorter than len+1
