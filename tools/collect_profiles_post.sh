@@ -1,0 +1,10 @@
+#!/bin/bash
+# gpurun_out/<tag>/ (made by tools/collect_profiles.sh) -> profiles/<tag>_*
+set -eu
+tag=$1
+src=gpurun_out/$tag
+for f in $src/bench_*.json; do cp $f profiles/${tag}_$(basename $f); done
+python tools/kernel_stats_md.py $src/trace profiles/${tag}_kernel_stats_cfg1_10M.md "rocprofv3 --kernel-trace --stats ($tag)" \
+  "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --cpu-sample 0"
+python tools/pmc_traffic.py $src/pmc_fetch $src/pmc_write profiles/${tag}_pmc_traffic.json \
+  "config=1 reads=10000000 len=150 variant=fused (bench.py --steps 2 --warmup 1), $tag"
