@@ -103,6 +103,7 @@ static OwnerView local_view(bf_ctx* ctx) {
     v.flags = ctx->d_flags.as<uint16_t>();
     v.frag = ctx->d_frag.as<uint8_t>(); v.frag_off = ctx->d_frag_off.as<uint64_t>(); v.frag_len = ctx->d_frag_len.as<uint16_t>();
     v.sigx = ctx->d_sigx.as<uint8_t>(); v.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
+    v.info = ctx->d_jrec.as<uint64_t>();
     return v;
 }
 static OwnerView imported_view(bf_ctx* ctx) {
@@ -114,14 +115,14 @@ static OwnerView imported_view(bf_ctx* ctx) {
     v.frag = ctx->i_frag.as<uint8_t>(); v.frag_off = ctx->i_frag_off.as<uint64_t>(); v.frag_len = ctx->i_frag_len.as<uint16_t>();
     v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
     v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>();
-    v.jrec = ctx->i_jrec.as<uint32_t>();
+    v.info = ctx->i_jrec.as<uint64_t>();
     return v;
 }
 
 static void free_all(bf_ctx* ctx) {
     DevBuf* all[] = {&ctx->g_blocks, &ctx->g_exc, &ctx->g_raw, &ctx->g_coarse, &ctx->g_coarse2, &ctx->g_contigs, &ctx->d_seq, &ctx->d_seq_off,
         &ctx->d_frag, &ctx->d_frag_off, &ctx->d_hits, &ctx->d_planes, &ctx->d_len, &ctx->d_frag_len, &ctx->d_fhash,
-        &ctx->d_key, &ctx->d_lpos, &ctx->d_rpos, &ctx->d_bp, &ctx->d_flags, &ctx->d_mask, &ctx->d_exact_list,
+        &ctx->d_key, &ctx->d_lpos, &ctx->d_rpos, &ctx->d_bp, &ctx->d_flags, &ctx->d_mask, &ctx->d_jrec, &ctx->d_exact_list,
         &ctx->d_counters, &ctx->d_sigx, &ctx->d_sigx_slot, &ctx->d_send, &ctx->d_part_key, &ctx->d_part_idx,
         &ctx->d_part_tmp, &ctx->i_key, &ctx->i_lpos, &ctx->i_rpos, &ctx->i_fhash, &ctx->i_bp, &ctx->i_len, &ctx->i_flags,
         &ctx->i_frag, &ctx->i_frag_off, &ctx->i_frag_len, &ctx->i_sigx, &ctx->i_sigx_slot, &ctx->i_src_rank,
@@ -421,7 +422,8 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
             constexpr int kMaxChunks = 8;
             const int nc = nr >= (1u << 16) ? kMaxChunks : 1;
             uint64_t off[kMaxChunks + 1];
-            BF_TRY(render_prepare(ctx, nr, d_idx, ctx->c_joff, nc, off));
+            // emit left every supporting read's record size next to the index lists
+            BF_TRY(render_prepare(ctx, nr, d_idx, ctx->c_joff, nc, off, ctx->c_rsrc.as<uint32_t>() + 3 * nr));
             const uint64_t total = off[nc];
             BF_TRY(patch_reads(ctx, ctx->c_joff.as<uint64_t>(), nr));
             BF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));

@@ -76,19 +76,16 @@ __host__ __device__ inline uint32_t junction_record_bytes(uint32_t L, uint32_t n
     const uint32_t g = (L + 31u) >> 5;
     return junction_sparse(L, n_lower) ? 8u + 8u * g + 4u * n_exc + ((2u * n_lower + 3u) & ~3u) : 8u + 12u * g + 4u * n_exc;
 }
-// from a render record: mask words + {bp, flags, len, n_exc}
-__host__ __device__ inline uint32_t junction_record_bytes_of(const uint64_t* rec, int stride, uint32_t max_packed) {
-    const uint64_t tail = rec[stride - 1];
-    uint32_t n_lower = 0;
-    for (int w = 0; w < stride - 1; w++) {
-#ifdef __HIP_DEVICE_COMPILE__
-        n_lower += (uint32_t)__popcll(rec[w]);
-#else
-        n_lower += (uint32_t)__builtin_popcountll(rec[w]);
-#endif
-    }
-    return junction_record_bytes((uint32_t)((tail >> 32) & 0xffff), (uint32_t)(tail >> 48), n_lower, max_packed);
+// What the cluster stage gathers per evidence record by sort permutation, in one 8-byte word instead of four
+// arrays (a random gather costs a whole line whatever it uses): junction record bytes (20 bits), evidence
+// flags (5 bits), breakpoint offset and read length.
+__host__ __device__ inline uint64_t read_info(uint32_t jrec, uint32_t flags, uint32_t bp, uint32_t len) {
+    return (uint64_t)(jrec & 0xfffffu) | ((uint64_t)(flags & 0x1fu) << 20) | ((uint64_t)(bp & 0xffffu) << 32) | ((uint64_t)(len & 0xffffu) << 48);
 }
+__host__ __device__ inline uint32_t info_jrec(uint64_t i) { return (uint32_t)i & 0xfffffu; }
+__host__ __device__ inline uint32_t info_flags(uint64_t i) { return (uint32_t)(i >> 20) & 0x1fu; }
+__host__ __device__ inline uint32_t info_bp(uint64_t i) { return (uint32_t)(i >> 32) & 0xffffu; }
+__host__ __device__ inline uint32_t info_len(uint64_t i) { return (uint32_t)(i >> 48); }
 
 // ---- wire record of the multi-GPU exchange ---------------------------------------------------
 struct WireHeader {     // 40 B, followed by frag bytes (fixed stride) and optionally 16 raw sig bytes
@@ -129,7 +126,7 @@ struct OwnerView {
     const uint32_t* sigx_slot = nullptr; // record -> slot (only read when the key's sigx bit is set)
     const uint32_t* src_rank = nullptr;  // nullptr = all from this rank
     const uint32_t* src_idx = nullptr;   // nullptr = identity
-    const uint32_t* jrec = nullptr;      // junction record bytes per record (imported views only)
+    const uint64_t* info = nullptr;      // per record, ONE word for the gathers of dedup and emit: read_info()
 };
 
 struct HostBuf {                         // pinned host staging (hipHostMalloc): full-rate D2H copies
@@ -187,7 +184,7 @@ struct bf_ctx {
     uint64_t n_sigx = 0;                        // evidence whose signature holds a non-ACGT byte
     uint64_t n_text_records = 0;                // resident reads whose junction record cannot be packed
     bf::DevBuf d_planes, d_len, d_frag_len, d_fhash;
-    bf::DevBuf d_key, d_lpos, d_rpos, d_bp, d_flags, d_mask;
+    bf::DevBuf d_key, d_lpos, d_rpos, d_bp, d_flags, d_mask, d_jrec;   // d_jrec: read_info() words
     bf::DevBuf d_exact_list, d_counters, d_sigx, d_sigx_slot;
 
     // multi-rank
@@ -255,7 +252,8 @@ struct Scope {
 // localise.hip ----------------------------------------------------------------------------------
 int genome_pack(bf_ctx* ctx);                       // raw image -> blocks + coarse bitmap
 int run_localise(bf_ctx* ctx);                      // encode + hash + fast + exact kernels
-int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, int n_chunks, uint64_t* chunk_off);
+int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, int n_chunks, uint64_t* chunk_off,
+                   const uint32_t* d_sizes = nullptr);   // d_sizes: record bytes per list entry when the caller has them
 int64_t junction_decode(const uint8_t* rec, uint64_t rec_len, uint8_t* out, uint64_t cap);   // api.hip, host
 int render_range(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const DevBuf& d_off, DevBuf& d_bytes);
 int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, DevBuf& d_bytes,

@@ -224,7 +224,7 @@ struct MemberView {
     uint32_t* members;      // sorted positions
     uint64_t* mkey;         // (cluster number << kMemberHashBits) | low bits of the fragment-id hash, per member slot
     uint32_t* mscore;       // longest-flank score per member slot (detect.rs:273-279)
-    const uint64_t* fhash; const uint16_t* bp; const uint16_t* len;
+    const uint64_t* fhash; const uint64_t* info;
 };
 
 // One wave per qualifying cluster: re-enumerate the seed's members in sweep order.
@@ -240,7 +240,8 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
         const uint32_t rec = v.perm[spos];
         m.members[slot] = (uint32_t)spos;
         m.mkey[slot] = (q << kMemberHashBits) | (m.fhash[rec] & ((1ull << kMemberHashBits) - 1));
-        const uint32_t l = m.bp[rec], r = (uint32_t)m.len[rec] - l;
+        const uint64_t info = m.info[rec];
+        const uint32_t l = info_bp(info), r = info_len(info) - l;
         m.mscore[slot] = min(l, r) * 10000u + max(l, r);
     };
     if (lane == 0) put(base, p);
@@ -347,9 +348,9 @@ struct EmitView {
     const uint32_t* members; const uint32_t* rep;
     const uint64_t* skey; const int32_t* slpos; const int32_t* srpos; const uint32_t* perm;
     const uint32_t* src_rank; const uint32_t* src_idx; const uint64_t* src_base;
-    const uint16_t* bp; const uint16_t* flags; const uint32_t* jrec;
+    const uint64_t* info;
     const uint32_t* rank2id; int cb;
-    bf_cluster* clusters; bf_read* reads; uint32_t* out_src_rank; uint32_t* out_src_idx; uint32_t* out_rec;
+    bf_cluster* clusters; bf_read* reads; uint32_t* out_src_rank; uint32_t* out_src_idx; uint32_t* out_rec; uint32_t* out_jrec;
 };
 
 // One wave per reported cluster: the printed row (detect.rs:233-235) and its surviving reads in
@@ -392,11 +393,13 @@ __global__ void __launch_bounds__(256) emit_kernel(const EmitView e, uint64_t ns
             bf_read rd;
             memset(&rd, 0, sizeof rd);
             rd.index = e.src_base[sr] + si;
-            rd.bp = e.bp[rec];
-            rd.swapped = (e.flags[rec] & kEvSwapped) ? 1 : 0;
-            if (e.jrec) rd.junction_len = e.jrec[rec];
+            const uint64_t info = e.info[rec];
+            rd.bp = (uint16_t)info_bp(info);
+            rd.swapped = (info_flags(info) & kEvSwapped) ? 1 : 0;
+            const uint32_t jr = info_jrec(info);
+            rd.junction_len = jr;
             e.reads[slot] = rd;
-            e.out_src_rank[slot] = sr; e.out_src_idx[slot] = si; e.out_rec[slot] = rec;
+            e.out_src_rank[slot] = sr; e.out_src_idx[slot] = si; e.out_rec[slot] = rec; e.out_jrec[slot] = jr;
         }
         cnt += __popcll(mask);
     }
@@ -493,7 +496,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     MemberView mv{};
     mv.qseed = ctx->c_qseed.as<uint32_t>(); mv.qoff = ctx->c_qoff.as<uint64_t>();
     mv.members = ctx->c_members.as<uint32_t>(); mv.mkey = ctx->c_k64a.as<uint64_t>(); mv.mscore = ctx->c_d32.as<uint32_t>();
-    mv.fhash = v.fhash; mv.bp = v.bp; mv.len = v.len;
+    mv.fhash = v.fhash; mv.info = v.info;
     FragView fv{perm, v.frag, v.frag_off, v.frag_len};
     {
         Scope t(ctx, "dedup");
@@ -552,7 +555,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     // 5. emit rows + surviving reads
     BF_TRY(ensure(ctx, ctx->c_clusters, ns * sizeof(bf_cluster)));
     BF_TRY(ensure(ctx, ctx->c_reads, std::max<uint64_t>(total_r, 1) * sizeof(bf_read)));
-    BF_TRY(ensure(ctx, ctx->c_rsrc, std::max<uint64_t>(total_r, 1) * 4 * 3));
+    BF_TRY(ensure(ctx, ctx->c_rsrc, std::max<uint64_t>(total_r, 1) * 4 * 4));
     std::vector<uint64_t> bases = ctx->src_index_base;
     if (bases.empty()) bases.assign(1, ctx->index_base);
     BF_TRY(ensure(ctx, ctx->c_tables, bases.size() * 8 + (size_t)ctx->n_contigs * 4 + 16));
@@ -565,10 +568,10 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     ev.members = ctx->c_members.as<uint32_t>(); ev.rep = ctx->c_rep.as<uint32_t>();
     ev.skey = sv.skey; ev.slpos = sv.slpos; ev.srpos = sv.srpos; ev.perm = perm;
     ev.src_rank = v.src_rank; ev.src_idx = v.src_idx; ev.src_base = (const uint64_t*)ctx->c_tables.p;
-    ev.bp = v.bp; ev.flags = v.flags; ev.jrec = v.jrec; ev.rank2id = d_rank2id; ev.cb = ctx->contig_bits;
+    ev.info = v.info; ev.rank2id = d_rank2id; ev.cb = ctx->contig_bits;
     ev.clusters = ctx->c_clusters.as<bf_cluster>(); ev.reads = ctx->c_reads.as<bf_read>();
     ev.out_src_rank = ctx->c_rsrc.as<uint32_t>(); ev.out_src_idx = ev.out_src_rank + total_r;
-    ev.out_rec = ev.out_src_idx + total_r;
+    ev.out_rec = ev.out_src_idx + total_r; ev.out_jrec = ev.out_rec + total_r;
     {
         Scope t(ctx, "emit");
         hipLaunchKernelGGL(emit_kernel, dim3(grid_for(ns * 64, B)), dim3(B), 0, st, ev, ns);
@@ -608,11 +611,11 @@ struct PackView {
     const uint16_t* bp; const uint16_t* len; const uint16_t* flags;
     const uint8_t* frag; const uint64_t* frag_off; const uint16_t* frag_len;
     const uint8_t* sigx; const uint32_t* sigx_slot;
-    const uint64_t* meta; int meta_stride; uint32_t max_packed;     // render records: {.., len, n_exc} -> junction record bytes
+    const uint64_t* info;                                           // read_info() words (localise): junction record bytes
     uint8_t* out;
 };
 __device__ __forceinline__ uint32_t pack_jrec(const PackView& v, uint32_t i) {
-    return junction_record_bytes_of(v.meta + (uint64_t)i * v.meta_stride, v.meta_stride, v.max_packed);
+    return info_jrec(v.info[i]);
 }
 __global__ void __launch_bounds__(256) pack_kernel(const PackView v) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -684,7 +687,7 @@ struct ImportView {
     const uint8_t* in; const uint64_t* src_start;   // n_ranks+1 prefix of src_counts
     uint64_t* key; int32_t* lpos; int32_t* rpos; uint64_t* fhash; uint16_t* bp; uint16_t* len; uint16_t* flags;
     uint8_t* frag; uint64_t* frag_off; uint16_t* frag_len; uint8_t* sigx; uint32_t* sigx_slot;
-    uint32_t* src_rank; uint32_t* src_idx; uint32_t* jrec;
+    uint32_t* src_rank; uint32_t* src_idx; uint64_t* info;
 };
 __global__ void __launch_bounds__(256) import_kernel(const ImportView v) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -692,7 +695,8 @@ __global__ void __launch_bounds__(256) import_kernel(const ImportView v) {
     const uint8_t* src = v.in + j * v.rec_bytes;
     const WireHeader h = *(const WireHeader*)src;
     v.key[j] = h.key; v.lpos[j] = h.lpos; v.rpos[j] = h.rpos; v.fhash[j] = h.fhash;
-    v.bp[j] = h.bp; v.len[j] = h.len; v.flags[j] = h.flags; v.frag_len[j] = h.frag_len; v.jrec[j] = h.jrec;
+    v.bp[j] = h.bp; v.len[j] = h.len; v.flags[j] = h.flags; v.frag_len[j] = h.frag_len;
+    v.info[j] = read_info(h.jrec, h.flags, h.bp, h.len);
     v.frag_off[j] = j * v.frag_stride;
     for (uint32_t k = 0; k < v.frag_stride; k++) v.frag[j * v.frag_stride + k] = src[sizeof(WireHeader) + k];
     v.sigx_slot[j] = (uint32_t)j;
@@ -716,7 +720,8 @@ __global__ void __launch_bounds__(256) import_lds_kernel(const ImportView v) {
     v.lpos[j] = (int32_t)(uint32_t)rec[1]; v.rpos[j] = (int32_t)(uint32_t)(rec[1] >> 32);
     v.fhash[j] = rec[2];
     v.src_idx[j] = (uint32_t)rec[3]; v.bp[j] = (uint16_t)(rec[3] >> 32); v.len[j] = (uint16_t)(rec[3] >> 48);
-    v.frag_len[j] = (uint16_t)rec[4]; v.flags[j] = (uint16_t)(rec[4] >> 16); v.jrec[j] = (uint32_t)(rec[4] >> 32);
+    v.frag_len[j] = (uint16_t)rec[4]; v.flags[j] = (uint16_t)(rec[4] >> 16);
+    v.info[j] = read_info((uint32_t)(rec[4] >> 32), (uint32_t)(uint16_t)(rec[4] >> 16), (uint32_t)(uint16_t)(rec[3] >> 32), (uint32_t)(rec[3] >> 48));
     v.frag_off[j] = j * v.frag_stride;
     uint64_t* fdst = (uint64_t*)(v.frag + j * v.frag_stride);
     for (uint32_t w = 0; w < fwords; w++) fdst[w] = rec[5 + w];
@@ -766,7 +771,7 @@ int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint
     pv.fhash = ctx->d_fhash.as<uint64_t>(); pv.bp = ctx->d_bp.as<uint16_t>(); pv.len = ctx->d_len.as<uint16_t>();
     pv.flags = ctx->d_flags.as<uint16_t>(); pv.frag = ctx->d_frag.as<uint8_t>(); pv.frag_off = ctx->d_frag_off.as<uint64_t>();
     pv.frag_len = ctx->d_frag_len.as<uint16_t>(); pv.sigx = ctx->d_sigx.as<uint8_t>(); pv.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
-    pv.meta = ctx->d_mask.as<uint64_t>(); pv.meta_stride = (int)ctx->mask_words + 1; pv.max_packed = 64u * ctx->plane_words;
+    pv.info = ctx->d_jrec.as<uint64_t>();
     pv.out = (uint8_t*)*dev_out;
     if (rec <= kWireLdsMaxRecord && ((uintptr_t)pv.out & 7) == 0)
         hipLaunchKernelGGL(pack_lds_kernel, dim3(grid_for(n, 256)), dim3(256), 256 * rec, st, pv);
@@ -801,7 +806,7 @@ int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts) {
     BF_TRY(ensure(ctx, ctx->i_frag_off, n * 8)); BF_TRY(ensure(ctx, ctx->i_frag_len, n * 2));
     BF_TRY(ensure(ctx, ctx->i_sigx, n * 16)); BF_TRY(ensure(ctx, ctx->i_sigx_slot, n * 4));
     BF_TRY(ensure(ctx, ctx->i_src_rank, n * 4)); BF_TRY(ensure(ctx, ctx->i_src_idx, n * 4));
-    BF_TRY(ensure(ctx, ctx->i_jrec, n * 4));
+    BF_TRY(ensure(ctx, ctx->i_jrec, n * 8));
     BF_TRY(ensure(ctx, ctx->d_part_tmp, (size_t)(R + 1) * 8));
     BF_HIP(ctx, hipMemcpyAsync(ctx->d_part_tmp.p, start.data(), (size_t)(R + 1) * 8, hipMemcpyHostToDevice, st));
     ImportView v{};
@@ -811,7 +816,7 @@ int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts) {
     v.fhash = ctx->i_fhash.as<uint64_t>(); v.bp = ctx->i_bp.as<uint16_t>(); v.len = ctx->i_len.as<uint16_t>();
     v.flags = ctx->i_flags.as<uint16_t>(); v.frag = ctx->i_frag.as<uint8_t>(); v.frag_off = ctx->i_frag_off.as<uint64_t>();
     v.frag_len = ctx->i_frag_len.as<uint16_t>(); v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
-    v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>(); v.jrec = ctx->i_jrec.as<uint32_t>();
+    v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>(); v.info = ctx->i_jrec.as<uint64_t>();
     Scope t(ctx, "exchange_import");
     if (v.rec_bytes <= kWireLdsMaxRecord && ((uintptr_t)v.in & 7) == 0)
         hipLaunchKernelGGL(import_lds_kernel, dim3(grid_for(n, 256)), dim3(256), 256 * v.rec_bytes, st, v);

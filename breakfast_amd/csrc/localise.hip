@@ -355,6 +355,7 @@ struct LocaliseArgs {
     uint16_t* flags;
     uint64_t* meta;          // render record per read: mask_words mask words + {bp, flags, len}
     int meta_stride;         // u64 per record = mask_words + 1
+    uint64_t* info;          // read_info(): junction record bytes, flags, bp, len in one word for the cluster stage's gathers
     uint32_t* exact_list;
     uint32_t* counters;      // [0] = reads routed to the exact kernel, [1] = raw-signature slots handed out,
                              // [2] = reads whose junction record is text (not packable)
@@ -592,16 +593,20 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
     const uint16_t fl = (uint16_t)((o.strand ? kEvStrand : 0) | (o.mstrand ? kEvMstrand : 0) | (o.swapped ? kEvSwapped : 0) |
                                    (sigx ? kEvSigx : 0));
     uint64_t* rec = a.meta + r * (uint64_t)a.meta_stride;
+    uint32_t n_lower = 0;        // bases printed in lower case (detect.rs:157,161)
 #pragma unroll
     for (int w = 0; w < W; w++) {
         const uint64_t lowB = low_mask(min(max(bp - 64 * w, 0), 64));
-        rec[w] = (ml[w] & lowB) | (mr[w] & ~lowB);
+        const uint64_t m = (ml[w] & lowB) | (mr[w] & ~lowB);
+        if (w < a.meta_stride - 1) rec[w] = m;
+        n_lower += (uint32_t)__popcll(m);
     }
     for (int w = W; w < a.meta_stride - 1; w++) rec[w] = 0;
     uint32_t n_exc = 0;          // read bases outside "ACGT": what the packed junction record lists one by one
 #pragma unroll
     for (int w = 0; w < W; w++) n_exc += (uint32_t)__popcll(rex[w]);
     if (!junction_packable((uint32_t)L, n_exc, 64u * W)) atomicAdd(&a.counters[2], 1u);
+    a.info[r] = read_info(junction_record_bytes((uint32_t)L, n_exc, n_lower, 64u * W), fl, (uint32_t)bp, (uint32_t)L);
     rec[a.meta_stride - 1] = (uint64_t)(uint16_t)bp | ((uint64_t)fl << 16) | ((uint64_t)(uint16_t)L << 32) | ((uint64_t)n_exc << 48);
     a.flags[r] = fl;
 }
@@ -631,6 +636,7 @@ struct ExactArgs {
     uint32_t max_packed;     // longest read a packed junction record can hold
     uint8_t* sigx;           // 16 bytes per slot
     uint32_t* sigx_slot;     // read -> slot
+    uint64_t* info;          // read_info() word
 };
 
 struct ExactRead {
@@ -719,11 +725,14 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
     const int bp = (int)(uint32_t)best;
 
     // combined mask: left-flank mismatches below bp, right-flank mismatches from bp on (detect.rs:155-162)
+    uint32_t n_lower = 0;
     for (int c = 0; c < a.mask_words; c++) {
         uint64_t ml = 0, mr = 0;
         if (c < n_chunks) words(c, ml, mr);
         const uint64_t lowB = low(bp - 64 * c);
-        if (lane == 0) a.meta[(uint64_t)r * (a.mask_words + 1) + c] = (ml & lowB) | (mr & ~lowB);
+        const uint64_t m = (ml & lowB) | (mr & ~lowB);
+        n_lower += (uint32_t)__popcll(m);
+        if (lane == 0) a.meta[(uint64_t)r * (a.mask_words + 1) + c] = m;
     }
 
     // signature (detect.rs:165-168): lanes 0..7 hold left[bp-8+k], lanes 8..15 right[bp+k-8]
@@ -757,6 +766,7 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
                                    (o.swapped ? kEvSwapped : 0) | kEvExact | (plain ? 0 : kEvSigx));
     a.flags[r] = fl;
     if (!junction_packable((uint32_t)L, n_exc, a.max_packed)) atomicAdd(&a.counters[2], 1u);
+    a.info[r] = read_info(junction_record_bytes((uint32_t)L, n_exc, n_lower, a.max_packed), fl, (uint32_t)bp, (uint32_t)L);
     a.meta[(uint64_t)r * (a.mask_words + 1) + a.mask_words] =
         (uint64_t)(uint16_t)bp | ((uint64_t)fl << 16) | ((uint64_t)(uint16_t)L << 32) | ((uint64_t)n_exc << 48);
 }
@@ -765,23 +775,21 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
 // Junction records of surviving reads (format: include/breakfast_hip.h, "Junction records").
 // Record sizes from the render records' last word {bp, flags, len, n_exc}.
 __global__ void __launch_bounds__(256) render_len_kernel(uint64_t n, const uint32_t* __restrict__ idx,
-                                                         const uint64_t* __restrict__ meta, int meta_stride,
-                                                         uint32_t max_packed, uint32_t* __restrict__ out_len) {
+                                                         const uint64_t* __restrict__ info, uint32_t* __restrict__ out_len) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out_len[i] = junction_record_bytes_of(meta + (uint64_t)idx[i] * meta_stride, meta_stride, max_packed);
+    if (i < n) out_len[i] = info_jrec(info[idx[i]]);
 }
 
 // lengths for a caller-supplied (device) index list: an index outside the resident reads is counted,
 // not dereferenced
 __global__ void __launch_bounds__(256) render_len_checked_kernel(uint64_t n, const uint32_t* __restrict__ idx,
-                                                                 const uint64_t* __restrict__ meta, int meta_stride,
-                                                                 uint32_t max_packed, uint64_t n_reads,
+                                                                 const uint64_t* __restrict__ info, uint64_t n_reads,
                                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ bad) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t r = idx[i];
     if (r >= n_reads) { out_len[i] = 0; atomicAdd(bad, 1u); return; }
-    out_len[i] = junction_record_bytes_of(meta + (uint64_t)r * meta_stride, meta_stride, max_packed);
+    out_len[i] = info_jrec(info[r]);
 }
 
 // render: 16 lanes per surviving read, 4 reads per wave, 16 reads per block.  The junction string is
@@ -1013,6 +1021,7 @@ int run_localise(bf_ctx* ctx) {
     BF_TRY(ensure(ctx, ctx->d_bp, n * 2));
     BF_TRY(ensure(ctx, ctx->d_flags, n * 2));
     BF_TRY(ensure(ctx, ctx->d_mask, (size_t)(Wm + 1) * n * 8));
+    BF_TRY(ensure(ctx, ctx->d_jrec, n * 8));
     BF_TRY(ensure(ctx, ctx->d_exact_list, n * 4));
     BF_TRY(ensure(ctx, ctx->d_sigx_slot, n * 4));
     BF_TRY(ensure(ctx, ctx->d_counters, 64));
@@ -1052,7 +1061,7 @@ int run_localise(bf_ctx* ctx) {
     a.sigx = ctx->d_sigx.as<uint8_t>(); a.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
     a.key = ctx->d_key.as<uint64_t>(); a.lpos = ctx->d_lpos.as<int32_t>(); a.rpos = ctx->d_rpos.as<int32_t>();
     a.bp = ctx->d_bp.as<uint16_t>(); a.flags = ctx->d_flags.as<uint16_t>(); a.meta = ctx->d_mask.as<uint64_t>();
-    a.meta_stride = (int)Wm + 1;
+    a.meta_stride = (int)Wm + 1; a.info = ctx->d_jrec.as<uint64_t>();
     a.exact_list = ctx->d_exact_list.as<uint32_t>(); a.counters = ctx->d_counters.as<uint32_t>();
     {
         Scope t(ctx, "localise");
@@ -1075,7 +1084,7 @@ int run_localise(bf_ctx* ctx) {
         e.seq = ctx->d_seq.as<uint8_t>(); e.seq_off = ctx->d_seq_off.as<uint64_t>();
         e.contigs = a.contigs; e.raw = ctx->g_raw.as<uint8_t>();
         e.key = a.key; e.lpos = a.lpos; e.rpos = a.rpos; e.bp = a.bp; e.flags = a.flags; e.meta = a.meta;
-        e.mask_words = (int)Wm; e.max_packed = 64u * W; e.sigx = ctx->d_sigx.as<uint8_t>(); e.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
+        e.mask_words = (int)Wm; e.max_packed = 64u * W; e.info = ctx->d_jrec.as<uint64_t>(); e.sigx = ctx->d_sigx.as<uint8_t>(); e.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
         Scope t(ctx, "localise_exact");
         hipLaunchKernelGGL(localise_exact_kernel, dim3(grid_for((uint64_t)n_exact * 64, 256)), dim3(256), 0, ctx->stream, e);
         BF_HIP(ctx, hipGetLastError());
@@ -1096,7 +1105,7 @@ __global__ void pick_offsets_kernel(const uint64_t* __restrict__ off, uint64_t n
 // Junction offsets of n surviving reads (exclusive scan of len+1).  chunk_off[c] = byte offset of
 // read n*c/n_chunks, so that the caller can render and copy out the text chunk by chunk.
 int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, int n_chunks,
-                   uint64_t* chunk_off) {
+                   uint64_t* chunk_off, const uint32_t* d_sizes) {
     for (int c = 0; c <= n_chunks; c++) chunk_off[c] = 0;
     BF_TRY(ensure(ctx, d_off, (n + 1) * 8));
     if (n == 0) {
@@ -1105,9 +1114,12 @@ int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf&
     }
     BF_TRY(ensure(ctx, ctx->c_misc, n * 4 + 16 + 64 * 8));
     Scope t(ctx, "render_offsets");
-    hipLaunchKernelGGL(render_len_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
-                       ctx->d_mask.as<uint64_t>(), (int)ctx->mask_words + 1, 64u * ctx->plane_words, ctx->c_misc.as<uint32_t>());
-    BF_TRY(scan_u32_to_u64(ctx, ctx->c_misc.as<uint32_t>(), d_off.as<uint64_t>(), n));
+    if (!d_sizes) {
+        hipLaunchKernelGGL(render_len_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
+                           ctx->d_jrec.as<uint64_t>(), ctx->c_misc.as<uint32_t>());
+        d_sizes = ctx->c_misc.as<uint32_t>();
+    }
+    BF_TRY(scan_u32_to_u64(ctx, d_sizes, d_off.as<uint64_t>(), n));
     // the chunk boundaries in ONE small copy (nine separate 8-byte copies cost 30 us each)
     uint64_t* d_pick = (uint64_t*)(ctx->c_misc.as<uint8_t>() + ((n * 4 + 15) & ~(size_t)15));
     hipLaunchKernelGGL(pick_offsets_kernel, dim3(1), dim3(64), 0, ctx->stream, d_off.as<uint64_t>(), n, n_chunks, d_pick);
@@ -1160,7 +1172,7 @@ int render_dev(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint64_t* d
     {
         Scope t(ctx, "render_offsets");
         hipLaunchKernelGGL(render_len_checked_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
-                           ctx->d_mask.as<uint64_t>(), (int)ctx->mask_words + 1, 64u * ctx->plane_words, ctx->n_reads, d_len, d_bad);
+                           ctx->d_jrec.as<uint64_t>(), ctx->n_reads, d_len, d_bad);
         BF_TRY(scan_u32_to_u64(ctx, d_len, d_off, n));
     }
     uint32_t bad = 0;
