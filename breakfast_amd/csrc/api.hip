@@ -128,7 +128,7 @@ static void free_all(bf_ctx* ctx) {
         &ctx->i_frag, &ctx->i_frag_off, &ctx->i_frag_len, &ctx->i_sigx, &ctx->i_sigx_slot, &ctx->i_src_rank,
         &ctx->i_src_idx, &ctx->i_jrec, &ctx->c_tmp, &ctx->c_a32, &ctx->c_b32, &ctx->c_c32, &ctx->c_d32, &ctx->c_k64a, &ctx->c_k64b,
         &ctx->c_slpos, &ctx->c_srpos, &ctx->c_reported, &ctx->c_csize, &ctx->c_flag, &ctx->c_scan, &ctx->c_qseed,
-        &ctx->c_qsize, &ctx->c_qoff, &ctx->c_members, &ctx->c_leader, &ctx->c_rep, &ctx->c_qnrep, &ctx->c_sel,
+        &ctx->c_qsize, &ctx->c_qoff, &ctx->c_members, &ctx->c_leader, &ctx->c_rep, &ctx->c_qnrep, &ctx->c_ctl, &ctx->c_sel,
         &ctx->c_ord, &ctx->c_clusters, &ctx->c_reads, &ctx->c_misc, &ctx->c_joff, &ctx->c_jbytes, &ctx->c_rsrc,
         &ctx->c_tables, &ctx->c_mkey_s, &ctx->c_slot, &ctx->c_big, &ctx->c_pos2, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
     for (DevBuf* b : all) release(ctx, *b);

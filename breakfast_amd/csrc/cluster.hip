@@ -203,10 +203,19 @@ __global__ void flag_ge_kernel(uint32_t* flag, const uint32_t* __restrict__ val,
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flag[i] = val[i] >= thr ? 1u : 0u;
 }
+// Clusters of up to kWaveDedupMax members are de-duplicated by the wave that enumerates them (fill_members_kernel);
+// n_big counts the others.
+constexpr uint32_t kWaveDedupMax = 256;
 __global__ void compact_seeds_kernel(const uint32_t* __restrict__ flag, const uint64_t* __restrict__ scan,
-                                     const uint32_t* __restrict__ csize, uint32_t* qseed, uint32_t* qsize, uint64_t n) {
+                                     const uint32_t* __restrict__ csize, uint32_t* qseed, uint32_t* qsize, uint64_t n,
+                                     uint32_t* __restrict__ n_big) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && flag[i]) { const uint64_t q = scan[i]; qseed[q] = (uint32_t)i; qsize[q] = csize[i]; }
+    if (i < n && flag[i]) {
+        const uint64_t q = scan[i];
+        const uint32_t c = csize[i];
+        qseed[q] = (uint32_t)i; qsize[q] = c;
+        if (c > kWaveDedupMax) atomicAdd(n_big, 1u);
+    }
 }
 __global__ void compact_index_kernel(const uint32_t* __restrict__ flag, const uint64_t* __restrict__ scan,
                                      uint32_t* out, uint64_t n) {
@@ -225,12 +234,36 @@ struct MemberView {
     uint64_t* mkey;         // (cluster number << kMemberHashBits) | low bits of the fragment-id hash, per member slot
     uint32_t* mscore;       // longest-flank score per member slot (detect.rs:273-279)
     const uint64_t* fhash; const uint64_t* info;
+    // in-wave dedup (WAVE_DEDUP): group leaders' representatives and the clusters' group counts
+    const uint32_t* qsize; uint32_t* rep; uint32_t* qnrep;
+    const uint8_t* frag; const uint64_t* frag_off; const uint16_t* frag_len;
+    uint64_t hash_mask;     // all ones; a few bits under BF_FLAG_WEAK_DEDUP_HASH (tests: forces the byte-wise redo)
 };
 
+__device__ __forceinline__ bool same_frag_bytes(const MemberView& m, uint32_t ra, uint32_t rb) {
+    const uint32_t la = m.frag_len[ra];
+    if (la != m.frag_len[rb]) return false;
+    const uint8_t* a = m.frag + m.frag_off[ra];
+    const uint8_t* b = m.frag + m.frag_off[rb];
+    uint32_t diff = 0;                       // no early exit: the hashes already agree, the ids almost surely too
+    for (uint32_t k = 0; k < la; k++) diff |= (uint32_t)(a[k] ^ b[k]);
+    return diff == 0;
+}
+
 // One wave per qualifying cluster: re-enumerate the seed's members in sweep order.
+// WAVE_DEDUP (every cluster has at most kWaveDedupMax members): the same wave then applies
+// remove_frag_id_duplicates (detect.rs:247-287) to its cluster -- member i's group leader is the first
+// member with the same fragment id (64-bit hashes compared against one broadcast member at a time, id BYTES
+// where the hashes agree), a leader's representative the first member of its group with the best score --
+// instead of a radix sort of all member slots by (cluster, hash) and a pass over the sorted runs.
+template <bool WAVE_DEDUP>
 __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, const MemberView m, uint64_t nq) {
+    __shared__ uint64_t s_fh[WAVE_DEDUP ? 4 : 1][WAVE_DEDUP ? kWaveDedupMax : 1];
+    __shared__ uint32_t s_sc[WAVE_DEDUP ? 4 : 1][WAVE_DEDUP ? kWaveDedupMax : 1];
+    __shared__ uint32_t s_rc[WAVE_DEDUP ? 4 : 1][WAVE_DEDUP ? kWaveDedupMax : 1];
+    __shared__ uint32_t s_ld[WAVE_DEDUP ? 4 : 1][WAVE_DEDUP ? kWaveDedupMax : 1];
     const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
     if (q >= nq) return;
     const uint64_t p = m.qseed[q];
     const uint64_t base = m.qoff[q];
@@ -239,10 +272,16 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
     auto put = [&](uint64_t slot, uint64_t spos) {
         const uint32_t rec = v.perm[spos];
         m.members[slot] = (uint32_t)spos;
-        m.mkey[slot] = (q << kMemberHashBits) | (m.fhash[rec] & ((1ull << kMemberHashBits) - 1));
         const uint64_t info = m.info[rec];
         const uint32_t l = info_bp(info), r = info_len(info) - l;
-        m.mscore[slot] = min(l, r) * 10000u + max(l, r);
+        const uint32_t score = min(l, r) * 10000u + max(l, r);       // detect.rs:273-279
+        if (WAVE_DEDUP) {
+            const uint32_t i = (uint32_t)(slot - base);
+            if (i < kWaveDedupMax) { s_fh[wv][i] = m.fhash[rec]; s_sc[wv][i] = score; s_rc[wv][i] = rec; }
+        } else {
+            m.mkey[slot] = (q << kMemberHashBits) | (m.fhash[rec] & ((1ull << kMemberHashBits) - 1));
+            m.mscore[slot] = score;
+        }
     };
     if (lane == 0) put(base, p);
     uint64_t cnt = 1;
@@ -256,6 +295,91 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
         cnt += __popcll(take_mask);
         if (live_mask != ~0ull) break;        // the break tests are monotone in sorted order
     }
+    if (!WAVE_DEDUP) return;
+
+    // LDS operations of one wave execute in order; only the compiler must not reorder them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t c = (uint32_t)min(cnt, (uint64_t)kWaveDedupMax);   // == qsize[q]
+    constexpr int R = kWaveDedupMax / 64;
+    const int rounds = (int)((c + 63) >> 6);
+    uint64_t fh[R]; uint32_t ld[R], rc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = 64u * r + lane;
+        fh[r] = i < c ? s_fh[wv][i] : 0; rc[r] = i < c ? s_rc[wv][i] : 0; ld[r] = i;
+    }
+    // Group leaders: the first member with the same fragment id (detect.rs:252-266).  First on the 64-bit hashes
+    // alone (no memory traffic: one broadcast LDS word per member), then every member that joined a group checks
+    // its id BYTES against its leader's, all lanes at once.  Equal ids hash equally, so if every check passes the
+    // groups are exact; if one fails (two ids with one hash) the wave redoes its cluster comparing bytes pair by pair.
+    for (uint32_t j = 0; j + 1 < c; j++) {
+        const uint64_t fj = s_fh[wv][j] & m.hash_mask;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (r < rounds) {
+                const uint32_t i = 64u * r + lane;
+                const bool cand = i > j && i < c && ld[r] == i && (fh[r] & m.hash_mask) == fj;
+                ld[r] = cand ? j : ld[r];
+            }
+        }
+    }
+    bool verified = true;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = 64u * r + lane;
+        if (r < rounds && i < c && ld[r] != i) verified = verified && same_frag_bytes(m, rc[r], s_rc[wv][ld[r]]);
+    }
+    if (__ballot(!verified)) {
+#pragma unroll
+        for (int r = 0; r < R; r++) ld[r] = 64u * r + lane;
+        for (uint32_t j = 0; j + 1 < c; j++) {
+            const uint64_t fj = s_fh[wv][j] & m.hash_mask;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                // (written as a select: hipcc 7.2 dropped the assignment from the short-circuit form
+                //  `if (... && same_frag_bytes(...)) ld[r] = j;` whenever the byte loop ran)
+                const uint32_t i = 64u * r + lane;
+                const bool cand = r < rounds && i > j && i < c && ld[r] == i && (fh[r] & m.hash_mask) == fj;
+                bool same = false;
+                if (cand) same = same_frag_bytes(m, rc[r], s_rc[wv][j]);
+                ld[r] = same ? j : ld[r];
+            }
+        }
+    }
+    bool joined = false;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = 64u * r + lane;
+        if (i < c) { s_ld[wv][i] = ld[r]; joined = joined || ld[r] != i; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // representatives: best score of the group, the first one on ties (strict >, detect.rs:280)
+    uint32_t best[R], bs[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { const uint32_t i = 64u * r + lane; best[r] = i; bs[r] = i < c ? s_sc[wv][i] : 0; }
+    if (__ballot(joined)) {
+        for (uint32_t i2 = 1; i2 < c; i2++) {
+            const uint32_t li = s_ld[wv][i2];                        // broadcast: uniform over the wave
+            if (li == i2) continue;
+            const uint32_t si = s_sc[wv][i2];
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (64u * r + lane == li && si > bs[r]) { bs[r] = si; best[r] = i2; }
+        }
+    }
+    uint32_t groups = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = 64u * r + lane;
+        const bool leads = i < c && ld[r] == i;
+        if (i < c) m.rep[base + i] = leads ? best[r] : kNone;
+        groups += (uint32_t)__popcll(__ballot(leads));
+    }
+    if (lane == 0) m.qnrep[q] = groups;
 }
 
 struct FragView {
@@ -483,11 +607,16 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     BF_TRY(ensure(ctx, ctx->c_qseed, nq * 4)); BF_TRY(ensure(ctx, ctx->c_qsize, nq * 4));
     BF_TRY(ensure(ctx, ctx->c_qoff, (nq + 1) * 8)); BF_TRY(ensure(ctx, ctx->c_qnrep, nq * 4));
     uint64_t total_m = 0;
+    BF_TRY(ensure(ctx, ctx->c_ctl, 64));
+    BF_HIP(ctx, hipMemsetAsync(ctx->c_ctl.p, 0, 64, st));
     hipLaunchKernelGGL(compact_seeds_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
                        ctx->c_scan.as<uint64_t>(), ctx->c_csize.as<uint32_t>(), ctx->c_qseed.as<uint32_t>(),
-                       ctx->c_qsize.as<uint32_t>(), n);
+                       ctx->c_qsize.as<uint32_t>(), n, ctx->c_ctl.as<uint32_t>());
     BF_TRY(scan_u32_to_u64(ctx, ctx->c_qsize.as<uint32_t>(), ctx->c_qoff.as<uint64_t>(), nq));
+    uint32_t n_big = 0;                                   // clusters too large for the in-wave dedup
+    BF_HIP(ctx, hipMemcpyAsync(&n_big, ctx->c_ctl.p, 4, hipMemcpyDeviceToHost, st));
     BF_TRY(fetch_u64(ctx, ctx->c_qoff.as<uint64_t>() + nq, &total_m));
+    const bool wave_dedup = n_big == 0 && !(ctx->cfg.flags & BF_FLAG_SORTED_DEDUP);
     if (total_m > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "cluster membership list too long (%llu)", (unsigned long long)total_m);
     BF_TRY(ensure(ctx, ctx->c_members, total_m * 4)); BF_TRY(ensure(ctx, ctx->c_k64a, std::max(total_m, n) * 8, false));
     BF_TRY(ensure(ctx, ctx->c_mkey_s, total_m * 8)); BF_TRY(ensure(ctx, ctx->c_slot, total_m * 4 * 2));
@@ -497,20 +626,27 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     mv.qseed = ctx->c_qseed.as<uint32_t>(); mv.qoff = ctx->c_qoff.as<uint64_t>();
     mv.members = ctx->c_members.as<uint32_t>(); mv.mkey = ctx->c_k64a.as<uint64_t>(); mv.mscore = ctx->c_d32.as<uint32_t>();
     mv.fhash = v.fhash; mv.info = v.info;
+    mv.qsize = ctx->c_qsize.as<uint32_t>(); mv.rep = ctx->c_rep.as<uint32_t>(); mv.qnrep = ctx->c_qnrep.as<uint32_t>();
+    mv.frag = v.frag; mv.frag_off = v.frag_off; mv.frag_len = v.frag_len;
+    mv.hash_mask = (ctx->cfg.flags & BF_FLAG_WEAK_DEDUP_HASH) ? 0x7ull : ~0ull;
     FragView fv{perm, v.frag, v.frag_off, v.frag_len};
     {
         Scope t(ctx, "dedup");
-        hipLaunchKernelGGL(fill_members_kernel, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, sv, mv, nq);
-        uint32_t* slot_in = ctx->c_slot.as<uint32_t>(); uint32_t* slot_s = slot_in + total_m;
-        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(total_m, B)), dim3(B), 0, st, slot_in, total_m);
-        unsigned qbits = 1; while ((1ull << qbits) < nq) qbits++;
-        BF_TRY(sort_pairs<uint64_t>(ctx, mv.mkey, ctx->c_mkey_s.as<uint64_t>(), slot_in, slot_s, total_m, 0, kMemberHashBits + qbits));
-        BF_HIP(ctx, hipMemsetAsync(ctx->c_leader.p, 0xff, total_m * 4, st));
-        BF_HIP(ctx, hipMemsetAsync(ctx->c_rep.p, 0xff, total_m * 4, st));
-        hipLaunchKernelGGL(dedup_runs_kernel, dim3(grid_for(total_m, B)), dim3(B), 0, st, total_m, ctx->c_mkey_s.as<uint64_t>(),
-                           slot_s, mv, fv, ctx->c_leader.as<uint32_t>(), ctx->c_rep.as<uint32_t>());
-        hipLaunchKernelGGL(count_groups_kernel, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, nq, ctx->c_qoff.as<uint64_t>(),
-                           ctx->c_rep.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>());
+        if (wave_dedup) {
+            hipLaunchKernelGGL(fill_members_kernel<true>, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, sv, mv, nq);
+        } else {
+            hipLaunchKernelGGL(fill_members_kernel<false>, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, sv, mv, nq);
+            uint32_t* slot_in = ctx->c_slot.as<uint32_t>(); uint32_t* slot_s = slot_in + total_m;
+            hipLaunchKernelGGL(iota_kernel, dim3(grid_for(total_m, B)), dim3(B), 0, st, slot_in, total_m);
+            unsigned qbits = 1; while ((1ull << qbits) < nq) qbits++;
+            BF_TRY(sort_pairs<uint64_t>(ctx, mv.mkey, ctx->c_mkey_s.as<uint64_t>(), slot_in, slot_s, total_m, 0, kMemberHashBits + qbits));
+            BF_HIP(ctx, hipMemsetAsync(ctx->c_leader.p, 0xff, total_m * 4, st));
+            BF_HIP(ctx, hipMemsetAsync(ctx->c_rep.p, 0xff, total_m * 4, st));
+            hipLaunchKernelGGL(dedup_runs_kernel, dim3(grid_for(total_m, B)), dim3(B), 0, st, total_m, ctx->c_mkey_s.as<uint64_t>(),
+                               slot_s, mv, fv, ctx->c_leader.as<uint32_t>(), ctx->c_rep.as<uint32_t>());
+            hipLaunchKernelGGL(count_groups_kernel, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, nq, ctx->c_qoff.as<uint64_t>(),
+                               ctx->c_rep.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>());
+        }
     }
     BF_HIP(ctx, hipGetLastError());
 

@@ -22,6 +22,8 @@ BF_FLAG_FORCE_EXACT = 2
 BF_FLAG_COOP_GATHER = 4
 BF_FLAG_SEPARATE_ENCODE = 8
 BF_FLAG_DEVICE_ROUTING = 16
+BF_FLAG_SORTED_DEDUP = 32
+BF_FLAG_WEAK_DEDUP_HASH = 64
 BF_EV_STRAND, BF_EV_MSTRAND, BF_EV_SWAPPED, BF_EV_EXACT, BF_EV_SIGX = 1, 2, 4, 8, 16
 
 HIT_DTYPE = np.dtype([("pos5", "<u4"), ("pos3", "<u4"), ("contig5", "<u2"), ("contig3", "<u2"),

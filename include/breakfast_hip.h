@@ -61,6 +61,10 @@ typedef struct {
 #define BF_FLAG_FORCE_EXACT   2u   /* route every read through the byte-exact kernel (tests)        */
 #define BF_FLAG_COOP_GATHER     4u /* A/B: separate encode kernel + cooperative (LDS-staged) flank gather */
 #define BF_FLAG_SEPARATE_ENCODE 8u /* A/B: separate encode kernel + per-lane flank gather               */
+#define BF_FLAG_SORTED_DEDUP   32u /* A/B + tests: fragment-id dedup by the sorted-run kernels even when every cluster
+                                      fits the in-wave form (they are the path of clusters above 256 members) */
+#define BF_FLAG_WEAK_DEDUP_HASH 64u /* tests: the in-wave dedup groups on 3 hash bits, so that its byte verification fails
+                                       and the pair-by-pair redo runs */
 #define BF_FLAG_DEVICE_ROUTING 16u /* multi-rank: bf_clusterise leaves the read table on the device (result.reads
                                       is NULL, n_reads is set) until bf_result_attach_junctions_dev copies the
                                       finished table out once */

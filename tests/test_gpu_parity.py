@@ -10,7 +10,8 @@ import oracle_lib as ol
 from conftest import golden_names, load_golden
 
 from breakfast_amd import engine, synth
-from breakfast_amd.engine import BF_FLAG_COOP_GATHER, BF_FLAG_FORCE_EXACT, BF_FLAG_KEEP_EVIDENCE, BF_FLAG_SEPARATE_ENCODE
+from breakfast_amd.engine import (BF_FLAG_COOP_GATHER, BF_FLAG_FORCE_EXACT, BF_FLAG_KEEP_EVIDENCE, BF_FLAG_SEPARATE_ENCODE,
+                                  BF_FLAG_SORTED_DEDUP, BF_FLAG_WEAK_DEDUP_HASH)
 
 pytestmark = pytest.mark.gpu
 
@@ -97,6 +98,32 @@ def test_scaled_baseline_config_ab_variants(cfg, scale, gscale, flag):
     g = synth.make_genome(contigs, **gk)
     b = synth.make_reads(g, spec)
     check_against_oracle(g, b, spec.anchor_len, flags=flag)
+
+
+@pytest.mark.parametrize("cfg,scale,gscale", [(0, 0.05, 0.02), (1, 0.004, 0.002), (3, 0.001, 0.002)])
+def test_scaled_baseline_config_sorted_dedup(cfg, scale, gscale):
+    # fragment-id dedup by the sorted-run kernels (the path of clusters above 256 members) instead of the in-wave form
+    contigs, gk, spec = synth.config(cfg, scale=scale, genome_scale=gscale)
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    check_against_oracle(g, b, spec.anchor_len, flags=BF_FLAG_SORTED_DEDUP)
+
+
+@pytest.mark.parametrize("n_reads,n_events", [(3000, 40), (6000, 30), (9000, 12)])
+def test_dedup_over_cluster_sizes(n_reads, n_events):
+    """Clusters of ~75 (one round of the in-wave dedup), ~200 (four rounds) and ~750 members (above 256: the
+    sorted-run kernels take over), 40 % of the reads sharing their fragment id with a mate at the same junction."""
+    contigs = [("chr1", 200000), ("chr2", 150000)]
+    g = synth.make_genome(contigs, seed=5)
+    spec = synth.ReadSpec(n_reads=n_reads, read_len=100, anchor_len=20, n_events=n_events, singleton_frac=0.0, mate_frac=0.4,
+                          seed=n_reads, margin=300)
+    b = synth.make_reads(g, spec)
+    res, ref = check_against_oracle(g, b, 20)
+    sizes = np.diff(np.stack([res.clusters["read_begin"], res.clusters["read_end"]], 1).astype(np.int64), axis=1)
+    assert sizes.max() >= {3000: 30, 6000: 80, 9000: 300}[n_reads]
+    check_against_oracle(g, b, 20, flags=BF_FLAG_SORTED_DEDUP)
+    # three hash bits: different fragment ids meet in one hash group, the byte check fails, the wave redoes its cluster
+    check_against_oracle(g, b, 20, flags=BF_FLAG_WEAK_DEDUP_HASH)
 
 
 def test_scaled_config_exact_kernel_only():
@@ -278,6 +305,8 @@ def test_dedup_survives_hash_collisions():
     assert expected.count(b";") == 2
     text = b"".join(l + b"\n" for l in f.lines)
     assert run_gpu_text(f.fasta(), text, 10, 5000, 2) == expected
+    assert run_gpu_text(f.fasta(), text, 10, 5000, 2, flags=BF_FLAG_SORTED_DEDUP) == expected
+    assert run_gpu_text(f.fasta(), text, 10, 5000, 2, flags=BF_FLAG_WEAK_DEDUP_HASH) == expected
 
 
 def test_long_reads_render_in_several_tiles():
