@@ -155,26 +155,25 @@ static const uint64_t* spread_table() {
 // Text of one junction record (include/breakfast_hip.h, "Junction records"): the read's bases, lower case
 // where they differ from the flank they were assigned to, with '|' at the breakpoint (detect.rs:155-162).
 // Returns len + 1, or -1 for a malformed record; writes only when `out` is given and cap suffices.
-int64_t junction_decode(const uint8_t* rec, uint64_t rec_len, uint8_t* out, uint64_t cap) {
-    if (!rec || rec_len < 6) return -1;
-    uint16_t h[3];
-    memcpy(h, rec, 6);
-    const uint32_t L = h[0], bp = h[1], nx = h[2];
+int64_t junction_decode(const uint8_t* rec, uint64_t rec_len, uint8_t* out, uint64_t cap, uint64_t* stored) {
+    if (!rec || rec_len < 8) return -1;
+    uint16_t h[4];
+    memcpy(h, rec, 8);
+    const uint32_t L = h[0], bp = h[1], nx = h[2], form = h[3];
     if (bp > L) return -1;
     const uint64_t text = (uint64_t)L + 1;
     if (nx == kJunctionText) {
-        if (rec_len < 6 + text) return -1;
-        if (out && cap >= text) memcpy(out, rec + 6, text);
+        if ((form & ~kJunctionSwapped) != 0 || rec_len < 8 + text) return -1;
+        if (stored) *stored = (8 + text + 3) & ~3ull;
+        if (out && cap >= text) memcpy(out, rec + 8, text);
         return (int64_t)text;
     }
     const uint32_t groups = (L + 31) >> 5;
-    if (rec_len < 8) return -1;
-    uint16_t form;
-    memcpy(&form, rec + 6, 2);
     const bool sparse = (form & kJunctionSparse) != 0;
-    const uint32_t n_lower = sparse ? (form & 0x7fffu) : 0u, gb = sparse ? 8u : 12u;
-    if (!sparse && form != 0) return -1;
+    const uint32_t n_lower = sparse ? (form & kJunctionCountMask) : 0u, gb = sparse ? 8u : 12u;
+    if (!sparse && (form & kJunctionCountMask) != 0) return -1;
     if (rec_len < 8 + (uint64_t)gb * groups + 4ull * nx + 2ull * n_lower) return -1;
+    if (stored) *stored = 8 + (uint64_t)gb * groups + 4ull * nx + ((2ull * n_lower + 3) & ~3ull);
     const uint8_t* g = rec + 8;
     const uint8_t* xe = g + (uint64_t)gb * groups;           // exception entries
     const uint8_t* pl = xe + 4ull * nx;                      // lower-case positions (sparse form)
@@ -496,8 +495,8 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t 
         if (k) sz += k - 1;                                                             // ';' separators
         for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
             const bf_read& rd = r->reads[i];
-            if (rd.junction_off + rd.junction_len > r->junction_size) return BF_ERR_INVALID;
-            const int64_t tl = junction_decode(r->junction_bytes + rd.junction_off, rd.junction_len, nullptr, 0);
+            if (rd.junction_off > r->junction_size) return BF_ERR_INVALID;
+            const int64_t tl = junction_decode(r->junction_bytes + rd.junction_off, r->junction_size - rd.junction_off, nullptr, 0);
             if (tl < 0) return BF_ERR_INVALID;
             sz += (uint64_t)tl;
         }
@@ -528,7 +527,7 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t 
             for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
                 if (i > cl.read_begin) *p++ = ';';
                 const bf_read& rd = r->reads[i];
-                p += junction_decode(r->junction_bytes + rd.junction_off, rd.junction_len, (uint8_t*)p, ~0ull);
+                p += junction_decode(r->junction_bytes + rd.junction_off, r->junction_size - rd.junction_off, (uint8_t*)p, ~0ull);
             }
             *p++ = '\t'; *p++ = '\t'; *p++ = '\n';                                      // detect.rs:240
         }
@@ -549,9 +548,15 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t 
     return (int64_t)total;
 }
 
-int64_t bf_junction_text(const uint8_t* record, uint64_t record_len, char* buf, uint64_t cap) {
-    const int64_t n = junction_decode(record, record_len, (uint8_t*)buf, buf ? cap : 0);
+int64_t bf_junction_text(const uint8_t* record, uint64_t avail, char* buf, uint64_t cap) {
+    const int64_t n = junction_decode(record, avail, (uint8_t*)buf, buf ? cap : 0);
     return n < 0 ? (int64_t)BF_ERR_INVALID : n;
+}
+
+int64_t bf_junction_record_bytes(const uint8_t* record, uint64_t avail) {
+    uint64_t stored = 0;
+    if (junction_decode(record, avail, nullptr, 0, &stored) < 0 || stored > ((avail + 3) & ~3ull)) return BF_ERR_INVALID;
+    return (int64_t)stored;
 }
 
 int64_t bf_result_junction_text(const bf_result* r, uint8_t* text, uint64_t cap, uint64_t* text_off) {
@@ -559,8 +564,8 @@ int64_t bf_result_junction_text(const bf_result* r, uint8_t* text, uint64_t cap,
     uint64_t total = 0;
     for (uint64_t i = 0; i < r->n_reads; i++) {
         const bf_read& rd = r->reads[i];
-        if (rd.junction_off + rd.junction_len > r->junction_size) return BF_ERR_INVALID;
-        const int64_t tl = junction_decode(r->junction_bytes + rd.junction_off, rd.junction_len, nullptr, 0);
+        if (rd.junction_off > r->junction_size) return BF_ERR_INVALID;
+        const int64_t tl = junction_decode(r->junction_bytes + rd.junction_off, r->junction_size - rd.junction_off, nullptr, 0);
         if (tl < 0) return BF_ERR_INVALID;
         text_off[i] = total;
         total += (uint64_t)tl;
@@ -571,8 +576,8 @@ int64_t bf_result_junction_text(const bf_result* r, uint8_t* text, uint64_t cap,
     const uint64_t nt = total < (8u << 20) ? 1 : std::max(1u, std::min(hw, 8u));
     auto fill = [&](uint64_t a, uint64_t b) {
         for (uint64_t i = a; i < b; i++)
-            junction_decode(r->junction_bytes + r->reads[i].junction_off, r->reads[i].junction_len, text + text_off[i],
-                            text_off[i + 1] - text_off[i]);
+            junction_decode(r->junction_bytes + r->reads[i].junction_off, r->junction_size - r->reads[i].junction_off,
+                            text + text_off[i], text_off[i + 1] - text_off[i]);
     };
     if (nt <= 1) { fill(0, r->n_reads); return (int64_t)total; }
     std::vector<std::thread> pool;
@@ -685,18 +690,18 @@ int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_i
     return render_dev(ctx, n, dev_local_index, dev_off, dev_bytes, dev_bytes_cap, total);
 }
 
-int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const uint32_t* dev_jlen,
-                                   const uint8_t* dev_bytes, uint64_t size, bf_result* out) {
+int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const uint8_t* dev_bytes, uint64_t size,
+                                   bf_result* out) {
     if (!ctx) return BF_ERR_INVALID;
     if (!out) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junctions_dev: null result");
     if (!ctx->imported || !ctx->clustered)
         return fail(ctx, BF_ERR_STATE, "bf_result_attach_junctions_dev is only meaningful after bf_exchange_import + bf_clusterise");
     const uint64_t nr = ctx->out.n_reads;
-    if (nr && (!dev_joff || !dev_jlen)) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junctions_dev: null offsets");
+    if (nr && !dev_joff) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junctions_dev: null offsets");
     if (size && !dev_bytes) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junctions_dev: null junction bytes");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     if (nr) {
-        BF_TRY(patch_reads_len(ctx, dev_joff, dev_jlen, nr));
+        BF_TRY(patch_reads_off(ctx, dev_joff, nr));
         BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
         BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
     }

@@ -67,12 +67,14 @@ __host__ __device__ inline bool junction_packable(uint32_t L, uint32_t n_exc, ui
 }
 // Packed records come in two forms: with a lower-case (mismatch) bit per base, or -- most reads differ from
 // their flanks in a base or two -- with the lower-case positions listed after the two code planes.
-constexpr uint32_t kJunctionSparse = 0x8000u;        // flag in the header's fourth u16; its low 15 bits = listed positions
+// header = {u16 len, u16 bp, u16 n_exc | 0xffff, u16 form}; form: bit 15 sparse, bit 14 the read was
+// reverse-complemented (detect.rs:112), low 14 bits = listed lower-case positions (sparse form)
+constexpr uint32_t kJunctionSparse = 0x8000u, kJunctionSwapped = 0x4000u, kJunctionCountMask = 0x3fffu;
 __host__ __device__ inline bool junction_sparse(uint32_t L, uint32_t n_lower) {
-    return n_lower < 0x8000u && ((2u * n_lower + 3u) & ~3u) < 4u * ((L + 31u) >> 5);
+    return n_lower <= kJunctionCountMask && ((2u * n_lower + 3u) & ~3u) < 4u * ((L + 31u) >> 5);
 }
 __host__ __device__ inline uint32_t junction_record_bytes(uint32_t L, uint32_t n_exc, uint32_t n_lower, uint32_t max_packed) {
-    if (!junction_packable(L, n_exc, max_packed)) return (6u + L + 1u + 3u) & ~3u;
+    if (!junction_packable(L, n_exc, max_packed)) return (8u + L + 1u + 3u) & ~3u;
     const uint32_t g = (L + 31u) >> 5;
     return junction_sparse(L, n_lower) ? 8u + 8u * g + 4u * n_exc + ((2u * n_lower + 3u) & ~3u) : 8u + 12u * g + 4u * n_exc;
 }
@@ -254,7 +256,7 @@ int genome_pack(bf_ctx* ctx);                       // raw image -> blocks + coa
 int run_localise(bf_ctx* ctx);                      // encode + hash + fast + exact kernels
 int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, int n_chunks, uint64_t* chunk_off,
                    const uint32_t* d_sizes = nullptr);   // d_sizes: record bytes per list entry when the caller has them
-int64_t junction_decode(const uint8_t* rec, uint64_t rec_len, uint8_t* out, uint64_t cap);   // api.hip, host
+int64_t junction_decode(const uint8_t* rec, uint64_t avail, uint8_t* out, uint64_t cap, uint64_t* stored = nullptr);   // api.hip, host
 int render_range(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const DevBuf& d_off, DevBuf& d_bytes);
 int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, DevBuf& d_bytes,
                uint64_t* total_bytes);              // junction strings for local reads
@@ -276,7 +278,6 @@ int radix_sort_pairs(bf_ctx* ctx, const uint64_t* kin, uint64_t* kout, const uin
 int scan_u32_to_u64(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n);  // exclusive, out has n+1
 int scan_max_u32_inplace(bf_ctx* ctx, uint32_t* data, uint64_t n);                // running maximum
 int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
-int patch_reads_len(bf_ctx* ctx, const uint64_t* d_joff, const uint32_t* d_jlen, uint64_t n);
 int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
 int read_sizes(bf_ctx* ctx, uint32_t* d_out, uint64_t n);
 

@@ -518,10 +518,7 @@ __global__ void __launch_bounds__(256) emit_kernel(const EmitView e, uint64_t ns
             memset(&rd, 0, sizeof rd);
             rd.index = e.src_base[sr] + si;
             const uint64_t info = e.info[rec];
-            rd.bp = (uint16_t)info_bp(info);
-            rd.swapped = (info_flags(info) & kEvSwapped) ? 1 : 0;
             const uint32_t jr = info_jrec(info);
-            rd.junction_len = jr;
             e.reads[slot] = rd;
             e.out_src_rank[slot] = sr; e.out_src_idx[slot] = si; e.out_rec[slot] = rec; e.out_jrec[slot] = jr;
         }
@@ -963,22 +960,10 @@ int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts) {
     return BF_OK;
 }
 
-// reads[i].junction_{off,len} from the render offsets
-__global__ void patch_reads_kernel(bf_read* reads, const uint64_t* __restrict__ joff, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { reads[i].junction_off = joff[i]; reads[i].junction_len = (uint32_t)(joff[i + 1] - joff[i]); }
-}
-__global__ void patch_reads_len_kernel(bf_read* reads, const uint64_t* __restrict__ joff, const uint32_t* __restrict__ jlen, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { reads[i].junction_off = joff[i]; reads[i].junction_len = jlen[i]; }
-}
+// reads[i].junction_off from the render offsets
 __global__ void patch_reads_off_kernel(bf_read* reads, const uint64_t* __restrict__ joff, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) reads[i].junction_off = joff[i];
-}
-__global__ void read_sizes_kernel(const bf_read* __restrict__ reads, uint32_t* __restrict__ out, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = reads[i].junction_len;
 }
 int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n) {
     if (n) hipLaunchKernelGGL(patch_reads_off_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
@@ -986,23 +971,11 @@ int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n) {
     BF_HIP(ctx, hipGetLastError());
     return BF_OK;
 }
+// record bytes of the result's supporting reads (left by emit next to the index lists)
 int read_sizes(bf_ctx* ctx, uint32_t* d_out, uint64_t n) {
-    if (n) hipLaunchKernelGGL(read_sizes_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
-                              ctx->c_reads.as<bf_read>(), d_out, n);
-    BF_HIP(ctx, hipGetLastError());
+    if (n) BF_HIP(ctx, hipMemcpyAsync(d_out, ctx->c_rsrc.as<uint32_t>() + 3 * n, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
     return BF_OK;
 }
-int patch_reads_len(bf_ctx* ctx, const uint64_t* d_joff, const uint32_t* d_jlen, uint64_t n) {
-    if (n) hipLaunchKernelGGL(patch_reads_len_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
-                              ctx->c_reads.as<bf_read>(), d_joff, d_jlen, n);
-    BF_HIP(ctx, hipGetLastError());
-    return BF_OK;
-}
-int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n) {
-    if (n) hipLaunchKernelGGL(patch_reads_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
-                              ctx->c_reads.as<bf_read>(), d_joff, n);
-    BF_HIP(ctx, hipGetLastError());
-    return BF_OK;
-}
+int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n) { return patch_reads_off(ctx, d_joff, n); }
 
 }  // namespace bf

@@ -828,12 +828,13 @@ render_kernel(uint64_t n, const uint32_t* __restrict__ idx,
     const int64_t bp = (int64_t)(tail & 0xffff), L = (int64_t)((tail >> 32) & 0xffff);
     const bool swapped = ((tail >> 16) & kEvSwapped) != 0;
     if (junction_packable((uint32_t)L, (uint32_t)(tail >> 48), max_packed)) return;      // render_packed_kernel's
-    if (l16 == 0) {                                                      // text record: {len, bp, 0xffff} + the string
+    if (l16 == 0) {                                                      // text record: {len, bp, 0xffff, form} + the string
         uint16_t* hd = (uint16_t*)(out + joff[i]);                       // records start on 4-byte boundaries
         hd[0] = (uint16_t)L; hd[1] = (uint16_t)bp; hd[2] = (uint16_t)kJunctionText;
-        for (int64_t q = 6 + L + 1; q & 3; q++) out[joff[i] + q] = 0;    // padding
+        hd[3] = (uint16_t)(swapped ? kJunctionSwapped : 0u);
+        for (int64_t q = 8 + L + 1; q & 3; q++) out[joff[i] + q] = 0;    // padding
     }
-    const int64_t dst0 = (int64_t)joff[i] + 6, out_len = L + 1;
+    const int64_t dst0 = (int64_t)joff[i] + 8, out_len = L + 1;
     const int64_t first_dw = dst0 >> 2, last_dw = (dst0 + out_len - 1) >> 2;
     const uint8_t* sbytes = (const uint8_t*)stage[g];
     for (int64_t t0 = first_dw; t0 <= last_dw; t0 += kRenderTileDw) {
@@ -928,7 +929,7 @@ __global__ void __launch_bounds__(256) render_packed_kernel(uint64_t n, const ui
     const int per_group = sparse ? 2 : 3;
     uint32_t* __restrict__ o32 = (uint32_t*)(out + joff[i]);
     o32[0] = (uint32_t)L | ((uint32_t)bp << 16);
-    o32[1] = n_exc | (sparse ? (kJunctionSparse | n_lower) << 16 : 0u);
+    o32[1] = n_exc | (((sparse ? (kJunctionSparse | n_lower) : 0u) | (swapped ? kJunctionSwapped : 0u)) << 16);
 #pragma unroll
     for (int g = 0; g < 2 * W; g++) {
         if (32 * g < L) {

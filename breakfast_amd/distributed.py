@@ -134,12 +134,11 @@ class HipStageEngine:
         total = self.eng.render_junctions_dev(n, idx.data_ptr() if n else 0, off.data_ptr(), by.data_ptr(), cap)
         return by[:total], off
 
-    def attach_junctions(self, res: Result, joff: torch.Tensor, jlen: torch.Tensor, text: torch.Tensor) -> Result:
+    def attach_junctions(self, res: Result, joff: torch.Tensor, text: torch.Tensor) -> Result:
         joff = joff.to(self.device, torch.int64).contiguous()
-        jlen = jlen.to(self.device, torch.int32).contiguous()
         text = text.to(self.device).contiguous()
         self._torch_done()
-        out = self.eng.attach_junctions_dev(joff.data_ptr() if joff.numel() else 0, jlen.data_ptr() if jlen.numel() else 0,
+        out = self.eng.attach_junctions_dev(joff.data_ptr() if joff.numel() else 0,
                                             text.data_ptr() if text.numel() else 0, int(text.numel()))
         out.src_rank, out.src_index = res.src_rank, res.src_index
         return out
@@ -282,7 +281,7 @@ class DistributedDetect:
         nr = res.reads.shape[0]
         sr = res.src_rank if nr else np.zeros(0, np.uint32)
         si = res.src_index if nr else np.zeros(0, np.uint32)
-        jl = res.reads["junction_len"] if nr else np.zeros(0, np.uint32)
+        jl = res.junction_sizes if nr else np.zeros(0, np.uint32)
         return (torch.from_numpy(sr.astype(np.int32)).to(dev), torch.from_numpy(si.astype(np.int32)).to(dev),
                 torch.from_numpy(jl.astype(np.int32)).to(dev))
 
@@ -425,12 +424,12 @@ def format_sv(res: Result, contig_names: Sequence[bytes]) -> bytes:
     single-GPU runs use the library's bf_format_sv)."""
     out = [SV_HEADER]
     from .engine import junction_text
-    jb = res.junction_bytes.tobytes()
+    jb = np.ascontiguousarray(res.junction_bytes, np.uint8)
     for c in res.clusters:
         out.append(b"%s\t%s\t%d\t\t%s\t%s\t%d\t\t" % (
             contig_names[int(c["contig"])], b"+" if c["strand"] else b"-", int(c["lpos"]) & ((1 << 64) - 1),
             contig_names[int(c["mcontig"])], b"+" if c["mstrand"] else b"-", int(c["rpos"]) & ((1 << 64) - 1)))
         rows = res.reads[int(c["read_begin"]):int(c["read_end"])]
-        out.append(b";".join(junction_text(jb[int(r["junction_off"]):int(r["junction_off"]) + int(r["junction_len"])]) for r in rows))
+        out.append(b";".join(junction_text(jb, int(r["junction_off"])) for r in rows))
         out.append(b"\t\t\n")
     return b"".join(out)

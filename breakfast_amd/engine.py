@@ -31,9 +31,8 @@ HIT_DTYPE = np.dtype([("pos5", "<u4"), ("pos3", "<u4"), ("contig5", "<u2"), ("co
 CLUSTER_DTYPE = np.dtype([("lpos", "<i8"), ("rpos", "<i8"), ("seed_index", "<u8"),
                           ("read_begin", "<u8"), ("read_end", "<u8"), ("contig", "<u4"),
                           ("mcontig", "<u4"), ("strand", "u1"), ("mstrand", "u1"), ("pad", "u1", (6,))])
-READ_DTYPE = np.dtype([("index", "<u8"), ("junction_off", "<u8"), ("junction_len", "<u4"),
-                       ("bp", "<u2"), ("swapped", "u1"), ("pad", "u1")])
-assert HIT_DTYPE.itemsize == 16 and CLUSTER_DTYPE.itemsize == 56 and READ_DTYPE.itemsize == 24
+READ_DTYPE = np.dtype([("index", "<u8"), ("junction_off", "<u8")])
+assert HIT_DTYPE.itemsize == 16 and CLUSTER_DTYPE.itemsize == 56 and READ_DTYPE.itemsize == 16
 
 
 class BfConfig(C.Structure):
@@ -74,7 +73,7 @@ ABI_SYMBOLS = [
     "bf_render_junctions", "bf_result_sources_dev", "bf_render_junctions_dev", "bf_result_attach_junctions_dev",
     "bf_evidence_fetch", "bf_kernel_times", "bf_stats", "bf_junction_text", "bf_result_junction_text",
     "bf_result_junction_sizes_dev", "bf_result_attach_offsets_dev", "bf_result_attach_junction_chunk_dev",
-    "bf_result_attach_finish", "bf_junction_record_bound",
+    "bf_result_attach_finish", "bf_junction_record_bound", "bf_junction_record_bytes",
 ]
 
 _lib = None
@@ -129,7 +128,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_render_junctions.argtypes = [vp, C.c_uint64, vp, C.POINTER(vp), C.POINTER(vp)]
     lib.bf_result_sources_dev.argtypes = [vp, vp, vp]
     lib.bf_render_junctions_dev.argtypes = [vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]
-    lib.bf_result_attach_junctions_dev.argtypes = [vp, vp, vp, vp, C.c_uint64, C.POINTER(BfResult)]
+    lib.bf_result_attach_junctions_dev.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(BfResult)]
+    lib.bf_junction_record_bytes.argtypes = [vp, C.c_uint64]
+    lib.bf_junction_record_bytes.restype = C.c_int64
     lib.bf_evidence_fetch.argtypes = [vp, C.POINTER(BfEvidenceView)]
     lib.bf_kernel_times.argtypes = [vp, C.POINTER(C.POINTER(BfKernelTime)), C.POINTER(C.c_uint32)]
     lib.bf_stats.argtypes = [vp, u64p, u64p]
@@ -183,12 +184,11 @@ class Result:
     src_rank: Optional[np.ndarray] = None
     src_index: Optional[np.ndarray] = None
     n_reads: int = -1         # supporting reads (== reads.shape[0] unless the table is still on the device)
+    junction_sizes: Optional[np.ndarray] = None   # record bytes per read (stand-in engines of the sharded path)
 
     def junction(self, k: int) -> bytes:
         """Junction string of supporting read k (detect.rs:155-162), expanded from its record."""
-        r = self.reads[k]
-        o, n = int(r["junction_off"]), int(r["junction_len"])
-        return junction_text(self.junction_bytes[o:o + n].tobytes())
+        return junction_text(self.junction_bytes, int(self.reads[k]["junction_off"]))
 
     def junction_texts(self) -> Tuple[np.ndarray, np.ndarray]:
         """All junction strings, concatenated in read order -> (uint8 text, uint64 offsets[n+1])."""
@@ -207,28 +207,41 @@ class Result:
         return text, off
 
 
-def junction_text(record: bytes) -> bytes:
-    """Expands one junction record (include/breakfast_hip.h, "Junction records") with the library's own
-    host decoder."""
+def junction_text(records, off: int = 0) -> bytes:
+    """Expands the junction record that starts at byte `off` of `records` (bytes or a uint8 array; see
+    include/breakfast_hip.h, "Junction records") with the library's own host decoder."""
     lib = load_library()
-    rec = np.frombuffer(record, np.uint8)
-    n = lib.bf_junction_text(rec.ctypes.data if rec.size else None, rec.size, None, 0)
+    rec = records if isinstance(records, np.ndarray) else np.frombuffer(records, np.uint8)
+    avail = max(int(rec.size) - off, 0)
+    ptr = rec.ctypes.data + off if avail else None
+    n = lib.bf_junction_text(ptr, avail, None, 0)
     if n < 0:
         raise BreakfastError(int(n), "malformed junction record")
     buf = C.create_string_buffer(int(n))
-    lib.bf_junction_text(rec.ctypes.data, rec.size, buf, n)
+    lib.bf_junction_text(ptr, avail, buf, n)
     return buf.raw[:n]
 
 
-def text_records(text: np.ndarray, off: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    """Wraps junction strings as TEXT records {u16 len, u16 bp, u16 0xffff} + string, padded to 4 bytes
-    (what an engine without the packed renderer hands to the exchange) -> (records, offsets[n+1])."""
+def junction_header(records, off: int = 0) -> Tuple[int, int, bool, int]:
+    """-> (read length, breakpoint offset, reverse-complemented, stored bytes) of the record at `off`."""
+    lib = load_library()
+    rec = records if isinstance(records, np.ndarray) else np.frombuffer(records, np.uint8)
+    size = lib.bf_junction_record_bytes(rec.ctypes.data + off if rec.size > off else None, max(int(rec.size) - off, 0))
+    if size < 0:
+        raise BreakfastError(int(size), "malformed junction record")
+    h = np.frombuffer(rec[off:off + 8].tobytes(), "<u2")
+    return int(h[0]), int(h[1]), bool(h[3] & 0x4000), int(size)
+
+
+def text_records(text: np.ndarray, off: np.ndarray, swapped: Optional[Sequence[bool]] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Wraps junction strings as TEXT records {u16 len, u16 bp, u16 0xffff, u16 form} + string, padded to 4
+    bytes (what an engine without the packed renderer hands to the exchange) -> (records, offsets[n+1])."""
     n = off.shape[0] - 1
     out, ro = [], np.zeros(n + 1, np.uint64)
     tb = np.ascontiguousarray(text, np.uint8).tobytes()
     for i in range(n):
         s = tb[int(off[i]):int(off[i + 1])]
-        rec = np.array([len(s) - 1, s.index(b"|"), 0xffff], "<u2").tobytes() + s
+        rec = np.array([len(s) - 1, s.index(b"|"), 0xffff, 0x4000 if swapped is not None and swapped[i] else 0], "<u2").tobytes() + s
         rec += b"\0" * (-len(rec) % 4)
         out.append(rec)
         ro[i + 1] = ro[i] + len(rec)
@@ -444,9 +457,9 @@ class Engine:
                                                      C.c_void_p(dev_bytes or None), cap, C.byref(total)))
         return int(total.value)
 
-    def attach_junctions_dev(self, dev_joff: int, dev_jlen: int, dev_bytes: int, size: int, copy: bool = False) -> Result:
+    def attach_junctions_dev(self, dev_joff: int, dev_bytes: int, size: int, copy: bool = False) -> Result:
         r = BfResult()
-        self._check(self.lib.bf_result_attach_junctions_dev(self.h, C.c_void_p(dev_joff or None), C.c_void_p(dev_jlen or None),
+        self._check(self.lib.bf_result_attach_junctions_dev(self.h, C.c_void_p(dev_joff or None),
                                                             C.c_void_p(dev_bytes or None), size, C.byref(r)))
         self._last = r
         return self._wrap(r, copy)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 2
+#define BF_ABI_VERSION 3
 
 enum {
     BF_OK = 0,
@@ -109,32 +109,30 @@ typedef struct {
  * leaves the GPU as a self-describing record, because the result copy over PCIe is the longest stage of
  * the path and 3 bits per base say what 8 bits of text say.  Records start on 4-byte boundaries; little endian:
  *     u16 len      read length L
- *     u16 bp       position of '|' in the string (0 <= bp <= L)
+ *     u16 bp       position of '|' in the string (0 <= bp <= L) = breakpoint offset in the re-oriented read
  *     u16 n_exc    number of exception entries, or 0xFFFF = text record
+ *     u16 form     bit 15: sparse form; bit 14: the read was reverse-complemented by the reorient step
+ *                  (detect.rs:108-113); low 14 bits: n_lower (sparse form only)
  *   text record (reads longer than the packed kernel's 256 bases, or with many bases outside ACGT):
  *     L+1 bytes    the string itself, then zero padding to a multiple of 4 bytes
  *   packed record, dense form:
- *     u16 0
  *     ceil(L/32) x { u32 lo, u32 hi, u32 lower }   bit j of group g = base k = 32g+j of the printed sequence:
  *                  letter "ACTG"[lo + 2*hi], printed in lower case when `lower` is set
  *     n_exc x { u16 k, u8 byte, u8 0 }             base k prints as `byte` (N and other IUPAC letters)
  *   packed record, sparse form (few mismatches, the usual case):
- *     u16 0x8000 | n_lower
  *     ceil(L/32) x { u32 lo, u32 hi }
  *     n_exc x { u16 k, u8 byte, u8 0 }
  *     n_lower x u16 k                               base k prints in lower case; zero padding to 4 bytes
  * bf_junction_text() expands one record, bf_result_junction_text() all records of a result, and
+ * A record's length follows from its header, so the read table holds only where it starts.
  * bf_format_sv() expands them while it prints.  52 bytes instead of 151 for a 150-base read with one mismatch. */
 
 /* One supporting read that survived frag-id dedup (detect.rs:247-287), in printed order. */
 typedef struct {
-    uint64_t index;          /* global input index (position in submit order, + ctx base)          */
-    uint64_t junction_off;   /* its junction record (see above) is                                  */
-    uint32_t junction_len;   /*   junction_bytes[junction_off .. junction_off+junction_len)          */
-    uint16_t bp;             /* breakpoint offset inside the (re-oriented) read (detect.rs:147-153) */
-    uint8_t  swapped;        /* read was reverse-complemented by the reorient step (detect.rs:108)  */
-    uint8_t  pad;
-} bf_read;
+    uint64_t index;          /* global input index (position in submit order, + ctx base)                         */
+    uint64_t junction_off;   /* its junction record (see above) starts at junction_bytes + junction_off; breakpoint */
+                             /* offset (detect.rs:147-153) and reorientation are in the record's header             */
+} bf_read;                   /* 16 bytes: this table and the records are what crosses PCIe per supporting read      */
 
 typedef struct {
     uint64_t          n_evidence;     /* the count the reference logs at detect.rs:190 */
@@ -193,8 +191,11 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* result, char* buf, uint
 
 /* The string detect.rs:155-162 builds for one read, from its junction record: writes len+1 bytes (no
  * terminator) when buf is given and cap suffices; returns len+1, or BF_ERR_INVALID for a malformed
- * record.  Pure host code, needs no ctx. */
-int64_t bf_junction_text(const uint8_t* record, uint64_t record_len, char* buf, uint64_t cap);
+ * record.  `avail` = bytes readable from `record` on (at least the record; e.g. junction_size - junction_off).
+ * Pure host code, needs no ctx. */
+int64_t bf_junction_text(const uint8_t* record, uint64_t avail, char* buf, uint64_t cap);
+/* Stored size of the record in bytes (a multiple of 4), or BF_ERR_INVALID. */
+int64_t bf_junction_record_bytes(const uint8_t* record, uint64_t avail);
 
 /* All junction strings of a result, concatenated in read order: text_off receives n_reads+1 offsets,
  * text (capacity cap) the bytes when given and large enough.  Returns the total size or a negative error. */
@@ -259,12 +260,12 @@ int bf_result_sources_dev(bf_ctx* ctx, uint32_t* dev_src_rank, uint32_t* dev_src
 int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_index, uint64_t* dev_off,
                             uint8_t* dev_bytes, uint64_t dev_bytes_cap, uint64_t* total);
 
-/* On an owner rank, after the junction text of its supporting reads has arrived in device memory:
- * dev_joff[i]/dev_jlen[i] locate read i's string inside dev_bytes (size bytes).  Patches the read
- * table, copies table and text to the ctx's pinned host memory and fills *out with the complete
- * result, laid out exactly as bf_finish returns it on one GPU. */
-int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const uint32_t* dev_jlen,
-                                   const uint8_t* dev_bytes, uint64_t size, bf_result* out);
+/* On an owner rank, after the junction records of its supporting reads have arrived in device memory:
+ * dev_joff[i] locates read i's record inside dev_bytes (size bytes).  Patches the read table, copies
+ * table and records to the ctx's pinned host memory and fills *out with the complete result, laid out
+ * as bf_finish returns it on one GPU. */
+int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const uint8_t* dev_bytes, uint64_t size,
+                                   bf_result* out);
 
 /* Pipelined form of bf_result_attach_junctions_dev (same state requirements, same finished result).  The
  * exchange carries every read's junction record size, so an owner rank can lay out its junction buffer

@@ -23,7 +23,7 @@ def test_header_symbols_are_all_exported():
     for s in syms:
         assert hasattr(lib, s), "libbreakfast_hip.so does not export %s" % s
     assert sorted(engine.ABI_SYMBOLS) == syms, "engine.ABI_SYMBOLS out of date with the header"
-    assert lib.bf_abi_version() == 2
+    assert lib.bf_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(engine.BfResult) == 56
     assert engine.HIT_DTYPE.itemsize == 16
     assert engine.CLUSTER_DTYPE.itemsize == 56
-    assert engine.READ_DTYPE.itemsize == 24
+    assert engine.READ_DTYPE.itemsize == 16
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -64,7 +64,7 @@ class OracleStage:
         sv, clusters = po.cluster_and_format(self.owned, self.F, self.E)
         cid = {n: i for i, n in enumerate(self.names)}
         cl = np.zeros(len(clusters), CLUSTER_DTYPE)
-        reads, src_rank, src_index = [], [], []
+        reads, sizes, src_rank, src_index = [], [], [], []
         for k, (seed, members) in enumerate(clusters):
             cl[k]["lpos"] = po._i64(seed.pos); cl[k]["rpos"] = po._i64(seed.mpos)
             cl[k]["seed_index"] = seed.read_num
@@ -73,18 +73,20 @@ class OracleStage:
             cl[k]["strand"] = seed.strand; cl[k]["mstrand"] = seed.mstrand
             for m in members:
                 # the record size travels with the exchange record: a text record here (no packed renderer)
-                reads.append((m.read_num, 0, (6 + len(m.sequence) + 3) & ~3, m.bp, m.swapped, 0))
+                reads.append((m.read_num, 0))
+                sizes.append((8 + len(m.sequence) + 3) & ~3)
                 r = int(np.searchsorted(self.bases, m.read_num, side="right") - 1)
                 src_rank.append(r); src_index.append(m.read_num - int(self.bases[r]))
         rd = np.array(reads, READ_DTYPE) if reads else np.zeros(0, READ_DTYPE)
-        return Result(len(self.owned), cl, rd, np.zeros(0, np.uint8), np.array(src_rank, np.uint32), np.array(src_index, np.uint32))
+        return Result(len(self.owned), cl, rd, np.zeros(0, np.uint8), np.array(src_rank, np.uint32), np.array(src_index, np.uint32),
+                      junction_sizes=np.array(sizes, np.uint32))
 
     def render_junctions(self, local_index):
         js = [self.local[int(i)].sequence for i in local_index]
         off = np.zeros(len(js) + 1, np.uint64)
         off[1:] = np.cumsum([len(j) for j in js])
         # junction strings travel as records (include/breakfast_hip.h); this stand-in has no packed renderer
-        return text_records(np.frombuffer(b"".join(js), np.uint8).copy(), off)
+        return text_records(np.frombuffer(b"".join(js), np.uint8).copy(), off, [self.local[int(i)].swapped for i in local_index])
 
 
 def make_case(seed=0):

@@ -9,7 +9,7 @@ from breakfast_amd import engine
 CODE = {ord("A"): 0, ord("C"): 1, ord("T"): 2, ord("G"): 3}
 
 
-def pack(junction: bytes, form: str = "auto") -> bytes:
+def pack(junction: bytes, form: str = "auto", swapped: bool = False) -> bytes:
     """Reference packer: the record the GPU writes for this string (form "auto"), or a given packed form."""
     bp = junction.index(b"|")
     seq = junction[:bp] + junction[bp + 1:]
@@ -28,7 +28,7 @@ def pack(junction: bytes, form: str = "auto") -> bytes:
         else:
             exc.append((k, c))
     sparse = ((2 * len(lower) + 3) & ~3) < 4 * groups if form == "auto" else form == "sparse"
-    out = np.array([L, bp, len(exc), (0x8000 | len(lower)) if sparse else 0], "<u2").tobytes()
+    out = np.array([L, bp, len(exc), ((0x8000 | len(lower)) if sparse else 0) | (0x4000 if swapped else 0)], "<u2").tobytes()
     for g in range(groups):
         out += np.array([lo[g], hi[g]] + ([] if sparse else [cs[g]]), "<u4").tobytes()
     for k, c in exc:
@@ -39,8 +39,8 @@ def pack(junction: bytes, form: str = "auto") -> bytes:
     return out
 
 
-def text_record(junction: bytes) -> bytes:
-    rec = np.array([len(junction) - 1, junction.index(b"|"), 0xffff], "<u2").tobytes() + junction
+def text_record(junction: bytes, swapped: bool = False) -> bytes:
+    rec = np.array([len(junction) - 1, junction.index(b"|"), 0xffff, 0x4000 if swapped else 0], "<u2").tobytes() + junction
     return rec + b"\0" * (-len(rec) % 4)
 
 
@@ -81,10 +81,10 @@ def test_malformed_records_are_rejected():
     sparse = pack(b"ACGTACgTAC|GTNACGTACGT", "sparse")
     for bad in (b"", good[:5], good[:12], good[:-1], sparse[:-4],
                 sparse[:-4] + np.array([99, 0], "<u2").tobytes(),                  # lower-case position past the end
-                good[:6] + b"\x01\x00" + good[8:],                               # unknown form
+                good[:6] + b"\x01\x00" + good[8:],                               # dense form with a count
                 np.array([4, 9, 0, 0], "<u2").tobytes() + b"\0" * 12,            # bp > len
                 np.array([4, 1, 1, 0], "<u2").tobytes() + b"\0" * 12 + np.array([7], "<u2").tobytes() + b"N\0",   # exception past the end
-                np.array([10, 1, 0xffff], "<u2").tobytes() + b"A|CG"):            # text shorter than len+1
+                np.array([10, 1, 0xffff, 0], "<u2").tobytes() + b"A|CG"):         # text shorter than len+1
         with pytest.raises(engine.BreakfastError):
             engine.junction_text(bad)
 
@@ -96,9 +96,16 @@ def test_result_junction_texts_batch():
     rd = np.zeros(len(js), engine.READ_DTYPE)
     off = 0
     for i, r in enumerate(recs):
-        rd[i]["junction_off"], rd[i]["junction_len"] = off, len(r)
+        rd[i]["junction_off"] = off
         off += len(r)
     res = engine.Result(len(js), np.zeros(0, engine.CLUSTER_DTYPE), rd, np.frombuffer(b"".join(recs), np.uint8))
     text, toff = res.junction_texts()
     assert [text[int(toff[i]):int(toff[i + 1])].tobytes() for i in range(len(js))] == js
     assert res.junction(17) == js[17]
+    # headers: length, breakpoint, reorientation flag, stored size
+    buf = np.frombuffer(b"".join(recs), np.uint8)
+    for i in (0, 1, 2, 250):
+        L, bp, sw, size = engine.junction_header(buf, int(rd[i]["junction_off"]))
+        assert (L, bp, sw, size) == (len(js[i]) - 1, js[i].index(b"|"), False, len(recs[i]))
+    assert engine.junction_header(pack(js[3], swapped=True))[2] and engine.junction_header(text_record(js[3], True))[2]
+    assert engine.junction_text(pack(js[3], swapped=True)) == js[3]
