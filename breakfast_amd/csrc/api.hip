@@ -264,6 +264,7 @@ void bf_ctx_destroy(bf_ctx* ctx) {
     for (auto& e2 : ctx->ev) if (e2) (void)hipEventDestroy(e2);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     delete reinterpret_cast<std::vector<PendingEvent>*>(ctx->timing_pending);
     delete ctx;
 }
@@ -399,6 +400,15 @@ int bf_localise(bf_ctx* ctx) {
     return run_localise(ctx);
 }
 
+// bf_finish: the host does not wait for the localise kernels' counters, the cluster stage's first
+// synchronisation brings them along
+static int localise_deferred(bf_ctx* ctx) {
+    if (ctx->n_contigs == 0) return fail(ctx, BF_ERR_STATE, "bf_localise before bf_genome_set");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->imported = false;
+    return run_localise(ctx, true);
+}
+
 int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     if (!ctx) return BF_ERR_INVALID;
     if (!out) return fail(ctx, BF_ERR_INVALID, "bf_clusterise: null result");
@@ -447,6 +457,7 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
         }
     }
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));        // the cluster rows went out on it
     out->n_evidence = ctx->n_evidence;
     out->n_clusters = ctx->out.n_clusters;
     out->n_reads = nr;
@@ -460,7 +471,7 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
 int bf_finish(bf_ctx* ctx, bf_result* out) {
     if (!ctx) return BF_ERR_INVALID;
     if (ctx->n_ranks > 1) return fail(ctx, BF_ERR_STATE, "bf_finish on a multi-rank ctx; use the stage calls");
-    BF_TRY(bf_localise(ctx));
+    BF_TRY(localise_deferred(ctx));
     return bf_clusterise(ctx, out);
 }
 
@@ -601,6 +612,7 @@ int bf_exchange_local(bf_ctx* ctx, bf_wire_local* out) {
     if (!ctx || !out) return BF_ERR_INVALID;
     if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_exchange_local before bf_localise");
     out->max_frag_len_bytes = ctx->max_frag;
+    BF_TRY(settle_counts(ctx));
     out->has_exact_sig = ctx->n_sigx ? 1 : 0;
     return BF_OK;
 }

@@ -185,6 +185,8 @@ struct bf_ctx {
     uint64_t n_exact = 0;
     uint64_t n_sigx = 0;                        // evidence whose signature holds a non-ACGT byte
     uint64_t n_text_records = 0;                // resident reads whose junction record cannot be packed
+    uint32_t* h_counts = nullptr;               // pinned: the localise kernels' counters on their way to the three fields above
+    bool counts_pending = false;                // ... not yet read back: settle_counts() after the next synchronisation
     bf::DevBuf d_planes, d_len, d_frag_len, d_fhash;
     bf::DevBuf d_key, d_lpos, d_rpos, d_bp, d_flags, d_mask, d_jrec;   // d_jrec: read_info() words
     bf::DevBuf d_exact_list, d_counters, d_sigx, d_sigx_slot;
@@ -253,7 +255,8 @@ struct Scope {
 
 // localise.hip ----------------------------------------------------------------------------------
 int genome_pack(bf_ctx* ctx);                       // raw image -> blocks + coarse bitmap
-int run_localise(bf_ctx* ctx);                      // encode + hash + fast + exact kernels
+int run_localise(bf_ctx* ctx, bool defer_counts = false);   // encode + hash + fast + exact kernels
+int settle_counts(bf_ctx* ctx);                     // n_exact / n_sigx / n_text_records valid on return
 int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, int n_chunks, uint64_t* chunk_off,
                    const uint32_t* d_sizes = nullptr);   // d_sizes: record bytes per list entry when the caller has them
 int64_t junction_decode(const uint8_t* rec, uint64_t avail, uint8_t* out, uint64_t cap, uint64_t* stored = nullptr);   // api.hip, host

@@ -135,9 +135,10 @@ __global__ void __launch_bounds__(256) tails_kernel(const SweepView v, const uin
 // one lane per listed short segment: the reference's two loops as they are
 __global__ void __launch_bounds__(64) sweep_list_kernel(const SweepView v, uint8_t* __restrict__ reported,
                                                         uint32_t* __restrict__ csize, const uint32_t* __restrict__ small_list,
-                                                        uint32_t n_small) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_small) return;
+                                                        const uint32_t* __restrict__ counts) {
+    // fixed grid; the list's length stays on the device (no host round trip between tails_kernel and this one)
+    const uint32_t n_small = counts[0];
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_small; k += gridDim.x * blockDim.x) {
     const uint64_t i = small_list[k];
     const uint64_t key = v.skey[i];
     uint64_t e = i + 1;
@@ -155,15 +156,16 @@ __global__ void __launch_bounds__(64) sweep_list_kernel(const SweepView v, uint8
         }
         csize[p] = cnt;
     }
+    }
 }
 
 // One wave per long segment: seeds are still taken in order (the sweep is sequential in the seeds),
 // but finding the next unreported read and testing a seed's window run 64 reads at a time.
 __global__ void __launch_bounds__(256) sweep_big_kernel(const SweepView v, uint8_t* reported, uint32_t* __restrict__ csize,
-                                                        const uint32_t* __restrict__ big_list, uint32_t n_big) {
-    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                                                        const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
-    if (b >= n_big) return;
+    const uint32_t n_big = counts[1], n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < n_big; b += n_waves) {      // wave-uniform
     const uint64_t i = big_list[b];
     const uint64_t key = v.skey[i];
     uint64_t e = i;                                          // segment end
@@ -196,6 +198,7 @@ __global__ void __launch_bounds__(256) sweep_big_kernel(const SweepView v, uint8
         // the marks written above are read back by other lanes of this wave in the next round
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         cursor = p + 1;
+    }
     }
 }
 
@@ -584,19 +587,15 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
         BF_TRY(scan_u32_to_u64(ctx, covered, ctx->c_scan.as<uint64_t>(), n));
         hipLaunchKernelGGL(tails_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, sv, head, ctx->c_scan.as<uint64_t>(),
                            ctx->c_csize.as<uint32_t>(), small_list, big_list, counts);
-        uint32_t n_walk[2] = {0, 0};
-        BF_HIP(ctx, hipMemcpyAsync(n_walk, counts, 8, hipMemcpyDeviceToHost, st));
-        BF_HIP(ctx, hipStreamSynchronize(st));
-        if (n_walk[0])
-            hipLaunchKernelGGL(sweep_list_kernel, dim3(grid_for(n_walk[0], 64)), dim3(64), 0, st, sv,
-                               ctx->c_reported.as<uint8_t>(), ctx->c_csize.as<uint32_t>(), small_list, n_walk[0]);
-        if (n_walk[1])
-            hipLaunchKernelGGL(sweep_big_kernel, dim3(grid_for((uint64_t)n_walk[1] * 64, B)), dim3(B), 0, st, sv,
-                               ctx->c_reported.as<uint8_t>(), ctx->c_csize.as<uint32_t>(), big_list, n_walk[1]);
+        hipLaunchKernelGGL(sweep_list_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, 64), 4096)), dim3(64), 0, st, sv,
+                           ctx->c_reported.as<uint8_t>(), ctx->c_csize.as<uint32_t>(), small_list, counts);
+        hipLaunchKernelGGL(sweep_big_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, kBigSegment) / 4 + 1, 1024)), dim3(B), 0, st, sv,
+                           ctx->c_reported.as<uint8_t>(), ctx->c_csize.as<uint32_t>(), big_list, counts);
         hipLaunchKernelGGL(flag_ge_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
                            ctx->c_csize.as<uint32_t>(), ctx->cfg.min_evidence, n);
         BF_TRY(scan_u32_to_u64(ctx, ctx->c_flag.as<uint32_t>(), ctx->c_scan.as<uint64_t>(), n));
         BF_TRY(fetch_u64(ctx, ctx->c_scan.as<uint64_t>() + n, &nq));
+        BF_TRY(settle_counts(ctx));                       // the localise counters came along with this synchronisation
     }
     if (nq == 0) return BF_OK;
 
@@ -713,7 +712,10 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     // host copies: the rows now; the reads after the junction offsets are patched in (api.hip)
     ctx->out.n_clusters = ns; ctx->out.n_reads = total_r;
     BF_TRY(ensure_host(ctx, ctx->out.clusters, ns * sizeof(bf_cluster)));
-    BF_HIP(ctx, hipMemcpyAsync(ctx->out.clusters.p, ctx->c_clusters.p, ns * sizeof(bf_cluster), hipMemcpyDeviceToHost, st));
+    // on the copy stream: 6 MB of rows would otherwise hold up the render kernels for 0.1 ms
+    BF_HIP(ctx, hipEventRecord(ctx->ev[11], st));
+    BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[11], 0));
+    BF_HIP(ctx, hipMemcpyAsync(ctx->out.clusters.p, ctx->c_clusters.p, ns * sizeof(bf_cluster), hipMemcpyDeviceToHost, ctx->copy_stream));
     if (total_r && v.src_rank) {          // multi-rank: the caller routes junction requests to the source ranks
         BF_TRY(ensure_host(ctx, ctx->out.src, total_r * 8));
         BF_HIP(ctx, hipMemcpyAsync(ctx->out.src.p, ev.out_src_rank, total_r * 8, hipMemcpyDeviceToHost, st));

@@ -664,9 +664,11 @@ struct ExactRead {
 // with words that come from byte compares.  Three passes over the chunks (mm[A]; the scan; the combined
 // mask once bp is known): the bytes are cache-resident after the first.
 __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) {
-    const uint32_t slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (slot >= a.counters[0]) return;                               // wave-uniform
+    // fixed grid, every wave takes list entries wave, wave + n_waves, ...: the list's length stays on the device
+    // (the host does not wait for the packed kernel to learn it)
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6, n_list = a.counters[0];
+    for (uint32_t slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; slot < n_list; slot += n_waves) {     // wave-uniform
     const uint32_t r = a.exact_list[slot];
     const bf_hit h = a.hits[r];
     const Oriented o = orient(h, a.contigs);
@@ -755,7 +757,7 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
         if (lane < 16) a.sigx[(uint64_t)xs * 16 + lane] = sc;
         if (lane == 0) a.sigx_slot[r] = xs;
     }
-    if (lane != 0) return;
+    if (lane != 0) continue;
     const int64_t lp = o.strand ? o.pos + bp - 1 : o.pos + A - bp;
     const int64_t rp = o.mstrand ? o.mpos + A - (L - bp) : o.mpos + (L - bp);
     a.key[r] = make_key(o, !plain, sig, a.cb);
@@ -769,6 +771,7 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
     a.info[r] = read_info(junction_record_bytes((uint32_t)L, n_exc, n_lower, a.max_packed), fl, (uint32_t)bp, (uint32_t)L);
     a.meta[(uint64_t)r * (a.mask_words + 1) + a.mask_words] =
         (uint64_t)(uint16_t)bp | ((uint64_t)fl << 16) | ((uint64_t)(uint16_t)L << 32) | ((uint64_t)n_exc << 48);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -998,7 +1001,15 @@ static void launch_fast(bf_ctx* ctx, const LocaliseArgs& a) {
         hipLaunchKernelGGL((localise_fast_kernel<W, false, true>), g, b, 0, ctx->stream, a);
 }
 
-int run_localise(bf_ctx* ctx) {
+int settle_counts(bf_ctx* ctx) {
+    if (!ctx->counts_pending) return BF_OK;
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_exact = ctx->h_counts[0]; ctx->n_sigx = ctx->h_counts[1]; ctx->n_text_records = ctx->h_counts[2];
+    ctx->counts_pending = false;
+    return BF_OK;
+}
+
+int run_localise(bf_ctx* ctx, bool defer_counts) {
     const uint64_t n = ctx->n_reads;
     ctx->n_exact = 0; ctx->n_sigx = 0; ctx->n_text_records = 0;
     ctx->localised = false;
@@ -1072,14 +1083,7 @@ int run_localise(bf_ctx* ctx) {
     }
     BF_HIP(ctx, hipGetLastError());
 
-    uint32_t cnt[3] = {0, 0, 0};
-    BF_HIP(ctx, hipMemcpyAsync(cnt, ctx->d_counters.p, 12, hipMemcpyDeviceToHost, ctx->stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t n_exact = cnt[0];
-    ctx->n_exact = n_exact;
-    ctx->n_sigx = cnt[1];
-    ctx->n_text_records = cnt[2];
-    if (n_exact) {
+    {
         ExactArgs e{};
         e.n_total = n; e.A = (int)A; e.cb = ctx->contig_bits; e.exact_list = a.exact_list; e.counters = a.counters; e.hits = a.hits;
         e.seq = ctx->d_seq.as<uint8_t>(); e.seq_off = ctx->d_seq_off.as<uint64_t>();
@@ -1087,15 +1091,15 @@ int run_localise(bf_ctx* ctx) {
         e.key = a.key; e.lpos = a.lpos; e.rpos = a.rpos; e.bp = a.bp; e.flags = a.flags; e.meta = a.meta;
         e.mask_words = (int)Wm; e.max_packed = 64u * W; e.info = ctx->d_jrec.as<uint64_t>(); e.sigx = ctx->d_sigx.as<uint8_t>(); e.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
         Scope t(ctx, "localise_exact");
-        hipLaunchKernelGGL(localise_exact_kernel, dim3(grid_for((uint64_t)n_exact * 64, 256)), dim3(256), 0, ctx->stream, e);
+        const unsigned blocks = (unsigned)std::min<uint64_t>(grid_for(n * 64, 256), 16384);   // oversubscribed: entries differ in length
+        hipLaunchKernelGGL(localise_exact_kernel, dim3(blocks), dim3(256), 0, ctx->stream, e);
         BF_HIP(ctx, hipGetLastError());
-        BF_HIP(ctx, hipMemcpyAsync(cnt, ctx->d_counters.p, 12, hipMemcpyDeviceToHost, ctx->stream));
-        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->n_sigx = cnt[1];
-        ctx->n_text_records = cnt[2];
     }
+    if (!ctx->h_counts) BF_HIP(ctx, hipHostMalloc((void**)&ctx->h_counts, 64, hipHostMallocDefault));
+    BF_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counters.p, 12, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->counts_pending = true;
     ctx->localised = true;
-    return BF_OK;
+    return defer_counts ? BF_OK : settle_counts(ctx);
 }
 
 __global__ void pick_offsets_kernel(const uint64_t* __restrict__ off, uint64_t n, int n_chunks, uint64_t* __restrict__ out) {
@@ -1141,6 +1145,7 @@ static int launch_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_idx, const u
     if (W == 2) hipLaunchKernelGGL(render_packed_kernel<2>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes);
     else if (W == 3) hipLaunchKernelGGL(render_packed_kernel<3>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes);
     else hipLaunchKernelGGL(render_packed_kernel<4>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes);
+    BF_TRY(settle_counts(ctx));
     if (ctx->n_text_records)
         hipLaunchKernelGGL(render_kernel, dim3(grid_for(n * 16, 256)), dim3(256), 0, ctx->stream, n, d_idx, d_off, seq, so, meta,
                            stride, 64u * W, d_bytes);
