@@ -5,6 +5,7 @@
 #include "bf_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <numeric>
@@ -187,25 +188,34 @@ int64_t junction_decode(const uint8_t* rec, uint64_t rec_len, uint8_t* out, uint
     }
     if (!out || cap < text) return (int64_t)text;
     const uint64_t* S = spread_table();
-    uint8_t* dst = out + 1;                                  // bases land one to the right; the left part moves down below
-    for (uint32_t k = 0; k < L; k += 8) {
+    auto eight = [&](uint32_t k) -> uint64_t {               // the 8 bases from k on, as printed
         const uint8_t* grp = g + gb * (k >> 5);
         const uint32_t b = (k >> 3) & 3;
         const uint8_t lo = grp[b], hi = grp[4 + b], cs = sparse ? 0 : grp[8 + b];
         // 'A' + 2*lo + 0x13*hi - 0x0f*(lo&hi) = A C T G for codes 0..3; + 0x20 = lower case
-        const uint64_t v = 0x4141414141414141ull + 2 * S[lo] + 0x13 * S[hi] - 0x0f * S[lo & hi] + 0x20 * S[cs];
-        const uint32_t take = L - k < 8 ? L - k : 8;
-        memcpy(dst + k, &v, take);
+        return 0x4141414141414141ull + 2 * S[lo] + 0x13 * S[hi] - 0x0f * S[lo & hi] + 0x20 * S[cs];
+    };
+    // base k prints at out[k] left of the breakpoint and at out[k + 1] right of it; whole 8-byte stores
+    // wherever the record has 8 more bases (nothing is ever written past out[L])
+    uint32_t k = 0;
+    for (; k + 8 <= L; k += 8) {
+        const uint64_t v = eight(k);
+        if (k + 8 <= bp) memcpy(out + k, &v, 8);
+        else if (k >= bp) memcpy(out + k + 1, &v, 8);
+        else { memcpy(out + k + 1, &v, 8); memcpy(out + k, &v, bp - k); }
+    }
+    if (k < L) {
+        const uint64_t v = eight(k);
+        for (uint32_t j = 0; k + j < L; j++) { const uint32_t q = k + j; out[q < bp ? q : q + 1] = (uint8_t)(v >> (8 * j)); }
     }
     for (uint32_t e = 0; e < n_lower; e++) {                 // plain ACGT bases: lower case is + 0x20
-        uint16_t k; memcpy(&k, pl + 2 * e, 2);
-        dst[k] |= 0x20;
+        uint16_t q; memcpy(&q, pl + 2 * e, 2);
+        out[q < bp ? q : q + 1u] |= 0x20;
     }
     for (uint32_t e = 0; e < nx; e++) {                      // exceptions are stored as printed
-        uint16_t k; memcpy(&k, xe + 4 * e, 2);
-        dst[k] = xe[4 * e + 2];
+        uint16_t q; memcpy(&q, xe + 4 * e, 2);
+        out[q < bp ? q : q + 1u] = xe[4 * e + 2];
     }
-    memmove(out, out + 1, bp);
     out[bp] = '|';
     return (int64_t)text;
 }
@@ -494,26 +504,42 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t 
     if (nc && (!r->clusters || (r->n_reads && !r->reads))) return BF_ERR_INVALID;
     std::vector<uint64_t> off(nc + 1);
     const size_t hdr = sizeof(kSvHeader) - 1;
-    uint64_t total = hdr;
-    for (uint64_t c = 0; c < nc; c++) {
-        const bf_cluster& cl = r->clusters[c];
-        if (cl.contig >= ctx->n_contigs || cl.mcontig >= ctx->n_contigs) return BF_ERR_INVALID;
-        if (cl.read_end < cl.read_begin || cl.read_end > r->n_reads) return BF_ERR_INVALID;
-        off[c] = total;
-        uint64_t sz = ctx->contig_names[cl.contig].size() + ctx->contig_names[cl.mcontig].size() +
-                      dec_len((uint64_t)cl.lpos) + dec_len((uint64_t)cl.rpos) + 13;   // 10 tabs, 2 strands, newline
-        const uint64_t k = cl.read_end - cl.read_begin;
-        if (k) sz += k - 1;                                                             // ';' separators
-        for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
-            const bf_read& rd = r->reads[i];
-            if (rd.junction_off > r->junction_size) return BF_ERR_INVALID;
-            const int64_t tl = junction_decode(r->junction_bytes + rd.junction_off, r->junction_size - rd.junction_off, nullptr, 0);
-            if (tl < 0) return BF_ERR_INVALID;
-            sz += (uint64_t)tl;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned max_threads = std::max(1u, std::min(hw, 16u));
+    // row sizes (this is where every record is validated), by several threads when there is much to look at
+    std::atomic<bool> bad{false};
+    auto sizes = [&](uint64_t c0, uint64_t c1) {
+        for (uint64_t c = c0; c < c1; c++) {
+            const bf_cluster& cl = r->clusters[c];
+            if (cl.contig >= ctx->n_contigs || cl.mcontig >= ctx->n_contigs || cl.read_end < cl.read_begin ||
+                cl.read_end > r->n_reads) { bad = true; return; }
+            uint64_t sz = ctx->contig_names[cl.contig].size() + ctx->contig_names[cl.mcontig].size() +
+                          dec_len((uint64_t)cl.lpos) + dec_len((uint64_t)cl.rpos) + 13;   // 10 tabs, 2 strands, newline
+            const uint64_t k = cl.read_end - cl.read_begin;
+            if (k) sz += k - 1;                                                             // ';' separators
+            for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
+                const bf_read& rd = r->reads[i];
+                if (rd.junction_off > r->junction_size) { bad = true; return; }
+                const int64_t tl = junction_decode(r->junction_bytes + rd.junction_off, r->junction_size - rd.junction_off, nullptr, 0);
+                if (tl < 0) { bad = true; return; }
+                sz += (uint64_t)tl;
+            }
+            off[c + 1] = sz;
         }
-        total += sz;
+    };
+    {
+        const uint64_t nt = r->n_reads < (1u << 16) ? 1 : std::min<uint64_t>(max_threads, nc);
+        if (nt <= 1) sizes(0, nc);
+        else {
+            std::vector<std::thread> pool;
+            for (uint64_t t = 0; t < nt; t++) pool.emplace_back(sizes, nc * t / nt, nc * (t + 1) / nt);
+            for (auto& th : pool) th.join();
+        }
+        if (bad) return BF_ERR_INVALID;
     }
-    off[nc] = total;
+    off[0] = hdr;
+    for (uint64_t c = 0; c < nc; c++) off[c + 1] += off[c];
+    const uint64_t total = off[nc];
     if (!buf) return (int64_t)total;
     if (cap < total) {                                   // truncated copy, as documented: size is still returned
         std::string tmp((size_t)total, '\0');
@@ -543,8 +569,7 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t 
             *p++ = '\t'; *p++ = '\t'; *p++ = '\n';                                      // detect.rs:240
         }
     };
-    const unsigned hw = std::thread::hardware_concurrency();
-    const uint64_t nt = total < (8u << 20) ? 1 : std::min<uint64_t>(std::max(1u, std::min(hw, 8u)), nc);
+    const uint64_t nt = total < (8u << 20) ? 1 : std::min<uint64_t>(max_threads, nc);
     if (nt <= 1) { fill(0, nc); return (int64_t)total; }
     std::vector<std::thread> pool;
     uint64_t c0 = 0;
