@@ -8,10 +8,11 @@
 // and `reported[]` is only ever set by a seed of the same class.  So the global sweep restricted to
 // one class, over that class's members in (lpos, input index) order, yields exactly the clusters
 // whose seeds are in that class.  We therefore
-//   1. stable-sort evidence by (class key, lpos)                  [input order breaks ties]
-//   2. run the sequential sweep inside each key segment, one segment per lane
-//      (a key segment may be coarser than a class when the signature holds non-ACGT bytes: the
-//       key then carries a hash and the sweep compares the 16 raw bytes, like detect.rs:223)
+//   1. stable-sort evidence by (signature bits of the class key, lpos)   [input order breaks ties]
+//   2. run the sequential sweep inside each segment of equal signature bits, comparing whole keys
+//      (a segment may be coarser than a class: other contigs/strands with the same signature, or a
+//       signature with non-ACGT bytes, whose key carries a hash -- there the sweep compares the 16
+//       raw bytes, like detect.rs:223)
 //   3. enumerate members, group them by fragment id, keep the longest-flank read per group
 //   4. order surviving clusters by the seed's rank in the reference's sort: (chr, lpos, input index).
 
@@ -102,9 +103,16 @@ __device__ __forceinline__ bool rpos_far(int32_t rs, int32_t rp, int64_t F) {
 // csize[p] = cluster size if p is a seed; csize is zero-initialised.
 constexpr uint32_t kBigSegment = 96;
 
+// A SEGMENT is a run of records with equal low 32 key bits (the signature, or its hash): the class keys are
+// sorted on those bits only -- four radix passes instead of six -- and the records of a segment are in
+// (lpos, input index) order whatever their class.  Records of different classes (other contigs or strands, same
+// signature: a few thousand pairs among 10M reads) may therefore share a segment; every membership test below
+// compares the whole key, like detect.rs:218-223 compares every field, and the break test on lpos stays monotone.
+__device__ __forceinline__ uint32_t seg_of(uint64_t key) { return (uint32_t)key; }
+
 __global__ void __launch_bounds__(256) head_mark_kernel(const uint64_t* __restrict__ skey, uint32_t* __restrict__ head, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) head[i] = (i == 0 || skey[i - 1] != skey[i]) ? (uint32_t)i : 0u;
+    if (i < n) head[i] = (i == 0 || seg_of(skey[i - 1]) != seg_of(skey[i])) ? (uint32_t)i : 0u;
 }
 
 __global__ void __launch_bounds__(256) covered_kernel(const SweepView v, const uint32_t* __restrict__ head,
@@ -114,7 +122,8 @@ __global__ void __launch_bounds__(256) covered_kernel(const SweepView v, const u
     const uint64_t h = head[i];
     bool ok = false;
     if (i != h)
-        ok = !beyond(v.slpos[i], v.slpos[h], v.F) && !rpos_far(v.srpos[i], v.srpos[h], v.F) && same_sigx(v, v.skey[i], h, i);
+        ok = v.skey[i] == v.skey[h] && !beyond(v.slpos[i], v.slpos[h], v.F) && !rpos_far(v.srpos[i], v.srpos[h], v.F) &&
+             same_sigx(v, v.skey[i], h, i);
     covered[i] = ok ? 1u : 0u;
 }
 
@@ -124,7 +133,7 @@ __global__ void __launch_bounds__(256) tails_kernel(const SweepView v, const uin
                                                     uint32_t* __restrict__ big_list, uint32_t* __restrict__ counts) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.n) return;
-    if (i + 1 < v.n && v.skey[i + 1] == v.skey[i]) return;          // not the last record of its segment
+    if (i + 1 < v.n && seg_of(v.skey[i + 1]) == seg_of(v.skey[i])) return;          // not the last record of its segment
     const uint64_t h = head[i];
     const uint64_t others = i - h, cov = cov_scan[i + 1] - cov_scan[h];
     if (cov == others) { csize[h] = (uint32_t)(others + 1); return; }
@@ -140,15 +149,17 @@ __global__ void __launch_bounds__(64) sweep_list_kernel(const SweepView v, uint8
     const uint32_t n_small = counts[0];
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_small; k += gridDim.x * blockDim.x) {
     const uint64_t i = small_list[k];
-    const uint64_t key = v.skey[i];
+    const uint32_t seg = seg_of(v.skey[i]);
     uint64_t e = i + 1;
-    while (e < v.n && v.skey[e] == key) e++;
+    while (e < v.n && seg_of(v.skey[e]) == seg) e++;
     for (uint64_t p = i; p < e; p++) {
         if (reported[p]) continue;
+        const uint64_t key = v.skey[p];
         const int32_t lp = v.slpos[p], rp = v.srpos[p];
         uint32_t cnt = 1;
         for (uint64_t s = p + 1; s < e; s++) {
             if (beyond(v.slpos[s], lp, v.F)) break;
+            if (v.skey[s] != key) continue;                          // another class (detect.rs:218-223)
             if (rpos_far(v.srpos[s], rp, v.F)) continue;
             if (!same_sigx(v, key, p, s)) continue;
             cnt++;
@@ -167,12 +178,12 @@ __global__ void __launch_bounds__(256) sweep_big_kernel(const SweepView v, uint8
     const uint32_t n_big = counts[1], n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < n_big; b += n_waves) {      // wave-uniform
     const uint64_t i = big_list[b];
-    const uint64_t key = v.skey[i];
+    const uint32_t seg = seg_of(v.skey[i]);
     uint64_t e = i;                                          // segment end
     for (;; e += 64) {
         const uint64_t s = e + lane;
-        const uint64_t same = __ballot(s < v.n && v.skey[s] == key);
-        if (same != ~0ull) { e += __popcll(same); break; }   // the key is constant over a prefix
+        const uint64_t same = __ballot(s < v.n && seg_of(v.skey[s]) == seg);
+        if (same != ~0ull) { e += __popcll(same); break; }   // the signature is constant over a prefix
     }
     uint64_t cursor = i;
     while (cursor < e) {
@@ -184,12 +195,13 @@ __global__ void __launch_bounds__(256) sweep_big_kernel(const SweepView v, uint8
             if (open) { p = c0 + __builtin_ctzll(open); break; }
         }
         if (p == ~0ull) break;
+        const uint64_t key = v.skey[p];
         const int32_t lp = v.slpos[p], rp = v.srpos[p];
         uint32_t cnt = 1;
         for (uint64_t s0 = p + 1;; s0 += 64) {
             const uint64_t s = s0 + lane;
             const bool live = s < e && !beyond(v.slpos[s], lp, v.F);
-            const bool take = live && !rpos_far(v.srpos[s], rp, v.F) && same_sigx(v, key, p, s);
+            const bool take = live && v.skey[s] == key && !rpos_far(v.srpos[s], rp, v.F) && same_sigx(v, key, p, s);
             if (take) reported[s] = 1;
             cnt += (uint32_t)__popcll(__ballot(take));
             if (__ballot(live) != ~0ull) break;
@@ -290,9 +302,9 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
     uint64_t cnt = 1;
     for (uint64_t s0 = p + 1;; s0 += 64) {
         const uint64_t s = s0 + lane;
-        bool live = s < v.n && v.skey[s] == key && !beyond(v.slpos[s], lp, v.F);
+        bool live = s < v.n && seg_of(v.skey[s]) == seg_of(key) && !beyond(v.slpos[s], lp, v.F);
         const uint64_t live_mask = __ballot(live);
-        bool take = live && !rpos_far(v.srpos[s], rp, v.F) && same_sigx(v, key, p, s);
+        bool take = live && v.skey[s] == key && !rpos_far(v.srpos[s], rp, v.F) && same_sigx(v, key, p, s);
         const uint64_t take_mask = __ballot(take);
         if (take) put(base + cnt + __popcll(take_mask & ((1ull << lane) - 1)), s);
         cnt += __popcll(take_mask);
@@ -554,8 +566,9 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
                                     ctx->c_c32.as<uint32_t>(), n, 0, 32));
         hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_k64a.as<uint64_t>(), v.key,
                            ctx->c_c32.as<uint32_t>(), n);
+        // on the 32 signature bits only (see seg_of): contig ranks and strands are compared, not sorted
         BF_TRY(sort_pairs<uint64_t>(ctx, ctx->c_k64a.as<uint64_t>(), ctx->c_k64b.as<uint64_t>(), ctx->c_c32.as<uint32_t>(),
-                                    perm, n, 0, key_bits(ctx->contig_bits)));
+                                    perm, n, 0, kKeySigBits));
         hipLaunchKernelGGL(gather_pos_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_slpos.as<int32_t>(),
                            ctx->c_srpos.as<int32_t>(), ctx->c_pos2.as<int2>(), perm, n);
     }

@@ -393,6 +393,43 @@ def test_segments_that_need_a_walk():
     check_against_oracle(g, b, A, F=100)
 
 
+def test_classes_that_share_a_signature():
+    """Different breakpoint classes with the SAME 8+8 signature bases (the flanks copied onto another contig):
+    the class keys are sorted on their signature bits only, so such classes share a segment, their records
+    interleaved by left position; every membership test has to compare the whole key (detect.rs:218-223).
+    Short segments (one-lane walk), long ones (one-wave walk) and the member enumeration all see the mix."""
+    rng = np.random.Generator(np.random.PCG64(321))
+    A, L = 20, 100
+    g = synth.make_genome([("c0", 300000), ("c1", 300000), ("c2", 300000)], seed=37)
+    seqs, frags, hits = [], [], []
+
+    def add_reads(cl, x1, cr, y1, count, tag):
+        for i in range(count):
+            b = int(rng.integers(A, L - A))
+            read = np.concatenate([g.seqs[cl][x1 - b + 1:x1 + 1], g.seqs[cr][y1:y1 + L - b]]).copy()
+            if rng.random() < 0.3:
+                k = int(rng.integers(A, L - A))
+                read[k] = ord("A") if read[k] != ord("A") else ord("C")
+            seqs.append(read.tobytes())
+            frags.append(b"%s_%d" % (tag, i // 2 if i % 4 == 0 else 100000 + i))
+            hits.append((x1 - b + 2, y1 + L - A - b + 1, cl, cr, 3))
+
+    for n_reads, x, y in ((14, 50000, 80000), (500, 150000, 200000)):
+        # the left flank of c0:x also at c2:x+10, the right flank of c1:y also at c1:y+40000 and c2:y
+        g.seqs[2][x + 10 - 300:x + 10 + 300] = g.seqs[0][x - 300:x + 300]
+        g.seqs[1][y + 40000 - 300:y + 40000 + 300] = g.seqs[1][y - 300:y + 300]
+        g.seqs[2][y - 300:y + 300] = g.seqs[1][y - 300:y + 300]
+        add_reads(0, x, 1, y, n_reads, b"a%d" % n_reads)               # class (c0, c1)
+        add_reads(2, x + 10, 1, y, n_reads, b"b%d" % n_reads)          # class (c2, c1): same signature, other left contig
+        add_reads(0, x, 2, y, n_reads, b"c%d" % n_reads)               # class (c0, c2): other right contig
+        add_reads(0, x, 1, y + 40000, n_reads // 2, b"d%d" % n_reads)  # class (c0, c1) again, right position far away
+    order = rng.permutation(len(seqs))
+    b = engine.make_batch([seqs[i] for i in order], [frags[i] for i in order], [hits[i] for i in order])
+    res, ref = check_against_oracle(g, b, A)
+    assert ref.n_clusters >= 8
+    check_against_oracle(g, b, A, flags=BF_FLAG_SORTED_DEDUP)
+
+
 def test_format_sv_size_query_truncation_and_threads():
     """bf_format_sv: NULL buffer = size query; a short buffer receives a prefix and the full size is still
     returned; a result large enough for the multi-threaded fill equals the oracle's text."""
