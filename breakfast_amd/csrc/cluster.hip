@@ -218,18 +218,17 @@ __global__ void flag_ge_kernel(uint32_t* flag, const uint32_t* __restrict__ val,
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flag[i] = val[i] >= thr ? 1u : 0u;
 }
-// Clusters of up to kWaveDedupMax members are de-duplicated by the wave that enumerates them (fill_members_kernel);
-// n_big counts the others.
+// Clusters of up to wave_max <= kWaveDedupMax members are de-duplicated by the wave that enumerates them
+// (fill_members_kernel); the members of larger clusters go through the sorted-run kernels: qbig[q] = their number.
 constexpr uint32_t kWaveDedupMax = 256;
 __global__ void compact_seeds_kernel(const uint32_t* __restrict__ flag, const uint64_t* __restrict__ scan,
                                      const uint32_t* __restrict__ csize, uint32_t* qseed, uint32_t* qsize, uint64_t n,
-                                     uint32_t* __restrict__ n_big) {
+                                     uint32_t wave_max, uint32_t* __restrict__ qbig) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && flag[i]) {
         const uint64_t q = scan[i];
         const uint32_t c = csize[i];
-        qseed[q] = (uint32_t)i; qsize[q] = c;
-        if (c > kWaveDedupMax) atomicAdd(n_big, 1u);
+        qseed[q] = (uint32_t)i; qsize[q] = c; qbig[q] = c > wave_max ? c : 0u;
     }
 }
 __global__ void compact_index_kernel(const uint32_t* __restrict__ flag, const uint64_t* __restrict__ scan,
@@ -246,7 +245,11 @@ constexpr int kMemberHashBits = 16;
 struct MemberView {
     const uint32_t* qseed; const uint64_t* qoff;
     uint32_t* members;      // sorted positions
-    uint64_t* mkey;         // (cluster number << kMemberHashBits) | low bits of the fragment-id hash, per member slot
+    // members of clusters above wave_max, compacted (qboff[q] = first compact index of cluster q):
+    uint64_t* mkey;         // (cluster number << kMemberHashBits) | low bits of the fragment-id hash
+    uint32_t* bslot;        // their member slot
+    const uint64_t* qboff;
+    uint32_t wave_max;
     uint32_t* mscore;       // longest-flank score per member slot (detect.rs:273-279)
     const uint64_t* fhash; const uint64_t* info;
     // in-wave dedup (WAVE_DEDUP): group leaders' representatives and the clusters' group counts
@@ -266,17 +269,18 @@ __device__ __forceinline__ bool same_frag_bytes(const MemberView& m, uint32_t ra
 }
 
 // One wave per qualifying cluster: re-enumerate the seed's members in sweep order.
-// WAVE_DEDUP (every cluster has at most kWaveDedupMax members): the same wave then applies
+// A cluster of at most wave_max (<= kWaveDedupMax) members: the same wave then applies
 // remove_frag_id_duplicates (detect.rs:247-287) to its cluster -- member i's group leader is the first
 // member with the same fragment id (64-bit hashes compared against one broadcast member at a time, id BYTES
 // where the hashes agree), a leader's representative the first member of its group with the best score --
-// instead of a radix sort of all member slots by (cluster, hash) and a pass over the sorted runs.
-template <bool WAVE_DEDUP>
+// instead of a radix sort of all member slots by (cluster, hash) and a pass over the sorted runs.  The members of
+// larger clusters (duplicate-heavy libraries pile thousands of reads on one junction) are written, compacted,
+// for exactly that sort.
 __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, const MemberView m, uint64_t nq) {
-    __shared__ uint64_t s_fh[WAVE_DEDUP ? 4 : 1][WAVE_DEDUP ? kWaveDedupMax : 1];
-    __shared__ uint32_t s_sc[WAVE_DEDUP ? 4 : 1][WAVE_DEDUP ? kWaveDedupMax : 1];
-    __shared__ uint32_t s_rc[WAVE_DEDUP ? 4 : 1][WAVE_DEDUP ? kWaveDedupMax : 1];
-    __shared__ uint32_t s_ld[WAVE_DEDUP ? 4 : 1][WAVE_DEDUP ? kWaveDedupMax : 1];
+    __shared__ uint64_t s_fh[4][kWaveDedupMax];
+    __shared__ uint32_t s_sc[4][kWaveDedupMax];
+    __shared__ uint32_t s_rc[4][kWaveDedupMax];
+    __shared__ uint32_t s_ld[4][kWaveDedupMax];
     const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
     if (q >= nq) return;
@@ -284,17 +288,21 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
     const uint64_t base = m.qoff[q];
     const uint64_t key = v.skey[p];
     const int32_t lp = v.slpos[p], rp = v.srpos[p];
+    const bool in_wave = m.qsize[q] <= m.wave_max;
+    const uint64_t cbase = in_wave ? 0 : m.qboff[q];
     auto put = [&](uint64_t slot, uint64_t spos) {
         const uint32_t rec = v.perm[spos];
         m.members[slot] = (uint32_t)spos;
         const uint64_t info = m.info[rec];
         const uint32_t l = info_bp(info), r = info_len(info) - l;
         const uint32_t score = min(l, r) * 10000u + max(l, r);       // detect.rs:273-279
-        if (WAVE_DEDUP) {
+        if (in_wave) {
             const uint32_t i = (uint32_t)(slot - base);
             if (i < kWaveDedupMax) { s_fh[wv][i] = m.fhash[rec]; s_sc[wv][i] = score; s_rc[wv][i] = rec; }
         } else {
-            m.mkey[slot] = (q << kMemberHashBits) | (m.fhash[rec] & ((1ull << kMemberHashBits) - 1));
+            const uint64_t ci = cbase + (slot - base);
+            m.mkey[ci] = (q << kMemberHashBits) | (m.fhash[rec] & ((1ull << kMemberHashBits) - 1));
+            m.bslot[ci] = (uint32_t)slot;
             m.mscore[slot] = score;
         }
     };
@@ -310,7 +318,7 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
         cnt += __popcll(take_mask);
         if (live_mask != ~0ull) break;        // the break tests are monotone in sorted order
     }
-    if (!WAVE_DEDUP) return;
+    if (!in_wave) return;                                            // wave-uniform
 
     // LDS operations of one wave execute in order; only the compiler must not reorder them
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -450,10 +458,11 @@ __global__ void __launch_bounds__(256) dedup_runs_kernel(uint64_t total_m, const
 
 // qnrep[q] = fragment-id groups of cluster q = member slots that lead a group (one wave per cluster)
 __global__ void __launch_bounds__(256) count_groups_kernel(uint64_t nq, const uint64_t* __restrict__ qoff,
-                                                           const uint32_t* __restrict__ rep, uint32_t* __restrict__ qnrep) {
+                                                           const uint32_t* __restrict__ rep, uint32_t* __restrict__ qnrep,
+                                                           const uint32_t* __restrict__ qsize, uint32_t wave_max) {
     const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (q >= nq) return;
+    if (q >= nq || qsize[q] <= wave_max) return;             // small clusters were counted by their own wave
     const uint64_t a = qoff[q], b = qoff[q + 1];
     uint32_t cnt = 0;
     for (uint64_t s = a + lane; s < b; s += 64) cnt += rep[s] != kNone;
@@ -616,24 +625,27 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     BF_TRY(ensure(ctx, ctx->c_qseed, nq * 4)); BF_TRY(ensure(ctx, ctx->c_qsize, nq * 4));
     BF_TRY(ensure(ctx, ctx->c_qoff, (nq + 1) * 8)); BF_TRY(ensure(ctx, ctx->c_qnrep, nq * 4));
     uint64_t total_m = 0;
-    BF_TRY(ensure(ctx, ctx->c_ctl, 64));
-    BF_HIP(ctx, hipMemsetAsync(ctx->c_ctl.p, 0, 64, st));
+    const uint32_t wave_max = (ctx->cfg.flags & BF_FLAG_SORTED_DEDUP) ? 0u : kWaveDedupMax;
+    BF_TRY(ensure(ctx, ctx->c_ctl, nq * 4 + (nq + 1) * 8 + 64));
+    uint64_t* qboff = ctx->c_ctl.as<uint64_t>();                       // nq + 1 compact offsets of the large clusters
+    uint32_t* qbig = (uint32_t*)(qboff + nq + 1);
     hipLaunchKernelGGL(compact_seeds_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
                        ctx->c_scan.as<uint64_t>(), ctx->c_csize.as<uint32_t>(), ctx->c_qseed.as<uint32_t>(),
-                       ctx->c_qsize.as<uint32_t>(), n, ctx->c_ctl.as<uint32_t>());
+                       ctx->c_qsize.as<uint32_t>(), n, wave_max, qbig);
     BF_TRY(scan_u32_to_u64(ctx, ctx->c_qsize.as<uint32_t>(), ctx->c_qoff.as<uint64_t>(), nq));
-    uint32_t n_big = 0;                                   // clusters too large for the in-wave dedup
-    BF_HIP(ctx, hipMemcpyAsync(&n_big, ctx->c_ctl.p, 4, hipMemcpyDeviceToHost, st));
+    BF_TRY(scan_u32_to_u64(ctx, qbig, qboff, nq));
+    uint64_t total_big = 0;                               // members of clusters too large for the in-wave dedup
+    BF_HIP(ctx, hipMemcpyAsync(&total_big, qboff + nq, 8, hipMemcpyDeviceToHost, st));
     BF_TRY(fetch_u64(ctx, ctx->c_qoff.as<uint64_t>() + nq, &total_m));
-    const bool wave_dedup = n_big == 0 && !(ctx->cfg.flags & BF_FLAG_SORTED_DEDUP);
     if (total_m > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "cluster membership list too long (%llu)", (unsigned long long)total_m);
-    BF_TRY(ensure(ctx, ctx->c_members, total_m * 4)); BF_TRY(ensure(ctx, ctx->c_k64a, std::max(total_m, n) * 8, false));
-    BF_TRY(ensure(ctx, ctx->c_mkey_s, total_m * 8)); BF_TRY(ensure(ctx, ctx->c_slot, total_m * 4 * 2));
+    BF_TRY(ensure(ctx, ctx->c_members, total_m * 4)); BF_TRY(ensure(ctx, ctx->c_k64a, std::max(total_big, n) * 8, false));
+    BF_TRY(ensure(ctx, ctx->c_mkey_s, std::max<uint64_t>(total_big, 1) * 8)); BF_TRY(ensure(ctx, ctx->c_slot, std::max<uint64_t>(total_big, 1) * 4 * 2));
     BF_TRY(ensure(ctx, ctx->c_d32, total_m * 4));
     BF_TRY(ensure(ctx, ctx->c_leader, total_m * 4)); BF_TRY(ensure(ctx, ctx->c_rep, total_m * 4));
     MemberView mv{};
     mv.qseed = ctx->c_qseed.as<uint32_t>(); mv.qoff = ctx->c_qoff.as<uint64_t>();
     mv.members = ctx->c_members.as<uint32_t>(); mv.mkey = ctx->c_k64a.as<uint64_t>(); mv.mscore = ctx->c_d32.as<uint32_t>();
+    mv.bslot = ctx->c_slot.as<uint32_t>(); mv.qboff = qboff; mv.wave_max = wave_max;
     mv.fhash = v.fhash; mv.info = v.info;
     mv.qsize = ctx->c_qsize.as<uint32_t>(); mv.rep = ctx->c_rep.as<uint32_t>(); mv.qnrep = ctx->c_qnrep.as<uint32_t>();
     mv.frag = v.frag; mv.frag_off = v.frag_off; mv.frag_len = v.frag_len;
@@ -641,20 +653,19 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     FragView fv{perm, v.frag, v.frag_off, v.frag_len};
     {
         Scope t(ctx, "dedup");
-        if (wave_dedup) {
-            hipLaunchKernelGGL(fill_members_kernel<true>, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, sv, mv, nq);
-        } else {
-            hipLaunchKernelGGL(fill_members_kernel<false>, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, sv, mv, nq);
-            uint32_t* slot_in = ctx->c_slot.as<uint32_t>(); uint32_t* slot_s = slot_in + total_m;
-            hipLaunchKernelGGL(iota_kernel, dim3(grid_for(total_m, B)), dim3(B), 0, st, slot_in, total_m);
-            unsigned qbits = 1; while ((1ull << qbits) < nq) qbits++;
-            BF_TRY(sort_pairs<uint64_t>(ctx, mv.mkey, ctx->c_mkey_s.as<uint64_t>(), slot_in, slot_s, total_m, 0, kMemberHashBits + qbits));
+        if (total_big) {                                 // the sorted-run kernels find their slots untouched
             BF_HIP(ctx, hipMemsetAsync(ctx->c_leader.p, 0xff, total_m * 4, st));
             BF_HIP(ctx, hipMemsetAsync(ctx->c_rep.p, 0xff, total_m * 4, st));
-            hipLaunchKernelGGL(dedup_runs_kernel, dim3(grid_for(total_m, B)), dim3(B), 0, st, total_m, ctx->c_mkey_s.as<uint64_t>(),
+        }
+        hipLaunchKernelGGL(fill_members_kernel, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, sv, mv, nq);
+        if (total_big) {
+            uint32_t* slot_in = mv.bslot; uint32_t* slot_s = slot_in + total_big;
+            unsigned qbits = 1; while ((1ull << qbits) < nq) qbits++;
+            BF_TRY(sort_pairs<uint64_t>(ctx, mv.mkey, ctx->c_mkey_s.as<uint64_t>(), slot_in, slot_s, total_big, 0, kMemberHashBits + qbits));
+            hipLaunchKernelGGL(dedup_runs_kernel, dim3(grid_for(total_big, B)), dim3(B), 0, st, total_big, ctx->c_mkey_s.as<uint64_t>(),
                                slot_s, mv, fv, ctx->c_leader.as<uint32_t>(), ctx->c_rep.as<uint32_t>());
             hipLaunchKernelGGL(count_groups_kernel, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, nq, ctx->c_qoff.as<uint64_t>(),
-                               ctx->c_rep.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>());
+                               ctx->c_rep.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>(), mv.qsize, wave_max);
         }
     }
     BF_HIP(ctx, hipGetLastError());
