@@ -393,6 +393,26 @@ def test_segments_that_need_a_walk():
     check_against_oracle(g, b, A, F=100)
 
 
+@pytest.mark.parametrize("E,F", [(1, 5000), (1, 0), (3, 50), (50, 5000)])
+def test_min_evidence_and_window_extremes(E, F):
+    """--min-evidence 1 (every read seeds or joins a reported cluster: as many clusters as classes), a zero
+    --max-frag-len window, and a threshold no cluster reaches (header only)."""
+    contigs, gk, spec = synth.config(1, scale=0.001, genome_scale=0.002)
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    res, ref = check_against_oracle(g, b, spec.anchor_len, F=F, E=E)
+    if E == 1:
+        assert ref.n_clusters > 1000
+
+
+def test_single_read_and_two_reads():
+    contigs, gk, spec = synth.config(1, scale=0.001, genome_scale=0.002)
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    for n in (1, 2, 3):
+        check_against_oracle(g, b.slice(0, n), spec.anchor_len, E=1)
+
+
 def test_classes_that_share_a_signature():
     """Different breakpoint classes with the SAME 8+8 signature bases (the flanks copied onto another contig):
     the class keys are sorted on their signature bits only, so such classes share a segment, their records
