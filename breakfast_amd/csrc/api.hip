@@ -131,9 +131,9 @@ static void free_all(bf_ctx* ctx) {
         &ctx->c_slpos, &ctx->c_srpos, &ctx->c_reported, &ctx->c_csize, &ctx->c_flag, &ctx->c_scan, &ctx->c_qseed,
         &ctx->c_qsize, &ctx->c_qoff, &ctx->c_members, &ctx->c_leader, &ctx->c_rep, &ctx->c_qnrep, &ctx->c_ctl, &ctx->c_sel,
         &ctx->c_ord, &ctx->c_clusters, &ctx->c_reads, &ctx->c_misc, &ctx->c_joff, &ctx->c_jbytes, &ctx->c_rsrc,
-        &ctx->c_tables, &ctx->c_mkey_s, &ctx->c_slot, &ctx->c_big, &ctx->c_pos2, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
+        &ctx->c_tables, &ctx->c_mkey_s, &ctx->c_slot, &ctx->c_big, &ctx->c_cjo, &ctx->c_pos2, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
     for (DevBuf* b : all) release(ctx, *b);
-    HostBuf* hosts[] = {&ctx->out.clusters, &ctx->out.reads, &ctx->out.src, &ctx->out.junction};
+    HostBuf* hosts[] = {&ctx->out.clusters, &ctx->out.reads, &ctx->out.src, &ctx->out.junction, &ctx->out.cjo};
     for (HostBuf* h : hosts) { if (h->p) (void)hipHostFree(h->p); h->p = nullptr; h->cap = 0; }
 }
 
@@ -427,16 +427,19 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     if (ctx->n_ranks > 1 && !ctx->imported) return fail(ctx, BF_ERR_STATE, "bf_clusterise on a multi-rank ctx before bf_exchange_import");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     const OwnerView v = ctx->imported ? imported_view(ctx) : local_view(ctx);
-    ctx->clustered = false; ctx->table_attached = false; ctx->junction_attached = 0;
+    ctx->clustered = false; ctx->table_attached = false; ctx->junction_attached = 0; ctx->reads_on_device = false;
     BF_TRY(run_cluster(ctx, v));
     ctx->clustered = true;
     const uint64_t nr = ctx->out.n_reads;
+    const uint64_t ncl = ctx->out.n_clusters;
     if (nr) {
-        BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
+        if (ctx->imported) { BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read))); }
         if (!ctx->imported) {
-            // single rank: the surviving reads are local.  Their junction strings are rendered chunk by
-            // chunk; every finished chunk (and the read table) goes to pinned host memory on the copy
-            // stream while the next chunk renders.
+            // single rank: the surviving reads are local.  Their junction records are rendered chunk by
+            // chunk, in printed order; every finished chunk goes to pinned host memory on the copy
+            // stream while the next chunk renders.  A cluster's records are contiguous and each says
+            // how long it is, so the host gets one offset per CLUSTER; the read table {index, offset}
+            // (16 bytes a read, a quarter of the copy) stays on the device until bf_result_reads asks.
             const uint32_t* d_idx = ctx->c_rsrc.as<uint32_t>() + nr;      // out_src_idx
             constexpr int kMaxChunks = 8;
             const int nc = nr >= (1u << 16) ? kMaxChunks : 1;
@@ -444,10 +447,12 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
             // emit left every supporting read's record size next to the index lists
             BF_TRY(render_prepare(ctx, nr, d_idx, ctx->c_joff, nc, off, ctx->c_rsrc.as<uint32_t>() + 3 * nr));
             const uint64_t total = off[nc];
-            BF_TRY(patch_reads(ctx, ctx->c_joff.as<uint64_t>(), nr));
+            BF_TRY(ensure(ctx, ctx->c_cjo, (ncl + 1) * 8));
+            BF_TRY(ensure_host(ctx, ctx->out.cjo, (ncl + 1) * 8));
+            BF_TRY(cluster_record_offsets(ctx, ctx->c_joff.as<uint64_t>(), ctx->c_cjo.as<uint64_t>(), ncl));
             BF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
             BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[0], 0));
-            BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->copy_stream));
+            BF_HIP(ctx, hipMemcpyAsync(ctx->out.cjo.p, ctx->c_cjo.p, (ncl + 1) * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
             ctx->out.junction_size = total;
             BF_TRY(ensure_host(ctx, ctx->out.junction, total));
             BF_TRY(ensure(ctx, ctx->c_jbytes, total ? total : 1));
@@ -460,6 +465,9 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
                                                off[c + 1] - off[c], hipMemcpyDeviceToHost, ctx->copy_stream));
                 }
             }
+            // the table is finished on the device behind the render kernels, while the copies run
+            BF_TRY(patch_reads(ctx, ctx->c_joff.as<uint64_t>(), nr));
+            ctx->reads_on_device = true;
             BF_HIP(ctx, hipEventRecord(ctx->ev[10], ctx->copy_stream));
             BF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[10], 0));
         } else if (!(ctx->cfg.flags & BF_FLAG_DEVICE_ROUTING)) {
@@ -472,9 +480,31 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     out->n_clusters = ctx->out.n_clusters;
     out->n_reads = nr;
     out->clusters = ctx->out.clusters.as<bf_cluster>();
-    out->reads = (ctx->imported && (ctx->cfg.flags & BF_FLAG_DEVICE_ROUTING)) ? nullptr : ctx->out.reads.as<bf_read>();
+    out->reads = (!ctx->imported || (ctx->cfg.flags & BF_FLAG_DEVICE_ROUTING)) ? nullptr : ctx->out.reads.as<bf_read>();
     out->junction_bytes = ctx->out.junction.as<uint8_t>();
     out->junction_size = ctx->out.junction_size;
+    out->cluster_junction_off = (!ctx->imported && nr) ? ctx->out.cjo.as<uint64_t>() : nullptr;
+    return BF_OK;
+}
+
+int bf_result_reads(bf_ctx* ctx, bf_result* result) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!result) return fail(ctx, BF_ERR_INVALID, "bf_result_reads: null result");
+    if (!ctx->clustered) return fail(ctx, BF_ERR_STATE, "bf_result_reads before bf_clusterise");
+    if (result->n_reads != ctx->out.n_reads || result->clusters != ctx->out.clusters.as<bf_cluster>())
+        return fail(ctx, BF_ERR_STATE, "bf_result_reads: not the result of this ctx's last bf_clusterise");
+    const uint64_t nr = ctx->out.n_reads;
+    if (ctx->imported) {                                  // multi-rank: the table reached the host with the attach calls
+        if ((ctx->cfg.flags & BF_FLAG_DEVICE_ROUTING) && !ctx->table_attached)
+            return fail(ctx, BF_ERR_STATE, "bf_result_reads before the read table was attached");
+    } else if (ctx->reads_on_device && nr) {
+        BF_HIP(ctx, hipSetDevice(ctx->device));
+        BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
+        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->reads_on_device = false;
+    }
+    result->reads = nr ? ctx->out.reads.as<bf_read>() : nullptr;
     return BF_OK;
 }
 
@@ -501,7 +531,9 @@ static const char kSvHeader[] = "CHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tCHROM
 int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t cap) {
     if (!ctx || !r) return BF_ERR_INVALID;
     const uint64_t nc = r->n_clusters;
-    if (nc && (!r->clusters || (r->n_reads && !r->reads))) return BF_ERR_INVALID;
+    // a read's record: through the read table when the result has one, else by walking the cluster's records
+    const uint64_t* cjo = r->reads ? nullptr : r->cluster_junction_off;
+    if (nc && (!r->clusters || (r->n_reads && !r->reads && !cjo))) return BF_ERR_INVALID;
     std::vector<uint64_t> off(nc + 1);
     const size_t hdr = sizeof(kSvHeader) - 1;
     const unsigned hw = std::thread::hardware_concurrency();
@@ -517,13 +549,22 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t 
                           dec_len((uint64_t)cl.lpos) + dec_len((uint64_t)cl.rpos) + 13;   // 10 tabs, 2 strands, newline
             const uint64_t k = cl.read_end - cl.read_begin;
             if (k) sz += k - 1;                                                             // ';' separators
+            uint64_t walk = 0, walk_end = 0;
+            if (cjo && k) {
+                walk = cjo[c]; walk_end = cjo[c + 1];
+                if (walk > walk_end || walk_end > r->junction_size) { bad = true; return; }
+            }
             for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
-                const bf_read& rd = r->reads[i];
-                if (rd.junction_off > r->junction_size) { bad = true; return; }
-                const int64_t tl = junction_decode(r->junction_bytes + rd.junction_off, r->junction_size - rd.junction_off, nullptr, 0);
+                const uint64_t at = cjo ? walk : r->reads[i].junction_off;
+                const uint64_t lim = cjo ? walk_end : r->junction_size;
+                if (at > lim) { bad = true; return; }
+                uint64_t stored = 0;
+                const int64_t tl = junction_decode(r->junction_bytes + at, lim - at, nullptr, 0, &stored);
                 if (tl < 0) { bad = true; return; }
                 sz += (uint64_t)tl;
+                walk += stored;
             }
+            if (cjo && k && walk != walk_end) { bad = true; return; }
             off[c + 1] = sz;
         }
     };
@@ -561,10 +602,13 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t 
             memcpy(p, n2.data(), n2.size()); p += n2.size();
             *p++ = '\t'; *p++ = cl.mstrand ? '+' : '-'; *p++ = '\t';
             p = put_dec(p, (uint64_t)cl.rpos); *p++ = '\t'; *p++ = '\t';                // detect.rs:233-235
+            uint64_t walk = cjo && cl.read_end > cl.read_begin ? cjo[c] : 0;
             for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
                 if (i > cl.read_begin) *p++ = ';';
-                const bf_read& rd = r->reads[i];
-                p += junction_decode(r->junction_bytes + rd.junction_off, r->junction_size - rd.junction_off, (uint8_t*)p, ~0ull);
+                const uint64_t at = cjo ? walk : r->reads[i].junction_off;
+                uint64_t stored = 0;
+                p += junction_decode(r->junction_bytes + at, r->junction_size - at, (uint8_t*)p, ~0ull, &stored);
+                walk += stored;
             }
             *p++ = '\t'; *p++ = '\t'; *p++ = '\n';                                      // detect.rs:240
         }
@@ -596,12 +640,35 @@ int64_t bf_junction_record_bytes(const uint8_t* record, uint64_t avail) {
 }
 
 int64_t bf_result_junction_text(const bf_result* r, uint8_t* text, uint64_t cap, uint64_t* text_off) {
-    if (!r || (r->n_reads && (!r->reads || !text_off))) return BF_ERR_INVALID;
+    if (!r || (r->n_reads && !text_off)) return BF_ERR_INVALID;
+    // where each record starts: the read table when the result has one, else a walk over every cluster's records
+    std::vector<uint64_t> walked;
+    if (r->n_reads && !r->reads) {
+        const uint64_t* cjo = r->cluster_junction_off;
+        if (!cjo || !r->clusters) return BF_ERR_INVALID;
+        walked.assign(r->n_reads, ~0ull);
+        for (uint64_t c = 0; c < r->n_clusters; c++) {
+            const bf_cluster& cl = r->clusters[c];
+            if (cl.read_end < cl.read_begin || cl.read_end > r->n_reads) return BF_ERR_INVALID;
+            if (cl.read_end == cl.read_begin) continue;
+            uint64_t at = cjo[c];
+            const uint64_t lim = cjo[c + 1];
+            if (at > lim || lim > r->junction_size) return BF_ERR_INVALID;
+            for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
+                uint64_t stored = 0;
+                if (at > lim || junction_decode(r->junction_bytes + at, lim - at, nullptr, 0, &stored) < 0) return BF_ERR_INVALID;
+                walked[i] = at;
+                at += stored;
+            }
+            if (at != lim) return BF_ERR_INVALID;
+        }
+    }
+    auto rec_off = [&](uint64_t i) { return walked.empty() ? r->reads[i].junction_off : walked[i]; };
     uint64_t total = 0;
     for (uint64_t i = 0; i < r->n_reads; i++) {
-        const bf_read& rd = r->reads[i];
-        if (rd.junction_off > r->junction_size) return BF_ERR_INVALID;
-        const int64_t tl = junction_decode(r->junction_bytes + rd.junction_off, r->junction_size - rd.junction_off, nullptr, 0);
+        const uint64_t at = rec_off(i);
+        if (at > r->junction_size) return BF_ERR_INVALID;
+        const int64_t tl = junction_decode(r->junction_bytes + at, r->junction_size - at, nullptr, 0);
         if (tl < 0) return BF_ERR_INVALID;
         text_off[i] = total;
         total += (uint64_t)tl;
@@ -612,7 +679,7 @@ int64_t bf_result_junction_text(const bf_result* r, uint8_t* text, uint64_t cap,
     const uint64_t nt = total < (8u << 20) ? 1 : std::max(1u, std::min(hw, 8u));
     auto fill = [&](uint64_t a, uint64_t b) {
         for (uint64_t i = a; i < b; i++)
-            junction_decode(r->junction_bytes + r->reads[i].junction_off, r->junction_size - r->reads[i].junction_off,
+            junction_decode(r->junction_bytes + rec_off(i), r->junction_size - rec_off(i),
                             text + text_off[i], text_off[i + 1] - text_off[i]);
     };
     if (nt <= 1) { fill(0, r->n_reads); return (int64_t)total; }

@@ -142,7 +142,8 @@ struct ClusterOut {                      // host copies of the cluster stage's r
     HostBuf clusters;                    // bf_cluster[n_clusters]
     HostBuf reads;                       // bf_read[n_reads]
     HostBuf src;                         // uint32 src_rank[n_reads], src_idx[n_reads] (multi-rank only)
-    HostBuf junction;                    // junction text
+    HostBuf junction;                    // junction records
+    HostBuf cjo;                         // uint64 cluster_junction_off[n_clusters + 1] (single rank)
 };
 
 struct Timing {
@@ -204,11 +205,12 @@ struct bf_ctx {
         i_sigx_slot, i_src_rank, i_src_idx, i_jrec;
     bool table_attached = false;                // the read table of the last bf_clusterise is (being) copied to the host
     uint64_t junction_attached = 0;             // junction bytes queued for the host so far
+    bool reads_on_device = false;               // single rank: the finished read table waits in c_reads for bf_result_reads
 
     // cluster stage scratch + results
     bf::DevBuf c_tmp, c_a32, c_b32, c_c32, c_d32, c_k64a, c_k64b, c_slpos, c_srpos, c_reported,
         c_csize, c_flag, c_scan, c_qseed, c_qsize, c_qoff, c_members, c_leader, c_rep, c_qnrep,
-        c_ctl, c_sel, c_ord, c_clusters, c_reads, c_misc, c_pos2, c_joff, c_jbytes, c_rsrc, c_tables, c_mkey_s, c_slot, c_big;
+        c_ctl, c_sel, c_ord, c_clusters, c_reads, c_misc, c_pos2, c_joff, c_jbytes, c_rsrc, c_tables, c_mkey_s, c_slot, c_big, c_cjo;
     bf::ClusterOut out;
     std::vector<uint64_t> render_off_host;
     std::vector<uint8_t> render_bytes_host;
@@ -282,6 +284,7 @@ int scan_u32_to_u64(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n);
 int scan_max_u32_inplace(bf_ctx* ctx, uint32_t* data, uint64_t n);                // running maximum
 int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
 int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
+int cluster_record_offsets(bf_ctx* ctx, const uint64_t* d_joff, uint64_t* d_out, uint64_t n_clusters);
 int read_sizes(bf_ctx* ctx, uint32_t* d_out, uint64_t n);
 
 }  // namespace bf

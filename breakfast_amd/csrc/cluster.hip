@@ -102,6 +102,7 @@ __device__ __forceinline__ bool rpos_far(int32_t rs, int32_t rp, int64_t F) {
 // libraries pile thousands of reads on one junction).
 // csize[p] = cluster size if p is a seed; csize is zero-initialised.
 constexpr uint32_t kBigSegment = 96;
+constexpr uint32_t kCtlWords = 16;       // head of c_big: two list lengths, then 64-bit sums for the host (flag_ge_kernel)
 
 // A SEGMENT is a run of records with equal low 32 key bits (the signature, or its hash): the class keys are
 // sorted on those bits only -- four radix passes instead of six -- and the records of a segment are in
@@ -214,9 +215,24 @@ __global__ void __launch_bounds__(256) sweep_big_kernel(const SweepView v, uint8
     }
 }
 
-__global__ void flag_ge_kernel(uint32_t* flag, const uint32_t* __restrict__ val, uint32_t thr, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = val[i] >= thr ? 1u : 0u;
+// flag[i] = val[i] >= thr, and the sums the host needs to size what follows, so that they come along with the
+// fetch of the flag count instead of costing a synchronisation each: sums[0] += the flagged values, sums[1] +=
+// those above wave_max.  Fixed grid: one atomic per wave with something to add.
+constexpr unsigned kFlagGrid = 1024;
+__global__ void __launch_bounds__(256) flag_ge_kernel(uint32_t* flag, const uint32_t* __restrict__ val, uint32_t thr, uint64_t n,
+                                                      uint32_t wave_max, unsigned long long* sums) {
+    unsigned long long s_all = 0, s_big = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t c = val[i];
+        const bool f = c >= thr;
+        flag[i] = f ? 1u : 0u;
+        if (f) { s_all += c; if (c > wave_max) s_big += c; }
+    }
+    for (int d = 32; d; d >>= 1) { s_all += __shfl_down(s_all, d); s_big += __shfl_down(s_big, d); }
+    if ((threadIdx.x & 63) == 0) {
+        if (s_all) atomicAdd(&sums[0], s_all);
+        if (s_big) atomicAdd(&sums[1], s_big);
+    }
 }
 // Clusters of up to wave_max <= kWaveDedupMax members are de-duplicated by the wave that enumerates them
 // (fill_members_kernel); the members of larger clusters go through the sorted-run kernels: qbig[q] = their number.
@@ -592,15 +608,20 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     BF_TRY(ensure(ctx, ctx->c_reported, n)); BF_TRY(ensure(ctx, ctx->c_csize, n * 4));
     BF_TRY(ensure(ctx, ctx->c_flag, n * 4)); BF_TRY(ensure(ctx, ctx->c_scan, (n + 1) * 8));
     uint64_t nq = 0;
+    uint64_t totals[2] = {0, 0};
+    const uint32_t wave_max = (ctx->cfg.flags & BF_FLAG_SORTED_DEDUP) ? 0u : kWaveDedupMax;
+    unsigned long long* sums = nullptr;
     {
         Scope t(ctx, "sweep");
         // lists of segments that need a walk: counts[0] short ones, counts[1] long ones
-        BF_TRY(ensure(ctx, ctx->c_big, (n + n / kBigSegment + 8) * 4));
+        // c_big: counts[2], then four 64-bit sums (flag_ge_kernel), then the lists
+        BF_TRY(ensure(ctx, ctx->c_big, (n + n / kBigSegment + 8 + kCtlWords) * 4));
         BF_HIP(ctx, hipMemsetAsync(ctx->c_reported.p, 0, n, st));
         BF_HIP(ctx, hipMemsetAsync(ctx->c_csize.p, 0, n * 4, st));
-        BF_HIP(ctx, hipMemsetAsync(ctx->c_big.p, 0, 8, st));
+        BF_HIP(ctx, hipMemsetAsync(ctx->c_big.p, 0, kCtlWords * 4, st));
         uint32_t* counts = ctx->c_big.as<uint32_t>();
-        uint32_t* big_list = counts + 2; uint32_t* small_list = big_list + n / kBigSegment + 2;
+        sums = (unsigned long long*)(counts + 2);
+        uint32_t* big_list = counts + kCtlWords; uint32_t* small_list = big_list + n / kBigSegment + 2;
         uint32_t* head = ctx->c_flag.as<uint32_t>();          // reused for the min_evidence flags below
         uint32_t* covered = ctx->c_b32.as<uint32_t>();        // free since the sort
         hipLaunchKernelGGL(head_mark_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, sv.skey, head, n);
@@ -613,9 +634,11 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
                            ctx->c_reported.as<uint8_t>(), ctx->c_csize.as<uint32_t>(), small_list, counts);
         hipLaunchKernelGGL(sweep_big_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, kBigSegment) / 4 + 1, 1024)), dim3(B), 0, st, sv,
                            ctx->c_reported.as<uint8_t>(), ctx->c_csize.as<uint32_t>(), big_list, counts);
-        hipLaunchKernelGGL(flag_ge_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
-                           ctx->c_csize.as<uint32_t>(), ctx->cfg.min_evidence, n);
+        hipLaunchKernelGGL(flag_ge_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, B), kFlagGrid)), dim3(B), 0, st,
+                           ctx->c_flag.as<uint32_t>(), ctx->c_csize.as<uint32_t>(), ctx->cfg.min_evidence, n, wave_max, sums);
         BF_TRY(scan_u32_to_u64(ctx, ctx->c_flag.as<uint32_t>(), ctx->c_scan.as<uint64_t>(), n));
+        // members of the qualifying clusters, and of those too large for the in-wave dedup: same synchronisation
+        BF_HIP(ctx, hipMemcpyAsync(totals, sums, 16, hipMemcpyDeviceToHost, st));
         BF_TRY(fetch_u64(ctx, ctx->c_scan.as<uint64_t>() + n, &nq));
         BF_TRY(settle_counts(ctx));                       // the localise counters came along with this synchronisation
     }
@@ -624,8 +647,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     // 3. members of qualifying clusters
     BF_TRY(ensure(ctx, ctx->c_qseed, nq * 4)); BF_TRY(ensure(ctx, ctx->c_qsize, nq * 4));
     BF_TRY(ensure(ctx, ctx->c_qoff, (nq + 1) * 8)); BF_TRY(ensure(ctx, ctx->c_qnrep, nq * 4));
-    uint64_t total_m = 0;
-    const uint32_t wave_max = (ctx->cfg.flags & BF_FLAG_SORTED_DEDUP) ? 0u : kWaveDedupMax;
+    const uint64_t total_m = totals[0], total_big = totals[1];
     BF_TRY(ensure(ctx, ctx->c_ctl, nq * 4 + (nq + 1) * 8 + 64));
     uint64_t* qboff = ctx->c_ctl.as<uint64_t>();                       // nq + 1 compact offsets of the large clusters
     uint32_t* qbig = (uint32_t*)(qboff + nq + 1);
@@ -634,9 +656,6 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
                        ctx->c_qsize.as<uint32_t>(), n, wave_max, qbig);
     BF_TRY(scan_u32_to_u64(ctx, ctx->c_qsize.as<uint32_t>(), ctx->c_qoff.as<uint64_t>(), nq));
     BF_TRY(scan_u32_to_u64(ctx, qbig, qboff, nq));
-    uint64_t total_big = 0;                               // members of clusters too large for the in-wave dedup
-    BF_HIP(ctx, hipMemcpyAsync(&total_big, qboff + nq, 8, hipMemcpyDeviceToHost, st));
-    BF_TRY(fetch_u64(ctx, ctx->c_qoff.as<uint64_t>() + nq, &total_m));
     if (total_m > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "cluster membership list too long (%llu)", (unsigned long long)total_m);
     BF_TRY(ensure(ctx, ctx->c_members, total_m * 4)); BF_TRY(ensure(ctx, ctx->c_k64a, std::max(total_big, n) * 8, false));
     BF_TRY(ensure(ctx, ctx->c_mkey_s, std::max<uint64_t>(total_big, 1) * 8)); BF_TRY(ensure(ctx, ctx->c_slot, std::max<uint64_t>(total_big, 1) * 4 * 2));
@@ -676,9 +695,10 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     BF_TRY(ensure(ctx, ctx->c_sel, nq * 4)); BF_TRY(ensure(ctx, ctx->c_ord, nq * 4));
     {
         Scope t(ctx, "order");
-        hipLaunchKernelGGL(flag_ge_kernel, dim3(grid_for(nq, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
-                           ctx->c_qnrep.as<uint32_t>(), ctx->cfg.min_evidence, nq);
+        hipLaunchKernelGGL(flag_ge_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(nq, B), kFlagGrid)), dim3(B), 0, st,
+                           ctx->c_flag.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>(), ctx->cfg.min_evidence, nq, 0u, sums + 2);
         BF_TRY(scan_u32_to_u64(ctx, ctx->c_flag.as<uint32_t>(), ctx->c_scan.as<uint64_t>(), nq));
+        BF_HIP(ctx, hipMemcpyAsync(&total_r, sums + 2, 8, hipMemcpyDeviceToHost, st));   // the reads that will be printed
         BF_TRY(fetch_u64(ctx, ctx->c_scan.as<uint64_t>() + nq, &ns));
         if (ns == 0) return BF_OK;
         hipLaunchKernelGGL(compact_index_kernel, dim3(grid_for(nq, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
@@ -705,7 +725,6 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
         hipLaunchKernelGGL(gather_u32_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, vb, ctx->c_qnrep.as<uint32_t>(),
                            ctx->c_ord.as<uint32_t>(), ns);
         BF_TRY(scan_u32_to_u64(ctx, vb, ctx->c_scan.as<uint64_t>(), ns));
-        BF_TRY(fetch_u64(ctx, ctx->c_scan.as<uint64_t>() + ns, &total_r));
     }
 
     // 5. emit rows + surviving reads
@@ -994,6 +1013,19 @@ __global__ void patch_reads_off_kernel(bf_read* reads, const uint64_t* __restric
 int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n) {
     if (n) hipLaunchKernelGGL(patch_reads_off_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
                               ctx->c_reads.as<bf_read>(), d_joff, n);
+    BF_HIP(ctx, hipGetLastError());
+    return BF_OK;
+}
+// out[c] = where cluster c's first record starts (c = n_clusters: the end), from the per-read offsets and the
+// clusters' read offsets the order stage left in c_scan
+__global__ void cluster_record_offsets_kernel(uint64_t* out, const uint64_t* __restrict__ joff,
+                                              const uint64_t* __restrict__ roff, uint64_t n) {
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) out[c] = joff[roff[c]];
+}
+int cluster_record_offsets(bf_ctx* ctx, const uint64_t* d_joff, uint64_t* d_out, uint64_t n_clusters) {
+    hipLaunchKernelGGL(cluster_record_offsets_kernel, dim3(grid_for(n_clusters + 1, 256)), dim3(256), 0, ctx->stream,
+                       d_out, d_joff, ctx->c_scan.as<uint64_t>(), n_clusters + 1);
     BF_HIP(ctx, hipGetLastError());
     return BF_OK;
 }

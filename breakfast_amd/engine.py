@@ -48,7 +48,7 @@ class BfBatch(C.Structure):
 class BfResult(C.Structure):
     _fields_ = [("n_evidence", C.c_uint64), ("n_clusters", C.c_uint64), ("n_reads", C.c_uint64),
                 ("clusters", C.c_void_p), ("reads", C.c_void_p), ("junction_bytes", C.c_void_p),
-                ("junction_size", C.c_uint64)]
+                ("junction_size", C.c_uint64), ("cluster_junction_off", C.c_void_p)]
 
 
 class BfWireLocal(C.Structure):
@@ -73,7 +73,7 @@ ABI_SYMBOLS = [
     "bf_render_junctions", "bf_result_sources_dev", "bf_render_junctions_dev", "bf_result_attach_junctions_dev",
     "bf_evidence_fetch", "bf_kernel_times", "bf_stats", "bf_junction_text", "bf_result_junction_text",
     "bf_result_junction_sizes_dev", "bf_result_attach_offsets_dev", "bf_result_attach_junction_chunk_dev",
-    "bf_result_attach_finish", "bf_junction_record_bound", "bf_junction_record_bytes",
+    "bf_result_attach_finish", "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
 ]
 
 _lib = None
@@ -116,6 +116,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_localise.argtypes = [vp]
     lib.bf_clusterise.argtypes = [vp, C.POINTER(BfResult)]
     lib.bf_finish.argtypes = [vp, C.POINTER(BfResult)]
+    lib.bf_result_reads.argtypes = [vp, C.POINTER(BfResult)]
     lib.bf_reset.argtypes = [vp]
     lib.bf_sync.argtypes = [vp]
     lib.bf_format_sv.argtypes = [vp, C.POINTER(BfResult), vp, C.c_uint64]
@@ -185,6 +186,7 @@ class Result:
     src_index: Optional[np.ndarray] = None
     n_reads: int = -1         # supporting reads (== reads.shape[0] unless the table is still on the device)
     junction_sizes: Optional[np.ndarray] = None   # record bytes per read (stand-in engines of the sharded path)
+    cluster_junction_off: Optional[np.ndarray] = None   # uint64[n_clusters + 1], one-GPU results (include/breakfast_hip.h)
 
     def junction(self, k: int) -> bytes:
         """Junction string of supporting read k (detect.rs:155-162), expanded from its record."""
@@ -196,7 +198,12 @@ class Result:
         rd = np.ascontiguousarray(self.reads, READ_DTYPE)
         jb = np.ascontiguousarray(self.junction_bytes, np.uint8)
         n = rd.shape[0]
-        r = BfResult(self.n_evidence, 0, n, None, _ptr(rd), _ptr(jb), jb.size)
+        r = BfResult(self.n_evidence, 0, n, None, _ptr(rd), _ptr(jb), jb.size, None)
+        if n == 0 and self.n_reads > 0 and self.cluster_junction_off is not None:       # table left on the device
+            cl = np.ascontiguousarray(self.clusters, CLUSTER_DTYPE)
+            cjo = np.ascontiguousarray(self.cluster_junction_off, np.uint64)
+            n = self.n_reads
+            r = BfResult(self.n_evidence, cl.shape[0], n, _ptr(cl), None, _ptr(jb), jb.size, _ptr(cjo))
         off = np.zeros(n + 1, np.uint64)
         total = lib.bf_result_junction_text(C.byref(r), None, 0, off.ctypes.data)
         if total < 0:
@@ -358,13 +365,17 @@ class Engine:
                 return np.zeros(0, dt)
             a = np.frombuffer((C.c_uint8 * (n * dt.itemsize)).from_address(ptr), dt)
             return a.copy() if copy else a
+        cjo = arr(r.cluster_junction_off, r.n_clusters + 1, np.dtype("<u8")) if r.cluster_junction_off else None
         return Result(int(r.n_evidence), arr(r.clusters, r.n_clusters, CLUSTER_DTYPE),
                       arr(r.reads, r.n_reads, READ_DTYPE),
-                      arr(r.junction_bytes, r.junction_size, np.dtype("u1")), n_reads=int(r.n_reads))
+                      arr(r.junction_bytes, r.junction_size, np.dtype("u1")), n_reads=int(r.n_reads),
+                      cluster_junction_off=cjo)
 
     def clusterise(self, copy: bool = True) -> Result:
         r = BfResult()
         self._check(self.lib.bf_clusterise(self.h, C.byref(r)))
+        if not r.reads and r.cluster_junction_off:          # a one-GPU result: the table is still on the device
+            self._check(self.lib.bf_result_reads(self.h, C.byref(r)))
         self._last = r
         res = self._wrap(r, copy)
         if copy and r.n_reads and getattr(self, "n_ranks", 1) > 1:
@@ -374,9 +385,13 @@ class Engine:
             res.src_index = np.frombuffer((C.c_uint32 * r.n_reads).from_address(si.value), np.uint32).copy()
         return res
 
-    def finish(self, copy: bool = True) -> Result:
+    def finish(self, copy: bool = True, reads: bool = True) -> Result:
+        """bf_finish; reads=False leaves the read table on the device (Result.reads is empty, the records are
+        found through Result.cluster_junction_off), as the C call does until bf_result_reads."""
         r = BfResult()
         self._check(self.lib.bf_finish(self.h, C.byref(r)))
+        if reads:
+            self._check(self.lib.bf_result_reads(self.h, C.byref(r)))
         self._last = r
         return self._wrap(r, copy)
 
@@ -398,7 +413,12 @@ class Engine:
         cl = np.ascontiguousarray(res.clusters, CLUSTER_DTYPE)
         rd = np.ascontiguousarray(res.reads, READ_DTYPE)
         jb = np.ascontiguousarray(res.junction_bytes, np.uint8)
-        r = BfResult(res.n_evidence, cl.shape[0], rd.shape[0], _ptr(cl), _ptr(rd), _ptr(jb), jb.size)
+        n_reads = rd.shape[0]
+        cjo = None
+        if n_reads == 0 and res.n_reads > 0 and res.cluster_junction_off is not None:   # table left on the device
+            cjo = np.ascontiguousarray(res.cluster_junction_off, np.uint64)
+            n_reads = res.n_reads
+        r = BfResult(res.n_evidence, cl.shape[0], n_reads, _ptr(cl), _ptr(rd), _ptr(jb), jb.size, _ptr(cjo))
         n = self.lib.bf_format_sv(self.h, C.byref(r), None, 0)
         self._check(n)
         buf = C.create_string_buffer(int(n) + 1)

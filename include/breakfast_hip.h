@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 3
+#define BF_ABI_VERSION 4
 
 enum {
     BF_OK = 0,
@@ -124,7 +124,7 @@ typedef struct {
  *     n_exc x { u16 k, u8 byte, u8 0 }
  *     n_lower x u16 k                               base k prints in lower case; zero padding to 4 bytes
  * bf_junction_text() expands one record, bf_result_junction_text() all records of a result, and
- * A record's length follows from its header, so the read table holds only where it starts.
+ * A record's length follows from its header, so records can be walked one after the other.
  * bf_format_sv() expands them while it prints.  52 bytes instead of 151 for a 150-base read with one mismatch. */
 
 /* One supporting read that survived frag-id dedup (detect.rs:247-287), in printed order. */
@@ -132,16 +132,24 @@ typedef struct {
     uint64_t index;          /* global input index (position in submit order, + ctx base)                         */
     uint64_t junction_off;   /* its junction record (see above) starts at junction_bytes + junction_off; breakpoint */
                              /* offset (detect.rs:147-153) and reorientation are in the record's header             */
-} bf_read;                   /* 16 bytes: this table and the records are what crosses PCIe per supporting read      */
+} bf_read;                   /* 16 bytes */
 
+/* What the reference prints (detect.rs:233-240) is the cluster rows and the strings of their reads, so that is what
+ * bf_finish / bf_clusterise bring to the host: rows, junction records in printed order (a cluster's records are
+ * contiguous, each says how long it is) and one offset per cluster.  The read table -- which input read each
+ * string came from, and each record's own offset -- is a quarter of the bytes; it is complete on the device and
+ * comes over when bf_result_reads() asks for it.  Multi-rank results (bf_result_attach_*) arrive with the table
+ * and without cluster_junction_off: their records lie in arrival order. */
 typedef struct {
     uint64_t          n_evidence;     /* the count the reference logs at detect.rs:190 */
     uint64_t          n_clusters;
     uint64_t          n_reads;
     const bf_cluster* clusters;       /* output order = the reference's print order */
-    const bf_read*    reads;
+    const bf_read*    reads;          /* NULL until bf_result_reads() (one-GPU results) */
     const uint8_t*    junction_bytes;
     uint64_t          junction_size;
+    const uint64_t*   cluster_junction_off;  /* n_clusters + 1: the records of cluster c's reads, in read order, are
+                                                junction_bytes[off[c] .. off[c+1]); NULL when `reads` locates them */
 } bf_result;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -177,6 +185,11 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out);
 
 /* bf_localise + bf_clusterise.  Idempotent: may be called repeatedly on the same resident reads. */
 int bf_finish(bf_ctx* ctx, bf_result* out);
+
+/* Completes `result` (the one the last bf_finish / bf_clusterise of this ctx returned) with the read table:
+ * copies it from the device if it is not on the host yet and sets result->reads.  The table is owned by the ctx
+ * like the rest of the result.  No counterpart in the reference, which prints sequences only (detect.rs:236-239). */
+int bf_result_reads(bf_ctx* ctx, bf_result* result);
 
 /* Drops the resident reads (the genome stays). */
 int bf_reset(bf_ctx* ctx);

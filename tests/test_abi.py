@@ -23,13 +23,13 @@ def test_header_symbols_are_all_exported():
     for s in syms:
         assert hasattr(lib, s), "libbreakfast_hip.so does not export %s" % s
     assert sorted(engine.ABI_SYMBOLS) == syms, "engine.ABI_SYMBOLS out of date with the header"
-    assert lib.bf_abi_version() == 3
+    assert lib.bf_abi_version() == 4
 
 
 def test_struct_layouts_match_header():
     assert C.sizeof(engine.BfConfig) == 32
     assert C.sizeof(engine.BfBatch) == 48
-    assert C.sizeof(engine.BfResult) == 56
+    assert C.sizeof(engine.BfResult) == 64
     assert engine.HIT_DTYPE.itemsize == 16
     assert engine.CLUSTER_DTYPE.itemsize == 56
     assert engine.READ_DTYPE.itemsize == 16

@@ -51,7 +51,17 @@ def check_against_oracle(g, b, A, F=5000, E=2, flags=0, expect_exact=None):
     try:
         eng.set_genome(g.names, g.seqs)
         eng.submit(b)
+        # what bf_finish itself brings to the host: rows, records, one offset per cluster; no read table
+        bare = eng.finish(reads=False)
+        assert bare.reads.shape[0] == 0
+        assert eng.format_sv(bare) == ref.sv, "stdout differs (records found through cluster_junction_off)"
         res = eng.finish()
+        assert bare.n_reads == res.reads.shape[0]
+        if res.reads.shape[0]:
+            first = res.clusters["read_begin"].astype(np.int64)
+            assert np.array_equal(res.reads["junction_off"][first], bare.cluster_junction_off[:-1])
+            assert int(bare.cluster_junction_off[-1]) == res.junction_bytes.size
+            assert np.array_equal(bare.junction_bytes, res.junction_bytes)
         ev = eng.evidence()
         n = b.n
         assert res.n_evidence == ref.n_evidence == n

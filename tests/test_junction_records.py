@@ -109,3 +109,39 @@ def test_result_junction_texts_batch():
         assert (L, bp, sw, size) == (len(js[i]) - 1, js[i].index(b"|"), False, len(recs[i]))
     assert engine.junction_header(pack(js[3], swapped=True))[2] and engine.junction_header(text_record(js[3], True))[2]
     assert engine.junction_text(pack(js[3], swapped=True)) == js[3]
+
+
+def test_records_found_through_cluster_offsets():
+    """A one-GPU result arrives without the read table: a cluster's records are contiguous, every record says
+    how long it is, cluster_junction_off says where each cluster starts (include/breakfast_hip.h, bf_result)."""
+    rng = np.random.default_rng(11)
+    js = [random_junction(rng, int(rng.integers(40, 300)), int(rng.integers(0, 4))) for _ in range(300)]
+    recs = [pack(j) if i % 4 else text_record(j) for i, j in enumerate(js)]
+    sizes = [0, 1, 2, 40, 7, 0, 250]                       # reads per cluster (empty clusters never occur; harmless)
+    assert sum(sizes) == len(js)
+    cl = np.zeros(len(sizes), engine.CLUSTER_DTYPE)
+    cjo = np.zeros(len(sizes) + 1, np.uint64)
+    k = 0
+    for c, m in enumerate(sizes):
+        cl[c]["read_begin"], cl[c]["read_end"] = k, k + m
+        cjo[c + 1] = cjo[c] + sum(len(r) for r in recs[k:k + m])
+        k += m
+    jb = np.frombuffer(b"".join(recs), np.uint8)
+    res = engine.Result(len(js), cl, np.zeros(0, engine.READ_DTYPE), jb, n_reads=len(js), cluster_junction_off=cjo)
+    text, toff = res.junction_texts()
+    assert [text[int(toff[i]):int(toff[i + 1])].tobytes() for i in range(len(js))] == js
+    # offsets that do not meet the records are refused, not followed
+    for c, delta in ((3, 4), (4, -4), (7, 8), (7, -4)):
+        bad = cjo.copy()
+        bad[c] = np.uint64(int(bad[c]) + delta)
+        with pytest.raises(engine.BreakfastError):
+            engine.Result(len(js), cl, np.zeros(0, engine.READ_DTYPE), jb, n_reads=len(js),
+                          cluster_junction_off=bad).junction_texts()
+    # neither table nor offsets
+    with pytest.raises(engine.BreakfastError):
+        lib = engine.load_library()
+        r = engine.BfResult(0, 0, 5, None, None, jb.ctypes.data, jb.size, None)
+        off = np.zeros(6, np.uint64)
+        n = lib.bf_result_junction_text(engine.C.byref(r), None, 0, off.ctypes.data)
+        if n < 0:
+            raise engine.BreakfastError(int(n), "no way to the records")
