@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--exchange", action="store_true",
                     help="with one GPU: run the sharded code path anyway (pack -> RCCL all-to-all with itself -> import -> "
                          "device junction routing), to time what the exchange adds per rank")
+    ap.add_argument("--junction-chunks", type=int, default=0, help="sharded path: pieces the junction records come in (0 = default)")
     ap.add_argument("--phases", action="store_true", help="sharded path: synchronise after every phase and report phase_ms "
                                                            "(diagnostic: the extra synchronisation slows the step)")
     ap.add_argument("--soft-mask", type=float, default=0.0,
@@ -142,8 +143,12 @@ def main():
         (time.time() - t3, (batch.seq_bytes.nbytes + batch.frag_bytes.nbytes) / 1e9 / max(time.time() - t3, 1e-9)))
 
     if world > 1 or forced:
-        dd = DistributedDetect(HipStageEngine(eng, dev), rank, world, rank * n_local, n_local, dev)
+        stage = HipStageEngine(eng, dev)
+        stage.fetch_reads = False     # as on one GPU: the read table stays on the device until bf_result_reads asks
+        dd = DistributedDetect(stage, rank, world, rank * n_local, n_local, dev)
         dd.profile = args.phases
+        if args.junction_chunks:
+            dd.junction_chunks = args.junction_chunks
         step = dd.step
     else:
         step = eng.finish_raw
@@ -175,7 +180,7 @@ def main():
     ktimes = eng.kernel_times()
     sharded = world > 1 or forced
     n_clusters = int(last.clusters.shape[0]) if sharded else int(last.n_clusters)
-    n_support = int(last.reads.shape[0]) if sharded else int(last.n_reads)
+    n_support = int(last.n_reads)
     if world > 1:                                      # totals over all owner ranks
         t = torch.tensor([n_clusters, n_support], dtype=torch.int64, device=dev)
         dist.all_reduce(t)

@@ -428,6 +428,7 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     BF_HIP(ctx, hipSetDevice(ctx->device));
     const OwnerView v = ctx->imported ? imported_view(ctx) : local_view(ctx);
     ctx->clustered = false; ctx->table_attached = false; ctx->junction_attached = 0; ctx->reads_on_device = false;
+    ctx->result_order = false;
     BF_TRY(run_cluster(ctx, v));
     ctx->clustered = true;
     const uint64_t nr = ctx->out.n_reads;
@@ -494,10 +495,9 @@ int bf_result_reads(bf_ctx* ctx, bf_result* result) {
     if (result->n_reads != ctx->out.n_reads || result->clusters != ctx->out.clusters.as<bf_cluster>())
         return fail(ctx, BF_ERR_STATE, "bf_result_reads: not the result of this ctx's last bf_clusterise");
     const uint64_t nr = ctx->out.n_reads;
-    if (ctx->imported) {                                  // multi-rank: the table reached the host with the attach calls
-        if ((ctx->cfg.flags & BF_FLAG_DEVICE_ROUTING) && !ctx->table_attached)
-            return fail(ctx, BF_ERR_STATE, "bf_result_reads before the read table was attached");
-    } else if (ctx->reads_on_device && nr) {
+    if (ctx->imported && (ctx->cfg.flags & BF_FLAG_DEVICE_ROUTING) && !ctx->table_attached)
+        return fail(ctx, BF_ERR_STATE, "bf_result_reads before bf_result_layout_dev / bf_result_attach_junctions_dev");
+    if (ctx->reads_on_device && nr) {
         BF_HIP(ctx, hipSetDevice(ctx->device));
         BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
         BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
@@ -815,6 +815,7 @@ int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const 
         BF_HIP(ctx, hipMemcpyAsync(ctx->out.junction.p, dev_bytes, size, hipMemcpyDeviceToHost, ctx->stream));
     }
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->table_attached = true;
     memset(out, 0, sizeof *out);
     out->n_evidence = ctx->n_evidence;
     out->n_clusters = ctx->out.n_clusters;
@@ -843,38 +844,73 @@ int bf_result_junction_sizes_dev(bf_ctx* ctx, uint32_t* dev_len) {
     return BF_OK;
 }
 
-int bf_result_attach_offsets_dev(bf_ctx* ctx, const uint64_t* dev_joff) {
+int bf_result_layout_dev(bf_ctx* ctx, uint32_t n_pieces, uint64_t* piece_read_begin, uint64_t* piece_byte_off) {
     if (!ctx) return BF_ERR_INVALID;
     if (!ctx->imported || !ctx->clustered)
-        return fail(ctx, BF_ERR_STATE, "bf_result_attach_offsets_dev is only meaningful after bf_exchange_import + bf_clusterise");
-    const uint64_t nr = ctx->out.n_reads;
-    if (nr && !dev_joff) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_offsets_dev: null offsets");
+        return fail(ctx, BF_ERR_STATE, "bf_result_layout_dev is only meaningful after bf_exchange_import + bf_clusterise");
+    if (n_pieces == 0 || n_pieces > 64 || !piece_read_begin || !piece_byte_off)
+        return fail(ctx, BF_ERR_INVALID, "bf_result_layout_dev: 1..64 pieces and two output arrays");
     BF_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t nr = ctx->out.n_reads, ncl = ctx->out.n_clusters;
+    ctx->piece_read.assign(n_pieces + 1, 0); ctx->piece_byte.assign(n_pieces + 1, 0);
+    ctx->piece_done.assign(n_pieces, 0);
+    for (uint32_t c = 0; c <= n_pieces; c++) ctx->piece_read[c] = nr * c / n_pieces;
+    ctx->junction_attached = 0;
     if (nr) {
-        BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
-        BF_TRY(patch_reads_off(ctx, dev_joff, nr));
-        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));            // dev_joff may be released by the caller on return
-        BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->copy_stream));
+        // record offsets in result order from the sizes the exchange brought along; the read table is finished
+        // on the device (bf_result_reads fetches it), the host gets one offset per cluster
+        BF_TRY(ensure(ctx, ctx->c_joff, (nr + 1) * 8));
+        BF_TRY(scan_u32_to_u64(ctx, ctx->c_rsrc.as<uint32_t>() + 3 * nr, ctx->c_joff.as<uint64_t>(), nr));
+        BF_TRY(patch_reads_off(ctx, ctx->c_joff.as<uint64_t>(), nr));
+        BF_TRY(ensure(ctx, ctx->c_cjo, (ncl + 1) * 8));
+        BF_TRY(ensure_host(ctx, ctx->out.cjo, (ncl + 1) * 8));
+        BF_TRY(cluster_record_offsets(ctx, ctx->c_joff.as<uint64_t>(), ctx->c_cjo.as<uint64_t>(), ncl));
+        BF_TRY(ensure(ctx, ctx->c_err, 16));
+        BF_HIP(ctx, hipMemsetAsync(ctx->c_err.p, 0, 16, ctx->stream));
+        for (uint32_t c = 0; c <= n_pieces; c++)
+            BF_HIP(ctx, hipMemcpyAsync(&ctx->piece_byte[c], ctx->c_joff.as<uint64_t>() + ctx->piece_read[c], 8,
+                                       hipMemcpyDeviceToHost, ctx->stream));
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.cjo.p, ctx->c_cjo.p, (ncl + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const uint64_t total = ctx->piece_byte[n_pieces];
+        BF_TRY(ensure(ctx, ctx->c_jbytes, total ? total : 1));
+        BF_TRY(ensure_host(ctx, ctx->out.junction, total));
+        ctx->out.junction_size = total;
+        ctx->reads_on_device = true;
+    } else {
+        ctx->out.junction_size = 0;
     }
-    ctx->table_attached = true;
+    ctx->result_order = true; ctx->table_attached = true;
+    for (uint32_t c = 0; c <= n_pieces; c++) { piece_read_begin[c] = ctx->piece_read[c]; piece_byte_off[c] = ctx->piece_byte[c]; }
     return BF_OK;
 }
 
-int bf_result_attach_junction_chunk_dev(bf_ctx* ctx, const uint8_t* dev_bytes, uint64_t size, uint64_t dst_off, uint64_t total_size) {
+int bf_result_attach_records_dev(bf_ctx* ctx, uint32_t piece, const uint8_t* dev_records, uint64_t size, const int64_t* dev_read_pos) {
     if (!ctx) return BF_ERR_INVALID;
-    if (!ctx->imported || !ctx->clustered)
-        return fail(ctx, BF_ERR_STATE, "bf_result_attach_junction_chunk_dev is only meaningful after bf_exchange_import + bf_clusterise");
-    if (dst_off + size > total_size) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junction_chunk_dev: chunk [%llu, +%llu) outside %llu bytes",
-                                                 (unsigned long long)dst_off, (unsigned long long)size, (unsigned long long)total_size);
-    if (size && !dev_bytes) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junction_chunk_dev: null chunk");
+    if (!ctx->imported || !ctx->clustered || !ctx->result_order)
+        return fail(ctx, BF_ERR_STATE, "bf_result_attach_records_dev before bf_result_layout_dev");
+    if (piece >= ctx->piece_done.size()) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: piece %u of %zu", piece, ctx->piece_done.size());
+    if (ctx->piece_done[piece]) return fail(ctx, BF_ERR_STATE, "bf_result_attach_records_dev: piece %u attached twice", piece);
+    const uint64_t r0 = ctx->piece_read[piece], r1 = ctx->piece_read[piece + 1];
+    const uint64_t b0 = ctx->piece_byte[piece], b1 = ctx->piece_byte[piece + 1];
+    if (size != b1 - b0)
+        return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: piece %u holds %llu record bytes, %llu given", piece,
+                    (unsigned long long)(b1 - b0), (unsigned long long)size);
+    if (r1 > r0 && (!dev_records || !dev_read_pos)) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: null argument");
+    if (((uintptr_t)dev_records & 3) || ((uintptr_t)dev_read_pos & 7))
+        return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: dev_records must be 4-byte, dev_read_pos 8-byte aligned");
     BF_HIP(ctx, hipSetDevice(ctx->device));
-    if (total_size > ctx->out.junction.cap || !ctx->out.junction.p) {
-        if (ctx->junction_attached) return fail(ctx, BF_ERR_STATE, "bf_result_attach_junction_chunk_dev: total size changed between chunks");
-        BF_TRY(ensure_host(ctx, ctx->out.junction, total_size));
+    if (r1 > r0) {
+        BF_TRY(scatter_records(ctx, r0, r1, dev_records, size, dev_read_pos));
+        if (size) {
+            hipEvent_t ev = ctx->ev[1 + piece % 8];
+            BF_HIP(ctx, hipEventRecord(ev, ctx->stream));
+            BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ev, 0));
+            BF_HIP(ctx, hipMemcpyAsync(ctx->out.junction.as<uint8_t>() + b0, ctx->c_jbytes.as<uint8_t>() + b0, size,
+                                       hipMemcpyDeviceToHost, ctx->copy_stream));
+        }
     }
-    ctx->out.junction_size = total_size;
-    // the caller keeps dev_bytes alive until bf_result_attach_finish
-    if (size) BF_HIP(ctx, hipMemcpyAsync(ctx->out.junction.as<uint8_t>() + dst_off, dev_bytes, size, hipMemcpyDeviceToHost, ctx->copy_stream));
+    ctx->piece_done[piece] = 1;
     ctx->junction_attached += size;
     return BF_OK;
 }
@@ -882,22 +918,28 @@ int bf_result_attach_junction_chunk_dev(bf_ctx* ctx, const uint8_t* dev_bytes, u
 int bf_result_attach_finish(bf_ctx* ctx, bf_result* out) {
     if (!ctx) return BF_ERR_INVALID;
     if (!out) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_finish: null result");
-    if (!ctx->imported || !ctx->clustered || !ctx->table_attached)
-        return fail(ctx, BF_ERR_STATE, "bf_result_attach_finish before bf_result_attach_offsets_dev");
-    BF_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    if (!ctx->imported || !ctx->clustered || !ctx->result_order)
+        return fail(ctx, BF_ERR_STATE, "bf_result_attach_finish before bf_result_layout_dev");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t err = 0;
+    if (ctx->out.n_reads) BF_HIP(ctx, hipMemcpyAsync(&err, ctx->c_err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     if (ctx->out.n_reads == 0) ctx->out.junction_size = 0;
     if (ctx->junction_attached != ctx->out.junction_size)
         return fail(ctx, BF_ERR_STATE, "bf_result_attach_finish: %llu of %llu junction bytes were attached",
                     (unsigned long long)ctx->junction_attached, (unsigned long long)ctx->out.junction_size);
+    if (err)
+        return fail(ctx, BF_ERR_INVALID, "bf_result_attach_finish: a piece's read positions or record bytes did not match the "
+                    "sizes the exchange announced (code %u)", err);
     memset(out, 0, sizeof *out);
     out->n_evidence = ctx->n_evidence;
     out->n_clusters = ctx->out.n_clusters;
     out->n_reads = ctx->out.n_reads;
     out->clusters = ctx->out.clusters.as<bf_cluster>();
-    out->reads = ctx->out.reads.as<bf_read>();
     out->junction_bytes = ctx->out.junction.as<uint8_t>();
     out->junction_size = ctx->out.junction_size;
+    out->cluster_junction_off = ctx->out.n_reads ? ctx->out.cjo.as<uint64_t>() : nullptr;   // reads: bf_result_reads
     return BF_OK;
 }
 

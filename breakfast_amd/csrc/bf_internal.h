@@ -205,12 +205,15 @@ struct bf_ctx {
         i_sigx_slot, i_src_rank, i_src_idx, i_jrec;
     bool table_attached = false;                // the read table of the last bf_clusterise is (being) copied to the host
     uint64_t junction_attached = 0;             // junction bytes queued for the host so far
-    bool reads_on_device = false;               // single rank: the finished read table waits in c_reads for bf_result_reads
+    bool reads_on_device = false;               // the finished read table waits in c_reads for bf_result_reads
+    bool result_order = false;                  // multi-rank: bf_result_layout_dev laid the records out in result order
+    std::vector<uint64_t> piece_read, piece_byte;   // its pieces: read ranges and their byte ranges (n_pieces + 1 each)
+    std::vector<uint8_t> piece_done;
 
     // cluster stage scratch + results
     bf::DevBuf c_tmp, c_a32, c_b32, c_c32, c_d32, c_k64a, c_k64b, c_slpos, c_srpos, c_reported,
         c_csize, c_flag, c_scan, c_qseed, c_qsize, c_qoff, c_members, c_leader, c_rep, c_qnrep,
-        c_ctl, c_sel, c_ord, c_clusters, c_reads, c_misc, c_pos2, c_joff, c_jbytes, c_rsrc, c_tables, c_mkey_s, c_slot, c_big, c_cjo;
+        c_ctl, c_sel, c_ord, c_clusters, c_reads, c_misc, c_pos2, c_joff, c_jbytes, c_rsrc, c_tables, c_mkey_s, c_slot, c_big, c_cjo, c_aoff, c_err;
     bf::ClusterOut out;
     std::vector<uint64_t> render_off_host;
     std::vector<uint8_t> render_bytes_host;
@@ -285,6 +288,7 @@ int scan_max_u32_inplace(bf_ctx* ctx, uint32_t* data, uint64_t n);              
 int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
 int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
 int cluster_record_offsets(bf_ctx* ctx, const uint64_t* d_joff, uint64_t* d_out, uint64_t n_clusters);
+int scatter_records(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_records, uint64_t size, const int64_t* d_pos);
 int read_sizes(bf_ctx* ctx, uint32_t* d_out, uint64_t n);
 
 }  // namespace bf

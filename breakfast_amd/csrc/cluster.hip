@@ -1029,6 +1029,50 @@ int cluster_record_offsets(bf_ctx* ctx, const uint64_t* d_joff, uint64_t* d_out,
     BF_HIP(ctx, hipGetLastError());
     return BF_OK;
 }
+// Multi-rank, result-order layout: the records of reads [r0, r1) arrived back to back in the order `pos` names
+// (grouped by source rank); each goes to where the scan of the record sizes put its read (c_joff).
+// err[0] becomes non-zero when the list or the bytes are not what the sizes say.
+__global__ void arrival_sizes_kernel(uint32_t* __restrict__ len, const int64_t* __restrict__ pos,
+                                     const uint32_t* __restrict__ jrec, uint64_t count, uint64_t r0, uint64_t r1,
+                                     uint32_t* err) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const int64_t p = pos[j];
+    const bool ok = p >= (int64_t)r0 && p < (int64_t)r1;
+    len[j] = ok ? jrec[p] : 0u;
+    if (!ok) err[0] = 1u;
+}
+__global__ void __launch_bounds__(256) scatter_records_kernel(uint32_t* __restrict__ dst, const uint64_t* __restrict__ joff,
+                                                              const uint32_t* __restrict__ src, const uint64_t* __restrict__ aoff,
+                                                              const int64_t* __restrict__ pos, uint64_t count, uint64_t size,
+                                                              uint64_t r0, uint64_t r1, uint32_t* err) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t j = g >> 4;                                     // 16 lanes per record
+    const uint32_t l = (uint32_t)g & 15u;
+    if (j >= count) return;
+    if (j == count - 1 && l == 0 && aoff[count] != size) err[0] = 2u;
+    const int64_t p = pos[j];
+    if (p < (int64_t)r0 || p >= (int64_t)r1) return;
+    const uint64_t a = aoff[j], words = (aoff[j + 1] - a) >> 2;
+    if (a + (words << 2) > size) { err[0] = 3u; return; }
+    const uint64_t d = joff[p] >> 2;
+    for (uint64_t w = l; w < words; w += 16) dst[d + w] = src[(a >> 2) + w];
+}
+int scatter_records(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_records, uint64_t size, const int64_t* d_pos) {
+    const uint64_t count = r1 - r0, nr = ctx->out.n_reads;
+    if (!count) return BF_OK;
+    BF_TRY(ensure(ctx, ctx->c_aoff, count * 4 + (count + 1) * 8 + 16));
+    uint64_t* aoff = ctx->c_aoff.as<uint64_t>();
+    uint32_t* len = (uint32_t*)(aoff + count + 1);
+    hipLaunchKernelGGL(arrival_sizes_kernel, dim3(grid_for(count, 256)), dim3(256), 0, ctx->stream, len, d_pos,
+                       ctx->c_rsrc.as<uint32_t>() + 3 * nr, count, r0, r1, ctx->c_err.as<uint32_t>());
+    BF_TRY(scan_u32_to_u64(ctx, len, aoff, count));
+    hipLaunchKernelGGL(scatter_records_kernel, dim3(grid_for(count * 16, 256)), dim3(256), 0, ctx->stream,
+                       ctx->c_jbytes.as<uint32_t>(), ctx->c_joff.as<uint64_t>(), (const uint32_t*)d_records, aoff, d_pos,
+                       count, size, r0, r1, ctx->c_err.as<uint32_t>());
+    BF_HIP(ctx, hipGetLastError());
+    return BF_OK;
+}
 // record bytes of the result's supporting reads (left by emit next to the index lists)
 int read_sizes(bf_ctx* ctx, uint32_t* d_out, uint64_t n) {
     if (n) BF_HIP(ctx, hipMemcpyAsync(d_out, ctx->c_rsrc.as<uint32_t>() + 3 * n, n * 4, hipMemcpyDeviceToDevice, ctx->stream));

@@ -143,18 +143,21 @@ class HipStageEngine:
         out.src_rank, out.src_index = res.src_rank, res.src_index
         return out
 
-    # pipelined attach: table first, records piece by piece (copies run on the library's copy stream)
-    def attach_offsets(self, res: Result, joff: torch.Tensor):
-        joff = joff.to(self.device, torch.int64).contiguous()
-        self._torch_done()
-        self.eng.attach_offsets_dev(joff.data_ptr() if joff.numel() else 0)
+    # pipelined attach in result order: layout first, then the records piece by piece (the library moves each
+    # record to its place and copies the piece to the host on its copy stream)
+    fetch_reads = True      # False: leave the read table on the device (bf_result_reads was not asked for)
 
-    def attach_chunk(self, res: Result, piece: torch.Tensor, dst_off: int, total: int):
-        self._torch_done()      # the all-to-all that filled `piece` ran on torch's stream
-        self.eng.attach_junction_chunk_dev(piece.data_ptr() if piece.numel() else 0, int(piece.numel()), dst_off, total)
+    def result_layout(self, res: Result, n_pieces: int):
+        self._torch_done()
+        return self.eng.result_layout_dev(n_pieces)
+
+    def attach_records(self, res: Result, piece: int, records: torch.Tensor, read_pos: torch.Tensor):
+        self._torch_done()      # the all-to-all that filled `records` ran on torch's stream
+        n = int(records.numel())
+        self.eng.attach_records_dev(piece, records.data_ptr() if n else 0, n, read_pos.data_ptr() if read_pos.numel() else 0)
 
     def attach_finish(self, res: Result) -> Result:
-        out = self.eng.attach_finish()
+        out = self.eng.attach_finish(reads=self.fetch_reads)
         out.src_rank, out.src_index = res.src_rank, res.src_index
         return out
 
@@ -219,8 +222,9 @@ class DistributedDetect:
         else:
             self.bases = np.array([index_base], np.uint64)
         self.stats = StepStats()
-        self.junction_chunks = 4        # pieces the junction records come in (each piece's host copy hides the next one's exchange)
-        self.chunk_threshold = 1 << 16  # fewer supporting reads than this: one piece
+        self.junction_chunks = 4        # pieces the junction records come in (each piece's host copy hides the next one's
+                                        # exchange); the same on every rank: each piece is a round of collectives
+        self.chunk_threshold = 0        # (unused: kept for callers that set it)
         self.profile = False            # True: synchronise after every phase and accumulate wall ms in phase_ms
         self.phase_ms = {}
         self._t = None
@@ -291,83 +295,95 @@ class DistributedDetect:
         by, off = self.stage.render_junctions(got.cpu().numpy().astype(np.uint32))
         return torch.from_numpy(by).to(dev), torch.from_numpy(off.astype(np.int64)).to(dev)
 
-    def _attach_offsets(self, res: Result, joff: torch.Tensor, total: int):
-        if hasattr(self.stage, "attach_offsets"):
-            return self.stage.attach_offsets(res, joff)
+    def _layout(self, res: Result, K: int):
+        """-> (first read, first junction byte) of each of the K result-order pieces, K + 1 entries each."""
+        if hasattr(self.stage, "result_layout"):
+            return self.stage.result_layout(res, K)
+        nr = res.reads.shape[0]
+        sizes = res.junction_sizes.astype(np.int64) if nr else np.zeros(0, np.int64)
+        joff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        rb = np.array([nr * c // K for c in range(K + 1)], np.int64)
         res.reads = res.reads.copy()
-        res.reads["junction_off"] = joff.cpu().numpy().astype(np.uint64)
-        res.junction_bytes = np.zeros(total, np.uint8)
+        res.reads["junction_off"] = joff[:-1].astype(np.uint64)
+        res.junction_bytes = np.zeros(int(joff[-1]), np.uint8)
+        self._host_layout = (joff, sizes)
+        return rb, joff[rb]
 
-    def _attach_chunk(self, res: Result, piece: torch.Tensor, dst_off: int, total: int):
-        if hasattr(self.stage, "attach_chunk"):
-            return self.stage.attach_chunk(res, piece, dst_off, total)
-        res.junction_bytes[dst_off:dst_off + int(piece.numel())] = piece.cpu().numpy()
+    def _attach_records(self, res: Result, piece: int, records: torch.Tensor, read_pos: torch.Tensor):
+        if hasattr(self.stage, "attach_records"):
+            return self.stage.attach_records(res, piece, records, read_pos)
+        joff, sizes = self._host_layout
+        m, a = records.cpu().numpy(), 0
+        for j in read_pos.cpu().numpy():
+            n = int(sizes[j])
+            res.junction_bytes[int(joff[j]):int(joff[j]) + n] = m[a:a + n]
+            a += n
+        assert a == m.shape[0]
 
     def _attach_finish(self, res: Result) -> Result:
         if hasattr(self.stage, "attach_finish"):
             return self.stage.attach_finish(res)
         return res
 
+    def _exchange_matrix(self, m: np.ndarray) -> np.ndarray:
+        """m[r] = K numbers for rank r -> what every rank sent me, same shape."""
+        K = m.shape[1]
+        inp = self._ctl([int(x) for x in m.ravel()])
+        out = torch.empty_like(inp)
+        _a2a(out, inp, [K] * self.world, [K] * self.world, self.group)
+        return out.cpu().numpy().astype(np.int64).reshape(self.world, K)
+
     def _route_junctions(self, res: Result) -> Result:
         """Owners request the junction records of their surviving reads from the source ranks (sequences and
         mismatch masks never leave their source rank).  All bulk data (index lists, records) stays in device
         tensors; only per-rank counts and piece boundaries visit the host.
 
-        The owner knows every record's size (it travelled in the exchange record), so it lays out its junction
-        buffer first and sends the read table to the host at once; the records then come in K pieces --
-        piece c holds, from every source rank s, the c-th K-th of the owner's requests to s -- and each piece's
-        copy to host memory runs behind the rendering and the all-to-all of the next one."""
+        The owner knows every record's size (it travelled in the exchange record), so the result is laid out as
+        on one GPU before any record has arrived: records in printed order.  They come in K pieces -- piece c =
+        the c-th K-th of the supporting reads in result order, requested from whichever ranks hold them -- and
+        each piece is put in place and copied to host memory behind the rendering and the all-to-all of the
+        next one.  Every rank runs the same K rounds, whatever its own share of the result."""
         W = self.world
         nccl = dist.get_backend(self.group) == "nccl"
         self._phase("route_requests")
         src_rank, src_index, jlen = self._sources(res, self.device if nccl else torch.device("cpu"))
         dev = src_rank.device
         nr = int(src_rank.numel())
-        # requests grouped by source rank (one radix pass on byte keys when the ranks fit a byte)
-        order = torch.argsort(src_rank.to(torch.uint8) if W <= 256 else src_rank, stable=True)
-        req_counts = torch.bincount(src_rank, minlength=W).cpu().numpy().astype(np.int64)
-        K = self.junction_chunks if nr >= self.chunk_threshold else 1
-        rb = np.concatenate([[0], np.cumsum(req_counts)]).astype(np.int64)
-        cut = np.array([[rb[s] + req_counts[s] * c // K for s in range(W)] for c in range(K + 1)], np.int64)   # (K+1, W)
-        seg_start, seg_len = cut[:-1].ravel(), (cut[1:] - cut[:-1]).ravel()      # piece (c, s) of the grouped list
-        out_start = np.cumsum(seg_len) - seg_len                                  # its place in chunk-major order
-        lens = jlen[order].to(torch.int64)
-        if K > 1:
-            shift = torch.from_numpy(seg_start - out_start).to(dev)
-            chunk_order = torch.arange(nr, device=dev) + torch.repeat_interleave(shift, torch.from_numpy(seg_len).to(dev),
-                                                                                 output_size=nr)
-            lens = lens[chunk_order]
-            place = order[chunk_order]
+        K = max(1, min(int(self.junction_chunks), 64))
+        rb, pb = self._layout(res, K)
+        # requests ordered by (piece, source rank), result order inside: one radix pass when the keys fit a byte
+        if K > 1 and nr:
+            piece_of = torch.bucketize(torch.arange(nr, device=dev), torch.from_numpy(rb[1:K].copy()).to(dev), right=True)
+            key = piece_of * W + src_rank.to(torch.int64)
         else:
-            place = order
+            key = src_rank.to(torch.int64)
+        order = torch.argsort(key.to(torch.uint8) if K * W <= 256 else key, stable=True)
+        cnt = torch.bincount(key, minlength=K * W).cpu().numpy().astype(np.int64).reshape(K, W)   # [piece, source]
+        got_cnt = self._exchange_matrix(np.ascontiguousarray(cnt.T))                              # [asking rank, piece]
+        cut = np.concatenate([[0], np.cumsum(cnt.ravel())]).astype(np.int64)
         csum = torch.zeros(nr + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(lens, 0, out=csum[1:])
-        joff = torch.empty(nr, dtype=torch.int64, device=dev)
-        joff[place] = csum[:-1]
-        pb = csum[torch.from_numpy(np.concatenate([out_start, [nr]])).to(dev)].cpu().numpy()   # byte bounds of the pieces
-        total = int(pb[-1])
-        self._attach_offsets(res, joff, total)                      # the read table leaves for the host now
-        got_counts = self._exchange_counts(req_counts)              # how many each rank asks of me
+        torch.cumsum(jlen[order].to(torch.int64), 0, out=csum[1:])
+        pbs = csum[torch.from_numpy(cut).to(dev)].cpu().numpy()         # byte bounds of every (piece, source) group
         req = src_index[order].contiguous()
-        got = torch.empty(int(got_counts.sum()), dtype=torch.int32, device=dev)
-        _a2a(got, req, [int(c) for c in got_counts], [int(c) for c in req_counts], self.group)
-        gb = np.concatenate([[0], np.cumsum(got_counts)]).astype(np.int64)
         keep = []
         for c in range(K):
             self._phase("render")
-            lo = [int(gb[r] + got_counts[r] * c // K) for r in range(W)]
-            hi = [int(gb[r] + got_counts[r] * (c + 1) // K) for r in range(W)]
-            idx_c = got[lo[0]:hi[0]] if W == 1 else torch.cat([got[a:b] for a, b in zip(lo, hi)])
-            by, off = self._render(idx_c, dev)
+            a, b = int(cut[c * W]), int(cut[(c + 1) * W])
+            assert (a, b) == (int(rb[c]), int(rb[c + 1])) and int(pbs[(c + 1) * W] - pbs[c * W]) == int(pb[c + 1] - pb[c])
+            asked = [int(x) for x in got_cnt[:, c]]
+            got = torch.empty(sum(asked), dtype=torch.int32, device=dev)
+            _a2a(got, req[a:b], asked, [int(x) for x in cnt[c]], self.group)
+            by, off = self._render(got, dev)
             self._phase("alltoall_junctions")
-            bounds = np.concatenate([[0], np.cumsum([b - a for a, b in zip(lo, hi)])]).astype(np.int64)
+            bounds = np.concatenate([[0], np.cumsum(asked)]).astype(np.int64)
             ob = off[torch.from_numpy(bounds).to(off.device)].cpu().numpy()
             out_bytes = [int(ob[r + 1] - ob[r]) for r in range(W)]
-            in_bytes = [int(pb[c * W + s + 1] - pb[c * W + s]) for s in range(W)]
+            in_bytes = [int(pbs[c * W + s + 1] - pbs[c * W + s]) for s in range(W)]
             mine = torch.empty(sum(in_bytes), dtype=torch.uint8, device=by.device)
             _a2a(mine, by[:int(ob[-1])], in_bytes, out_bytes, self.group)
-            self._attach_chunk(res, mine, int(pb[c * W]), total)
-            keep.append((mine, by))
+            pos = order[a:b].contiguous()
+            self._attach_records(res, c, mine, pos)
+            keep.append((mine, by, pos))
         self._phase("attach_to_host")
         out = self._attach_finish(res)
         del keep

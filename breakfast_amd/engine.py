@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "bf_exchange_local", "bf_exchange_pack", "bf_exchange_import", "bf_result_sources",
     "bf_render_junctions", "bf_result_sources_dev", "bf_render_junctions_dev", "bf_result_attach_junctions_dev",
     "bf_evidence_fetch", "bf_kernel_times", "bf_stats", "bf_junction_text", "bf_result_junction_text",
-    "bf_result_junction_sizes_dev", "bf_result_attach_offsets_dev", "bf_result_attach_junction_chunk_dev",
+    "bf_result_junction_sizes_dev", "bf_result_layout_dev", "bf_result_attach_records_dev",
     "bf_result_attach_finish", "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
 ]
 
@@ -136,8 +136,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_kernel_times.argtypes = [vp, C.POINTER(C.POINTER(BfKernelTime)), C.POINTER(C.c_uint32)]
     lib.bf_stats.argtypes = [vp, u64p, u64p]
     lib.bf_result_junction_sizes_dev.argtypes = [vp, vp]
-    lib.bf_result_attach_offsets_dev.argtypes = [vp, vp]
-    lib.bf_result_attach_junction_chunk_dev.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    lib.bf_result_layout_dev.argtypes = [vp, C.c_uint32, u64p, u64p]
+    lib.bf_result_attach_records_dev.argtypes = [vp, C.c_uint32, vp, C.c_uint64, vp]
     lib.bf_result_attach_finish.argtypes = [vp, C.POINTER(BfResult)]
     lib.bf_junction_record_bound.argtypes = [vp]
     lib.bf_junction_record_bound.restype = C.c_uint64
@@ -487,15 +487,23 @@ class Engine:
     def result_junction_sizes_dev(self, dev_len: int) -> None:
         self._check(self.lib.bf_result_junction_sizes_dev(self.h, C.c_void_p(dev_len or None)))
 
-    def attach_offsets_dev(self, dev_joff: int) -> None:
-        self._check(self.lib.bf_result_attach_offsets_dev(self.h, C.c_void_p(dev_joff or None)))
+    def result_layout_dev(self, n_pieces: int) -> Tuple[np.ndarray, np.ndarray]:
+        """-> (piece_read_begin, piece_byte_off), n_pieces + 1 entries each (bf_result_layout_dev)."""
+        rb = (C.c_uint64 * (n_pieces + 1))()
+        bo = (C.c_uint64 * (n_pieces + 1))()
+        self._check(self.lib.bf_result_layout_dev(self.h, n_pieces, rb, bo))
+        return np.array(rb[:], np.int64), np.array(bo[:], np.int64)
 
-    def attach_junction_chunk_dev(self, dev_bytes: int, size: int, dst_off: int, total_size: int) -> None:
-        self._check(self.lib.bf_result_attach_junction_chunk_dev(self.h, C.c_void_p(dev_bytes or None), size, dst_off, total_size))
+    def attach_records_dev(self, piece: int, dev_records: int, size: int, dev_read_pos: int) -> None:
+        self._check(self.lib.bf_result_attach_records_dev(self.h, piece, C.c_void_p(dev_records or None), size,
+                                                          C.c_void_p(dev_read_pos or None)))
 
-    def attach_finish(self, copy: bool = False) -> Result:
+    def attach_finish(self, copy: bool = False, reads: bool = True) -> Result:
+        """bf_result_attach_finish; reads=True also fetches the read table (bf_result_reads)."""
         r = BfResult()
         self._check(self.lib.bf_result_attach_finish(self.h, C.byref(r)))
+        if reads:
+            self._check(self.lib.bf_result_reads(self.h, C.byref(r)))
         self._last = r
         return self._wrap(r, copy)
 

@@ -66,8 +66,7 @@ typedef struct {
 #define BF_FLAG_WEAK_DEDUP_HASH 64u /* tests: the in-wave dedup groups on 3 hash bits, so that its byte verification fails
                                        and the pair-by-pair redo runs */
 #define BF_FLAG_DEVICE_ROUTING 16u /* multi-rank: bf_clusterise leaves the read table on the device (result.reads
-                                      is NULL, n_reads is set) until bf_result_attach_junctions_dev copies the
-                                      finished table out once */
+                                      is NULL, n_reads is set); the bf_result_attach_* calls complete the result */
 
 /* One pair of anchor alignments = the fields the consume loop parses out of a `5p:`/`3p:` line
  * pair (detect.rs:94-103): bowtie's strand, contig and 1-based leftmost offset (-B1) of each anchor.
@@ -138,8 +137,9 @@ typedef struct {
  * bf_finish / bf_clusterise bring to the host: rows, junction records in printed order (a cluster's records are
  * contiguous, each says how long it is) and one offset per cluster.  The read table -- which input read each
  * string came from, and each record's own offset -- is a quarter of the bytes; it is complete on the device and
- * comes over when bf_result_reads() asks for it.  Multi-rank results (bf_result_attach_*) arrive with the table
- * and without cluster_junction_off: their records lie in arrival order. */
+ * comes over when bf_result_reads() asks for it.  Multi-rank results are laid out the same way
+ * (bf_result_layout_dev ... bf_result_attach_finish); only the one-shot bf_result_attach_junctions_dev, whose
+ * caller chooses the record order, returns the table and no cluster_junction_off. */
 typedef struct {
     uint64_t          n_evidence;     /* the count the reference logs at detect.rs:190 */
     uint64_t          n_clusters;
@@ -280,22 +280,27 @@ int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_i
 int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const uint8_t* dev_bytes, uint64_t size,
                                    bf_result* out);
 
-/* Pipelined form of bf_result_attach_junctions_dev (same state requirements, same finished result).  The
- * exchange carries every read's junction record size, so an owner rank can lay out its junction buffer
- * before any record has arrived:
+/* Pipelined form, which lays the result out exactly as bf_finish does on one GPU (records in printed order, one
+ * offset per cluster, the read table left on the device for bf_result_reads).  The exchange carries every
+ * read's junction record size, so an owner rank knows where each record belongs before any has arrived:
  *   bf_result_junction_sizes_dev   record bytes of the result.n_reads supporting reads -> dev_len[n_reads]
- *   bf_result_attach_offsets_dev   sets reads[i].junction_off = dev_joff[i] and starts the copy of the read
- *                                  table to pinned host memory on the ctx's copy stream
- *   bf_result_attach_junction_chunk_dev   queues bytes [dst_off, dst_off+size) of the total_size-byte junction
- *                                  buffer for the host (same copy stream; returns at once; the caller keeps
- *                                  dev_bytes alive until bf_result_attach_finish)
- *   bf_result_attach_finish        waits for the copies and fills *out
- * so that table and record copies overlap the caller's remaining collectives.  No counterpart in the
- * reference (one process). */
+ *   bf_result_layout_dev           cuts the supporting reads into n_pieces (<= 64) ranges of result order:
+ *                                  piece c = reads [piece_read_begin[c], piece_read_begin[c+1]), whose records
+ *                                  are bytes [piece_byte_off[c], piece_byte_off[c+1]) of the junction buffer
+ *                                  (both arrays: n_pieces + 1 entries, host memory)
+ *   bf_result_attach_records_dev   the records of one piece as they arrived: back to back in dev_records, in the
+ *                                  order of dev_read_pos (result positions of the piece's reads, each once;
+ *                                  any order, e.g. grouped by source rank).  Moves each record to its place and
+ *                                  queues the piece's bytes for the host on the ctx's copy stream; returns at
+ *                                  once (the caller keeps both buffers alive until bf_result_attach_finish)
+ *   bf_result_attach_finish        waits for the copies, checks that every piece came and that sizes agreed,
+ *                                  fills *out
+ * so that each piece's host copy runs behind the caller's render + all-to-all of the next one.  No counterpart
+ * in the reference (one process). */
 int bf_result_junction_sizes_dev(bf_ctx* ctx, uint32_t* dev_len);
-int bf_result_attach_offsets_dev(bf_ctx* ctx, const uint64_t* dev_joff);
-int bf_result_attach_junction_chunk_dev(bf_ctx* ctx, const uint8_t* dev_bytes, uint64_t size, uint64_t dst_off,
-                                        uint64_t total_size);
+int bf_result_layout_dev(bf_ctx* ctx, uint32_t n_pieces, uint64_t* piece_read_begin, uint64_t* piece_byte_off);
+int bf_result_attach_records_dev(bf_ctx* ctx, uint32_t piece, const uint8_t* dev_records, uint64_t size,
+                                 const int64_t* dev_read_pos);
 int bf_result_attach_finish(bf_ctx* ctx, bf_result* out);
 /* Upper bound of a resident read's junction record in bytes (sizing of bf_render_junctions_dev buffers). */
 uint64_t bf_junction_record_bound(const bf_ctx* ctx);
