@@ -111,9 +111,75 @@ def _worker_nccl_single(rank, world, port, out_path):
             res = dd.step()
         merged = dd.gather_result(res, g.names)
         open(out_path, "wb").write(format_sv(merged, g.names))
+        _check_layout_and_attach_calls(eng, dd.stage, res, g, b, A, F, E, dev)
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def _check_layout_and_attach_calls(eng, stage, res, g, b, A, F, E, dev):
+    """The sharded result is laid out as bf_finish lays it out on one GPU -- with one rank it IS that result,
+    byte for byte --, and bf_result_layout_dev / bf_result_attach_records_dev refuse what does not fit."""
+    one = engine.Engine(A, F, E, device=0)
+    one.set_genome(g.names, g.seqs)
+    one.submit(b)
+    r1 = one.finish()
+    assert res.cluster_junction_off is not None
+    assert np.array_equal(res.cluster_junction_off, r1.cluster_junction_off)
+    assert np.array_equal(res.junction_bytes, r1.junction_bytes)
+    assert np.array_equal(res.clusters, r1.clusters) and np.array_equal(res.reads, r1.reads)
+    bare = one.finish(reads=False)
+    assert one.format_sv(bare) == eng.format_sv(res)
+    one.close()
+
+    nr = res.n_reads
+    sr, si, jl = stage.result_sources_tensors(res)
+    rng = np.random.default_rng(3)
+
+    def piece_records(r0, r1_, shuffled):
+        pos = np.arange(r0, r1_, dtype=np.int64)
+        if shuffled:
+            rng.shuffle(pos)
+        pos_t = torch.from_numpy(pos).to(dev)
+        by, off = stage.render_junctions_tensor(si[pos_t])
+        return by, pos_t
+
+    # the same result again through the calls themselves: 5 pieces, records of a piece in shuffled order
+    rb, pb = eng.result_layout_dev(5)
+    assert list(rb) == [nr * c // 5 for c in range(6)] and int(pb[0]) == 0 and int(pb[-1]) == res.junction_bytes.size
+    keep = []
+    for c in (3, 0, 4, 1, 2):                                           # pieces in any order
+        by, pos_t = piece_records(int(rb[c]), int(rb[c + 1]), shuffled=True)
+        assert by.numel() == int(pb[c + 1] - pb[c])
+        stage.attach_records(res, c, by, pos_t)
+        keep.append((by, pos_t))
+    again = eng.attach_finish()
+    assert np.array_equal(again.junction_bytes, res.junction_bytes) and np.array_equal(again.reads, res.reads)
+    assert np.array_equal(again.cluster_junction_off, res.cluster_junction_off)
+
+    # refused: wrong byte count, unknown piece, a piece twice, finish with a piece missing
+    rb, pb = eng.result_layout_dev(2)
+    by0, pos0 = piece_records(int(rb[0]), int(rb[1]), shuffled=False)
+    for call, code in ((lambda: eng.attach_records_dev(0, by0.data_ptr(), by0.numel() - 4, pos0.data_ptr()), -1),
+                       (lambda: eng.attach_records_dev(2, by0.data_ptr(), by0.numel(), pos0.data_ptr()), -1),
+                       (lambda: eng.attach_finish(), -4)):
+        with pytest.raises(engine.BreakfastError) as ei:
+            call()
+        assert ei.value.code == code
+    stage.attach_records(res, 0, by0, pos0)
+    with pytest.raises(engine.BreakfastError) as ei:
+        eng.attach_records_dev(0, by0.data_ptr(), by0.numel(), pos0.data_ptr())
+    assert ei.value.code == -4
+    # positions outside the piece / records that do not add up to the announced sizes: caught at the end
+    by1, pos1 = piece_records(int(rb[1]), int(rb[2]), shuffled=False)
+    wrong = pos1.clone()
+    wrong[0] = 0
+    stage.attach_records(res, 1, by1, wrong)
+    with pytest.raises(engine.BreakfastError) as ei:
+        eng.attach_finish()
+    assert ei.value.code == -1
+    with pytest.raises(engine.BreakfastError):
+        eng.result_layout_dev(65)
 
 
 def test_sharded_path_over_rccl_with_one_rank(tmp_path):
