@@ -428,7 +428,7 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     BF_HIP(ctx, hipSetDevice(ctx->device));
     const OwnerView v = ctx->imported ? imported_view(ctx) : local_view(ctx);
     ctx->clustered = false; ctx->table_attached = false; ctx->junction_attached = 0; ctx->reads_on_device = false;
-    ctx->result_order = false;
+    ctx->result_order = false; ctx->sources_on_device = false;
     BF_TRY(run_cluster(ctx, v));
     ctx->clustered = true;
     const uint64_t nr = ctx->out.n_reads;
@@ -730,7 +730,16 @@ int bf_exchange_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_co
 
 int bf_result_sources(bf_ctx* ctx, const uint32_t** src_rank, const uint32_t** src_index) {
     if (!ctx || !src_rank || !src_index) return BF_ERR_INVALID;
-    if (!ctx->imported) return fail(ctx, BF_ERR_STATE, "bf_result_sources is only meaningful after bf_exchange_import + bf_clusterise");
+    if (!ctx->imported || !ctx->clustered)
+        return fail(ctx, BF_ERR_STATE, "bf_result_sources is only meaningful after bf_exchange_import + bf_clusterise");
+    if (ctx->sources_on_device) {
+        const uint64_t nr = ctx->out.n_reads;
+        BF_HIP(ctx, hipSetDevice(ctx->device));
+        BF_TRY(ensure_host(ctx, ctx->out.src, nr * 8));
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.src.p, ctx->c_rsrc.p, nr * 8, hipMemcpyDeviceToHost, ctx->stream));
+        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->sources_on_device = false;
+    }
     *src_rank = ctx->out.src.as<uint32_t>(); *src_index = ctx->out.src.as<uint32_t>() + ctx->out.n_reads;
     return BF_OK;
 }

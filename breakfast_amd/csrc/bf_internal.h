@@ -206,6 +206,7 @@ struct bf_ctx {
     bool table_attached = false;                // the read table of the last bf_clusterise is (being) copied to the host
     uint64_t junction_attached = 0;             // junction bytes queued for the host so far
     bool reads_on_device = false;               // the finished read table waits in c_reads for bf_result_reads
+    bool sources_on_device = false;             // multi-rank: out.src not copied yet (bf_result_sources does it)
     bool result_order = false;                  // multi-rank: bf_result_layout_dev laid the records out in result order
     std::vector<uint64_t> piece_read, piece_byte;   // its pieces: read ranges and their byte ranges (n_pieces + 1 each)
     std::vector<uint8_t> piece_done;

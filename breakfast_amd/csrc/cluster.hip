@@ -759,10 +759,10 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     BF_HIP(ctx, hipEventRecord(ctx->ev[11], st));
     BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[11], 0));
     BF_HIP(ctx, hipMemcpyAsync(ctx->out.clusters.p, ctx->c_clusters.p, ns * sizeof(bf_cluster), hipMemcpyDeviceToHost, ctx->copy_stream));
-    if (total_r && v.src_rank) {          // multi-rank: the caller routes junction requests to the source ranks
-        BF_TRY(ensure_host(ctx, ctx->out.src, total_r * 8));
-        BF_HIP(ctx, hipMemcpyAsync(ctx->out.src.p, ev.out_src_rank, total_r * 8, hipMemcpyDeviceToHost, st));
-    }
+    // multi-rank: (source rank, source index) of every supporting read wait in c_rsrc; bf_result_sources copies
+    // them for a host that routes the junction requests itself, bf_result_sources_dev hands them to one that
+    // routes on the device
+    ctx->sources_on_device = total_r && v.src_rank;
     return BF_OK;
 }
 
