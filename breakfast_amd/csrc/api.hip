@@ -853,34 +853,34 @@ int bf_result_junction_sizes_dev(bf_ctx* ctx, uint32_t* dev_len) {
     return BF_OK;
 }
 
-int bf_result_layout_dev(bf_ctx* ctx, uint32_t n_pieces, uint64_t* piece_read_begin, uint64_t* piece_byte_off) {
-    if (!ctx) return BF_ERR_INVALID;
-    if (!ctx->imported || !ctx->clustered)
-        return fail(ctx, BF_ERR_STATE, "bf_result_layout_dev is only meaningful after bf_exchange_import + bf_clusterise");
-    if (n_pieces == 0 || n_pieces > 64 || !piece_read_begin || !piece_byte_off)
-        return fail(ctx, BF_ERR_INVALID, "bf_result_layout_dev: 1..64 pieces and two output arrays");
-    BF_HIP(ctx, hipSetDevice(ctx->device));
+// bf_result_layout_dev in two halves, so that bf_result_requests_dev can put its own work before the one
+// synchronisation: everything queued / everything the host does with the numbers that came back.
+static int layout_enqueue(bf_ctx* ctx, uint32_t n_pieces) {
     const uint64_t nr = ctx->out.n_reads, ncl = ctx->out.n_clusters;
     ctx->piece_read.assign(n_pieces + 1, 0); ctx->piece_byte.assign(n_pieces + 1, 0);
     ctx->piece_done.assign(n_pieces, 0);
     for (uint32_t c = 0; c <= n_pieces; c++) ctx->piece_read[c] = nr * c / n_pieces;
-    ctx->junction_attached = 0;
-    if (nr) {
-        // record offsets in result order from the sizes the exchange brought along; the read table is finished
-        // on the device (bf_result_reads fetches it), the host gets one offset per cluster
-        BF_TRY(ensure(ctx, ctx->c_joff, (nr + 1) * 8));
-        BF_TRY(scan_u32_to_u64(ctx, ctx->c_rsrc.as<uint32_t>() + 3 * nr, ctx->c_joff.as<uint64_t>(), nr));
-        BF_TRY(patch_reads_off(ctx, ctx->c_joff.as<uint64_t>(), nr));
-        BF_TRY(ensure(ctx, ctx->c_cjo, (ncl + 1) * 8));
-        BF_TRY(ensure_host(ctx, ctx->out.cjo, (ncl + 1) * 8));
-        BF_TRY(cluster_record_offsets(ctx, ctx->c_joff.as<uint64_t>(), ctx->c_cjo.as<uint64_t>(), ncl));
-        BF_TRY(ensure(ctx, ctx->c_err, 16));
-        BF_HIP(ctx, hipMemsetAsync(ctx->c_err.p, 0, 16, ctx->stream));
-        for (uint32_t c = 0; c <= n_pieces; c++)
-            BF_HIP(ctx, hipMemcpyAsync(&ctx->piece_byte[c], ctx->c_joff.as<uint64_t>() + ctx->piece_read[c], 8,
-                                       hipMemcpyDeviceToHost, ctx->stream));
-        BF_HIP(ctx, hipMemcpyAsync(ctx->out.cjo.p, ctx->c_cjo.p, (ncl + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->junction_attached = 0; ctx->requests_ordered = false;
+    if (!nr) return BF_OK;
+    // record offsets in result order from the sizes the exchange brought along; the read table is finished
+    // on the device (bf_result_reads fetches it), the host gets one offset per cluster
+    BF_TRY(ensure(ctx, ctx->c_joff, (nr + 1) * 8));
+    BF_TRY(scan_u32_to_u64(ctx, ctx->c_rsrc.as<uint32_t>() + 3 * nr, ctx->c_joff.as<uint64_t>(), nr));
+    BF_TRY(patch_reads_off(ctx, ctx->c_joff.as<uint64_t>(), nr));
+    BF_TRY(ensure(ctx, ctx->c_cjo, (ncl + 1) * 8));
+    BF_TRY(ensure_host(ctx, ctx->out.cjo, (ncl + 1) * 8));
+    BF_TRY(cluster_record_offsets(ctx, ctx->c_joff.as<uint64_t>(), ctx->c_cjo.as<uint64_t>(), ncl));
+    BF_TRY(ensure(ctx, ctx->c_err, 16));
+    BF_HIP(ctx, hipMemsetAsync(ctx->c_err.p, 0, 16, ctx->stream));
+    for (uint32_t c = 0; c <= n_pieces; c++)
+        BF_HIP(ctx, hipMemcpyAsync(&ctx->piece_byte[c], ctx->c_joff.as<uint64_t>() + ctx->piece_read[c], 8,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    BF_HIP(ctx, hipMemcpyAsync(ctx->out.cjo.p, ctx->c_cjo.p, (ncl + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return BF_OK;
+}
+static int layout_complete(bf_ctx* ctx, uint32_t n_pieces, uint64_t* piece_read_begin, uint64_t* piece_byte_off) {
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->out.n_reads) {
         const uint64_t total = ctx->piece_byte[n_pieces];
         BF_TRY(ensure(ctx, ctx->c_jbytes, total ? total : 1));
         BF_TRY(ensure_host(ctx, ctx->out.junction, total));
@@ -891,6 +891,46 @@ int bf_result_layout_dev(bf_ctx* ctx, uint32_t n_pieces, uint64_t* piece_read_be
     }
     ctx->result_order = true; ctx->table_attached = true;
     for (uint32_t c = 0; c <= n_pieces; c++) { piece_read_begin[c] = ctx->piece_read[c]; piece_byte_off[c] = ctx->piece_byte[c]; }
+    return BF_OK;
+}
+
+int bf_result_layout_dev(bf_ctx* ctx, uint32_t n_pieces, uint64_t* piece_read_begin, uint64_t* piece_byte_off) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!ctx->imported || !ctx->clustered)
+        return fail(ctx, BF_ERR_STATE, "bf_result_layout_dev is only meaningful after bf_exchange_import + bf_clusterise");
+    if (n_pieces == 0 || n_pieces > 64 || !piece_read_begin || !piece_byte_off)
+        return fail(ctx, BF_ERR_INVALID, "bf_result_layout_dev: 1..64 pieces and two output arrays");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    BF_TRY(layout_enqueue(ctx, n_pieces));
+    return layout_complete(ctx, n_pieces, piece_read_begin, piece_byte_off);
+}
+
+int bf_result_requests_dev(bf_ctx* ctx, uint32_t n_pieces, uint32_t* dev_req, uint64_t* counts, uint64_t* bytes,
+                           uint64_t* piece_read_begin, uint64_t* piece_byte_off) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!ctx->imported || !ctx->clustered)
+        return fail(ctx, BF_ERR_STATE, "bf_result_requests_dev is only meaningful after bf_exchange_import + bf_clusterise");
+    if (n_pieces == 0 || n_pieces > 64 || !counts || !bytes || !piece_read_begin || !piece_byte_off)
+        return fail(ctx, BF_ERR_INVALID, "bf_result_requests_dev: 1..64 pieces and four output arrays");
+    const uint64_t nr = ctx->out.n_reads;
+    if (nr && !dev_req) return fail(ctx, BF_ERR_INVALID, "bf_result_requests_dev: null request list");
+    if ((uintptr_t)dev_req & 3) return fail(ctx, BF_ERR_INVALID, "bf_result_requests_dev: dev_req must be 4-byte aligned");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t groups = n_pieces * ctx->n_ranks;
+    BF_TRY(layout_enqueue(ctx, n_pieces));
+    std::vector<uint64_t> start(groups + 1, 0), bound(groups + 1, 0);
+    if (nr) {
+        uint64_t *d_start = nullptr, *d_bytes = nullptr;
+        BF_TRY(order_requests(ctx, n_pieces, dev_req, &d_start, &d_bytes));
+        BF_HIP(ctx, hipMemcpyAsync(start.data(), d_start, (groups + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        BF_HIP(ctx, hipMemcpyAsync(bound.data(), d_bytes, (groups + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    BF_TRY(layout_complete(ctx, n_pieces, piece_read_begin, piece_byte_off));
+    for (uint32_t k = 0; k < groups; k++) { counts[k] = start[k + 1] - start[k]; bytes[k] = bound[k + 1] - bound[k]; }
+    for (uint32_t c = 0; c <= n_pieces && nr; c++)          // a piece's groups are exactly its reads and its bytes
+        if (start[c * ctx->n_ranks] != ctx->piece_read[c] || bound[c * ctx->n_ranks] != ctx->piece_byte[c])
+            return fail(ctx, BF_ERR_HIP, "bf_result_requests_dev: piece %u: request order and layout disagree", c);
+    ctx->requests_ordered = nr > 0;
     return BF_OK;
 }
 
@@ -905,12 +945,20 @@ int bf_result_attach_records_dev(bf_ctx* ctx, uint32_t piece, const uint8_t* dev
     if (size != b1 - b0)
         return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: piece %u holds %llu record bytes, %llu given", piece,
                     (unsigned long long)(b1 - b0), (unsigned long long)size);
-    if (r1 > r0 && (!dev_records || !dev_read_pos)) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: null argument");
+    if (r1 > r0 && !dev_records) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: null records");
+    if (r1 > r0 && !dev_read_pos && !ctx->requests_ordered)
+        return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: null read positions without bf_result_requests_dev");
     if (((uintptr_t)dev_records & 3) || ((uintptr_t)dev_read_pos & 7))
         return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: dev_records must be 4-byte, dev_read_pos 8-byte aligned");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     if (r1 > r0) {
-        BF_TRY(scatter_records(ctx, r0, r1, dev_records, size, dev_read_pos));
+        if (dev_read_pos) {
+            if (ctx->requests_ordered) return fail(ctx, BF_ERR_STATE, "bf_result_attach_records_dev: after bf_result_requests_dev the "
+                                                   "records come in its order (dev_read_pos == NULL)");
+            BF_TRY(scatter_records(ctx, r0, r1, dev_records, size, dev_read_pos));
+        } else {
+            BF_TRY(scatter_ordered(ctx, r0, r1, dev_records, size));
+        }
         if (size) {
             hipEvent_t ev = ctx->ev[1 + piece % 8];
             BF_HIP(ctx, hipEventRecord(ev, ctx->stream));

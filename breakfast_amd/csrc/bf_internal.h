@@ -207,6 +207,7 @@ struct bf_ctx {
     uint64_t junction_attached = 0;             // junction bytes queued for the host so far
     bool reads_on_device = false;               // the finished read table waits in c_reads for bf_result_reads
     bool sources_on_device = false;             // multi-rank: out.src not copied yet (bf_result_sources does it)
+    bool requests_ordered = false;              // bf_result_requests_dev left its order in c_d32 / c_aoff
     bool result_order = false;                  // multi-rank: bf_result_layout_dev laid the records out in result order
     std::vector<uint64_t> piece_read, piece_byte;   // its pieces: read ranges and their byte ranges (n_pieces + 1 each)
     std::vector<uint8_t> piece_done;
@@ -289,6 +290,8 @@ int scan_max_u32_inplace(bf_ctx* ctx, uint32_t* data, uint64_t n);              
 int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
 int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
 int cluster_record_offsets(bf_ctx* ctx, const uint64_t* d_joff, uint64_t* d_out, uint64_t n_clusters);
+int order_requests(bf_ctx* ctx, uint32_t K, uint32_t* d_req, uint64_t** d_start, uint64_t** d_bytes);
+int scatter_ordered(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_records, uint64_t size);
 int scatter_records(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_records, uint64_t size, const int64_t* d_pos);
 int read_sizes(bf_ctx* ctx, uint32_t* d_out, uint64_t n);
 

@@ -1073,6 +1073,84 @@ int scatter_records(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_reco
     BF_HIP(ctx, hipGetLastError());
     return BF_OK;
 }
+// Owner side of the junction routing in one go: the supporting reads ordered by (piece, source rank), result
+// order inside; what each (piece, rank) group asks for and how many record bytes it will bring back.
+__global__ void request_keys_kernel(uint32_t* __restrict__ key, uint32_t* __restrict__ val, const uint32_t* __restrict__ src_rank,
+                                    uint64_t nr, uint32_t K, uint32_t W) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nr) return;
+    uint32_t c = (uint32_t)((i * K) / nr);                    // piece c = reads [nr*c/K, nr*(c+1)/K)
+    while (c + 1 < K && ((uint64_t)(c + 1) * nr) / K <= i) c++;
+    key[i] = c * W + src_rank[i];
+    val[i] = (uint32_t)i;
+}
+__global__ void request_gather_kernel(uint32_t* __restrict__ req, uint32_t* __restrict__ len, const uint32_t* __restrict__ order,
+                                      const uint32_t* __restrict__ src_idx, const uint32_t* __restrict__ jrec, uint64_t nr) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nr) return;
+    const uint32_t i = order[j];
+    req[j] = src_idx[i];
+    len[j] = jrec[i];
+}
+// start[k] = first position whose key is >= k (k = groups: the end), bytes[k] = arrival offset there
+__global__ void request_bounds_kernel(uint64_t* __restrict__ start, uint64_t* __restrict__ bytes, const uint32_t* __restrict__ skey,
+                                      const uint64_t* __restrict__ aoff, uint64_t nr, uint32_t groups) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > groups) return;
+    uint64_t lo = 0, hi = nr;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (skey[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    start[k] = lo; bytes[k] = aoff[lo];
+}
+__global__ void __launch_bounds__(256) scatter_ordered_kernel(uint32_t* __restrict__ dst, const uint64_t* __restrict__ joff,
+                                                              const uint32_t* __restrict__ src, const uint64_t* __restrict__ aoff,
+                                                              const uint32_t* __restrict__ order, uint64_t r0, uint64_t r1,
+                                                              uint64_t size, uint32_t* err) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t j = r0 + (g >> 4);                              // 16 lanes per record
+    const uint32_t l = (uint32_t)g & 15u;
+    if (j >= r1) return;
+    const uint64_t a = aoff[j] - aoff[r0], words = (aoff[j + 1] - aoff[j]) >> 2;
+    if (a + (words << 2) > size) { err[0] = 3u; return; }
+    const uint64_t d = joff[order[j]] >> 2;
+    for (uint64_t w = l; w < words; w += 16) dst[d + w] = src[(a >> 2) + w];
+}
+// c_aoff: u64 aoff[nr + 1], u64 start[groups + 1], u64 bytes[groups + 1], u32 len[nr]; c_d32 = order; the caller's dev_req
+int order_requests(bf_ctx* ctx, uint32_t K, uint32_t* d_req, uint64_t** d_start, uint64_t** d_bytes) {
+    const uint64_t nr = ctx->out.n_reads;
+    const uint32_t W = ctx->n_ranks, groups = K * W;
+    const hipStream_t st = ctx->stream;
+    BF_TRY(ensure(ctx, ctx->c_a32, nr * 4, false)); BF_TRY(ensure(ctx, ctx->c_b32, nr * 4, false));
+    BF_TRY(ensure(ctx, ctx->c_c32, nr * 4, false)); BF_TRY(ensure(ctx, ctx->c_d32, nr * 4, false));
+    BF_TRY(ensure(ctx, ctx->c_aoff, (nr + 1) * 8 + (size_t)(groups + 1) * 16 + nr * 4 + 16));
+    uint64_t* aoff = ctx->c_aoff.as<uint64_t>();
+    uint64_t* start = aoff + nr + 1; uint64_t* bytes = start + groups + 1;
+    uint32_t* len = (uint32_t*)(bytes + groups + 1);
+    const uint32_t* src = ctx->c_rsrc.as<uint32_t>();               // out_src_rank, out_src_idx, out_rec, out_jrec
+    hipLaunchKernelGGL(request_keys_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, st, ctx->c_a32.as<uint32_t>(),
+                       ctx->c_c32.as<uint32_t>(), src, nr, K, W);
+    unsigned bits = 1; while ((1u << bits) < groups) bits++;
+    BF_TRY(sort_pairs<uint32_t>(ctx, ctx->c_a32.as<uint32_t>(), ctx->c_b32.as<uint32_t>(), ctx->c_c32.as<uint32_t>(),
+                                ctx->c_d32.as<uint32_t>(), nr, 0, bits));
+    hipLaunchKernelGGL(request_gather_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, st, d_req, len, ctx->c_d32.as<uint32_t>(),
+                       src + nr, src + 3 * nr, nr);
+    BF_TRY(scan_u32_to_u64(ctx, len, aoff, nr));
+    hipLaunchKernelGGL(request_bounds_kernel, dim3(grid_for(groups + 1, 256)), dim3(256), 0, st, start, bytes,
+                       ctx->c_b32.as<uint32_t>(), aoff, nr, groups);
+    BF_HIP(ctx, hipGetLastError());
+    *d_start = start; *d_bytes = bytes;
+    return BF_OK;
+}
+int scatter_ordered(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_records, uint64_t size) {
+    if (r1 <= r0) return BF_OK;
+    hipLaunchKernelGGL(scatter_ordered_kernel, dim3(grid_for((r1 - r0) * 16, 256)), dim3(256), 0, ctx->stream,
+                       ctx->c_jbytes.as<uint32_t>(), ctx->c_joff.as<uint64_t>(), (const uint32_t*)d_records,
+                       ctx->c_aoff.as<uint64_t>(), ctx->c_d32.as<uint32_t>(), r0, r1, size, ctx->c_err.as<uint32_t>());
+    BF_HIP(ctx, hipGetLastError());
+    return BF_OK;
+}
 // record bytes of the result's supporting reads (left by emit next to the index lists)
 int read_sizes(bf_ctx* ctx, uint32_t* d_out, uint64_t n) {
     if (n) BF_HIP(ctx, hipMemcpyAsync(d_out, ctx->c_rsrc.as<uint32_t>() + 3 * n, n * 4, hipMemcpyDeviceToDevice, ctx->stream));

@@ -151,10 +151,21 @@ class HipStageEngine:
         self._torch_done()
         return self.eng.result_layout_dev(n_pieces)
 
-    def attach_records(self, res: Result, piece: int, records: torch.Tensor, read_pos: torch.Tensor):
+    def result_requests(self, res: Result, n_pieces: int, n_ranks: int):
+        """One library call for the owner's side of the routing -> (request tensor int32[n_reads] ordered by
+        (piece, source rank), counts[piece, rank], bytes[piece, rank], piece_read_begin, piece_byte_off)."""
+        nr = res.n_reads if res.n_reads >= 0 else int(res.reads.shape[0])
+        req = torch.empty(nr, dtype=torch.int32, device=self.device)
+        self._torch_done()
+        cnt, by, rb, pb = self.eng.result_requests_dev(n_pieces, n_ranks, req.data_ptr() if nr else 0)
+        return req, cnt, by, rb, pb
+
+    def attach_records(self, res: Result, piece: int, records: torch.Tensor, read_pos: Optional[torch.Tensor]):
+        """read_pos None: the records come in the order result_requests chose."""
         self._torch_done()      # the all-to-all that filled `records` ran on torch's stream
         n = int(records.numel())
-        self.eng.attach_records_dev(piece, records.data_ptr() if n else 0, n, read_pos.data_ptr() if read_pos.numel() else 0)
+        pos = read_pos.data_ptr() if read_pos is not None and read_pos.numel() else 0
+        self.eng.attach_records_dev(piece, records.data_ptr() if n else 0, n, pos)
 
     def attach_finish(self, res: Result) -> Result:
         out = self.eng.attach_finish(reads=self.fetch_reads)
@@ -346,30 +357,36 @@ class DistributedDetect:
         W = self.world
         nccl = dist.get_backend(self.group) == "nccl"
         self._phase("route_requests")
-        src_rank, src_index, jlen = self._sources(res, self.device if nccl else torch.device("cpu"))
-        dev = src_rank.device
-        nr = int(src_rank.numel())
         K = max(1, min(int(self.junction_chunks), 64))
-        rb, pb = self._layout(res, K)
-        # requests ordered by (piece, source rank), result order inside: one radix pass when the keys fit a byte
-        if K > 1 and nr:
-            piece_of = torch.bucketize(torch.arange(nr, device=dev), torch.from_numpy(rb[1:K].copy()).to(dev), right=True)
-            key = piece_of * W + src_rank.to(torch.int64)
+        if hasattr(self.stage, "result_requests"):
+            # the library orders, counts and lays out in one call (one synchronisation)
+            req, cnt, gbytes, rb, pb = self.stage.result_requests(res, K, W)
+            dev, order = req.device, None
         else:
-            key = src_rank.to(torch.int64)
-        order = torch.argsort(key.to(torch.uint8) if K * W <= 256 else key, stable=True)
-        cnt = torch.bincount(key, minlength=K * W).cpu().numpy().astype(np.int64).reshape(K, W)   # [piece, source]
+            src_rank, src_index, jlen = self._sources(res, self.device if nccl else torch.device("cpu"))
+            dev = src_rank.device
+            nr = int(src_rank.numel())
+            rb, pb = self._layout(res, K)
+            # requests ordered by (piece, source rank), result order inside: one radix pass when the keys fit a byte
+            if K > 1 and nr:
+                piece_of = torch.bucketize(torch.arange(nr, device=dev), torch.from_numpy(rb[1:K].copy()).to(dev), right=True)
+                key = piece_of * W + src_rank.to(torch.int64)
+            else:
+                key = src_rank.to(torch.int64)
+            order = torch.argsort(key.to(torch.uint8) if K * W <= 256 else key, stable=True)
+            cnt = torch.bincount(key, minlength=K * W).cpu().numpy().astype(np.int64).reshape(K, W)   # [piece, source]
+            csum = torch.zeros(nr + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(jlen[order].to(torch.int64), 0, out=csum[1:])
+            cuts = np.concatenate([[0], np.cumsum(cnt.ravel())]).astype(np.int64)
+            gbytes = np.diff(csum[torch.from_numpy(cuts).to(dev)].cpu().numpy()).reshape(K, W)   # record bytes per group
+            req = src_index[order].contiguous()
         got_cnt = self._exchange_matrix(np.ascontiguousarray(cnt.T))                              # [asking rank, piece]
         cut = np.concatenate([[0], np.cumsum(cnt.ravel())]).astype(np.int64)
-        csum = torch.zeros(nr + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(jlen[order].to(torch.int64), 0, out=csum[1:])
-        pbs = csum[torch.from_numpy(cut).to(dev)].cpu().numpy()         # byte bounds of every (piece, source) group
-        req = src_index[order].contiguous()
         keep = []
         for c in range(K):
             self._phase("render")
             a, b = int(cut[c * W]), int(cut[(c + 1) * W])
-            assert (a, b) == (int(rb[c]), int(rb[c + 1])) and int(pbs[(c + 1) * W] - pbs[c * W]) == int(pb[c + 1] - pb[c])
+            assert (a, b) == (int(rb[c]), int(rb[c + 1])) and int(gbytes[c].sum()) == int(pb[c + 1] - pb[c])
             asked = [int(x) for x in got_cnt[:, c]]
             got = torch.empty(sum(asked), dtype=torch.int32, device=dev)
             _a2a(got, req[a:b], asked, [int(x) for x in cnt[c]], self.group)
@@ -378,10 +395,10 @@ class DistributedDetect:
             bounds = np.concatenate([[0], np.cumsum(asked)]).astype(np.int64)
             ob = off[torch.from_numpy(bounds).to(off.device)].cpu().numpy()
             out_bytes = [int(ob[r + 1] - ob[r]) for r in range(W)]
-            in_bytes = [int(pbs[c * W + s + 1] - pbs[c * W + s]) for s in range(W)]
+            in_bytes = [int(x) for x in gbytes[c]]
             mine = torch.empty(sum(in_bytes), dtype=torch.uint8, device=by.device)
             _a2a(mine, by[:int(ob[-1])], in_bytes, out_bytes, self.group)
-            pos = order[a:b].contiguous()
+            pos = order[a:b].contiguous() if order is not None else None
             self._attach_records(res, c, mine, pos)
             keep.append((mine, by, pos))
         self._phase("attach_to_host")

@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "bf_exchange_local", "bf_exchange_pack", "bf_exchange_import", "bf_result_sources",
     "bf_render_junctions", "bf_result_sources_dev", "bf_render_junctions_dev", "bf_result_attach_junctions_dev",
     "bf_evidence_fetch", "bf_kernel_times", "bf_stats", "bf_junction_text", "bf_result_junction_text",
-    "bf_result_junction_sizes_dev", "bf_result_layout_dev", "bf_result_attach_records_dev",
+    "bf_result_junction_sizes_dev", "bf_result_layout_dev", "bf_result_attach_records_dev", "bf_result_requests_dev",
     "bf_result_attach_finish", "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
 ]
 
@@ -137,6 +137,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_stats.argtypes = [vp, u64p, u64p]
     lib.bf_result_junction_sizes_dev.argtypes = [vp, vp]
     lib.bf_result_layout_dev.argtypes = [vp, C.c_uint32, u64p, u64p]
+    lib.bf_result_requests_dev.argtypes = [vp, C.c_uint32, vp, u64p, u64p, u64p, u64p]
     lib.bf_result_attach_records_dev.argtypes = [vp, C.c_uint32, vp, C.c_uint64, vp]
     lib.bf_result_attach_finish.argtypes = [vp, C.POINTER(BfResult)]
     lib.bf_junction_record_bound.argtypes = [vp]
@@ -493,6 +494,15 @@ class Engine:
         bo = (C.c_uint64 * (n_pieces + 1))()
         self._check(self.lib.bf_result_layout_dev(self.h, n_pieces, rb, bo))
         return np.array(rb[:], np.int64), np.array(bo[:], np.int64)
+
+    def result_requests_dev(self, n_pieces: int, n_ranks: int, dev_req: int):
+        """-> (counts[piece, rank], bytes[piece, rank], piece_read_begin, piece_byte_off) (bf_result_requests_dev)."""
+        g = n_pieces * n_ranks
+        cnt, by = (C.c_uint64 * g)(), (C.c_uint64 * g)()
+        rb, bo = (C.c_uint64 * (n_pieces + 1))(), (C.c_uint64 * (n_pieces + 1))()
+        self._check(self.lib.bf_result_requests_dev(self.h, n_pieces, C.c_void_p(dev_req or None), cnt, by, rb, bo))
+        return (np.array(cnt[:], np.int64).reshape(n_pieces, n_ranks), np.array(by[:], np.int64).reshape(n_pieces, n_ranks),
+                np.array(rb[:], np.int64), np.array(bo[:], np.int64))
 
     def attach_records_dev(self, piece: int, dev_records: int, size: int, dev_read_pos: int) -> None:
         self._check(self.lib.bf_result_attach_records_dev(self.h, piece, C.c_void_p(dev_records or None), size,

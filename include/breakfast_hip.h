@@ -293,12 +293,21 @@ int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const 
  *                                  any order, e.g. grouped by source rank).  Moves each record to its place and
  *                                  queues the piece's bytes for the host on the ctx's copy stream; returns at
  *                                  once (the caller keeps both buffers alive until bf_result_attach_finish)
+ *   bf_result_requests_dev         bf_result_layout_dev plus the request lists, in one call and one
+ *                                  synchronisation: orders the supporting reads by (piece, source rank), result
+ *                                  order inside; dev_req[n_reads] receives their source-local indices in that
+ *                                  order (a piece's part, split by counts, is what its index all-to-all sends);
+ *                                  counts[p * n_ranks + s] = requests of piece p to rank s, bytes[...] = the
+ *                                  record bytes they bring back.  bf_result_attach_records_dev then takes a
+ *                                  piece's records in exactly that order, with dev_read_pos == NULL
  *   bf_result_attach_finish        waits for the copies, checks that every piece came and that sizes agreed,
  *                                  fills *out
  * so that each piece's host copy runs behind the caller's render + all-to-all of the next one.  No counterpart
  * in the reference (one process). */
 int bf_result_junction_sizes_dev(bf_ctx* ctx, uint32_t* dev_len);
 int bf_result_layout_dev(bf_ctx* ctx, uint32_t n_pieces, uint64_t* piece_read_begin, uint64_t* piece_byte_off);
+int bf_result_requests_dev(bf_ctx* ctx, uint32_t n_pieces, uint32_t* dev_req, uint64_t* counts /* n_pieces * n_ranks */,
+                           uint64_t* bytes /* n_pieces * n_ranks */, uint64_t* piece_read_begin, uint64_t* piece_byte_off);
 int bf_result_attach_records_dev(bf_ctx* ctx, uint32_t piece, const uint8_t* dev_records, uint64_t size,
                                  const int64_t* dev_read_pos);
 int bf_result_attach_finish(bf_ctx* ctx, bf_result* out);

@@ -157,6 +157,22 @@ def _check_layout_and_attach_calls(eng, stage, res, g, b, A, F, E, dev):
     assert np.array_equal(again.junction_bytes, res.junction_bytes) and np.array_equal(again.reads, res.reads)
     assert np.array_equal(again.cluster_junction_off, res.cluster_junction_off)
 
+    # the library's own request order (bf_result_requests_dev): with one rank, result order; records of a piece
+    # then go in without positions
+    req, cnt, gby, rb, pb = stage.result_requests(res, 3, 1)
+    assert torch.equal(req, si) and cnt.shape == (3, 1)
+    assert list(cnt[:, 0]) == [int(rb[c + 1] - rb[c]) for c in range(3)]
+    assert list(gby[:, 0]) == [int(pb[c + 1] - pb[c]) for c in range(3)]
+    keep = []
+    for c in (2, 0, 1):
+        by, off = stage.render_junctions_tensor(req[int(rb[c]):int(rb[c + 1])])
+        with pytest.raises(engine.BreakfastError):          # positions are not accepted in this mode
+            eng.attach_records_dev(c, by.data_ptr(), by.numel(), off.data_ptr())
+        stage.attach_records(res, c, by, None)
+        keep.append(by)
+    again = eng.attach_finish()
+    assert np.array_equal(again.junction_bytes, res.junction_bytes) and np.array_equal(again.reads, res.reads)
+
     # refused: wrong byte count, unknown piece, a piece twice, finish with a piece missing
     rb, pb = eng.result_layout_dev(2)
     by0, pos0 = piece_records(int(rb[0]), int(rb[1]), shuffled=False)
