@@ -131,7 +131,7 @@ static void free_all(bf_ctx* ctx) {
         &ctx->c_slpos, &ctx->c_srpos, &ctx->c_reported, &ctx->c_csize, &ctx->c_flag, &ctx->c_scan, &ctx->c_qseed,
         &ctx->c_qsize, &ctx->c_qoff, &ctx->c_members, &ctx->c_leader, &ctx->c_rep, &ctx->c_qnrep, &ctx->c_ctl, &ctx->c_sel,
         &ctx->c_ord, &ctx->c_clusters, &ctx->c_reads, &ctx->c_misc, &ctx->c_joff, &ctx->c_jbytes, &ctx->c_rsrc,
-        &ctx->c_tables, &ctx->c_mkey_s, &ctx->c_slot, &ctx->c_big, &ctx->c_cjo, &ctx->c_pos2, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
+        &ctx->c_tables, &ctx->c_mkey_s, &ctx->c_slot, &ctx->c_big, &ctx->c_cjo, &ctx->c_aoff, &ctx->c_err, &ctx->c_tmp2, &ctx->c_qord, &ctx->c_pos2, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
     for (DevBuf* b : all) release(ctx, *b);
     HostBuf* hosts[] = {&ctx->out.clusters, &ctx->out.reads, &ctx->out.src, &ctx->out.junction, &ctx->out.cjo};
     for (HostBuf* h : hosts) { if (h->p) (void)hipHostFree(h->p); h->p = nullptr; h->cap = 0; }
@@ -257,7 +257,11 @@ int bf_ctx_create(const bf_config* cfg, bf_ctx** out) {
         delete ctx;
         return fail(nullptr, BF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
-    bool ok = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    // the copy stream also runs the small print-order sorts beside the dedup kernels (cluster.hip): highest
+    // priority, so that their short launches are not queued behind the big kernels' workgroups
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    bool ok = hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio_high) == hipSuccess;
     for (auto& e2 : ctx->ev) ok = ok && hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
     if (!ok) { bf_ctx_destroy(ctx); return fail(nullptr, BF_ERR_HIP, "could not create the copy stream / events"); }
     *out = ctx;

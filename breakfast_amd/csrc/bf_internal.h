@@ -162,7 +162,7 @@ struct bf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;          // result D2H, overlapped with the render kernel
-    hipEvent_t ev[12] = {};                     // untimed events chaining the two streams
+    hipEvent_t ev[14] = {};                     // untimed events chaining the two streams
     std::string err;
 
     // genome
@@ -215,7 +215,7 @@ struct bf_ctx {
     // cluster stage scratch + results
     bf::DevBuf c_tmp, c_a32, c_b32, c_c32, c_d32, c_k64a, c_k64b, c_slpos, c_srpos, c_reported,
         c_csize, c_flag, c_scan, c_qseed, c_qsize, c_qoff, c_members, c_leader, c_rep, c_qnrep,
-        c_ctl, c_sel, c_ord, c_clusters, c_reads, c_misc, c_pos2, c_joff, c_jbytes, c_rsrc, c_tables, c_mkey_s, c_slot, c_big, c_cjo, c_aoff, c_err;
+        c_ctl, c_sel, c_ord, c_clusters, c_reads, c_misc, c_pos2, c_joff, c_jbytes, c_rsrc, c_tables, c_mkey_s, c_slot, c_big, c_cjo, c_aoff, c_err, c_tmp2, c_qord;
     bf::ClusterOut out;
     std::vector<uint64_t> render_off_host;
     std::vector<uint8_t> render_bytes_host;

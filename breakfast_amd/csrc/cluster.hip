@@ -220,10 +220,11 @@ __global__ void __launch_bounds__(256) sweep_big_kernel(const SweepView v, uint8
 // those above wave_max.  Fixed grid: one atomic per wave with something to add.
 constexpr unsigned kFlagGrid = 1024;
 __global__ void __launch_bounds__(256) flag_ge_kernel(uint32_t* flag, const uint32_t* __restrict__ val, uint32_t thr, uint64_t n,
-                                                      uint32_t wave_max, unsigned long long* sums) {
+                                                      uint32_t wave_max, unsigned long long* sums,
+                                                      const uint32_t* __restrict__ idx = nullptr) {
     unsigned long long s_all = 0, s_big = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-        const uint32_t c = val[i];
+        const uint32_t c = val[idx ? idx[i] : i];
         const bool f = c >= thr;
         flag[i] = f ? 1u : 0u;
         if (f) { s_all += c; if (c > wave_max) s_big += c; }
@@ -248,10 +249,17 @@ __global__ void compact_seeds_kernel(const uint32_t* __restrict__ flag, const ui
     }
 }
 __global__ void compact_index_kernel(const uint32_t* __restrict__ flag, const uint64_t* __restrict__ scan,
-                                     uint32_t* out, uint64_t n) {
+                                     uint32_t* out, uint64_t n, const uint32_t* __restrict__ value = nullptr) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && flag[i]) out[scan[i]] = (uint32_t)i;
+    if (i < n && flag[i]) out[scan[i]] = value ? value[i] : (uint32_t)i;
 }
+// Host code is single-threaded per ctx: while this object lives, everything queued through ctx->stream (and the
+// sort / scan workspace c_tmp) goes to the copy stream with a workspace of its own instead.
+struct OnCopyStream {
+    bf_ctx* ctx;
+    explicit OnCopyStream(bf_ctx* c) : ctx(c) { std::swap(ctx->stream, ctx->copy_stream); std::swap(ctx->c_tmp, ctx->c_tmp2); }
+    ~OnCopyStream() { std::swap(ctx->stream, ctx->copy_stream); std::swap(ctx->c_tmp, ctx->c_tmp2); }
+};
 
 // Hash bits in the member sort key: enough to keep runs of equal keys short (a cluster rarely holds
 // more than a few hundred fragments), few enough to save two radix passes over 32 bits.  A collision
@@ -494,7 +502,7 @@ struct OrderView {
 __global__ void cluster_keys_kernel(const OrderView o, const uint32_t* __restrict__ sel, uint64_t* kpos, uint64_t* kidx, uint64_t ns) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ns) return;
-    const uint32_t p = o.qseed[sel[k]];
+    const uint32_t p = o.qseed[sel ? sel[k] : k];
     const uint32_t rec = o.perm[p];
     kpos[k] = ((o.skey[p] >> key_rank_shift(o.cb)) << 32) | (uint32_t)o.slpos[p];
     const uint64_t sr = o.src_rank ? o.src_rank[rec] : 0, si = o.src_idx ? o.src_idx[rec] : rec;
@@ -654,6 +662,33 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     hipLaunchKernelGGL(compact_seeds_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
                        ctx->c_scan.as<uint64_t>(), ctx->c_csize.as<uint32_t>(), ctx->c_qseed.as<uint32_t>(),
                        ctx->c_qsize.as<uint32_t>(), n, wave_max, qbig);
+    // The reference's print order of the QUALIFYING clusters (their seeds are known now; which of them survive
+    // the dedup only selects from this order): two small, latency-bound radix sorts, queued on the copy stream
+    // so that they run beside the member / dedup kernels instead of after them.
+    BF_TRY(ensure(ctx, ctx->c_qord, nq * 4));
+    BF_TRY(ensure(ctx, ctx->c_misc, nq * 8 * 4));
+    BF_HIP(ctx, hipEventRecord(ctx->ev[9], st));
+    BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[9], 0));
+    {
+        OnCopyStream aux(ctx);
+        Scope t(ctx, "order");
+        const hipStream_t as = ctx->stream;
+        uint64_t* kpos = ctx->c_misc.as<uint64_t>();
+        uint64_t* kidx = kpos + nq; uint64_t* kpos2 = kidx + nq; uint64_t* kidx2 = kpos2 + nq;
+        OrderView ov{ctx->c_qseed.as<uint32_t>(), sv.skey, sv.slpos, perm, v.src_rank, v.src_idx, ctx->contig_bits};
+        hipLaunchKernelGGL(cluster_keys_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, ov, (const uint32_t*)nullptr, kpos, kidx, nq);
+        // LSD: input order first, then (contig rank, lpos).  values = q; c_b32 / c_c32 are free since the sweep
+        uint32_t* va = ctx->c_b32.as<uint32_t>(); uint32_t* vb = ctx->c_c32.as<uint32_t>();
+        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, va, nq);
+        // significant bits of (source rank << 32 | source index): on one rank the index alone, below n
+        unsigned idx_bits = 64;
+        if (!v.src_rank) { idx_bits = 1; while (idx_bits < 32 && (1ull << idx_bits) < n) idx_bits++; }
+        else { unsigned rb = 1; while ((1u << rb) < ctx->n_ranks) rb++; idx_bits = 32 + rb; }
+        BF_TRY(sort_pairs<uint64_t>(ctx, kidx, kidx2, va, vb, nq, 0, idx_bits));
+        hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, kpos2, kpos, vb, nq);
+        BF_TRY(sort_pairs<uint64_t>(ctx, kpos2, kidx2, vb, ctx->c_qord.as<uint32_t>(), nq, 0, 32 + ctx->contig_bits));
+        BF_HIP(ctx, hipEventRecord(ctx->ev[12], as));
+    }
     BF_TRY(scan_u32_to_u64(ctx, ctx->c_qsize.as<uint32_t>(), ctx->c_qoff.as<uint64_t>(), nq));
     BF_TRY(scan_u32_to_u64(ctx, qbig, qboff, nq));
     if (total_m > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "cluster membership list too long (%llu)", (unsigned long long)total_m);
@@ -689,39 +724,24 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     }
     BF_HIP(ctx, hipGetLastError());
 
-    // 4. surviving clusters in the reference's print order
+    // 4. surviving clusters in the reference's print order: the survivors of the order computed beside the dedup
     uint64_t ns = 0, total_r = 0;
     BF_TRY(ensure(ctx, ctx->c_flag, std::max(nq, n) * 4, false));
-    BF_TRY(ensure(ctx, ctx->c_sel, nq * 4)); BF_TRY(ensure(ctx, ctx->c_ord, nq * 4));
+    BF_TRY(ensure(ctx, ctx->c_ord, nq * 4));
+    BF_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[12], 0));
     {
-        Scope t(ctx, "order");
+        Scope t(ctx, "select");
+        const uint32_t* qord = ctx->c_qord.as<uint32_t>();
         hipLaunchKernelGGL(flag_ge_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(nq, B), kFlagGrid)), dim3(B), 0, st,
-                           ctx->c_flag.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>(), ctx->cfg.min_evidence, nq, 0u, sums + 2);
+                           ctx->c_flag.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>(), ctx->cfg.min_evidence, nq, 0u, sums + 2, qord);
         BF_TRY(scan_u32_to_u64(ctx, ctx->c_flag.as<uint32_t>(), ctx->c_scan.as<uint64_t>(), nq));
         BF_HIP(ctx, hipMemcpyAsync(&total_r, sums + 2, 8, hipMemcpyDeviceToHost, st));   // the reads that will be printed
         BF_TRY(fetch_u64(ctx, ctx->c_scan.as<uint64_t>() + nq, &ns));
         if (ns == 0) return BF_OK;
+        // ord[k'] = the k'-th surviving cluster in print order; nrep in that order -> read offsets
         hipLaunchKernelGGL(compact_index_kernel, dim3(grid_for(nq, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
-                           ctx->c_scan.as<uint64_t>(), ctx->c_sel.as<uint32_t>(), nq);
-        BF_TRY(ensure(ctx, ctx->c_misc, ns * 8 * 4));
-        uint64_t* kpos = ctx->c_misc.as<uint64_t>();
-        uint64_t* kidx = kpos + ns; uint64_t* kpos2 = kidx + ns; uint64_t* kidx2 = kpos2 + ns;
-        OrderView ov{ctx->c_qseed.as<uint32_t>(), sv.skey, sv.slpos, perm, v.src_rank, v.src_idx, ctx->contig_bits};
-        hipLaunchKernelGGL(cluster_keys_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, ov, ctx->c_sel.as<uint32_t>(), kpos, kidx, ns);
-        // LSD: input order first, then (contig rank, lpos).  values = positions in sel
-        BF_TRY(ensure(ctx, ctx->c_b32, std::max(n, ns) * 4, false)); BF_TRY(ensure(ctx, ctx->c_c32, std::max(n, ns) * 4, false));
-        uint32_t* va = ctx->c_b32.as<uint32_t>(); uint32_t* vb = ctx->c_c32.as<uint32_t>();
-        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, va, ns);
-        // significant bits of (source rank << 32 | source index): on one rank the index alone, below n
-        unsigned idx_bits = 64;
-        if (!v.src_rank) { idx_bits = 1; while (idx_bits < 32 && (1ull << idx_bits) < n) idx_bits++; }
-        else { unsigned rb = 1; while ((1u << rb) < ctx->n_ranks) rb++; idx_bits = 32 + rb; }
-        BF_TRY(sort_pairs<uint64_t>(ctx, kidx, kidx2, va, vb, ns, 0, idx_bits));
-        hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, kpos2, kpos, vb, ns);
-        BF_TRY(sort_pairs<uint64_t>(ctx, kpos2, kidx2, vb, va, ns, 0, 32 + ctx->contig_bits));
-        // ord[k] = sel[va[k]]; nrep in output order -> read offsets
-        hipLaunchKernelGGL(gather_u32_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, ctx->c_ord.as<uint32_t>(),
-                           ctx->c_sel.as<uint32_t>(), va, ns);
+                           ctx->c_scan.as<uint64_t>(), ctx->c_ord.as<uint32_t>(), nq, qord);
+        uint32_t* vb = ctx->c_c32.as<uint32_t>();
         hipLaunchKernelGGL(gather_u32_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, vb, ctx->c_qnrep.as<uint32_t>(),
                            ctx->c_ord.as<uint32_t>(), ns);
         BF_TRY(scan_u32_to_u64(ctx, vb, ctx->c_scan.as<uint64_t>(), ns));
