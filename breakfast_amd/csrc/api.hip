@@ -257,11 +257,7 @@ int bf_ctx_create(const bf_config* cfg, bf_ctx** out) {
         delete ctx;
         return fail(nullptr, BF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
-    // the copy stream also runs the small print-order sorts beside the dedup kernels (cluster.hip): highest
-    // priority, so that their short launches are not queued behind the big kernels' workgroups
-    int prio_low = 0, prio_high = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-    bool ok = hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio_high) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess;
     for (auto& e2 : ctx->ev) ok = ok && hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
     if (!ok) { bf_ctx_destroy(ctx); return fail(nullptr, BF_ERR_HIP, "could not create the copy stream / events"); }
     *out = ctx;
@@ -859,7 +855,7 @@ int bf_result_junction_sizes_dev(bf_ctx* ctx, uint32_t* dev_len) {
 
 // bf_result_layout_dev in two halves, so that bf_result_requests_dev can put its own work before the one
 // synchronisation: everything queued / everything the host does with the numbers that came back.
-static int layout_enqueue(bf_ctx* ctx, uint32_t n_pieces) {
+static int layout_enqueue(bf_ctx* ctx, uint32_t n_pieces, bool fetch_piece_bytes) {
     const uint64_t nr = ctx->out.n_reads, ncl = ctx->out.n_clusters;
     ctx->piece_read.assign(n_pieces + 1, 0); ctx->piece_byte.assign(n_pieces + 1, 0);
     ctx->piece_done.assign(n_pieces, 0);
@@ -876,14 +872,13 @@ static int layout_enqueue(bf_ctx* ctx, uint32_t n_pieces) {
     BF_TRY(cluster_record_offsets(ctx, ctx->c_joff.as<uint64_t>(), ctx->c_cjo.as<uint64_t>(), ncl));
     BF_TRY(ensure(ctx, ctx->c_err, 16));
     BF_HIP(ctx, hipMemsetAsync(ctx->c_err.p, 0, 16, ctx->stream));
-    for (uint32_t c = 0; c <= n_pieces; c++)
+    for (uint32_t c = 0; c <= n_pieces && fetch_piece_bytes; c++)      // (small copies cost 30 us each)
         BF_HIP(ctx, hipMemcpyAsync(&ctx->piece_byte[c], ctx->c_joff.as<uint64_t>() + ctx->piece_read[c], 8,
                                    hipMemcpyDeviceToHost, ctx->stream));
     BF_HIP(ctx, hipMemcpyAsync(ctx->out.cjo.p, ctx->c_cjo.p, (ncl + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     return BF_OK;
 }
 static int layout_complete(bf_ctx* ctx, uint32_t n_pieces, uint64_t* piece_read_begin, uint64_t* piece_byte_off) {
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->out.n_reads) {
         const uint64_t total = ctx->piece_byte[n_pieces];
         BF_TRY(ensure(ctx, ctx->c_jbytes, total ? total : 1));
@@ -905,7 +900,8 @@ int bf_result_layout_dev(bf_ctx* ctx, uint32_t n_pieces, uint64_t* piece_read_be
     if (n_pieces == 0 || n_pieces > 64 || !piece_read_begin || !piece_byte_off)
         return fail(ctx, BF_ERR_INVALID, "bf_result_layout_dev: 1..64 pieces and two output arrays");
     BF_HIP(ctx, hipSetDevice(ctx->device));
-    BF_TRY(layout_enqueue(ctx, n_pieces));
+    BF_TRY(layout_enqueue(ctx, n_pieces, true));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return layout_complete(ctx, n_pieces, piece_read_begin, piece_byte_off);
 }
 
@@ -921,7 +917,7 @@ int bf_result_requests_dev(bf_ctx* ctx, uint32_t n_pieces, uint32_t* dev_req, ui
     if ((uintptr_t)dev_req & 3) return fail(ctx, BF_ERR_INVALID, "bf_result_requests_dev: dev_req must be 4-byte aligned");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t groups = n_pieces * ctx->n_ranks;
-    BF_TRY(layout_enqueue(ctx, n_pieces));
+    BF_TRY(layout_enqueue(ctx, n_pieces, false));
     std::vector<uint64_t> start(groups + 1, 0), bound(groups + 1, 0);
     if (nr) {
         uint64_t *d_start = nullptr, *d_bytes = nullptr;
@@ -929,11 +925,19 @@ int bf_result_requests_dev(bf_ctx* ctx, uint32_t n_pieces, uint32_t* dev_req, ui
         BF_HIP(ctx, hipMemcpyAsync(start.data(), d_start, (groups + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
         BF_HIP(ctx, hipMemcpyAsync(bound.data(), d_bytes, (groups + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
+    uint64_t total_check = 0;
+    if (nr) BF_HIP(ctx, hipMemcpyAsync(&total_check, ctx->c_joff.as<uint64_t>() + nr, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // a piece's groups are exactly its reads, so the byte bounds of its first group are the piece's own
+    for (uint32_t c = 0; c <= n_pieces && nr; c++) {
+        if (start[c * ctx->n_ranks] != ctx->piece_read[c])
+            return fail(ctx, BF_ERR_HIP, "bf_result_requests_dev: piece %u: request order and layout disagree", c);
+        ctx->piece_byte[c] = bound[c * ctx->n_ranks];
+    }
+    if (nr && ctx->piece_byte[n_pieces] != total_check)
+        return fail(ctx, BF_ERR_HIP, "bf_result_requests_dev: record bytes in request order and in result order disagree");
     BF_TRY(layout_complete(ctx, n_pieces, piece_read_begin, piece_byte_off));
     for (uint32_t k = 0; k < groups; k++) { counts[k] = start[k + 1] - start[k]; bytes[k] = bound[k + 1] - bound[k]; }
-    for (uint32_t c = 0; c <= n_pieces && nr; c++)          // a piece's groups are exactly its reads and its bytes
-        if (start[c * ctx->n_ranks] != ctx->piece_read[c] || bound[c * ctx->n_ranks] != ctx->piece_byte[c])
-            return fail(ctx, BF_ERR_HIP, "bf_result_requests_dev: piece %u: request order and layout disagree", c);
     ctx->requests_ordered = nr > 0;
     return BF_OK;
 }

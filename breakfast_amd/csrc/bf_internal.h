@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -258,6 +259,14 @@ struct Scope {
     bf_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
     Scope(bf_ctx* c, const char* n);
     ~Scope();
+};
+
+// Host code is single-threaded per ctx: while this object lives, everything queued through ctx->stream (and the
+// sort / scan workspace c_tmp) goes to the copy stream with a workspace of its own instead.
+struct OnCopyStream {
+    bf_ctx* ctx;
+    explicit OnCopyStream(bf_ctx* c) : ctx(c) { std::swap(ctx->stream, ctx->copy_stream); std::swap(ctx->c_tmp, ctx->c_tmp2); }
+    ~OnCopyStream() { std::swap(ctx->stream, ctx->copy_stream); std::swap(ctx->c_tmp, ctx->c_tmp2); }
 };
 
 // localise.hip ----------------------------------------------------------------------------------

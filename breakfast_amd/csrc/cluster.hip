@@ -253,13 +253,6 @@ __global__ void compact_index_kernel(const uint32_t* __restrict__ flag, const ui
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && flag[i]) out[scan[i]] = value ? value[i] : (uint32_t)i;
 }
-// Host code is single-threaded per ctx: while this object lives, everything queued through ctx->stream (and the
-// sort / scan workspace c_tmp) goes to the copy stream with a workspace of its own instead.
-struct OnCopyStream {
-    bf_ctx* ctx;
-    explicit OnCopyStream(bf_ctx* c) : ctx(c) { std::swap(ctx->stream, ctx->copy_stream); std::swap(ctx->c_tmp, ctx->c_tmp2); }
-    ~OnCopyStream() { std::swap(ctx->stream, ctx->copy_stream); std::swap(ctx->c_tmp, ctx->c_tmp2); }
-};
 
 // Hash bits in the member sort key: enough to keep runs of equal keys short (a cluster rarely holds
 // more than a few hundred fragments), few enough to save two radix passes over 32 bits.  A collision
