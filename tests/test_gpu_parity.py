@@ -248,6 +248,42 @@ def test_error_behaviour():
         eng.close()
 
 
+def test_read_table_on_request():
+    """bf_finish leaves the read table on the device; bf_result_reads completes the result it is given, and only
+    the result of this ctx's last bf_finish."""
+    import ctypes as C
+    contigs, gk, spec = synth.config(1, scale=0.002, genome_scale=0.002)
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    eng = engine.Engine(spec.anchor_len, 5000, 2)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        r = engine.BfResult()
+        assert eng.lib.bf_result_reads(eng.h, C.byref(r)) == -4            # nothing clustered yet
+        eng.submit(b)
+        r = eng.finish_raw()
+        assert r.n_reads > 0 and not r.reads and r.cluster_junction_off
+        stale = engine.BfResult(r.n_evidence, r.n_clusters, r.n_reads + 1, r.clusters, None, r.junction_bytes,
+                                r.junction_size, r.cluster_junction_off)
+        assert eng.lib.bf_result_reads(eng.h, C.byref(stale)) == -4        # not this ctx's result
+        assert eng.lib.bf_result_reads(eng.h, None) == -1
+        for _ in range(2):                                                  # asking twice is fine
+            assert eng.lib.bf_result_reads(eng.h, C.byref(r)) == 0 and r.reads
+        res = eng._wrap(r)
+        # the table agrees with a walk over the records: offsets, and the input read behind every string
+        off = 0
+        for k in range(res.n_reads):
+            assert int(res.reads[k]["junction_off"]) == off
+            L, bp, sw, size = engine.junction_header(res.junction_bytes, off)
+            assert L == int(b.seq_off[int(res.reads[k]["index"]) + 1] - b.seq_off[int(res.reads[k]["index"])])
+            off += size
+        assert off == res.junction_bytes.size
+        eng.reset()
+        assert eng.lib.bf_result_reads(eng.h, C.byref(r)) in (0, -4)       # never a crash after a reset
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("name", ["kat_survey", "hz_contig_order", "hz_ref_alphabet", "hz_pairing", "hz_wrapped_coords"])
 def test_cli_driver_reproduces_golden(name, tmp_path):
     """`breakfast-hip detect` (the C++ host driver over the C ABI): same argv shape and stdout as the reference."""
