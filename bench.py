@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--exchange", action="store_true",
                     help="with one GPU: run the sharded code path anyway (pack -> RCCL all-to-all with itself -> import -> "
                          "device junction routing), to time what the exchange adds per rank")
+    ap.add_argument("--groups", type=int, default=0, help="contig groups of the cluster stage (0 = library default, 1 = one go)")
     ap.add_argument("--junction-chunks", type=int, default=0, help="sharded path: pieces the junction records come in (0 = default)")
     ap.add_argument("--phases", action="store_true", help="sharded path: synchronise after every phase and report phase_ms "
                                                            "(diagnostic: the extra synchronisation slows the step)")
@@ -128,7 +129,7 @@ def main():
 
     # ---- resident inputs -------------------------------------------------------------------------
     routing = engine.BF_FLAG_DEVICE_ROUTING if (world > 1 or forced) else 0
-    eng = engine.Engine(A, 5000, 2, device=local, flags=routing | {"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER,
+    eng = engine.Engine(A, 5000, 2, device=local, groups=args.groups, flags=routing | {"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER,
                                                                                "exact": engine.BF_FLAG_FORCE_EXACT}[args.variant])
     t2 = time.time()
     eng.set_genome(genome.names, genome.seqs)

@@ -131,7 +131,7 @@ static void free_all(bf_ctx* ctx) {
         &ctx->c_slpos, &ctx->c_srpos, &ctx->c_reported, &ctx->c_csize, &ctx->c_flag, &ctx->c_scan, &ctx->c_qseed,
         &ctx->c_qsize, &ctx->c_qoff, &ctx->c_members, &ctx->c_leader, &ctx->c_rep, &ctx->c_qnrep, &ctx->c_ctl, &ctx->c_sel,
         &ctx->c_ord, &ctx->c_clusters, &ctx->c_reads, &ctx->c_misc, &ctx->c_joff, &ctx->c_jbytes, &ctx->c_rsrc,
-        &ctx->c_tables, &ctx->c_mkey_s, &ctx->c_slot, &ctx->c_big, &ctx->c_cjo, &ctx->c_aoff, &ctx->c_err, &ctx->c_tmp2, &ctx->c_qord, &ctx->c_pos2, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
+        &ctx->c_tables, &ctx->c_mkey_s, &ctx->c_slot, &ctx->c_big, &ctx->c_cjo, &ctx->c_aoff, &ctx->c_err, &ctx->c_tmp2, &ctx->c_qord, &ctx->c_gidx, &ctx->c_hist, &ctx->c_pos2, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
     for (DevBuf* b : all) release(ctx, *b);
     HostBuf* hosts[] = {&ctx->out.clusters, &ctx->out.reads, &ctx->out.src, &ctx->out.junction, &ctx->out.cjo};
     for (HostBuf* h : hosts) { if (h->p) (void)hipHostFree(h->p); h->p = nullptr; h->cap = 0; }
@@ -419,6 +419,81 @@ static int localise_deferred(bf_ctx* ctx) {
     return run_localise(ctx, true);
 }
 
+static int fill_single_rank_result(bf_ctx* ctx, bf_result* out) {
+    out->n_evidence = ctx->n_evidence;
+    out->n_clusters = ctx->out.n_clusters;
+    out->n_reads = ctx->out.n_reads;
+    out->clusters = ctx->out.clusters.as<bf_cluster>();
+    out->reads = nullptr;                                          // bf_result_reads
+    out->junction_bytes = ctx->out.junction.as<uint8_t>();
+    out->junction_size = ctx->out.junction_size;
+    out->cluster_junction_off = ctx->out.n_reads ? ctx->out.cjo.as<uint64_t>() : nullptr;
+    return BF_OK;
+}
+
+// The cluster stage a few contig ranks at a time (cluster.hip, cluster_groups): the records of a finished group go
+// to the host on the copy stream while the next group is sorted, swept and de-duplicated.  The result is the
+// same bytes as in one go: the print order is contig-major, so the groups' rows, reads and records are appended.
+constexpr uint64_t kGroupMinReads = 1u << 21;
+constexpr uint32_t kMaxGroups = 8;
+static int clusterise_in_groups(bf_ctx* ctx, const OwnerView& v, bool* done) {
+    *done = false;
+    std::vector<uint64_t> gb;
+    uint64_t bound = 0;
+    // a group costs about 0.35 ms of launches and host round trips whatever its size: one per 5M reads, 2 to 8
+    // (bf_config.reserved[0] overrides; measured on configs[1]: 1 group 7.85 ms, 2: 7.58, 3: 7.86, 4: 8.33)
+    const uint32_t fit = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(v.n / 5000000, 2), kMaxGroups);
+    const uint32_t want = ctx->cfg.reserved[0] ? std::min<uint32_t>(ctx->cfg.reserved[0], 64u) : fit;
+    BF_TRY(cluster_groups(ctx, v, want, gb, &bound));
+    if (gb.size() <= 2) return BF_OK;                              // one contig holds it all: nothing to pipeline
+    // every output buffer at its final size before the first copy is queued: nothing may move under a copy
+    BF_TRY(ensure(ctx, ctx->c_jbytes, bound ? bound : 1, false));
+    BF_TRY(ensure_host(ctx, ctx->out.junction, bound));
+    uint64_t cl_base = 0, rd_base = 0, byte_base = 0;
+    for (size_t g = 0; g + 1 < gb.size(); g++) {
+        ClusterGroup grp{ctx->c_gidx.as<uint32_t>() + gb[g], gb[g + 1] - gb[g], cl_base, rd_base, v.n};
+        BF_TRY(run_cluster(ctx, v, &grp));
+        if (!grp.nr) continue;
+        const uint64_t stride = ctx->rsrc_stride;
+        const uint32_t* d_idx = ctx->c_rsrc.as<uint32_t>() + stride + rd_base;       // out_src_idx of this group
+        constexpr int kMaxChunks = 2;
+        const int nc = grp.nr >= (1u << 16) ? kMaxChunks : 1;
+        uint64_t off[kMaxChunks + 1];
+        BF_TRY(render_prepare(ctx, grp.nr, d_idx, ctx->c_joff, nc, off, ctx->c_rsrc.as<uint32_t>() + 3 * stride + rd_base));
+        const uint64_t total = off[nc];
+        if (byte_base + total > bound) return fail(ctx, BF_ERR_HIP, "group records exceed the bound computed from all reads");
+        BF_TRY(ensure(ctx, ctx->c_cjo, (cl_base + grp.ns + 1) * 8, true));                  // earlier groups' offsets stay
+        BF_TRY(cluster_record_offsets(ctx, ctx->c_joff.as<uint64_t>(), ctx->c_cjo.as<uint64_t>() + cl_base, grp.ns, byte_base));
+        for (int c = 0; c < nc; c++) {
+            BF_TRY(render_range_at(ctx, grp.nr * (uint64_t)c / nc, grp.nr * (uint64_t)(c + 1) / nc, d_idx, ctx->c_joff.as<uint64_t>(),
+                                   ctx->c_jbytes.as<uint8_t>() + byte_base));
+            if (off[c + 1] > off[c]) {
+                BF_HIP(ctx, hipEventRecord(ctx->ev[1 + c], ctx->stream));
+                BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[1 + c], 0));
+                BF_HIP(ctx, hipMemcpyAsync(ctx->out.junction.as<uint8_t>() + byte_base + off[c], ctx->c_jbytes.as<uint8_t>() + byte_base + off[c],
+                                           off[c + 1] - off[c], hipMemcpyDeviceToHost, ctx->copy_stream));
+            }
+        }
+        BF_TRY(patch_reads_off(ctx, ctx->c_joff.as<uint64_t>(), grp.nr, rd_base, byte_base));   // the table, for bf_result_reads
+        cl_base += grp.ns; rd_base += grp.nr; byte_base += total;
+    }
+    ctx->clustered = true;
+    ctx->out.n_clusters = cl_base; ctx->out.n_reads = rd_base; ctx->out.junction_size = byte_base;
+    if (cl_base) {
+        BF_TRY(ensure_host(ctx, ctx->out.clusters, cl_base * sizeof(bf_cluster)));
+        BF_TRY(ensure_host(ctx, ctx->out.cjo, (cl_base + 1) * 8));
+        BF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+        BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[0], 0));
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.clusters.p, ctx->c_clusters.p, cl_base * sizeof(bf_cluster), hipMemcpyDeviceToHost, ctx->copy_stream));
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.cjo.p, ctx->c_cjo.p, (cl_base + 1) * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
+        ctx->reads_on_device = true;
+    }
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    *done = true;
+    return BF_OK;
+}
+
 int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     if (!ctx) return BF_ERR_INVALID;
     if (!out) return fail(ctx, BF_ERR_INVALID, "bf_clusterise: null result");
@@ -429,6 +504,11 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     const OwnerView v = ctx->imported ? imported_view(ctx) : local_view(ctx);
     ctx->clustered = false; ctx->table_attached = false; ctx->junction_attached = 0; ctx->reads_on_device = false;
     ctx->result_order = false; ctx->sources_on_device = false;
+    if (!ctx->imported && (v.n >= kGroupMinReads || (ctx->cfg.flags & BF_FLAG_GROUPS_ALWAYS)) && !(ctx->cfg.flags & BF_FLAG_ONE_GROUP)) {
+        bool done = false;
+        BF_TRY(clusterise_in_groups(ctx, v, &done));
+        if (done) return fill_single_rank_result(ctx, out);
+    }
     BF_TRY(run_cluster(ctx, v));
     ctx->clustered = true;
     const uint64_t nr = ctx->out.n_reads;

@@ -208,6 +208,7 @@ struct bf_ctx {
     uint64_t junction_attached = 0;             // junction bytes queued for the host so far
     bool reads_on_device = false;               // the finished read table waits in c_reads for bf_result_reads
     bool sources_on_device = false;             // multi-rank: out.src not copied yet (bf_result_sources does it)
+    uint64_t rsrc_stride = 0;                   // c_rsrc = 4 arrays of this many entries (source rank, source index, record, bytes)
     bool requests_ordered = false;              // bf_result_requests_dev left its order in c_d32 / c_aoff
     bool result_order = false;                  // multi-rank: bf_result_layout_dev laid the records out in result order
     std::vector<uint64_t> piece_read, piece_byte;   // its pieces: read ranges and their byte ranges (n_pieces + 1 each)
@@ -216,7 +217,7 @@ struct bf_ctx {
     // cluster stage scratch + results
     bf::DevBuf c_tmp, c_a32, c_b32, c_c32, c_d32, c_k64a, c_k64b, c_slpos, c_srpos, c_reported,
         c_csize, c_flag, c_scan, c_qseed, c_qsize, c_qoff, c_members, c_leader, c_rep, c_qnrep,
-        c_ctl, c_sel, c_ord, c_clusters, c_reads, c_misc, c_pos2, c_joff, c_jbytes, c_rsrc, c_tables, c_mkey_s, c_slot, c_big, c_cjo, c_aoff, c_err, c_tmp2, c_qord;
+        c_ctl, c_sel, c_ord, c_clusters, c_reads, c_misc, c_pos2, c_joff, c_jbytes, c_rsrc, c_tables, c_mkey_s, c_slot, c_big, c_cjo, c_aoff, c_err, c_tmp2, c_qord, c_gidx, c_hist;
     bf::ClusterOut out;
     std::vector<uint64_t> render_off_host;
     std::vector<uint8_t> render_bytes_host;
@@ -277,6 +278,7 @@ int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf&
                    const uint32_t* d_sizes = nullptr);   // d_sizes: record bytes per list entry when the caller has them
 int64_t junction_decode(const uint8_t* rec, uint64_t avail, uint8_t* out, uint64_t cap, uint64_t* stored = nullptr);   // api.hip, host
 int render_range(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const DevBuf& d_off, DevBuf& d_bytes);
+int render_range_at(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const uint64_t* d_off, uint8_t* d_bytes);
 int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, DevBuf& d_bytes,
                uint64_t* total_bytes);              // junction strings for local reads
 
@@ -284,7 +286,16 @@ int render_dev(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint64_t* d
                uint64_t d_bytes_cap, uint64_t* total);
 
 // cluster.hip -----------------------------------------------------------------------------------
-int run_cluster(bf_ctx* ctx, const OwnerView& v);   // fills ctx->out (without junction text)
+// One group of whole contig ranks (api.hip cuts the evidence into a few, so that a group's result crosses PCIe
+// while the next group is clustered): the record ids of the group, where its rows and reads go in the result,
+// and the capacity of the per-read result arrays.
+struct ClusterGroup {
+    const uint32_t* idx; uint64_t m;
+    uint64_t cl_base, rd_base, cap;
+    uint64_t ns = 0, nr = 0;           // out: clusters and supporting reads this group added
+};
+int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::vector<uint64_t>& bounds, uint64_t* record_bytes);
+int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* g = nullptr);   // fills ctx->out (without junction text)
 int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint64_t dev_send_bytes, uint64_t* counts,
                   void** dev_out, uint32_t* record_bytes);
 int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts);
@@ -297,8 +308,8 @@ int radix_sort_pairs(bf_ctx* ctx, const uint64_t* kin, uint64_t* kout, const uin
 int scan_u32_to_u64(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n);  // exclusive, out has n+1
 int scan_max_u32_inplace(bf_ctx* ctx, uint32_t* data, uint64_t n);                // running maximum
 int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
-int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
-int cluster_record_offsets(bf_ctx* ctx, const uint64_t* d_joff, uint64_t* d_out, uint64_t n_clusters);
+int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n, uint64_t rd_base = 0, uint64_t byte_base = 0);
+int cluster_record_offsets(bf_ctx* ctx, const uint64_t* d_joff, uint64_t* d_out, uint64_t n_clusters, uint64_t byte_base = 0);
 int order_requests(bf_ctx* ctx, uint32_t K, uint32_t* d_req, uint64_t** d_start, uint64_t** d_bytes);
 int scatter_ordered(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_records, uint64_t size);
 int scatter_records(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_records, uint64_t size, const int64_t* d_pos);

@@ -17,6 +17,7 @@
 //   4. order surviving clusters by the seed's rank in the reference's sort: (chr, lpos, input index).
 
 #include "bf_internal.h"
+#include <memory>
 
 namespace bf {
 
@@ -516,6 +517,7 @@ struct EmitView {
     const uint64_t* info;
     const uint32_t* rank2id; int cb;
     bf_cluster* clusters; bf_read* reads; uint32_t* out_src_rank; uint32_t* out_src_idx; uint32_t* out_rec; uint32_t* out_jrec;
+    uint64_t rd_base;           // reads[], out_*[] start at this group's first read: read_begin / read_end count from here
 };
 
 // One wave per reported cluster: the printed row (detect.rs:233-235) and its surviving reads in
@@ -539,7 +541,7 @@ __global__ void __launch_bounds__(256) emit_kernel(const EmitView e, uint64_t ns
         memset(&cl, 0, sizeof cl);
         cl.lpos = e.slpos[p]; cl.rpos = e.srpos[p];
         cl.seed_index = e.src_base[sr] + si;
-        cl.read_begin = rbase; cl.read_end = e.roff[k + 1];
+        cl.read_begin = e.rd_base + rbase; cl.read_end = e.rd_base + e.roff[k + 1];
         cl.contig = e.rank2id[(key >> key_rank_shift(e.cb)) & ((1u << e.cb) - 1)];
         cl.mcontig = e.rank2id[(key >> kKeyMrankShift) & ((1u << e.cb) - 1)];
         cl.strand = (key >> kKeyStrandBit) & 1; cl.mstrand = (key >> kKeyMstrandBit) & 1;
@@ -567,12 +569,84 @@ __global__ void __launch_bounds__(256) emit_kernel(const EmitView e, uint64_t ns
     }
 }
 
-// ---- the cluster stage -----------------------------------------------------------------------
-int run_cluster(bf_ctx* ctx, const OwnerView& v) {
+// ---- groups of whole contig ranks --------------------------------------------------------------
+// Classes never interact and the print order is contig-major, so the evidence can be clustered a few contig
+// ranks at a time and the results appended; api.hip copies a group's records to the host while the next group
+// is clustered.  rank32[i] = left contig rank of record i, hist[r] = records of rank r, hist[bins] = sum of all
+// records' junction record bytes (the bound the output buffers are sized with).
+constexpr uint32_t kMaxRankBins = 4096;
+__global__ void __launch_bounds__(256) rank_histogram_kernel(const uint64_t* __restrict__ key, const uint64_t* __restrict__ info,
+                                                             uint64_t n, int shift, uint32_t bins, uint32_t* __restrict__ rank32,
+                                                             unsigned long long* hist) {
+    extern __shared__ uint32_t s_hist[];
+    for (uint32_t b = threadIdx.x; b < bins; b += 256) s_hist[b] = 0;
+    __syncthreads();
+    unsigned long long bytes = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t r = (uint32_t)(key[i] >> shift) & (bins - 1);
+        rank32[i] = r;
+        atomicAdd(&s_hist[r], 1u);
+        bytes += info_jrec(info[i]);
+    }
+    for (int d = 32; d; d >>= 1) bytes += __shfl_down(bytes, d);
+    if ((threadIdx.x & 63) == 0 && bytes) atomicAdd(&hist[bins], bytes);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < bins; b += 256)
+        if (s_hist[b]) atomicAdd(&hist[b], (unsigned long long)s_hist[b]);
+}
+// -> bounds: positions in c_gidx (record ids ordered by contig rank, input order inside) where the groups start;
+// one group (bounds = {0, n}) when there is nothing to gain.
+int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::vector<uint64_t>& bounds, uint64_t* record_bytes) {
     const uint64_t n = v.n;
+    const hipStream_t st = ctx->stream;
+    const uint32_t bins = 1u << ctx->contig_bits;
+    bounds.assign(1, 0); bounds.push_back(n);
+    *record_bytes = 0;
+    if (max_groups < 2 || bins > kMaxRankBins || n == 0) return BF_OK;
+    BF_TRY(ensure(ctx, ctx->c_gidx, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_hist, (size_t)(bins + 1) * 8, false));
+    BF_TRY(ensure(ctx, ctx->c_a32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_b32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_c32, n * 4, false));
+    BF_HIP(ctx, hipMemsetAsync(ctx->c_hist.p, 0, (size_t)(bins + 1) * 8, st));
+    hipLaunchKernelGGL(rank_histogram_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, 256), 2048)), dim3(256), bins * 4, st,
+                       v.key, v.info, n, key_rank_shift(ctx->contig_bits), bins, ctx->c_b32.as<uint32_t>(),
+                       (unsigned long long*)ctx->c_hist.p);
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, ctx->c_c32.as<uint32_t>(), n);
+    BF_TRY(sort_pairs<uint32_t>(ctx, ctx->c_b32.as<uint32_t>(), ctx->c_a32.as<uint32_t>(), ctx->c_c32.as<uint32_t>(),
+                                ctx->c_gidx.as<uint32_t>(), n, 0, (unsigned)ctx->contig_bits));
+    std::vector<uint64_t> hist(bins + 1);
+    BF_HIP(ctx, hipMemcpyAsync(hist.data(), ctx->c_hist.p, (size_t)(bins + 1) * 8, hipMemcpyDeviceToHost, st));
+    BF_HIP(ctx, hipStreamSynchronize(st));
+    BF_TRY(settle_counts(ctx));                           // the localise counters came along with this synchronisation
+    *record_bytes = hist[bins];
+    // cut after the rank where the running count passes the next multiple of n / max_groups
+    bounds.assign(1, 0);
+    uint64_t run = 0;
+    for (uint32_t r = 0; r < bins; r++) {
+        run += hist[r];
+        if (run >= n * bounds.size() / max_groups && run > bounds.back() && run < n) bounds.push_back(run);
+    }
+    bounds.push_back(n);
+    return BF_OK;
+}
+// sort keys and record ids of a group
+__global__ void group_keys_kernel(uint32_t* __restrict__ key, uint32_t* __restrict__ val, const uint32_t* __restrict__ idx,
+                                  const int32_t* __restrict__ lpos, uint64_t m) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) { const uint32_t i = idx[j]; val[j] = i; key[j] = (uint32_t)lpos[i]; }
+}
+__global__ void zip_pos_kernel(int2* __restrict__ pos2, const int32_t* __restrict__ lpos, const int32_t* __restrict__ rpos, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pos2[i] = make_int2(lpos[i], rpos[i]);
+}
+
+// ---- the cluster stage -----------------------------------------------------------------------
+int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
+    const uint64_t n = grp ? grp->m : v.n;                 // records in sorted space; record ids stay v's
     hipStream_t st = ctx->stream;
-    ctx->out.n_clusters = ctx->out.n_reads = ctx->out.junction_size = 0;
-    ctx->n_evidence = n;
+    if (!grp || grp->cl_base + grp->rd_base == 0) {
+        ctx->out.n_clusters = ctx->out.n_reads = ctx->out.junction_size = 0;
+        ctx->n_evidence = v.n;
+    }
+    if (grp) grp->ns = grp->nr = 0;
     if (n == 0) return BF_OK;
     if (n > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "too many evidence records for one GPU (%llu)", (unsigned long long)n);
     const unsigned B = 256;
@@ -582,13 +656,23 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     BF_TRY(ensure(ctx, ctx->c_c32, n * 4));
     BF_TRY(ensure(ctx, ctx->c_k64a, n * 8)); BF_TRY(ensure(ctx, ctx->c_k64b, n * 8));
     BF_TRY(ensure(ctx, ctx->c_slpos, n * 4)); BF_TRY(ensure(ctx, ctx->c_srpos, n * 4));
-    BF_TRY(ensure(ctx, ctx->c_pos2, n * 8));
+    BF_TRY(ensure(ctx, ctx->c_pos2, v.n * 8));
     uint32_t* perm = ctx->c_a32.as<uint32_t>();
     {
         Scope t(ctx, "sort");
-        hipLaunchKernelGGL(iota_zip_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_a32.as<uint32_t>(), ctx->c_pos2.as<int2>(),
-                           v.lpos, v.rpos, n);
-        BF_TRY(sort_pairs<uint32_t>(ctx, (const uint32_t*)v.lpos, ctx->c_b32.as<uint32_t>(), ctx->c_a32.as<uint32_t>(),
+        const uint32_t* keys1 = (const uint32_t*)v.lpos;
+        if (!grp) {
+            hipLaunchKernelGGL(iota_zip_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_a32.as<uint32_t>(), ctx->c_pos2.as<int2>(),
+                               v.lpos, v.rpos, n);
+        } else {
+            if (grp->cl_base + grp->rd_base == 0 && grp->idx == ctx->c_gidx.as<uint32_t>())   // first group: positions of all records
+                hipLaunchKernelGGL(zip_pos_kernel, dim3(grid_for(v.n, B)), dim3(B), 0, st, ctx->c_pos2.as<int2>(), v.lpos, v.rpos, v.n);
+            BF_TRY(ensure(ctx, ctx->c_d32, n * 4, false));
+            hipLaunchKernelGGL(group_keys_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_d32.as<uint32_t>(),
+                               ctx->c_a32.as<uint32_t>(), grp->idx, v.lpos, n);
+            keys1 = ctx->c_d32.as<uint32_t>();
+        }
+        BF_TRY(sort_pairs<uint32_t>(ctx, keys1, ctx->c_b32.as<uint32_t>(), ctx->c_a32.as<uint32_t>(),
                                     ctx->c_c32.as<uint32_t>(), n, 0, 32));
         hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_k64a.as<uint64_t>(), v.key,
                            ctx->c_c32.as<uint32_t>(), n);
@@ -660,10 +744,14 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     // so that they run beside the member / dedup kernels instead of after them.
     BF_TRY(ensure(ctx, ctx->c_qord, nq * 4));
     BF_TRY(ensure(ctx, ctx->c_misc, nq * 8 * 4));
-    BF_HIP(ctx, hipEventRecord(ctx->ev[9], st));
-    BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[9], 0));
+    // (with groups the copy stream is busy with the previous group's records: the sorts stay in line)
+    if (!grp) {
+        BF_HIP(ctx, hipEventRecord(ctx->ev[9], st));
+        BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[9], 0));
+    }
     {
-        OnCopyStream aux(ctx);
+        std::unique_ptr<OnCopyStream> aux;
+        if (!grp) aux.reset(new OnCopyStream(ctx));
         Scope t(ctx, "order");
         const hipStream_t as = ctx->stream;
         uint64_t* kpos = ctx->c_misc.as<uint64_t>();
@@ -675,12 +763,12 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
         hipLaunchKernelGGL(iota_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, va, nq);
         // significant bits of (source rank << 32 | source index): on one rank the index alone, below n
         unsigned idx_bits = 64;
-        if (!v.src_rank) { idx_bits = 1; while (idx_bits < 32 && (1ull << idx_bits) < n) idx_bits++; }
+        if (!v.src_rank) { idx_bits = 1; while (idx_bits < 32 && (1ull << idx_bits) < v.n) idx_bits++; }
         else { unsigned rb = 1; while ((1u << rb) < ctx->n_ranks) rb++; idx_bits = 32 + rb; }
         BF_TRY(sort_pairs<uint64_t>(ctx, kidx, kidx2, va, vb, nq, 0, idx_bits));
         hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, kpos2, kpos, vb, nq);
         BF_TRY(sort_pairs<uint64_t>(ctx, kpos2, kidx2, vb, ctx->c_qord.as<uint32_t>(), nq, 0, 32 + ctx->contig_bits));
-        BF_HIP(ctx, hipEventRecord(ctx->ev[12], as));
+        if (!grp) BF_HIP(ctx, hipEventRecord(ctx->ev[12], as));
     }
     BF_TRY(scan_u32_to_u64(ctx, ctx->c_qsize.as<uint32_t>(), ctx->c_qoff.as<uint64_t>(), nq));
     BF_TRY(scan_u32_to_u64(ctx, qbig, qboff, nq));
@@ -721,7 +809,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     uint64_t ns = 0, total_r = 0;
     BF_TRY(ensure(ctx, ctx->c_flag, std::max(nq, n) * 4, false));
     BF_TRY(ensure(ctx, ctx->c_ord, nq * 4));
-    BF_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[12], 0));
+    if (!grp) BF_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[12], 0));
     {
         Scope t(ctx, "select");
         const uint32_t* qord = ctx->c_qord.as<uint32_t>();
@@ -741,9 +829,13 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     }
 
     // 5. emit rows + surviving reads
-    BF_TRY(ensure(ctx, ctx->c_clusters, ns * sizeof(bf_cluster)));
-    BF_TRY(ensure(ctx, ctx->c_reads, std::max<uint64_t>(total_r, 1) * sizeof(bf_read)));
-    BF_TRY(ensure(ctx, ctx->c_rsrc, std::max<uint64_t>(total_r, 1) * 4 * 4));
+    const uint64_t cl_base = grp ? grp->cl_base : 0, rd_base = grp ? grp->rd_base : 0;
+    const uint64_t stride = grp ? grp->cap : total_r;      // the per-read arrays: sized for every read when groups append
+    if (grp && rd_base + total_r > stride) return fail(ctx, BF_ERR_RANGE, "group results exceed their capacity");
+    BF_TRY(ensure(ctx, ctx->c_clusters, (cl_base + ns) * sizeof(bf_cluster), grp != nullptr));   // earlier groups' rows stay
+    BF_TRY(ensure(ctx, ctx->c_reads, std::max<uint64_t>(grp ? stride : total_r, 1) * sizeof(bf_read)));
+    BF_TRY(ensure(ctx, ctx->c_rsrc, std::max<uint64_t>(stride, 1) * 4 * 4));
+    ctx->rsrc_stride = stride;
     std::vector<uint64_t> bases = ctx->src_index_base;
     if (bases.empty()) bases.assign(1, ctx->index_base);
     BF_TRY(ensure(ctx, ctx->c_tables, bases.size() * 8 + (size_t)ctx->n_contigs * 4 + 16));
@@ -757,15 +849,22 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v) {
     ev.skey = sv.skey; ev.slpos = sv.slpos; ev.srpos = sv.srpos; ev.perm = perm;
     ev.src_rank = v.src_rank; ev.src_idx = v.src_idx; ev.src_base = (const uint64_t*)ctx->c_tables.p;
     ev.info = v.info; ev.rank2id = d_rank2id; ev.cb = ctx->contig_bits;
-    ev.clusters = ctx->c_clusters.as<bf_cluster>(); ev.reads = ctx->c_reads.as<bf_read>();
-    ev.out_src_rank = ctx->c_rsrc.as<uint32_t>(); ev.out_src_idx = ev.out_src_rank + total_r;
-    ev.out_rec = ev.out_src_idx + total_r; ev.out_jrec = ev.out_rec + total_r;
+    ev.clusters = ctx->c_clusters.as<bf_cluster>() + cl_base; ev.reads = ctx->c_reads.as<bf_read>() + rd_base;
+    ev.out_src_rank = ctx->c_rsrc.as<uint32_t>() + rd_base; ev.out_src_idx = ev.out_src_rank + stride;
+    ev.out_rec = ev.out_src_idx + stride; ev.out_jrec = ev.out_rec + stride;
+    ev.rd_base = rd_base;
     {
         Scope t(ctx, "emit");
         hipLaunchKernelGGL(emit_kernel, dim3(grid_for(ns * 64, B)), dim3(B), 0, st, ev, ns);
     }
     BF_HIP(ctx, hipGetLastError());
     // host copies: the rows now; the reads after the junction offsets are patched in (api.hip)
+    if (grp) {                                            // the caller copies the rows when the last group is through
+        grp->ns = ns; grp->nr = total_r;
+        ctx->out.n_clusters = cl_base + ns; ctx->out.n_reads = rd_base + total_r;
+        ctx->sources_on_device = false;
+        return BF_OK;
+    }
     ctx->out.n_clusters = ns; ctx->out.n_reads = total_r;
     BF_TRY(ensure_host(ctx, ctx->out.clusters, ns * sizeof(bf_cluster)));
     // on the copy stream: 6 MB of rows would otherwise hold up the render kernels for 0.1 ms
@@ -1019,26 +1118,28 @@ int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts) {
 }
 
 // reads[i].junction_off from the render offsets
-__global__ void patch_reads_off_kernel(bf_read* reads, const uint64_t* __restrict__ joff, uint64_t n) {
+__global__ void patch_reads_off_kernel(bf_read* reads, const uint64_t* __restrict__ joff, uint64_t n, uint64_t byte_base) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) reads[i].junction_off = joff[i];
+    if (i < n) reads[i].junction_off = byte_base + joff[i];
 }
-int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n) {
+// reads [rd_base, rd_base + n) of the table: junction_off = byte_base + d_joff[i]
+int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n, uint64_t rd_base, uint64_t byte_base) {
     if (n) hipLaunchKernelGGL(patch_reads_off_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
-                              ctx->c_reads.as<bf_read>(), d_joff, n);
+                              ctx->c_reads.as<bf_read>() + rd_base, d_joff, n, byte_base);
     BF_HIP(ctx, hipGetLastError());
     return BF_OK;
 }
 // out[c] = where cluster c's first record starts (c = n_clusters: the end), from the per-read offsets and the
 // clusters' read offsets the order stage left in c_scan
 __global__ void cluster_record_offsets_kernel(uint64_t* out, const uint64_t* __restrict__ joff,
-                                              const uint64_t* __restrict__ roff, uint64_t n) {
+                                              const uint64_t* __restrict__ roff, uint64_t n, uint64_t byte_base) {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n) out[c] = joff[roff[c]];
+    if (c < n) out[c] = byte_base + joff[roff[c]];
 }
-int cluster_record_offsets(bf_ctx* ctx, const uint64_t* d_joff, uint64_t* d_out, uint64_t n_clusters) {
+// d_out[0 .. n_clusters] for the clusters whose read offsets the order stage just left in c_scan (a group's, or all)
+int cluster_record_offsets(bf_ctx* ctx, const uint64_t* d_joff, uint64_t* d_out, uint64_t n_clusters, uint64_t byte_base) {
     hipLaunchKernelGGL(cluster_record_offsets_kernel, dim3(grid_for(n_clusters + 1, 256)), dim3(256), 0, ctx->stream,
-                       d_out, d_joff, ctx->c_scan.as<uint64_t>(), n_clusters + 1);
+                       d_out, d_joff, ctx->c_scan.as<uint64_t>(), n_clusters + 1, byte_base);
     BF_HIP(ctx, hipGetLastError());
     return BF_OK;
 }

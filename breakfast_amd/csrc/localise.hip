@@ -1160,6 +1160,13 @@ int render_range(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_id
     return launch_render(ctx, b - a, d_local_idx + a, d_off.as<uint64_t>() + a, d_bytes.as<uint8_t>());
 }
 
+// The same with plain pointers: offsets relative to d_bytes (a group's part of the junction buffer).
+int render_range_at(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const uint64_t* d_off, uint8_t* d_bytes) {
+    if (b <= a) return BF_OK;
+    Scope t(ctx, "render");
+    return launch_render(ctx, b - a, d_local_idx + a, d_off + a, d_bytes);
+}
+
 // Junction strings for a DEVICE list of local read indices into caller-owned device memory (the
 // multi-GPU route: nothing crosses PCIe here).  d_off receives n+1 offsets; when d_bytes is null only
 // the offsets and *total are produced.

@@ -24,6 +24,8 @@ BF_FLAG_SEPARATE_ENCODE = 8
 BF_FLAG_DEVICE_ROUTING = 16
 BF_FLAG_SORTED_DEDUP = 32
 BF_FLAG_WEAK_DEDUP_HASH = 64
+BF_FLAG_ONE_GROUP = 128
+BF_FLAG_GROUPS_ALWAYS = 256
 BF_EV_STRAND, BF_EV_MSTRAND, BF_EV_SWAPPED, BF_EV_EXACT, BF_EV_SIGX = 1, 2, 4, 8, 16
 
 HIT_DTYPE = np.dtype([("pos5", "<u4"), ("pos3", "<u4"), ("contig5", "<u2"), ("contig3", "<u2"),
@@ -309,9 +311,9 @@ class Engine:
     """One bf_ctx = one GPU.  Mirrors the stages of detect::main (detect.rs:39-242)."""
 
     def __init__(self, anchor_len: int = 30, max_frag_len: int = 5000, min_evidence: int = 2,
-                 device: int = -1, flags: int = 0, lib_path: Optional[str] = None):
+                 device: int = -1, flags: int = 0, lib_path: Optional[str] = None, groups: int = 0):
         self.lib = load_library(lib_path)
-        cfg = BfConfig(anchor_len, max_frag_len, min_evidence, device, flags, (C.c_uint32 * 3)(0, 0, 0))
+        cfg = BfConfig(anchor_len, max_frag_len, min_evidence, device, flags, (C.c_uint32 * 3)(groups, 0, 0))
         h = C.c_void_p()
         rc = self.lib.bf_ctx_create(C.byref(cfg), C.byref(h))
         if rc != 0:

@@ -54,7 +54,7 @@ typedef struct {
     uint32_t min_evidence;   /* --min-evidence [default 2] */
     int32_t  device;         /* HIP device ordinal, -1 = current device */
     uint32_t flags;          /* BF_FLAG_* */
-    uint32_t reserved[3];
+    uint32_t reserved[3];    /* [0]: contig groups of the cluster stage (0 = chosen from the input size; A/B), rest 0 */
 } bf_config;
 
 #define BF_FLAG_KEEP_EVIDENCE 1u   /* keep per-read evidence readable via bf_evidence_fetch (tests) */
@@ -65,6 +65,9 @@ typedef struct {
                                       fits the in-wave form (they are the path of clusters above 256 members) */
 #define BF_FLAG_WEAK_DEDUP_HASH 64u /* tests: the in-wave dedup groups on 3 hash bits, so that its byte verification fails
                                        and the pair-by-pair redo runs */
+#define BF_FLAG_ONE_GROUP    128u   /* A/B + tests: cluster all contigs in one go instead of a few contig ranks at a time with
+                                      each group's records copied to the host behind the next group's kernels */
+#define BF_FLAG_GROUPS_ALWAYS 256u  /* tests: the groups even for inputs below the size where they pay (2M reads) */
 #define BF_FLAG_DEVICE_ROUTING 16u /* multi-rank: bf_clusterise leaves the read table on the device (result.reads
                                       is NULL, n_reads is set); the bf_result_attach_* calls complete the result */
 

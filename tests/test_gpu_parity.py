@@ -11,7 +11,7 @@ from conftest import golden_names, load_golden
 
 from breakfast_amd import engine, synth
 from breakfast_amd.engine import (BF_FLAG_COOP_GATHER, BF_FLAG_FORCE_EXACT, BF_FLAG_KEEP_EVIDENCE, BF_FLAG_SEPARATE_ENCODE,
-                                  BF_FLAG_SORTED_DEDUP, BF_FLAG_WEAK_DEDUP_HASH)
+                                  BF_FLAG_SORTED_DEDUP, BF_FLAG_WEAK_DEDUP_HASH, BF_FLAG_GROUPS_ALWAYS, BF_FLAG_ONE_GROUP)
 
 pytestmark = pytest.mark.gpu
 
@@ -24,6 +24,13 @@ def run_gpu_text(fa, lines, A, F, E, flags=0):
 def test_golden_fixture(name):
     fa, lines, (A, F, E), sv = load_golden(name)
     assert run_gpu_text(fa, lines, A, F, E) == sv
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fixture_in_contig_groups(name):
+    # the cluster stage a few contig ranks at a time (what inputs of 2M reads and more get): same bytes
+    fa, lines, (A, F, E), sv = load_golden(name)
+    assert run_gpu_text(fa, lines, A, F, E, flags=BF_FLAG_GROUPS_ALWAYS) == sv
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -117,6 +124,23 @@ def test_scaled_baseline_config_sorted_dedup(cfg, scale, gscale):
     g = synth.make_genome(contigs, **gk)
     b = synth.make_reads(g, spec)
     check_against_oracle(g, b, spec.anchor_len, flags=BF_FLAG_SORTED_DEDUP)
+
+
+@pytest.mark.parametrize("cfg,scale,gscale", [(0, 0.05, 0.02), (1, 0.004, 0.002), (3, 0.001, 0.002), (4, 0.002, 0.002)])
+def test_scaled_baseline_config_in_contig_groups(cfg, scale, gscale):
+    """Sort / sweep / dedup / order / emit / render per group of whole contig ranks, results appended
+    (api.hip, clusterise_in_groups); also together with the sorted-run dedup."""
+    contigs, gk, spec = synth.config(cfg, scale=scale, genome_scale=gscale)
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    res, ref = check_against_oracle(g, b, spec.anchor_len, flags=BF_FLAG_GROUPS_ALWAYS)
+    if cfg:                                                       # (configs[0] is one contig)
+        assert len(set(res.clusters["contig"].tolist())) > 2      # several groups had something to report
+    check_against_oracle(g, b, spec.anchor_len, flags=BF_FLAG_GROUPS_ALWAYS | BF_FLAG_SORTED_DEDUP)
+    # one contig: nothing to cut, the one-go path takes over
+    g1 = synth.make_genome([("only", 400000)], seed=5)
+    spec1 = synth.ReadSpec(n_reads=4000, read_len=100, anchor_len=20, n_events=40, singleton_frac=0.3, mate_frac=0.0, seed=9, margin=300)
+    check_against_oracle(g1, synth.make_reads(g1, spec1), 20, flags=BF_FLAG_GROUPS_ALWAYS)
 
 
 @pytest.mark.parametrize("n_reads,n_events", [(3000, 40), (6000, 30), (9000, 12)])
