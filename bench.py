@@ -200,7 +200,8 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": pmc_traffic(args, n_local, L),
                 "algorithmic_bytes_per_read": bpr, "reads_per_launch": n_local, "avg_launch_ms": round(loc_avg_ms, 4)}
-    stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in ktimes.items()}
+    # per step (a stage runs once per contig group and step; the roofline kernel above once per step)
+    stages = {k: round(v[0] / args.steps, 4) for k, v in ktimes.items()}
 
     # ---- CPU baseline (rank 0, single GPU run only) -------------------------------------------------
     cpu = None
