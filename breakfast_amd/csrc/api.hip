@@ -434,7 +434,7 @@ static int fill_single_rank_result(bf_ctx* ctx, bf_result* out) {
 // The cluster stage a few contig ranks at a time (cluster.hip, cluster_groups): the records of a finished group go
 // to the host on the copy stream while the next group is sorted, swept and de-duplicated.  The result is the
 // same bytes as in one go: the print order is contig-major, so the groups' rows, reads and records are appended.
-constexpr uint64_t kGroupMinReads = 1u << 21;
+constexpr uint64_t kGroupMinReads = 1u << 22;    // below: the hidden half of the copy is shorter than what two groups cost
 constexpr uint32_t kMaxGroups = 8;
 static int clusterise_in_groups(bf_ctx* ctx, const OwnerView& v, bool* done) {
     *done = false;

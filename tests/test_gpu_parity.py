@@ -28,7 +28,7 @@ def test_golden_fixture(name):
 
 @pytest.mark.parametrize("name", golden_names())
 def test_golden_fixture_in_contig_groups(name):
-    # the cluster stage a few contig ranks at a time (what inputs of 2M reads and more get): same bytes
+    # the cluster stage a few contig ranks at a time (what inputs of 4M reads and more get): same bytes
     fa, lines, (A, F, E), sv = load_golden(name)
     assert run_gpu_text(fa, lines, A, F, E, flags=BF_FLAG_GROUPS_ALWAYS) == sv
 
