@@ -258,6 +258,7 @@ int bf_ctx_create(const bf_config* cfg, bf_ctx** out) {
         return fail(nullptr, BF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     bool ok = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) == hipSuccess;
     for (auto& e2 : ctx->ev) ok = ok && hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
     if (!ok) { bf_ctx_destroy(ctx); return fail(nullptr, BF_ERR_HIP, "could not create the copy stream / events"); }
     *out = ctx;
@@ -269,10 +270,12 @@ void bf_ctx_destroy(bf_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     drop_pending(ctx);
     free_all(ctx);
     for (auto& e2 : ctx->ev) if (e2) (void)hipEventDestroy(e2);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     delete reinterpret_cast<std::vector<PendingEvent>*>(ctx->timing_pending);

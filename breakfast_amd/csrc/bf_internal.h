@@ -162,6 +162,7 @@ struct bf_ctx {
     bf_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;          // small kernels that need not wait in line (print-order sorts beside the dedup)
     hipStream_t copy_stream = nullptr;          // result D2H, overlapped with the render kernel
     hipEvent_t ev[14] = {};                     // untimed events chaining the two streams
     std::string err;
@@ -263,11 +264,11 @@ struct Scope {
 };
 
 // Host code is single-threaded per ctx: while this object lives, everything queued through ctx->stream (and the
-// sort / scan workspace c_tmp) goes to the copy stream with a workspace of its own instead.
-struct OnCopyStream {
+// sort / scan workspace c_tmp) goes to the side stream with a workspace of its own instead.
+struct OnSideStream {
     bf_ctx* ctx;
-    explicit OnCopyStream(bf_ctx* c) : ctx(c) { std::swap(ctx->stream, ctx->copy_stream); std::swap(ctx->c_tmp, ctx->c_tmp2); }
-    ~OnCopyStream() { std::swap(ctx->stream, ctx->copy_stream); std::swap(ctx->c_tmp, ctx->c_tmp2); }
+    explicit OnSideStream(bf_ctx* c) : ctx(c) { std::swap(ctx->stream, ctx->side_stream); std::swap(ctx->c_tmp, ctx->c_tmp2); }
+    ~OnSideStream() { std::swap(ctx->stream, ctx->side_stream); std::swap(ctx->c_tmp, ctx->c_tmp2); }
 };
 
 // localise.hip ----------------------------------------------------------------------------------

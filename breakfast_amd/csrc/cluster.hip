@@ -740,18 +740,14 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
                        ctx->c_scan.as<uint64_t>(), ctx->c_csize.as<uint32_t>(), ctx->c_qseed.as<uint32_t>(),
                        ctx->c_qsize.as<uint32_t>(), n, wave_max, qbig);
     // The reference's print order of the QUALIFYING clusters (their seeds are known now; which of them survive
-    // the dedup only selects from this order): two small, latency-bound radix sorts, queued on the copy stream
+    // the dedup only selects from this order): two small, latency-bound radix sorts, queued on the side stream
     // so that they run beside the member / dedup kernels instead of after them.
     BF_TRY(ensure(ctx, ctx->c_qord, nq * 4));
     BF_TRY(ensure(ctx, ctx->c_misc, nq * 8 * 4));
-    // (with groups the copy stream is busy with the previous group's records: the sorts stay in line)
-    if (!grp) {
-        BF_HIP(ctx, hipEventRecord(ctx->ev[9], st));
-        BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[9], 0));
-    }
+    BF_HIP(ctx, hipEventRecord(ctx->ev[9], st));
+    BF_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev[9], 0));
     {
-        std::unique_ptr<OnCopyStream> aux;
-        if (!grp) aux.reset(new OnCopyStream(ctx));
+        OnSideStream aux(ctx);
         Scope t(ctx, "order");
         const hipStream_t as = ctx->stream;
         uint64_t* kpos = ctx->c_misc.as<uint64_t>();
@@ -768,7 +764,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
         BF_TRY(sort_pairs<uint64_t>(ctx, kidx, kidx2, va, vb, nq, 0, idx_bits));
         hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, kpos2, kpos, vb, nq);
         BF_TRY(sort_pairs<uint64_t>(ctx, kpos2, kidx2, vb, ctx->c_qord.as<uint32_t>(), nq, 0, 32 + ctx->contig_bits));
-        if (!grp) BF_HIP(ctx, hipEventRecord(ctx->ev[12], as));
+        BF_HIP(ctx, hipEventRecord(ctx->ev[12], as));
     }
     BF_TRY(scan_u32_to_u64(ctx, ctx->c_qsize.as<uint32_t>(), ctx->c_qoff.as<uint64_t>(), nq));
     BF_TRY(scan_u32_to_u64(ctx, qbig, qboff, nq));
@@ -809,7 +805,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
     uint64_t ns = 0, total_r = 0;
     BF_TRY(ensure(ctx, ctx->c_flag, std::max(nq, n) * 4, false));
     BF_TRY(ensure(ctx, ctx->c_ord, nq * 4));
-    if (!grp) BF_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[12], 0));
+    BF_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[12], 0));
     {
         Scope t(ctx, "select");
         const uint32_t* qord = ctx->c_qord.as<uint32_t>();
