@@ -650,6 +650,9 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
     if (n == 0) return BF_OK;
     if (n > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "too many evidence records for one GPU (%llu)", (unsigned long long)n);
     const unsigned B = 256;
+    // `cluster.len() < min_evidence` (detect.rs:229,231) is never true for 0, and a cluster always holds its seed:
+    // --min-evidence=0 prints what 1 prints.  (Unclamped, `csize >= 0` would also flag the non-seeds, whose csize is 0.)
+    const uint32_t min_evidence = std::max(ctx->cfg.min_evidence, 1u);
 
     // 1. stable sort by (key, lpos): LSD, lpos first
     BF_TRY(ensure(ctx, ctx->c_a32, n * 4)); BF_TRY(ensure(ctx, ctx->c_b32, n * 4));
@@ -720,7 +723,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
         hipLaunchKernelGGL(sweep_big_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, kBigSegment) / 4 + 1, 1024)), dim3(B), 0, st, sv,
                            ctx->c_reported.as<uint8_t>(), ctx->c_csize.as<uint32_t>(), big_list, counts);
         hipLaunchKernelGGL(flag_ge_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, B), kFlagGrid)), dim3(B), 0, st,
-                           ctx->c_flag.as<uint32_t>(), ctx->c_csize.as<uint32_t>(), ctx->cfg.min_evidence, n, wave_max, sums);
+                           ctx->c_flag.as<uint32_t>(), ctx->c_csize.as<uint32_t>(), min_evidence, n, wave_max, sums);
         BF_TRY(scan_u32_to_u64(ctx, ctx->c_flag.as<uint32_t>(), ctx->c_scan.as<uint64_t>(), n));
         // members of the qualifying clusters, and of those too large for the in-wave dedup: same synchronisation
         BF_HIP(ctx, hipMemcpyAsync(totals, sums, 16, hipMemcpyDeviceToHost, st));
@@ -810,7 +813,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
         Scope t(ctx, "select");
         const uint32_t* qord = ctx->c_qord.as<uint32_t>();
         hipLaunchKernelGGL(flag_ge_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(nq, B), kFlagGrid)), dim3(B), 0, st,
-                           ctx->c_flag.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>(), ctx->cfg.min_evidence, nq, 0u, sums + 2, qord);
+                           ctx->c_flag.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>(), min_evidence, nq, 0u, sums + 2, qord);
         BF_TRY(scan_u32_to_u64(ctx, ctx->c_flag.as<uint32_t>(), ctx->c_scan.as<uint64_t>(), nq));
         BF_HIP(ctx, hipMemcpyAsync(&total_r, sums + 2, 8, hipMemcpyDeviceToHost, st));   // the reads that will be printed
         BF_TRY(fetch_u64(ctx, ctx->c_scan.as<uint64_t>() + nq, &ns));

@@ -330,16 +330,20 @@ def hz_empty():
     f.write()
 
 
-def hz_min_evidence_1():
-    # min_evidence = 1: singletons are printed; frag-id duplicates still collapse
+def hz_min_evidence_1(E=1):
+    # min_evidence = 1: singletons are printed; frag-id duplicates still collapse.
+    # min_evidence = 0 (same input): `cluster.len() < 0` is never true (detect.rs:229,231), so the reference
+    # prints exactly what it prints for 1 -- asserted here.
     g, _ = base_genome(24)
-    f = Fixture("hz_min_evidence_1", g, (10, 100, 1))
+    f = Fixture("hz_min_evidence_%d" % E, g, (10, 100, E))
     f.add(b"x0", *split_read(g, b"chr1", 300, True, b"chr2", 200, True, 50, 20, 10))
     f.add(b"x1", *split_read(g, b"chr2", 100, False, b"chr1", 50, False, 50, 30, 10))
     f.add(b"x0", *split_read(g, b"chr1", 300, True, b"chr2", 200, True, 50, 24, 10))
     # same class but rpos further than max_frag_len=100 apart -> separate clusters
     f.add(b"x3", *split_read(g, b"chr2", 100, False, b"chr1", 350, False, 50, 30, 10))
-    f.write()
+    sv = f.write()
+    if E == 0:
+        assert sv == open(os.path.join(HERE, "hz_min_evidence_1.sv"), "rb").read()
 
 
 if __name__ == "__main__":
@@ -358,3 +362,4 @@ if __name__ == "__main__":
     hz_pairing()
     hz_empty()
     hz_min_evidence_1()
+    hz_min_evidence_1(E=0)

@@ -23,7 +23,8 @@ def test_header_symbols_are_all_exported():
     for s in syms:
         assert hasattr(lib, s), "libbreakfast_hip.so does not export %s" % s
     assert sorted(engine.ABI_SYMBOLS) == syms, "engine.ABI_SYMBOLS out of date with the header"
-    assert lib.bf_abi_version() == 4
+    header = open(os.path.join(ROOT, "include", "breakfast_hip.h")).read()
+    assert lib.bf_abi_version() == int(re.search(r"#define BF_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_struct_layouts_match_header():
