@@ -260,7 +260,13 @@ int bf_ctx_create(const bf_config* cfg, bf_ctx** out) {
     bool ok = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) == hipSuccess;
     for (auto& e2 : ctx->ev) ok = ok && hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&ctx->h_counts, 64, hipHostMallocDefault) == hipSuccess;
     if (!ok) { bf_ctx_destroy(ctx); return fail(nullptr, BF_ERR_HIP, "could not create the copy stream / events"); }
+    if (scratch_setup(ctx) != BF_OK) {               // the device is current (hipSetDevice above)
+        const std::string why = ctx->err;
+        bf_ctx_destroy(ctx);
+        return fail(nullptr, BF_ERR_HIP, "%s", why.c_str());
+    }
     *out = ctx;
     return BF_OK;
 }

@@ -188,7 +188,9 @@ struct bf_ctx {
     uint64_t n_exact = 0;
     uint64_t n_sigx = 0;                        // evidence whose signature holds a non-ACGT byte
     uint64_t n_text_records = 0;                // resident reads whose junction record cannot be packed
-    uint32_t* h_counts = nullptr;               // pinned: the localise kernels' counters on their way to the three fields above
+    uint32_t* h_counts = nullptr;               // pinned, 64 B (bf_ctx_create): words 0-2 the localise kernels' counters on their way
+                                                // to the three fields above, words 8-11 the read-backs of bf_render_junctions_dev_static
+    void* scratch = nullptr;                    // this device's copy of the static scratch array (localise.hip, scratch_setup)
     bool counts_pending = false;                // ... not yet read back: settle_counts() after the next synchronisation
     bf::DevBuf d_planes, d_len, d_frag_len, d_fhash;
     bf::DevBuf d_key, d_lpos, d_rpos, d_bp, d_flags, d_mask, d_jrec;   // d_jrec: read_info() words
@@ -285,6 +287,7 @@ int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_o
 
 int render_dev(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint64_t* d_off, uint8_t* d_bytes,
                uint64_t d_bytes_cap, uint64_t* total);
+int scratch_setup(bf_ctx* ctx);                     // this device's address of the static scratch array -> ctx->scratch
 
 // cluster.hip -----------------------------------------------------------------------------------
 // One group of whole contig ranks (api.hip cuts the evidence into a few, so that a group's result crosses PCIe
@@ -307,6 +310,8 @@ int radix_sort_pairs(bf_ctx* ctx, const uint32_t* kin, uint32_t* kout, const uin
 int radix_sort_pairs(bf_ctx* ctx, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n,
                      unsigned begin_bit, unsigned end_bit);
 int scan_u32_to_u64(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n);  // exclusive, out has n+1
+uint64_t scan_workspace_bytes(uint64_t n);
+int scan_u32_to_u64_ws(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* workspace);   // allocates nothing
 int scan_max_u32_inplace(bf_ctx* ctx, uint32_t* data, uint64_t n);                // running maximum
 int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
 int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n, uint64_t rd_base = 0, uint64_t byte_base = 0);

@@ -1095,7 +1095,6 @@ int run_localise(bf_ctx* ctx, bool defer_counts) {
         hipLaunchKernelGGL(localise_exact_kernel, dim3(blocks), dim3(256), 0, ctx->stream, e);
         BF_HIP(ctx, hipGetLastError());
     }
-    if (!ctx->h_counts) BF_HIP(ctx, hipHostMalloc((void**)&ctx->h_counts, 64, hipHostMallocDefault));
     BF_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counters.p, 12, hipMemcpyDeviceToHost, ctx->stream));
     ctx->counts_pending = true;
     ctx->localised = true;
@@ -1206,6 +1205,69 @@ int render_dev(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint64_t* d
     return BF_OK;
 }
 
+// ---- the entry point that allocates nothing (include/breakfast_hip.h, bf_render_junctions_dev_static) ----------
+// bf_render_junctions_dev keeps three things in device memory besides its inputs and outputs: one record size per
+// list entry, the tile totals of the scan that turns sizes into offsets, and the counter of bad indices.  Here
+// they live in a file-scope device array, so the call needs no hipMalloc.  In host code the array's NAME is a
+// host-side stand-in, not a device address: the address of this device's copy comes from hipGetSymbolAddress,
+// once per device (scratch_setup, called by bf_ctx_create with the ctx's device current), and only that pointer
+// is ever handed to a kernel, a memset or a copy.
+constexpr uint64_t kStaticMaxReads = BF_STATIC_RENDER_MAX_READS;
+constexpr uint64_t kStaticLenBytes = kStaticMaxReads * 4;                              // u32 record size per list entry
+constexpr uint64_t kStaticScanBytes = ((kStaticMaxReads + 4095) / 4096) * 8 + 256;     // = scan_workspace_bytes(max)
+constexpr uint64_t kStaticScratchBytes = kStaticLenBytes + kStaticScanBytes + 256;     // + the bad-index counter
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+int scratch_setup(bf_ctx* ctx) {
+    void* ptr = nullptr;
+    BF_HIP(ctx, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(ctx, BF_ERR_HIP, "hipGetSymbolAddress gave no address for the static scratch array");
+    ctx->scratch = ptr;                               // every GPU holds its own copy at its own address: one ctx, one device
+    return BF_OK;
+}
+
+static int render_dev_static(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint64_t* d_off, uint8_t* d_bytes,
+                             uint64_t d_bytes_cap, uint64_t* total) {
+    *total = 0;
+    if (n > kStaticMaxReads)
+        return fail(ctx, BF_ERR_RANGE, "bf_render_junctions_dev_static: %llu reads in one call; the static scratch buffer holds %llu "
+                    "(use bf_render_junctions_dev, or several calls)", (unsigned long long)n, (unsigned long long)kStaticMaxReads);
+    if (scan_workspace_bytes(n) > kStaticScanBytes) return fail(ctx, BF_ERR_RANGE, "bf_render_junctions_dev_static: scan workspace");
+    if (!ctx->scratch || !ctx->h_counts) return fail(ctx, BF_ERR_STATE, "bf_render_junctions_dev_static: the ctx has no scratch pointer");
+    if (n == 0) {
+        BF_HIP(ctx, hipMemsetAsync(d_off, 0, 8, ctx->stream));
+        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return BF_OK;
+    }
+    uint8_t* base = (uint8_t*)ctx->scratch;           // never the array's name
+    uint32_t* d_len = (uint32_t*)base;
+    uint64_t* d_scan = (uint64_t*)(base + kStaticLenBytes);
+    uint32_t* d_bad = (uint32_t*)(base + kStaticLenBytes + kStaticScanBytes);
+    // the array keeps the previous call's contents: the counter must start at zero; sizes and tile totals are
+    // written for [0, n) before they are read
+    BF_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(render_len_checked_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
+                       ctx->d_jrec.as<uint64_t>(), ctx->n_reads, d_len, d_bad);
+    BF_TRY(scan_u32_to_u64_ws(ctx, d_len, d_off, n, d_scan));
+    // read-backs through the ctx's pinned words (a copy to pageable memory may stage through memory the runtime allocates)
+    volatile uint32_t* hw = ctx->h_counts + 8;
+    BF_HIP(ctx, hipMemcpyAsync((void*)(ctx->h_counts + 8), d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BF_HIP(ctx, hipMemcpyAsync((void*)(ctx->h_counts + 10), d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t tot = (uint64_t)hw[0] | ((uint64_t)hw[1] << 32);
+    const uint32_t bad = hw[2];
+    *total = tot;
+    if (bad) return fail(ctx, BF_ERR_INVALID, "bf_render_junctions_dev_static: %u of %llu indices are outside the %llu resident reads",
+                         bad, (unsigned long long)n, (unsigned long long)ctx->n_reads);
+    if (!d_bytes) return BF_OK;
+    if (d_bytes_cap < tot)
+        return fail(ctx, BF_ERR_INVALID, "bf_render_junctions_dev_static: buffer of %llu bytes, %llu needed",
+                    (unsigned long long)d_bytes_cap, (unsigned long long)tot);
+    BF_TRY(launch_render(ctx, n, d_local_idx, d_off, d_bytes));      // no timing scope: events would be created
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BF_OK;
+}
+
 int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, DevBuf& d_bytes,
                uint64_t* total_bytes) {
     uint64_t off[2];
@@ -1216,3 +1278,15 @@ int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_o
 }
 
 }  // namespace bf
+
+extern "C" int bf_render_junctions_dev_static(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_index, uint64_t* dev_off,
+                                              uint8_t* dev_bytes, uint64_t dev_bytes_cap, uint64_t* total) {
+    using namespace bf;
+    if (!ctx || !total) return BF_ERR_INVALID;
+    if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_render_junctions_dev_static before bf_localise");
+    if (!dev_off || (n && !dev_local_index)) return fail(ctx, BF_ERR_INVALID, "bf_render_junctions_dev_static: null argument");
+    if (((uintptr_t)dev_bytes & 3) || ((uintptr_t)dev_off & 7) || ((uintptr_t)dev_local_index & 3))
+        return fail(ctx, BF_ERR_INVALID, "bf_render_junctions_dev_static: dev_bytes/dev_local_index must be 4-byte and dev_off 8-byte aligned");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    return render_dev_static(ctx, n, dev_local_index, dev_off, dev_bytes, dev_bytes_cap, total);
+}

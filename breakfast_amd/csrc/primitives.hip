@@ -350,12 +350,15 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, Out
         if (first + i < n) out[first + i] = (Out)Op::apply(before, v[i]);
 }
 
+// `tot`: workspace of scan_workspace_bytes(n) bytes (one total per tile); nullptr = the ctx's own (c_tmp, grown on demand)
 template <class Op, class Out>
-static int scan_impl(bf_ctx* ctx, const uint32_t* in, Out* out, uint64_t n) {
+static int scan_impl(bf_ctx* ctx, const uint32_t* in, Out* out, uint64_t n, uint64_t* tot = nullptr) {
     if (n == 0) return BF_OK;
     const uint64_t tiles = (n + kScanTile - 1) / kScanTile;
-    BF_TRY(ensure(ctx, ctx->c_tmp, tiles * 8 + 256, false));
-    uint64_t* tot = ctx->c_tmp.as<uint64_t>();
+    if (!tot) {
+        BF_TRY(ensure(ctx, ctx->c_tmp, tiles * 8 + 256, false));
+        tot = ctx->c_tmp.as<uint64_t>();
+    }
     hipLaunchKernelGGL((scan_totals_kernel<Op>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, in, n, tot);
     hipLaunchKernelGGL((scan_carry_kernel<Op>), dim3(1), dim3(256), 0, ctx->stream, tot, tiles);
     hipLaunchKernelGGL((scan_apply_kernel<Op, Out>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, in, out, n, tot);
@@ -367,6 +370,13 @@ static int scan_impl(bf_ctx* ctx, const uint32_t* in, Out* out, uint64_t n) {
 int scan_u32_to_u64(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n) {
     BF_HIP(ctx, hipMemsetAsync(out, 0, 8, ctx->stream));
     return scan_impl<OpSumU64, uint64_t>(ctx, in, out + 1, n);
+}
+
+// the same with the tile totals in caller-provided device memory: allocates nothing
+uint64_t scan_workspace_bytes(uint64_t n) { return ((n + kScanTile - 1) / kScanTile) * 8 + 256; }
+int scan_u32_to_u64_ws(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* workspace) {
+    BF_HIP(ctx, hipMemsetAsync(out, 0, 8, ctx->stream));
+    return scan_impl<OpSumU64, uint64_t>(ctx, in, out + 1, n, workspace);
 }
 
 // data[i] = max(data[0..i]), in place (a tile reads its elements before it writes them; tiles are disjoint)

@@ -76,6 +76,7 @@ ABI_SYMBOLS = [
     "bf_evidence_fetch", "bf_kernel_times", "bf_stats", "bf_junction_text", "bf_result_junction_text",
     "bf_result_junction_sizes_dev", "bf_result_layout_dev", "bf_result_attach_records_dev", "bf_result_requests_dev",
     "bf_result_attach_finish", "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
+    "bf_render_junctions_dev_static",
 ]
 
 _lib = None
@@ -131,6 +132,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_render_junctions.argtypes = [vp, C.c_uint64, vp, C.POINTER(vp), C.POINTER(vp)]
     lib.bf_result_sources_dev.argtypes = [vp, vp, vp]
     lib.bf_render_junctions_dev.argtypes = [vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]
+    lib.bf_render_junctions_dev_static.argtypes = [vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]
     lib.bf_result_attach_junctions_dev.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(BfResult)]
     lib.bf_junction_record_bytes.argtypes = [vp, C.c_uint64]
     lib.bf_junction_record_bytes.restype = C.c_int64
@@ -478,6 +480,13 @@ class Engine:
         total = C.c_uint64()
         self._check(self.lib.bf_render_junctions_dev(self.h, n, C.c_void_p(dev_index or None), C.c_void_p(dev_off),
                                                      C.c_void_p(dev_bytes or None), cap, C.byref(total)))
+        return int(total.value)
+
+    def render_junctions_dev_static(self, n: int, dev_index: int, dev_off: int, dev_bytes: int = 0, cap: int = 0) -> int:
+        """bf_render_junctions_dev_static: the same call on the library's static scratch array (allocates nothing)."""
+        total = C.c_uint64()
+        self._check(self.lib.bf_render_junctions_dev_static(self.h, n, C.c_void_p(dev_index or None), C.c_void_p(dev_off),
+                                                            C.c_void_p(dev_bytes or None), cap, C.byref(total)))
         return int(total.value)
 
     def attach_junctions_dev(self, dev_joff: int, dev_bytes: int, size: int, copy: bool = False) -> Result:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 4
+#define BF_ABI_VERSION 5
 
 enum {
     BF_OK = 0,
@@ -275,6 +275,18 @@ int bf_result_sources_dev(bf_ctx* ctx, uint32_t* dev_src_rank, uint32_t* dev_src
  * dev_bytes and dev_local_index must be 4-byte aligned, dev_off 8-byte aligned. */
 int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_index, uint64_t* dev_off,
                             uint8_t* dev_bytes, uint64_t dev_bytes_cap, uint64_t* total);
+
+/* bf_render_junctions_dev for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same results, but
+ * the call makes no hipMalloc / hipFree / hipHostMalloc and creates no events: the per-entry record sizes, the
+ * scan's tile totals and the bad-index counter -- which bf_render_junctions_dev keeps in ctx-owned device memory
+ * that grows on demand -- live in a static device array of 4 MiB + 2.5 KiB that every GPU the library runs on holds
+ * until the process ends.  At most BF_STATIC_RENDER_MAX_READS list entries per call (BF_ERR_RANGE beyond; split
+ * the list).  All ctxs of a process on one GPU share that GPU's array: calls that overlap on one GPU race (the
+ * array is not locked); one after the other they are independent (what must start at zero is cleared). */
+#define BF_STATIC_RENDER_MAX_READS (1u << 20)
+int bf_render_junctions_dev_static(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_index, uint64_t* dev_off,
+                                   uint8_t* dev_bytes, uint64_t dev_bytes_cap, uint64_t* total);
 
 /* On an owner rank, after the junction records of its supporting reads have arrived in device memory:
  * dev_joff[i] locates read i's record inside dev_bytes (size bytes).  Patches the read table, copies
