@@ -10,7 +10,14 @@ workload configs[1]: 10M unaligned 2x150 bp reads with anchor hits on an hg38-si
 step     one pass of the hot path over the resident batch: encode + localise (+ exact path) ->
          [N>1: pack, all-to-all, import] -> sort -> sweep -> dedup -> order -> junction strings ->
          cluster table in host memory.  Inputs (ASCII reads, fragment ids, hit records, packed
-         genome) are resident in HBM before the timed region starts.
+         genome) are resident in HBM before the timed region starts: that is `value`, as the round's
+         measurement contract words it.
+host_to_host  SURVEY.md section 8d's own wording of the metric -- parsed anchor-hit batches in HOST memory in,
+         cluster table in host memory out -- measured in the same run (one GPU): every step is bf_reset +
+         bf_submit of the whole batch (asynchronous, piece by piece, the per-read kernels queued behind every
+         uploaded piece) + bf_finish.  Reported for batches in bf_host_alloc (pinned) memory, which is what a
+         parser that writes into the library's buffers holds, and for ordinary pageable arrays (staged through
+         pinned slots by host threads).  PCIe bounds both; `value` never includes them.
 roofline the dominant kernel, `localise`: algorithmic bytes/read (SURVEY.md section 8d,
          B_A(L) = ceil(L/2) + 2*ceil(L/4) + 16 + 16 + ceil(L/8) = 202 B at L=150) x reads / its average
          duration measured with HIP events on the library's stream, against 8 TB/s HBM3E.
@@ -81,6 +88,8 @@ def main():
                     help="fraction of the genome in lowercase (soft-masked repeats, as in UCSC hg38.fa), in runs of 300-30000 "
                          "bases; 0 = the all-uppercase genome of BASELINE's config (diagnostic for the byte-exact path)")
     ap.add_argument("--check", action="store_true", help="also compare the GPU .sv with the oracle's on the sample")
+    ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host loops (resident-input value only)")
+    ap.add_argument("--host-threads", type=int, default=0, help="staging threads of bf_submit (0 = library default)")
     args = ap.parse_args()
 
     rank, world, local = init_from_env()
@@ -129,7 +138,7 @@ def main():
 
     # ---- resident inputs -------------------------------------------------------------------------
     routing = engine.BF_FLAG_DEVICE_ROUTING if (world > 1 or forced) else 0
-    eng = engine.Engine(A, 5000, 2, device=local, groups=args.groups, flags=routing | {"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER,
+    eng = engine.Engine(A, 5000, 2, device=local, groups=args.groups, host_threads=args.host_threads, flags=routing | {"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER,
                                                                                "exact": engine.BF_FLAG_FORCE_EXACT}[args.variant])
     t2 = time.time()
     eng.set_genome(genome.names, genome.seqs)
@@ -140,8 +149,10 @@ def main():
     chunk = 1 << 21
     for a in range(0, n_local, chunk):
         eng.submit(batch.slice(a, min(n_local, a + chunk)))
-    log(rank, "reads resident in HBM in %.1fs (host->device rate %.2f GB/s incl. pageable staging)" %
-        (time.time() - t3, (batch.seq_bytes.nbytes + batch.frag_bytes.nbytes) / 1e9 / max(time.time() - t3, 1e-9)))
+    eng.submit_wait()
+    in_bytes = sum(x.nbytes for x in (batch.seq_bytes, batch.seq_off, batch.frag_bytes, batch.frag_off, batch.hits))
+    log(rank, "reads resident in HBM in %.2fs (first hand-over, buffers still growing: %.2f GB/s)" %
+        (time.time() - t3, in_bytes / 1e9 / max(time.time() - t3, 1e-9)))
 
     if world > 1 or forced:
         stage = HipStageEngine(eng, dev)
@@ -191,6 +202,40 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_reads * args.steps / elapsed
 
+    # ---- host memory in, host memory out (SURVEY 8d's wording), one GPU -------------------------------
+    h2h = None
+    if not sharded and not args.no_h2h:
+        def timed(source, name):
+            def one():
+                eng.reset()
+                eng.submit(source)
+                return eng.finish_raw()
+            for _ in range(max(args.warmup, 1)):
+                one()
+            eng.kernel_times()
+            barrier()
+            t0_ = time.perf_counter()
+            for _ in range(args.steps):
+                r_ = one()
+            barrier()
+            dt = (time.perf_counter() - t0_) / args.steps
+            kt = eng.kernel_times()
+            assert int(r_.n_clusters) == n_clusters and int(r_.n_reads) == n_support, "host-to-host result differs"
+            log(rank, "%s: %.2f ms per step, %.1f M reads/s, h2d %.2f ms (%.1f GB/s)" %
+                (name, dt * 1e3, n_local / dt / 1e6, kt.get("h2d", (0, 1))[0] / args.steps,
+                 in_bytes / 1e9 / max(kt.get("h2d", (0, 1))[0] / args.steps * 1e-3, 1e-9)))
+            return {"value": round(n_local / dt, 1), "unit": "reads/s", "ms_per_step": round(dt * 1e3, 3),
+                    "stage_ms": {k: round(v[0] / args.steps, 4) for k, v in kt.items()}}
+        t4 = time.time()
+        pinned = eng.pin_batch(batch)
+        log(rank, "batch copied into bf_host_alloc memory in %.1fs" % (time.time() - t4))
+        h2h = timed(pinned, "host-to-host, pinned batches")
+        h2h["input"] = "the whole batch in bf_host_alloc (pinned) memory, one bf_submit per step"
+        h2h["input_bytes"] = int(in_bytes)
+        h2h["pcie_bound_ms"] = round(in_bytes / 55e9 * 1e3, 2)       # ~55 GB/s achievable on PCIe 5.0 x16
+        h2h["pageable"] = timed(batch, "host-to-host, pageable batches")
+        h2h["pageable"]["input"] = "the same batch in ordinary numpy arrays, staged by the library's host threads"
+
     # ---- roofline of the dominant kernel -----------------------------------------------------------
     loc_ms, loc_n = ktimes.get("localise", (0.0, 0))
     loc_avg_ms = loc_ms / max(loc_n, 1)
@@ -211,13 +256,15 @@ def main():
         sample = batch.slice(0, ns)
         og = ol.OracleGenome(genome.names, genome.seqs)
         tc = time.perf_counter()
-        ref = ol.detect_batch(og, genome.names, sample, A, 5000, 2)
+        ref = ol.detect_batch(og, genome.names, sample, A, 5000, 2, stage=3)
         dt = time.perf_counter() - tc
         cpu = {"value": round(ns / dt, 1), "unit": "reads/s", "cores": 1, "kind": "port",
-               "sample": "first %d reads of the same batch (localise + sort + cluster + dedup + .sv text), "
-                         "C++ restatement of detect.rs:105-287, single thread, %.1fs" % (ns, dt),
+               "sample": "first %d reads of the same batch, the GPU step's scope (localise + sort + cluster + dedup -> "
+                         "cluster table, no .sv text), C++ restatement of detect.rs:105-287, single thread, %.1fs"
+                         % (ns, dt),
                "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
         if args.check:
+            ref = ol.detect_batch(og, genome.names, sample, A, 5000, 2)
             e2 = engine.Engine(A, 5000, 2, device=local)
             e2.set_genome(genome.names, genome.seqs)
             e2.submit(sample)
@@ -238,7 +285,8 @@ def main():
                        "reads_per_gpu": n_local, "read_len": L, "anchor_len": A, "max_frag_len": 5000, "min_evidence": 2,
                        "parallelism": "shard%d+alltoall" % world if sharded else "single"},
             "result": {"clusters": n_clusters, "supporting_reads": n_support},
-            "stage_ms": stages, "roofline": roofline, "cpu_baseline": cpu,
+            "stage_ms": stages, "roofline": roofline, "cpu_baseline": cpu, "host_to_host": h2h,
+            "pipeline": pipeline_headline(n_local, L, ms_per_step),
             **({"phase_ms": {k: round(v / args.steps, 3) for k, v in dd.phase_ms.items()}} if sharded_run and args.phases else {}),
             "published_reference": "~40M BAM reads/min/core whole-file scan (README.md:6), a different stage",
         }
@@ -247,6 +295,15 @@ def main():
     eng.close()
     if world > 1 or forced:
         dist.destroy_process_group()
+
+
+def pipeline_headline(n_local, L, ms_per_step):
+    """SURVEY.md section 8d's pipeline headline: N * (B_A + B_S) / t_device_pipeline, B_S = 424 B/read as the survey
+    prices an 8-bit-digit LSD sort of the full key (this library sorts 8 passes, not 12; the figure is the survey's)."""
+    b_a, b_s = algorithmic_bytes_per_read(L), 424
+    gbps = n_local * (b_a + b_s) / (ms_per_step * 1e-3) / 1e9
+    return {"algorithmic_bytes_per_read": b_a + b_s, "achieved": round(gbps, 1), "unit": "GB/s",
+            "frac": round(gbps / HBM_PEAK_GBPS, 4), "note": "whole device pipeline incl. the PCIe copy of the result"}
 
 
 def pmc_traffic(args, n_local, L):

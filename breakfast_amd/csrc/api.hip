@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <numeric>
 #include <thread>
 
@@ -259,6 +260,12 @@ int bf_ctx_create(const bf_config* cfg, bf_ctx** out) {
     }
     bool ok = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) == hipSuccess;
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        ctx->host_threads = cfg->reserved[1] ? std::min<uint32_t>(cfg->reserved[1], 64u) : std::max(1u, std::min(hw ? hw : 1u, 16u));
+    }
     for (auto& e2 : ctx->ev) ok = ok && hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&ctx->h_counts, 64, hipHostMallocDefault) == hipSuccess;
     if (!ok) { bf_ctx_destroy(ctx); return fail(nullptr, BF_ERR_HIP, "could not create the copy stream / events"); }
@@ -277,7 +284,14 @@ void bf_ctx_destroy(bf_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
+    if (ctx->in_stream) (void)hipStreamSynchronize(ctx->in_stream);
     drop_pending(ctx);
+    for (auto& sl : ctx->slots) { if (sl.p) (void)hipHostFree(sl.p); if (sl.ev) (void)hipEventDestroy(sl.ev); }
+    ctx->slots.clear();
+    for (auto& pr : ctx->pinned) (void)hipHostFree((void*)pr.first);
+    ctx->pinned.clear();
+    if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
+    if (ctx->in_stream) (void)hipStreamDestroy(ctx->in_stream);
     free_all(ctx);
     for (auto& e2 : ctx->ev) if (e2) (void)hipEventDestroy(e2);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -350,11 +364,170 @@ int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, con
 
 int bf_reset(bf_ctx* ctx) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_HIP(ctx, hipStreamSynchronize(ctx->in_stream));
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->in_pending = false; ctx->n_localised = 0; ctx->consumed = false;
     ctx->n_reads = 0; ctx->seq_bytes = 0; ctx->frag_bytes = 0;
     ctx->max_len = 0; ctx->min_len = 0xffffffffu; ctx->max_frag = 0;
     ctx->localised = false; ctx->imported = false; ctx->clustered = false; ctx->n_imported = 0; ctx->n_exact = 0;
     ctx->out.n_clusters = ctx->out.n_reads = ctx->out.junction_size = 0;
+    return BF_OK;
+}
+
+// ---- bf_submit: the host -> device hand-over ---------------------------------------------------------------------
+// The reference consumes reads as Bowtie emits them (detect.rs:76-188).  Here a batch is cut into pieces of
+// kPieceReads reads; every piece is validated and uploaded on in_stream -- bytes the caller keeps in
+// bf_host_alloc memory straight from there, everything else through a ring of pinned staging slots that a few
+// host threads fill (a single thread copies at ~10 GB/s, PCIe takes 55) -- and the packed kernel for the piece is
+// queued behind its upload, so that the reads of piece k are localised while piece k+1 is still on PCIe.
+// bf_finish is then left with the last piece, the exact kernel and the cluster stage.
+constexpr size_t kStageSlotBytes = 8u << 20;
+constexpr uint64_t kPieceReads = 1u << 20;        // also the granularity of the eager localise launches
+constexpr uint64_t kEagerReads = 1u << 18;        // smaller submits are gathered up to this many before a launch
+constexpr uint64_t kInlineBytes = 1u << 20;       // pieces below this are staged by the calling thread
+
+static bool is_pinned(const bf_ctx* ctx, const void* p, size_t n) {
+    const uint8_t* b = (const uint8_t*)p;
+    for (auto& r : ctx->pinned) if (b >= r.first && b + n <= r.first + r.second) return true;
+    return false;
+}
+
+struct SubmitJob {
+    int kind;              // 0: offsets + hits of reads [a, b); 1: sequence bytes [a, b); 2: fragment id bytes [a, b)
+    uint64_t a, b;
+};
+
+struct SubmitShared {
+    bf_ctx* ctx; const bf_batch* bat;
+    uint64_t r_base;       // first read of the piece inside the batch
+    uint64_t n0, seq0, frag0;          // resident reads / bytes before the BATCH
+    bool hits_direct;
+    std::vector<SubmitJob> jobs;
+    std::atomic<size_t> next{0};
+    std::mutex mu;
+    uint64_t err_read = ~0ull; int err_code = BF_OK; std::string err_msg;
+    uint32_t mx = 0, mn = 0xffffffffu, mf = 0;
+    void error(uint64_t read, int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        std::lock_guard<std::mutex> g(mu);
+        if (read < err_read) { err_read = read; err_code = code; err_msg = buf; }     // the first offending read names the error
+    }
+};
+
+static bool slot_ready(bf_ctx* ctx, bf_ctx::StageSlot& sl) {
+    if (!sl.p) {
+        if (hipHostMalloc((void**)&sl.p, kStageSlotBytes, hipHostMallocDefault) != hipSuccess) { sl.p = nullptr; return false; }
+        if (hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) return false;
+    }
+    if (sl.used && hipEventSynchronize(sl.ev) != hipSuccess) return false;     // its previous upload has left the slot
+    (void)ctx;
+    return true;
+}
+
+static void submit_worker(SubmitShared* sh, int slot_id) {
+    bf_ctx* ctx = sh->ctx;
+    const bf_batch* b = sh->bat;
+    if (hipSetDevice(ctx->device) != hipSuccess) { sh->error(0, BF_ERR_HIP, "hipSetDevice failed in a staging thread"); return; }
+    bf_ctx::StageSlot& sl = ctx->slots[slot_id];
+    uint32_t mx = 0, mn = 0xffffffffu, mf = 0;
+    for (size_t j; (j = sh->next.fetch_add(1)) < sh->jobs.size();) {
+        const SubmitJob& job = sh->jobs[j];
+        if (!slot_ready(ctx, sl)) { sh->error(job.a, BF_ERR_NOMEM, "pinned staging memory is not available"); return; }
+        hipError_t e = hipSuccess;
+        if (job.kind == 0) {
+            // offsets rebased onto the resident arrays, lengths and hits validated on the way (detect.rs:92, :115)
+            const uint64_t cnt = job.b - job.a;
+            const uint64_t n_off = cnt + 1;                  // entry job.b too: every job's reads are complete in themselves
+            uint64_t* so = (uint64_t*)sl.p;
+            uint64_t* fo = so + (cnt + 1);
+            bf_hit* hh = (bf_hit*)(fo + (cnt + 1));
+            const uint64_t s0 = b->seq_off[0], f0 = b->frag_off[0];
+            bool ok = true;
+            for (uint64_t i = job.a; i < job.b; i++) {
+                const uint64_t sa = b->seq_off[i], sb = b->seq_off[i + 1], fa = b->frag_off[i], fb = b->frag_off[i + 1];
+                if (sb < sa || fb < fa) { sh->error(i, BF_ERR_INVALID, "bf_submit: offsets not monotone at read %llu", (unsigned long long)i); ok = false; break; }
+                const uint64_t L = sb - sa, fl = fb - fa;
+                if (L > 65535) { sh->error(i, BF_ERR_RANGE, "read %llu has %llu bases; at most 65535 are supported", (unsigned long long)i, (unsigned long long)L); ok = false; break; }
+                if (fl > 65535) { sh->error(i, BF_ERR_RANGE, "fragment id of read %llu has %llu bytes; at most 65535", (unsigned long long)i, (unsigned long long)fl); ok = false; break; }
+                mx = std::max<uint32_t>(mx, (uint32_t)L); mn = std::min<uint32_t>(mn, (uint32_t)L); mf = std::max<uint32_t>(mf, (uint32_t)fl);
+                const bf_hit& h = b->hits[i];
+                if (h.contig5 >= ctx->n_contigs || h.contig3 >= ctx->n_contigs) {
+                    sh->error(i, BF_ERR_INVALID, "read %llu names contig id %u/%u but the genome has %u contigs (the reference panics on an unknown contig, detect.rs:115)",
+                              (unsigned long long)i, h.contig5, h.contig3, ctx->n_contigs);
+                    ok = false; break;
+                }
+                if (h.pos5 >= 0x80000000u || h.pos3 >= 0x80000000u) { sh->error(i, BF_ERR_RANGE, "read %llu: anchor position >= 2^31", (unsigned long long)i); ok = false; break; }
+                so[i - job.a] = sh->seq0 + (sa - s0);
+                fo[i - job.a] = sh->frag0 + (fa - f0);
+                if (!sh->hits_direct) hh[i - job.a] = h;
+            }
+            if (!ok) return;
+            so[cnt] = sh->seq0 + (b->seq_off[job.b] - s0); fo[cnt] = sh->frag0 + (b->frag_off[job.b] - f0);
+            e = hipMemcpyAsync(ctx->d_seq_off.as<uint64_t>() + sh->n0 + job.a, so, n_off * 8, hipMemcpyHostToDevice, ctx->in_stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_frag_off.as<uint64_t>() + sh->n0 + job.a, fo, n_off * 8, hipMemcpyHostToDevice, ctx->in_stream);
+            if (e == hipSuccess && !sh->hits_direct)
+                e = hipMemcpyAsync(ctx->d_hits.as<bf_hit>() + sh->n0 + job.a, hh, cnt * sizeof(bf_hit), hipMemcpyHostToDevice, ctx->in_stream);
+        } else {
+            const uint8_t* src = job.kind == 1 ? b->seq_bytes + b->seq_off[0] : b->frag_bytes + b->frag_off[0];
+            uint8_t* dst = job.kind == 1 ? ctx->d_seq.as<uint8_t>() + sh->seq0 : ctx->d_frag.as<uint8_t>() + sh->frag0;
+            memcpy(sl.p, src + job.a, job.b - job.a);
+            e = hipMemcpyAsync(dst + job.a, sl.p, job.b - job.a, hipMemcpyHostToDevice, ctx->in_stream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(sl.ev, ctx->in_stream);
+        if (e != hipSuccess) { sh->error(job.a, BF_ERR_HIP, "upload failed: %s", hipGetErrorString(e)); return; }
+        sl.used = true;
+    }
+    std::lock_guard<std::mutex> g(sh->mu);
+    sh->mx = std::max(sh->mx, mx); sh->mn = std::min(sh->mn, mn); sh->mf = std::max(sh->mf, mf);
+}
+
+static int reserve_input(bf_ctx* ctx, uint64_t reads, uint64_t seq_bytes, uint64_t frag_bytes) {
+    if (reads > ctx->cap_reads) BF_TRY(grow_reads(ctx, std::max<uint64_t>({reads, ctx->cap_reads * 2, (uint64_t)1 << 16})));
+    if (seq_bytes + 64 > ctx->d_seq.cap || frag_bytes + 64 > ctx->d_frag.cap || !ctx->d_seq.p || !ctx->d_frag.p) {
+        BF_HIP(ctx, hipStreamSynchronize(ctx->in_stream));
+        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (seq_bytes + 64 > ctx->d_seq.cap || !ctx->d_seq.p) BF_TRY(ensure(ctx, ctx->d_seq, std::max<uint64_t>(seq_bytes + 64, ctx->d_seq.cap * 2), true));
+        if (frag_bytes + 64 > ctx->d_frag.cap || !ctx->d_frag.p) BF_TRY(ensure(ctx, ctx->d_frag, std::max<uint64_t>(frag_bytes + 64, ctx->d_frag.cap * 2), true));
+    }
+    return BF_OK;
+}
+
+int bf_reserve(bf_ctx* ctx, uint64_t n_reads, uint64_t seq_bytes, uint64_t frag_bytes) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (n_reads > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "more than 2^32-16 reads in one ctx");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    return reserve_input(ctx, n_reads, seq_bytes, frag_bytes);
+}
+
+int bf_host_alloc(bf_ctx* ctx, uint64_t bytes, void** out) {
+    if (!ctx || !out) return BF_ERR_INVALID;
+    *out = nullptr;
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, std::max<uint64_t>(bytes, 64), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, BF_ERR_NOMEM, "hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    ctx->pinned.emplace_back((const uint8_t*)p, (size_t)std::max<uint64_t>(bytes, 64));
+    *out = p;
+    return BF_OK;
+}
+
+int bf_host_free(bf_ctx* ctx, void* p) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!p) return BF_OK;
+    for (size_t i = 0; i < ctx->pinned.size(); i++)
+        if (ctx->pinned[i].first == (const uint8_t*)p) {
+            BF_HIP(ctx, hipStreamSynchronize(ctx->in_stream));       // no upload may still be reading it
+            (void)hipHostFree(p);
+            ctx->pinned.erase(ctx->pinned.begin() + (long)i);
+            return BF_OK;
+        }
+    return fail(ctx, BF_ERR_INVALID, "bf_host_free: not a bf_host_alloc pointer of this ctx");
+}
+
+int bf_submit_wait(bf_ctx* ctx) {
+    if (!ctx) return BF_ERR_INVALID;
+    BF_HIP(ctx, hipStreamSynchronize(ctx->in_stream));
     return BF_OK;
 }
 
@@ -366,48 +539,92 @@ int bf_submit(bf_ctx* ctx, const bf_batch* b) {
     if (m == 0) return BF_OK;
     if (!b->seq_bytes || !b->seq_off || !b->frag_off || !b->hits) return fail(ctx, BF_ERR_INVALID, "bf_submit: null array");
     if (ctx->n_reads + m > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "more than 2^32-16 reads in one ctx");
-    BF_HIP(ctx, hipSetDevice(ctx->device));
-    // validate + rebase offsets
-    std::vector<uint64_t> so(m + 1), fo(m + 1);
-    uint32_t mx = ctx->max_len, mn = ctx->min_len, mf = ctx->max_frag;
-    for (uint64_t i = 0; i <= m; i++) {
-        so[i] = ctx->seq_bytes + (b->seq_off[i] - b->seq_off[0]);
-        fo[i] = ctx->frag_bytes + (b->frag_off[i] - b->frag_off[0]);
-        if (i) {
-            if (b->seq_off[i] < b->seq_off[i - 1] || b->frag_off[i] < b->frag_off[i - 1])
-                return fail(ctx, BF_ERR_INVALID, "bf_submit: offsets not monotone at read %llu", (unsigned long long)(i - 1));
-            const uint64_t L = b->seq_off[i] - b->seq_off[i - 1], fl = b->frag_off[i] - b->frag_off[i - 1];
-            if (L > 65535) return fail(ctx, BF_ERR_RANGE, "read %llu has %llu bases; at most 65535 are supported", (unsigned long long)(i - 1), (unsigned long long)L);
-            if (fl > 65535) return fail(ctx, BF_ERR_RANGE, "fragment id of read %llu has %llu bytes; at most 65535", (unsigned long long)(i - 1), (unsigned long long)fl);
-            mx = std::max<uint32_t>(mx, (uint32_t)L); mn = std::min<uint32_t>(mn, (uint32_t)L); mf = std::max<uint32_t>(mf, (uint32_t)fl);
-        }
-    }
-    if (mn < 2 * ctx->cfg.anchor_len)
-        return fail(ctx, BF_ERR_RANGE, "a read of length %u is shorter than 2 * anchor_len = %u (detect.rs:311 never emits such reads)", mn, 2 * ctx->cfg.anchor_len);
-    for (uint64_t i = 0; i < m; i++) {
-        const bf_hit& h = b->hits[i];
-        if (h.contig5 >= ctx->n_contigs || h.contig3 >= ctx->n_contigs)
-            return fail(ctx, BF_ERR_INVALID, "read %llu names contig id %u/%u but the genome has %u contigs (the reference panics on an unknown contig, detect.rs:115)",
-                        (unsigned long long)i, h.contig5, h.contig3, ctx->n_contigs);
-        if (h.pos5 >= 0x80000000u || h.pos3 >= 0x80000000u)
-            return fail(ctx, BF_ERR_RANGE, "read %llu: anchor position >= 2^31", (unsigned long long)i);
-    }
+    if (b->seq_off[m] < b->seq_off[0] || b->frag_off[m] < b->frag_off[0]) return fail(ctx, BF_ERR_INVALID, "bf_submit: offsets not monotone");
     const uint64_t sb = b->seq_off[m] - b->seq_off[0], fb = b->frag_off[m] - b->frag_off[0];
     if (fb && !b->frag_bytes) return fail(ctx, BF_ERR_INVALID, "bf_submit: null frag_bytes");
-    const uint64_t n0 = ctx->n_reads;
-    BF_TRY(ensure(ctx, ctx->d_seq, ctx->seq_bytes + sb + 64, true));
-    BF_TRY(ensure(ctx, ctx->d_frag, ctx->frag_bytes + fb + 64, true));
-    BF_TRY(ensure(ctx, ctx->d_seq_off, (n0 + m + 1) * 8, true));
-    BF_TRY(ensure(ctx, ctx->d_frag_off, (n0 + m + 1) * 8, true));
-    BF_TRY(ensure(ctx, ctx->d_hits, (n0 + m) * sizeof(bf_hit), true));
-    BF_HIP(ctx, hipMemcpy(ctx->d_seq.as<uint8_t>() + ctx->seq_bytes, b->seq_bytes + b->seq_off[0], sb, hipMemcpyHostToDevice));
-    if (fb) BF_HIP(ctx, hipMemcpy(ctx->d_frag.as<uint8_t>() + ctx->frag_bytes, b->frag_bytes + b->frag_off[0], fb, hipMemcpyHostToDevice));
-    BF_HIP(ctx, hipMemcpy(ctx->d_seq_off.as<uint64_t>() + n0, so.data(), (m + 1) * 8, hipMemcpyHostToDevice));
-    BF_HIP(ctx, hipMemcpy(ctx->d_frag_off.as<uint64_t>() + n0, fo.data(), (m + 1) * 8, hipMemcpyHostToDevice));
-    BF_HIP(ctx, hipMemcpy(ctx->d_hits.as<bf_hit>() + n0, b->hits, m * sizeof(bf_hit), hipMemcpyHostToDevice));
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    BF_TRY(reserve_input(ctx, ctx->n_reads + m, ctx->seq_bytes + sb, ctx->frag_bytes + fb));
+    const bool seq_direct = is_pinned(ctx, b->seq_bytes + b->seq_off[0], sb);
+    const bool frag_direct = fb == 0 || is_pinned(ctx, b->frag_bytes + b->frag_off[0], fb);
+    // "h2d" in bf_kernel_times: from this call's first upload to its last, on the copy-in stream
+    hipEvent_t t_a = nullptr, t_b = nullptr;
+    if (pending(ctx).size() < 8192 && hipEventCreate(&t_a) == hipSuccess && hipEventCreate(&t_b) == hipSuccess) {
+        (void)hipEventRecord(t_a, ctx->in_stream);
+    } else {
+        if (t_a) (void)hipEventDestroy(t_a);
+        t_a = t_b = nullptr;
+    }
+    struct TimerGuard {                               // whichever way the call ends, the pair is recorded or dropped
+        bf_ctx* c; hipEvent_t a, b; bool ok = false;
+        ~TimerGuard() {
+            if (!a) return;
+            if (ok && hipEventRecord(b, c->in_stream) == hipSuccess) pending(c).push_back(PendingEvent{"h2d", a, b});
+            else { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+        }
+    } timer{ctx, t_a, t_b};
+    SubmitShared sh;
+    sh.ctx = ctx; sh.bat = b; sh.n0 = ctx->n_reads; sh.seq0 = ctx->seq_bytes; sh.frag0 = ctx->frag_bytes;
+    sh.hits_direct = is_pinned(ctx, b->hits, m * sizeof(bf_hit));
+    if (ctx->slots.size() < ctx->host_threads) ctx->slots.resize(ctx->host_threads);
+    // (the A/B variants of the localise stage keep their one launch over the whole set)
+    const bool eager = !(ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE));
+    // reads per offsets job: two offset arrays (+1 entry each) and the hits share one slot
+    const uint64_t per_job = (kStageSlotBytes - 64) / (8 + 8 + sizeof(bf_hit)) - 2;
+    uint32_t mx = ctx->max_len, mn = ctx->min_len, mf = ctx->max_frag;
+    const uint64_t piece_reads = ctx->cfg.reserved[2] ? ctx->cfg.reserved[2] : kPieceReads;
+    for (uint64_t p0 = 0; p0 < m; p0 += piece_reads) {
+        const uint64_t p1 = std::min(m, p0 + piece_reads);
+        // the byte ranges behind the piece's reads (offsets are checked job by job; a bad batch is caught below
+        // before any kernel sees these reads)
+        uint64_t sa = b->seq_off[p0] - b->seq_off[0], se = b->seq_off[p1] - b->seq_off[0];
+        uint64_t fa = b->frag_off[p0] - b->frag_off[0], fe = b->frag_off[p1] - b->frag_off[0];
+        if ((se < sa || se > sb || fe < fa || fe > fb) && p0) ctx->n_localised = 0;
+        if (se < sa || se > sb || fe < fa || fe > fb) return fail(ctx, BF_ERR_INVALID, "bf_submit: offsets not monotone near read %llu", (unsigned long long)p0);
+        sh.jobs.clear(); sh.next = 0;
+        for (uint64_t a = p0; a < p1; a += per_job) sh.jobs.push_back(SubmitJob{0, a, std::min(p1, a + per_job)});
+        if (!seq_direct) for (uint64_t a = sa; a < se; a += kStageSlotBytes) sh.jobs.push_back(SubmitJob{1, a, std::min(se, a + kStageSlotBytes)});
+        if (!frag_direct) for (uint64_t a = fa; a < fe; a += kStageSlotBytes) sh.jobs.push_back(SubmitJob{2, a, std::min(fe, a + kStageSlotBytes)});
+        const uint64_t staged = (p1 - p0) * 32 + (seq_direct ? 0 : se - sa) + (frag_direct ? 0 : fe - fa);
+        const size_t nt = staged < kInlineBytes ? 1 : std::min<size_t>(ctx->host_threads, sh.jobs.size());
+        if (nt <= 1) submit_worker(&sh, 0);
+        else {
+            std::vector<std::thread> pool;
+            for (size_t t = 0; t < nt; t++) pool.emplace_back(submit_worker, &sh, (int)t);
+            for (auto& th : pool) th.join();
+        }
+        if (sh.err_code != BF_OK) {
+            // nothing of this batch becomes resident: its uploads only touched memory beyond n_reads, and whatever
+            // was localised behind them is dropped (the next bf_finish localises the resident reads afresh)
+            if (p0) ctx->n_localised = 0;
+            return fail(ctx, sh.err_code, "%s", sh.err_msg.c_str());
+        }
+        mx = std::max(mx, sh.mx); mn = std::min(mn, sh.mn); mf = std::max(mf, sh.mf);
+        if (mn < 2 * ctx->cfg.anchor_len && p0) ctx->n_localised = 0;
+        if (mn < 2 * ctx->cfg.anchor_len)
+            return fail(ctx, BF_ERR_RANGE, "a read of length %u is shorter than 2 * anchor_len = %u (detect.rs:311 never emits such reads)", mn, 2 * ctx->cfg.anchor_len);
+        if (seq_direct && se > sa)
+            BF_HIP(ctx, hipMemcpyAsync(ctx->d_seq.as<uint8_t>() + sh.seq0 + sa, b->seq_bytes + b->seq_off[0] + sa, se - sa, hipMemcpyHostToDevice, ctx->in_stream));
+        if (frag_direct && fe > fa)
+            BF_HIP(ctx, hipMemcpyAsync(ctx->d_frag.as<uint8_t>() + sh.frag0 + fa, b->frag_bytes + b->frag_off[0] + fa, fe - fa, hipMemcpyHostToDevice, ctx->in_stream));
+        if (sh.hits_direct)
+            BF_HIP(ctx, hipMemcpyAsync(ctx->d_hits.as<bf_hit>() + sh.n0 + p0, b->hits + p0, (p1 - p0) * sizeof(bf_hit), hipMemcpyHostToDevice, ctx->in_stream));
+        if (p1 < m && eager) {
+            // a finished piece in the middle of a large batch: localise it behind its upload.  (The batch becomes
+            // resident only when its last piece has been checked; a rejected batch drops the evidence again.)
+            BF_HIP(ctx, hipEventRecord(ctx->ev_in, ctx->in_stream));
+            ctx->in_pending = true;
+            const int rc = localise_uploaded(ctx, sh.n0 + p1, mx);
+            if (rc != BF_OK) { ctx->n_localised = 0; return rc; }
+        }
+    }
     ctx->n_reads += m; ctx->seq_bytes += sb; ctx->frag_bytes += fb;
     ctx->max_len = mx; ctx->min_len = mn; ctx->max_frag = mf;
-    ctx->localised = false; ctx->imported = false;
+    ctx->localised = false; ctx->imported = false; ctx->consumed = false;
+    timer.ok = true;
+    BF_HIP(ctx, hipEventRecord(ctx->ev_in, ctx->in_stream));
+    ctx->in_pending = true;
+    if (eager && ctx->n_reads - std::min(ctx->n_localised, ctx->n_reads) >= std::min(kEagerReads, piece_reads))
+        BF_TRY(localise_uploaded(ctx, ctx->n_reads, ctx->max_len));
     return BF_OK;
 }
 
@@ -416,7 +633,7 @@ int bf_localise(bf_ctx* ctx) {
     if (ctx->n_contigs == 0) return fail(ctx, BF_ERR_STATE, "bf_localise before bf_genome_set");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     ctx->imported = false;
-    return run_localise(ctx);
+    return run_localise(ctx, false, true);
 }
 
 // bf_finish: the host does not wait for the localise kernels' counters, the cluster stage's first
@@ -425,7 +642,9 @@ static int localise_deferred(bf_ctx* ctx) {
     if (ctx->n_contigs == 0) return fail(ctx, BF_ERR_STATE, "bf_localise before bf_genome_set");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     ctx->imported = false;
-    return run_localise(ctx, true);
+    // reads bf_submit localised behind their upload are done; when nothing has arrived since the last bf_finish the
+    // call runs the whole path again on the resident reads (idempotence, and what a timing loop wants to measure)
+    return run_localise(ctx, true, ctx->consumed);
 }
 
 static int fill_single_rank_result(bf_ctx* ctx, bf_result* out) {
@@ -601,7 +820,9 @@ int bf_finish(bf_ctx* ctx, bf_result* out) {
     if (!ctx) return BF_ERR_INVALID;
     if (ctx->n_ranks > 1) return fail(ctx, BF_ERR_STATE, "bf_finish on a multi-rank ctx; use the stage calls");
     BF_TRY(localise_deferred(ctx));
-    return bf_clusterise(ctx, out);
+    BF_TRY(bf_clusterise(ctx, out));
+    ctx->consumed = true;
+    return BF_OK;
 }
 
 static inline unsigned dec_len(uint64_t v) { unsigned n = 1; while (v >= 10) { v /= 10; n++; } return n; }
@@ -1131,6 +1352,7 @@ int bf_evidence_fetch(bf_ctx* ctx, bf_evidence_view* v) {
 
 int bf_kernel_times(bf_ctx* ctx, const bf_kernel_time** out, uint32_t* n) {
     if (!ctx || !out || !n) return BF_ERR_INVALID;
+    BF_HIP(ctx, hipStreamSynchronize(ctx->in_stream));
     BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->timing.clear();
     for (auto& p : pending(ctx)) {

@@ -177,6 +177,21 @@ struct bf_ctx {
     uint64_t genome_bases = 0;                  // padded total (multiple of 64)
     bf::DevBuf g_blocks, g_exc, g_raw, g_coarse, g_coarse2, g_contigs;
 
+    // host -> device hand-over (bf_submit): uploads run on in_stream from pinned memory -- the caller's own when it
+    // came from bf_host_alloc, else a ring of pinned staging slots filled by a few host threads -- and the reads
+    // of every uploaded piece are localised behind it on `stream`, while the next piece is still on PCIe
+    hipStream_t in_stream = nullptr;
+    hipEvent_t ev_in = nullptr;                 // recorded on in_stream after the uploads queued so far
+    bool in_pending = false;                    // ... and `stream` has not been told to wait for it yet
+    struct StageSlot { uint8_t* p = nullptr; hipEvent_t ev = nullptr; bool used = false; };
+    std::vector<StageSlot> slots;               // one per host thread, kStageSlotBytes each (allocated on first use)
+    std::vector<std::pair<const uint8_t*, size_t>> pinned;   // bf_host_alloc ranges
+    uint32_t host_threads = 0;                  // bf_config.reserved[1], or chosen from the machine
+    uint64_t cap_reads = 0;                     // capacity of every per-read array below (inputs and evidence)
+    uint64_t n_localised = 0;                   // reads [0, n_localised) have evidence under (plane_words, mask_words)
+    bool consumed = false;                      // a bf_finish has clustered exactly this read set: the next one without
+                                                // new reads runs the whole path again (bf_finish is idempotent)
+
     // source-side resident reads
     uint64_t n_reads = 0;
     uint64_t seq_bytes = 0, frag_bytes = 0;
@@ -275,7 +290,10 @@ struct OnSideStream {
 
 // localise.hip ----------------------------------------------------------------------------------
 int genome_pack(bf_ctx* ctx);                       // raw image -> blocks + coarse bitmap
-int run_localise(bf_ctx* ctx, bool defer_counts = false);   // encode + hash + fast + exact kernels
+int run_localise(bf_ctx* ctx, bool defer_counts = false, bool all = true);   // read_meta + packed + exact kernels; all = false:
+                                                    // only the reads bf_submit has not localised behind their upload yet
+int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len);   // bf_submit: the packed kernel over reads [n_localised, n)
+int grow_reads(bf_ctx* ctx, uint64_t cap);          // per-read arrays for `cap` reads, contents kept
 int settle_counts(bf_ctx* ctx);                     // n_exact / n_sigx / n_text_records valid on return
 int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, int n_chunks, uint64_t* chunk_off,
                    const uint32_t* d_sizes = nullptr);   // d_sizes: record bytes per list entry when the caller has them

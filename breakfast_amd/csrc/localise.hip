@@ -121,13 +121,13 @@ __global__ void __launch_bounds__(256) encode_reads_kernel(uint64_t n, const uin
 }
 
 // lengths + FNV-1a/64 with a final avalanche of the fragment id bytes
-__global__ void __launch_bounds__(256) read_meta_kernel(uint64_t n, const uint64_t* __restrict__ seq_off,
+__global__ void __launch_bounds__(256) read_meta_kernel(uint64_t r0, uint64_t n, const uint64_t* __restrict__ seq_off,
                                                         const uint8_t* __restrict__ frag,
                                                         const uint64_t* __restrict__ frag_off,
                                                         uint16_t* __restrict__ len,
                                                         uint16_t* __restrict__ frag_len,
                                                         uint64_t* __restrict__ fhash) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r = r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;     // reads [r0, n)
     if (r >= n) return;
     len[r] = (uint16_t)(seq_off[r + 1] - seq_off[r]);
     const uint64_t o = frag_off[r];
@@ -330,7 +330,7 @@ __device__ __forceinline__ void encode_ascii(const uint8_t* __restrict__ seq, ui
 }
 
 struct LocaliseArgs {
-    uint64_t n;
+    uint64_t r0, n;          // this launch covers reads [r0, n): bf_submit localises every uploaded piece on its own
     int A;
     int cb;                  // bits per contig rank in the class key
     uint32_t force_exact;
@@ -396,7 +396,7 @@ __device__ __forceinline__ uint64_t make_key(const Oriented& o, bool sigx, uint3
 template <int W, bool COOP, bool FUSED>
 __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a) {
     __shared__ uint4 lds[COOP ? 4 * 2 * CoopGeom<W>::WAVE_U4 : 1];
-    const uint64_t r_raw = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r_raw = a.r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r_raw < a.n;
     if (!COOP && !live) return;
     const uint64_t r = live ? r_raw : a.n - 1;           // COOP: every lane of the wave takes part in the gather
@@ -620,7 +620,8 @@ struct ExactArgs {
     int A;
     int cb;
     const uint32_t* exact_list;
-    uint32_t* counters;      // [0] = length of exact_list, [1] = raw-signature slots handed out
+    uint32_t* counters;      // [0] = length of exact_list, [1] = raw-signature slots handed out, [3] = list entries
+                             // earlier launches have done (reads localised behind their upload add to the list)
     const bf_hit* hits;
     const uint8_t* seq;
     const uint64_t* seq_off;
@@ -667,8 +668,8 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
     const int lane = threadIdx.x & 63;
     // fixed grid, every wave takes list entries wave, wave + n_waves, ...: the list's length stays on the device
     // (the host does not wait for the packed kernel to learn it)
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6, n_list = a.counters[0];
-    for (uint32_t slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; slot < n_list; slot += n_waves) {     // wave-uniform
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6, n_list = a.counters[0], first = a.counters[3];
+    for (uint32_t slot = first + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6); slot < n_list; slot += n_waves) {     // wave-uniform
     const uint32_t r = a.exact_list[slot];
     const bf_hit h = a.hits[r];
     const Oriented o = orient(h, a.contigs);
@@ -773,6 +774,8 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
         (uint64_t)(uint16_t)bp | ((uint64_t)fl << 16) | ((uint64_t)(uint16_t)L << 32) | ((uint64_t)n_exc << 48);
     }
 }
+
+__global__ void exact_done_kernel(uint32_t* counters) { counters[3] = counters[0]; }
 
 // ---------------------------------------------------------------------------------------------
 // Junction records of surviving reads (format: include/breakfast_hip.h, "Junction records").
@@ -992,7 +995,7 @@ int genome_pack(bf_ctx* ctx) {
 
 template <int W>
 static void launch_fast(bf_ctx* ctx, const LocaliseArgs& a) {
-    const dim3 g(grid_for(a.n, 256)), b(256);
+    const dim3 g(grid_for(a.n - a.r0, 256)), b(256);
     if (ctx->cfg.flags & BF_FLAG_COOP_GATHER)
         hipLaunchKernelGGL((localise_fast_kernel<W, true, false>), g, b, 0, ctx->stream, a);
     else if (ctx->cfg.flags & BF_FLAG_SEPARATE_ENCODE)
@@ -1009,38 +1012,64 @@ int settle_counts(bf_ctx* ctx) {
     return BF_OK;
 }
 
-int run_localise(bf_ctx* ctx, bool defer_counts) {
-    const uint64_t n = ctx->n_reads;
-    ctx->n_exact = 0; ctx->n_sigx = 0; ctx->n_text_records = 0;
-    ctx->localised = false;
-    if (n == 0) { ctx->localised = true; ctx->plane_words = 1; ctx->mask_words = 1; return BF_OK; }
-    const uint32_t A = ctx->cfg.anchor_len;
-    if (ctx->min_len < 2 * A)
-        return fail(ctx, BF_ERR_RANGE, "a read of length %u is shorter than 2 * anchor_len = %u "
-                    "(the reference only emits reads with len >= 2*anchor_len, detect.rs:311)",
-                    ctx->min_len, 2 * A);
-    const uint32_t Wm = (ctx->max_len + 63) / 64;
-    uint32_t W = Wm <= 2 ? 2 : Wm == 3 ? 3 : 4;
-    ctx->plane_words = W;
-    ctx->mask_words = Wm;
+static inline uint32_t mask_words_for(uint32_t max_len) { return (max_len + 63) / 64; }
+static inline uint32_t plane_words_for(uint32_t wm) { return wm <= 2 ? 2 : wm == 3 ? 3 : 4; }
 
-    BF_TRY(ensure(ctx, ctx->d_len, n * 2));
-    BF_TRY(ensure(ctx, ctx->d_frag_len, n * 2));
-    BF_TRY(ensure(ctx, ctx->d_fhash, n * 8));
-    BF_TRY(ensure(ctx, ctx->d_key, n * 8));
-    BF_TRY(ensure(ctx, ctx->d_lpos, n * 4));
-    BF_TRY(ensure(ctx, ctx->d_rpos, n * 4));
-    BF_TRY(ensure(ctx, ctx->d_bp, n * 2));
-    BF_TRY(ensure(ctx, ctx->d_flags, n * 2));
-    BF_TRY(ensure(ctx, ctx->d_mask, (size_t)(Wm + 1) * n * 8));
-    BF_TRY(ensure(ctx, ctx->d_jrec, n * 8));
-    BF_TRY(ensure(ctx, ctx->d_exact_list, n * 4));
-    BF_TRY(ensure(ctx, ctx->d_sigx_slot, n * 4));
+// Every per-read array for `cap` reads, contents kept: the inputs bf_submit appends to, and -- once reads have been
+// localised behind their upload -- the evidence the packed kernel wrote for them.  Waits for all queued work.
+int grow_reads(bf_ctx* ctx, uint64_t cap) {
+    if (cap <= ctx->cap_reads) return BF_OK;
+    if (ctx->in_stream) BF_HIP(ctx, hipStreamSynchronize(ctx->in_stream));
+    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_TRY(ensure(ctx, ctx->d_seq_off, (cap + 1) * 8, true));
+    BF_TRY(ensure(ctx, ctx->d_frag_off, (cap + 1) * 8, true));
+    BF_TRY(ensure(ctx, ctx->d_hits, cap * sizeof(bf_hit), true));
+    if (ctx->n_localised) {
+        const uint64_t stride = (uint64_t)ctx->mask_words + 1;
+        BF_TRY(ensure(ctx, ctx->d_len, cap * 2, true)); BF_TRY(ensure(ctx, ctx->d_frag_len, cap * 2, true));
+        BF_TRY(ensure(ctx, ctx->d_fhash, cap * 8, true)); BF_TRY(ensure(ctx, ctx->d_key, cap * 8, true));
+        BF_TRY(ensure(ctx, ctx->d_lpos, cap * 4, true)); BF_TRY(ensure(ctx, ctx->d_rpos, cap * 4, true));
+        BF_TRY(ensure(ctx, ctx->d_bp, cap * 2, true)); BF_TRY(ensure(ctx, ctx->d_flags, cap * 2, true));
+        BF_TRY(ensure(ctx, ctx->d_mask, stride * cap * 8, true)); BF_TRY(ensure(ctx, ctx->d_jrec, cap * 8, true));
+        BF_TRY(ensure(ctx, ctx->d_exact_list, cap * 4, true)); BF_TRY(ensure(ctx, ctx->d_sigx_slot, cap * 4, true));
+        BF_TRY(ensure(ctx, ctx->d_sigx, cap * 16, true));
+    }
+    ctx->cap_reads = cap;
+    return BF_OK;
+}
+
+// The packed kernel (and the fragment-id hashes) for the reads that are resident but not localised yet,
+// [n_localised, n): called by bf_submit behind every uploaded piece (n = the reads uploaded so far, max_len = the
+// longest of them) and by run_localise for what is left.
+// The evidence layout depends on the longest read seen (mask words per render record; the plane words of the
+// kernel instance, which also bound a packed junction record): a piece that changes it starts the whole set over.
+int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len) {
+    if (n == 0) return BF_OK;
+    const uint32_t A = ctx->cfg.anchor_len;
+    const uint32_t Wm = mask_words_for(max_len), W = plane_words_for(Wm);
+    if (ctx->n_localised && Wm != ctx->mask_words) ctx->n_localised = 0;
+    const uint64_t r0 = ctx->n_localised;
+    if (r0 >= n) return BF_OK;
+    const bool keep = r0 > 0;
+    const uint64_t cap = std::max<uint64_t>(ctx->cap_reads, n);
+    ctx->plane_words = W; ctx->mask_words = Wm;
+    BF_TRY(ensure(ctx, ctx->d_len, cap * 2, keep)); BF_TRY(ensure(ctx, ctx->d_frag_len, cap * 2, keep));
+    BF_TRY(ensure(ctx, ctx->d_fhash, cap * 8, keep)); BF_TRY(ensure(ctx, ctx->d_key, cap * 8, keep));
+    BF_TRY(ensure(ctx, ctx->d_lpos, cap * 4, keep)); BF_TRY(ensure(ctx, ctx->d_rpos, cap * 4, keep));
+    BF_TRY(ensure(ctx, ctx->d_bp, cap * 2, keep)); BF_TRY(ensure(ctx, ctx->d_flags, cap * 2, keep));
+    BF_TRY(ensure(ctx, ctx->d_mask, (size_t)(Wm + 1) * cap * 8, keep)); BF_TRY(ensure(ctx, ctx->d_jrec, cap * 8, keep));
+    BF_TRY(ensure(ctx, ctx->d_exact_list, cap * 4, keep)); BF_TRY(ensure(ctx, ctx->d_sigx_slot, cap * 4, keep));
+    // raw signature bytes: one 16-byte slot per read at most (handed out with an atomic counter by both kernels)
+    BF_TRY(ensure(ctx, ctx->d_sigx, (size_t)cap * 16, keep));
     BF_TRY(ensure(ctx, ctx->d_counters, 64));
-    BF_HIP(ctx, hipMemsetAsync(ctx->d_counters.p, 0, 64, ctx->stream));
+    if (r0 == 0) BF_HIP(ctx, hipMemsetAsync(ctx->d_counters.p, 0, 64, ctx->stream));
+    if (ctx->in_pending) {                                 // the uploads these kernels read
+        BF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));
+        ctx->in_pending = false;
+    }
 
     const bool separate = (ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE)) != 0;
-    if (separate) {
+    if (separate) {                                        // A/B variants: always the whole set (run_localise sees to it)
         BF_TRY(ensure(ctx, ctx->d_planes, (size_t)3 * W * n * 8));
         Scope t(ctx, "encode_reads");
         const dim3 eg(grid_for(((n + 63) / 64) * 64, 256));
@@ -1053,7 +1082,7 @@ int run_localise(bf_ctx* ctx, bool defer_counts) {
     }
     {
         Scope t(ctx, "read_meta");
-        hipLaunchKernelGGL(read_meta_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n,
+        hipLaunchKernelGGL(read_meta_kernel, dim3(grid_for(n - r0, 256)), dim3(256), 0, ctx->stream, r0, n,
                            ctx->d_seq_off.as<uint64_t>(), ctx->d_frag.as<uint8_t>(),
                            ctx->d_frag_off.as<uint64_t>(), ctx->d_len.as<uint16_t>(),
                            ctx->d_frag_len.as<uint16_t>(), ctx->d_fhash.as<uint64_t>());
@@ -1061,15 +1090,13 @@ int run_localise(bf_ctx* ctx, bool defer_counts) {
     BF_HIP(ctx, hipGetLastError());
 
     LocaliseArgs a{};
-    a.n = n; a.A = (int)A; a.cb = ctx->contig_bits; a.force_exact = (ctx->cfg.flags & BF_FLAG_FORCE_EXACT) ? 1u : 0u;
+    a.r0 = r0; a.n = n; a.A = (int)A; a.cb = ctx->contig_bits; a.force_exact = (ctx->cfg.flags & BF_FLAG_FORCE_EXACT) ? 1u : 0u;
     a.hits = ctx->d_hits.as<bf_hit>(); a.len = ctx->d_len.as<uint16_t>();
     a.planes = ctx->d_planes.as<uint64_t>(); a.len_out = ctx->d_len.as<uint16_t>();
     a.seq = ctx->d_seq.as<uint8_t>(); a.seq_off = ctx->d_seq_off.as<uint64_t>(); a.contigs = ctx->g_contigs.as<ContigDev>();
     a.blocks = ctx->g_blocks.as<GenomeBlock>(); a.coarse = ctx->g_coarse.as<uint64_t>();
     a.coarse2 = ctx->g_coarse2.as<uint32_t>();
     a.exc = ctx->g_exc.as<uint64_t>(); a.raw = ctx->g_raw.as<uint8_t>();
-    // raw signature bytes: one 16-byte slot per read at most (handed out with an atomic counter by both kernels)
-    BF_TRY(ensure(ctx, ctx->d_sigx, (size_t)n * 16));
     a.sigx = ctx->d_sigx.as<uint8_t>(); a.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
     a.key = ctx->d_key.as<uint64_t>(); a.lpos = ctx->d_lpos.as<int32_t>(); a.rpos = ctx->d_rpos.as<int32_t>();
     a.bp = ctx->d_bp.as<uint16_t>(); a.flags = ctx->d_flags.as<uint16_t>(); a.meta = ctx->d_mask.as<uint64_t>();
@@ -1082,17 +1109,36 @@ int run_localise(bf_ctx* ctx, bool defer_counts) {
         else launch_fast<4>(ctx, a);
     }
     BF_HIP(ctx, hipGetLastError());
+    ctx->n_localised = n;
+    return BF_OK;
+}
 
+int run_localise(bf_ctx* ctx, bool defer_counts, bool all) {
+    const uint64_t n = ctx->n_reads;
+    ctx->n_exact = 0; ctx->n_sigx = 0; ctx->n_text_records = 0;
+    ctx->localised = false;
+    if (n == 0) { ctx->localised = true; ctx->plane_words = 1; ctx->mask_words = 1; ctx->n_localised = 0; return BF_OK; }
+    const uint32_t A = ctx->cfg.anchor_len;
+    if (ctx->min_len < 2 * A)
+        return fail(ctx, BF_ERR_RANGE, "a read of length %u is shorter than 2 * anchor_len = %u "
+                    "(the reference only emits reads with len >= 2*anchor_len, detect.rs:311)",
+                    ctx->min_len, 2 * A);
+    if (all || (ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE))) ctx->n_localised = 0;
+    BF_TRY(localise_uploaded(ctx, n, ctx->max_len));
+    const uint32_t Wm = ctx->mask_words, W = ctx->plane_words;
     {
         ExactArgs e{};
-        e.n_total = n; e.A = (int)A; e.cb = ctx->contig_bits; e.exact_list = a.exact_list; e.counters = a.counters; e.hits = a.hits;
+        e.n_total = n; e.A = (int)A; e.cb = ctx->contig_bits; e.exact_list = ctx->d_exact_list.as<uint32_t>();
+        e.counters = ctx->d_counters.as<uint32_t>(); e.hits = ctx->d_hits.as<bf_hit>();
         e.seq = ctx->d_seq.as<uint8_t>(); e.seq_off = ctx->d_seq_off.as<uint64_t>();
-        e.contigs = a.contigs; e.raw = ctx->g_raw.as<uint8_t>();
-        e.key = a.key; e.lpos = a.lpos; e.rpos = a.rpos; e.bp = a.bp; e.flags = a.flags; e.meta = a.meta;
+        e.contigs = ctx->g_contigs.as<ContigDev>(); e.raw = ctx->g_raw.as<uint8_t>();
+        e.key = ctx->d_key.as<uint64_t>(); e.lpos = ctx->d_lpos.as<int32_t>(); e.rpos = ctx->d_rpos.as<int32_t>();
+        e.bp = ctx->d_bp.as<uint16_t>(); e.flags = ctx->d_flags.as<uint16_t>(); e.meta = ctx->d_mask.as<uint64_t>();
         e.mask_words = (int)Wm; e.max_packed = 64u * W; e.info = ctx->d_jrec.as<uint64_t>(); e.sigx = ctx->d_sigx.as<uint8_t>(); e.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
         Scope t(ctx, "localise_exact");
         const unsigned blocks = (unsigned)std::min<uint64_t>(grid_for(n * 64, 256), 16384);   // oversubscribed: entries differ in length
         hipLaunchKernelGGL(localise_exact_kernel, dim3(blocks), dim3(256), 0, ctx->stream, e);
+        hipLaunchKernelGGL(exact_done_kernel, dim3(1), dim3(1), 0, ctx->stream, e.counters);
         BF_HIP(ctx, hipGetLastError());
     }
     BF_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counters.p, 12, hipMemcpyDeviceToHost, ctx->stream));

@@ -76,7 +76,7 @@ ABI_SYMBOLS = [
     "bf_evidence_fetch", "bf_kernel_times", "bf_stats", "bf_junction_text", "bf_result_junction_text",
     "bf_result_junction_sizes_dev", "bf_result_layout_dev", "bf_result_attach_records_dev", "bf_result_requests_dev",
     "bf_result_attach_finish", "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
-    "bf_render_junctions_dev_static",
+    "bf_render_junctions_dev_static", "bf_host_alloc", "bf_host_free", "bf_submit_wait", "bf_reserve",
 ]
 
 _lib = None
@@ -116,6 +116,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_last_error.restype = C.c_char_p
     lib.bf_genome_set.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(vp), u64p]
     lib.bf_submit.argtypes = [vp, C.POINTER(BfBatch)]
+    lib.bf_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    lib.bf_host_free.argtypes = [vp, vp]
+    lib.bf_submit_wait.argtypes = [vp]
+    lib.bf_reserve.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
     lib.bf_localise.argtypes = [vp]
     lib.bf_clusterise.argtypes = [vp, C.POINTER(BfResult)]
     lib.bf_finish.argtypes = [vp, C.POINTER(BfResult)]
@@ -313,9 +317,10 @@ class Engine:
     """One bf_ctx = one GPU.  Mirrors the stages of detect::main (detect.rs:39-242)."""
 
     def __init__(self, anchor_len: int = 30, max_frag_len: int = 5000, min_evidence: int = 2,
-                 device: int = -1, flags: int = 0, lib_path: Optional[str] = None, groups: int = 0):
+                 device: int = -1, flags: int = 0, lib_path: Optional[str] = None, groups: int = 0,
+                 host_threads: int = 0, piece_reads: int = 0):
         self.lib = load_library(lib_path)
-        cfg = BfConfig(anchor_len, max_frag_len, min_evidence, device, flags, (C.c_uint32 * 3)(groups, 0, 0))
+        cfg = BfConfig(anchor_len, max_frag_len, min_evidence, device, flags, (C.c_uint32 * 3)(groups, host_threads, piece_reads))
         h = C.c_void_p()
         rc = self.lib.bf_ctx_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -360,6 +365,31 @@ class Engine:
                 np.ascontiguousarray(b.hits, HIT_DTYPE)]
         cb = BfBatch(b.n, *[a.ctypes.data for a in arrs])
         self._check(self.lib.bf_submit(self.h, C.byref(cb)))
+
+    def host_alloc(self, nbytes: int, dtype=np.uint8) -> np.ndarray:
+        """A numpy array over bf_host_alloc memory (pinned; owned by the ctx, valid until close())."""
+        dt = np.dtype(dtype)
+        p = C.c_void_p()
+        self._check(self.lib.bf_host_alloc(self.h, max(int(nbytes), 1), C.byref(p)))
+        if nbytes == 0:
+            return np.zeros(0, dt)
+        return np.frombuffer((C.c_uint8 * int(nbytes)).from_address(p.value), dt)
+
+    def pin_batch(self, b: Batch) -> Batch:
+        """Copy of the batch in bf_host_alloc memory: what a parser that writes into pinned buffers holds."""
+        def pin(a, dt):
+            a = np.ascontiguousarray(a, dt)
+            out = self.host_alloc(a.nbytes, dt)
+            out[...] = a
+            return out
+        return Batch(pin(b.seq_bytes, np.uint8), pin(b.seq_off, np.uint64), pin(b.frag_bytes, np.uint8),
+                     pin(b.frag_off, np.uint64), pin(b.hits, HIT_DTYPE))
+
+    def submit_wait(self) -> None:
+        self._check(self.lib.bf_submit_wait(self.h))
+
+    def reserve(self, n_reads: int, seq_bytes: int, frag_bytes: int) -> None:
+        self._check(self.lib.bf_reserve(self.h, n_reads, seq_bytes, frag_bytes))
 
     def localise(self) -> None:
         self._check(self.lib.bf_localise(self.h))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 5
+#define BF_ABI_VERSION 6
 
 enum {
     BF_OK = 0,
@@ -54,7 +54,9 @@ typedef struct {
     uint32_t min_evidence;   /* --min-evidence [default 2] */
     int32_t  device;         /* HIP device ordinal, -1 = current device */
     uint32_t flags;          /* BF_FLAG_* */
-    uint32_t reserved[3];    /* [0]: contig groups of the cluster stage (0 = chosen from the input size; A/B), rest 0 */
+    uint32_t reserved[3];    /* [0]: contig groups of the cluster stage (0 = chosen from the input size; A/B),
+                                [1]: host threads that stage pageable bf_submit batches (0 = chosen, at most 16),
+                                [2]: reads per upload piece of bf_submit (0 = 2^20; tests) */
 } bf_config;
 
 #define BF_FLAG_KEEP_EVIDENCE 1u   /* keep per-read evidence readable via bf_evidence_fetch (tests) */
@@ -174,8 +176,27 @@ int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names,
 /* ---- the hot path -------------------------------------------------------------------------- */
 
 /* Appends a batch of parsed anchor-hit pairs (what the consume loop holds after detect.rs:89-103)
- * to the ctx's HBM-resident read set.  Copies synchronously; inputs may be freed on return. */
+ * to the ctx's HBM-resident read set.  ASYNCHRONOUS, as the reference consumes reads while Bowtie still emits
+ * them (detect.rs:76-188): the call validates the batch (offsets, lengths, contig ids, positions: errors are
+ * reported here, and a rejected batch leaves the ctx as it was), queues the uploads on the ctx's copy-in stream
+ * and queues the per-read kernels of detect.rs:105-187 behind every uploaded piece of about a million reads, so
+ * that reads are localised while later ones are still on PCIe; bf_finish is left with the cluster stage.
+ *   - arrays in ordinary (pageable) memory are staged through pinned slots by a few host threads
+ *     (bf_config.reserved[1] = how many, 0 = chosen from the machine, at most 16): they may be freed on return;
+ *   - arrays that lie in memory from bf_host_alloc (pinned; e.g. the buffers a parser writes its batches into) are
+ *     uploaded from where they are, without a copy: they must stay untouched until bf_submit_wait, bf_finish or
+ *     bf_localise returns.  Each of the five arrays is looked at on its own. */
 int bf_submit(bf_ctx* ctx, const bf_batch* batch);
+
+/* Pinned host memory for batches (bf_submit uploads from it without staging).  Owned by the ctx: freed by
+ * bf_host_free or bf_ctx_destroy.  No counterpart in the reference (its reads never leave host memory). */
+int bf_host_alloc(bf_ctx* ctx, uint64_t bytes, void** out);
+int bf_host_free(bf_ctx* ctx, void* p);
+/* Returns when every upload queued by bf_submit has left host memory (pinned batch buffers may be reused). */
+int bf_submit_wait(bf_ctx* ctx);
+/* Optional: sizes the resident arrays for this many reads / sequence bytes / fragment id bytes up front, so that no
+ * bf_submit has to grow them (growing waits for all queued work and copies).  bf_reset keeps the memory. */
+int bf_reserve(bf_ctx* ctx, uint64_t n_reads, uint64_t seq_bytes, uint64_t frag_bytes);
 
 /* Replaces detect.rs:105-187 (reorient, flank gather, split scan, junction masks, signature,
  * coordinates) for every resident read: kernels encode_reads + localise (+ exact path). */
@@ -186,7 +207,8 @@ int bf_localise(bf_ctx* ctx);
  * by the ctx and valid until the next bf_clusterise/bf_finish/bf_reset/bf_ctx_destroy. */
 int bf_clusterise(bf_ctx* ctx, bf_result* out);
 
-/* bf_localise + bf_clusterise.  Idempotent: may be called repeatedly on the same resident reads. */
+/* bf_localise (only for the reads bf_submit has not localised behind their upload yet) + bf_clusterise.
+ * Idempotent: called again with no bf_submit in between, it runs the whole path over the resident reads again. */
 int bf_finish(bf_ctx* ctx, bf_result* out);
 
 /* Completes `result` (the one the last bf_finish / bf_clusterise of this ctx returned) with the read table:

@@ -185,7 +185,7 @@ std::vector<const Evidence*> remove_frag_id_duplicates(const std::vector<const E
 struct Run {
     std::vector<Evidence> evidence;       // in consume order until clustered (then sorted)
     std::string sv;
-    uint64_t n_clusters = 0;
+    uint64_t n_clusters = 0, n_support = 0;
     // consume-order snapshots for kernel-level parity (filled before sorting)
     std::vector<uint32_t> bp, len;
     std::vector<uint8_t> flags;           // bit0 strand, bit1 mstrand, bit2 swapped
@@ -213,7 +213,9 @@ void append_u64(std::string& s, uint64_t v) {
 }
 
 // Sort, cluster, dedup, print: detect.rs:193-241.
-void cluster_and_format(Run& r, uint64_t max_frag_len, uint64_t min_evidence) {
+// emit_text = false (bench.py's CPU baseline only): everything but the row text, so that the timed scope is the
+// GPU step's -- evidence in, cluster table out; the printing is bf_format_sv's job there and is timed apart.
+void cluster_and_format(Run& r, uint64_t max_frag_len, uint64_t min_evidence, bool emit_text = true) {
     std::vector<Evidence>& evidence = r.evidence;
     std::stable_sort(evidence.begin(), evidence.end(), [](const Evidence& a, const Evidence& b) {
         int c = a.chr.compare(b.chr);                     // byte-wise, like Rust String Ord
@@ -244,6 +246,8 @@ void cluster_and_format(Run& r, uint64_t max_frag_len, uint64_t min_evidence) {
         if (cluster.size() < min_evidence) continue;
         cluster = remove_frag_id_duplicates(cluster);
         if (cluster.size() < min_evidence) continue;
+        r.n_clusters++;
+        if (!emit_text) { r.n_support += cluster.size(); continue; }
         out += read.chr; out += '\t'; out += read.strand ? '+' : '-'; out += '\t';
         append_u64(out, read.pos); out += "\t\t";
         out += read.mchr; out += '\t'; out += read.mstrand ? '+' : '-'; out += '\t';
@@ -253,7 +257,7 @@ void cluster_and_format(Run& r, uint64_t max_frag_len, uint64_t min_evidence) {
             out.append((const char*)cluster[k]->sequence.data(), cluster[k]->sequence.size());
         }
         out += "\t\t\n";
-        r.n_clusters++;
+        r.n_support += cluster.size();
     }
 }
 
@@ -372,7 +376,7 @@ void* oracle_detect_text(void* g, const char* lines, uint64_t n, uint64_t anchor
 
 // Batch path: the same per-read math, sort, clustering and dedup on an in-memory parsed batch
 // (what the consume loop holds after detect.rs:89-103).  Used for the timed CPU baseline.
-// stage: 1 = localise only, 2 = localise + sort/cluster/dedup/format.
+// stage: 1 = localise only, 2 = localise + sort/cluster/dedup/format, 3 = as 2 without the row text (timing).
 void* oracle_detect_batch(void* g, const char* const* contig_names, uint64_t n_reads,
                           const uint8_t* seq_bytes, const uint64_t* seq_off,
                           const uint8_t* frag_bytes, const uint64_t* frag_off,
@@ -389,13 +393,14 @@ void* oracle_detect_batch(void* g, const char* const* contig_names, uint64_t n_r
                  h.pos3, r->evidence, i);
     }
     if (keep_evidence) snapshot(*r);
-    if (stage >= 2) cluster_and_format(*r, max_frag_len, min_evidence);
+    if (stage >= 2) cluster_and_format(*r, max_frag_len, min_evidence, stage != 3);
     return r;
 }
 
 const char* oracle_sv(void* run, uint64_t* n) { Run* r = (Run*)run; *n = r->sv.size(); return r->sv.data(); }
 uint64_t oracle_n_evidence(void* run) { return ((Run*)run)->evidence.size(); }
 uint64_t oracle_n_clusters(void* run) { return ((Run*)run)->n_clusters; }
+uint64_t oracle_n_support(void* run) { return ((Run*)run)->n_support; }
 const uint32_t* oracle_ev_bp(void* run) { return ((Run*)run)->bp.data(); }
 const uint32_t* oracle_ev_len(void* run) { return ((Run*)run)->len.data(); }
 const uint8_t* oracle_ev_flags(void* run) { return ((Run*)run)->flags.data(); }

@@ -36,7 +36,7 @@ def lib() -> C.CDLL:
         L.oracle_detect_batch.argtypes = [vp, C.POINTER(C.c_char_p), u64, vp, vp, vp, vp, vp, u64, u64, u64, C.c_int, C.c_int]
         L.oracle_sv.restype = vp
         L.oracle_sv.argtypes = [vp, C.POINTER(u64)]
-        for f in ("oracle_n_evidence", "oracle_n_clusters"):
+        for f in ("oracle_n_evidence", "oracle_n_clusters", "oracle_n_support"):
             getattr(L, f).restype = u64
             getattr(L, f).argtypes = [vp]
         for f in ("oracle_ev_bp", "oracle_ev_len", "oracle_ev_flags", "oracle_ev_lpos", "oracle_ev_rpos",
@@ -81,6 +81,7 @@ class OracleRun:
         self.sv = C.string_at(p, n.value) if n.value else b""
         self.n_evidence = int(L.oracle_n_evidence(h))
         self.n_clusters = int(L.oracle_n_clusters(h))
+        self.n_support = int(L.oracle_n_support(h))
         if keep:
             m = self.n_evidence
 

@@ -1,0 +1,218 @@
+"""The host -> device hand-over (bf_submit): asynchronous, piece by piece, with the per-read kernels queued behind
+every uploaded piece (the reference consumes reads as they arrive, detect.rs:76-188).  However a read set is cut
+into batches and pieces, pinned or pageable, the .sv must be the oracle's, byte for byte.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+from breakfast_amd import engine, synth
+from breakfast_amd.engine import BF_FLAG_FORCE_EXACT, BF_FLAG_KEEP_EVIDENCE
+
+pytestmark = pytest.mark.gpu
+
+
+def case(n_reads=24000, L=120, seed=5, n_frac=0.0):
+    contigs = [("chr1", 300000), ("chr10", 200000), ("chr2", 250000)]
+    g = synth.make_genome(contigs, seed=seed, n_runs=[(0, 5000, 2000)], lower_runs=[(2, 100000, 30000)])
+    spec = synth.ReadSpec(n_reads=n_reads, read_len=L, anchor_len=20, n_events=250, singleton_frac=0.3, mate_frac=0.4,
+                          seed=seed + 1, margin=300, subst_rate=0.01)
+    b = synth.make_reads(g, spec)
+    if n_frac:
+        rng = np.random.default_rng(seed)
+        sb = b.seq_bytes.copy()
+        pos = rng.integers(0, sb.size, size=int(sb.size * n_frac))
+        sb[pos] = ord("N")
+        b.seq_bytes = sb
+    return g, b
+
+
+def oracle_sv(g, b, A=20, F=5000, E=2):
+    return ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, A, F, E).sv
+
+
+def concat(batches):
+    seq = np.concatenate([x.seq_bytes for x in batches])
+    frag = np.concatenate([x.frag_bytes for x in batches])
+    so, fo = [np.zeros(1, np.uint64)], [np.zeros(1, np.uint64)]
+    for x in batches:
+        so.append(x.seq_off[1:] - x.seq_off[0] + so[-1][-1])
+        fo.append(x.frag_off[1:] - x.frag_off[0] + fo[-1][-1])
+    return engine.Batch(seq, np.concatenate(so), frag, np.concatenate(fo), np.concatenate([x.hits for x in batches]))
+
+
+def cuts_for(n, sizes):
+    out, a, k = [], 0, 0
+    while a < n:
+        b = min(n, a + sizes[k % len(sizes)])
+        out.append((a, b))
+        a, k = b, k + 1
+    return out
+
+
+@pytest.mark.parametrize("piece", [0, 1000, 4097])
+@pytest.mark.parametrize("sizes", [(10 ** 9,), (1, 7, 5000, 300, 12000), (2500,)])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_any_cut_into_batches_and_pieces_gives_the_oracle_bytes(piece, sizes, pinned):
+    g, b = case()
+    ref = oracle_sv(g, b)
+    eng = engine.Engine(20, 5000, 2, piece_reads=piece, host_threads=4)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        held = []
+        for a, e in cuts_for(b.n, sizes):
+            part = b.slice(a, e)
+            if pinned:
+                part = eng.pin_batch(part)
+                held.append(part)                       # pinned batches stay untouched until the hand-over is over
+            eng.submit(part)
+        res = eng.finish()
+        assert res.n_evidence == b.n
+        assert eng.format_sv(res) == ref
+        # again without new reads: the whole path runs again on the resident reads
+        assert eng.format_sv(eng.finish()) == ref
+        # explicit stage calls: every read localised in one go
+        eng.localise()
+        assert eng.format_sv(eng.clusterise()) == ref
+    finally:
+        eng.close()
+
+
+def test_evidence_of_reads_localised_behind_their_upload_equals_one_launch():
+    g, b = case(n_frac=0.002)
+    outs = []
+    for piece, sizes in ((0, (10 ** 9,)), (777, (5000, 1, 9000))):
+        eng = engine.Engine(20, 5000, 2, piece_reads=piece, flags=BF_FLAG_KEEP_EVIDENCE)
+        try:
+            eng.set_genome(g.names, g.seqs)
+            for a, e in cuts_for(b.n, sizes):
+                eng.submit(b.slice(a, e))
+            res = eng.finish()
+            ev = eng.evidence()
+            by, off = eng.render_junctions(np.arange(b.n, dtype=np.uint32))
+            outs.append((eng.format_sv(res), ev, by, off))
+        finally:
+            eng.close()
+    assert outs[0][0] == outs[1][0] == oracle_sv(g, b)
+    for k in ("class_key", "lpos", "rpos", "bp", "mask"):
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+    assert np.array_equal(outs[0][1]["flags"] & 0x17, outs[1][1]["flags"] & 0x17)
+    assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3])
+
+
+@pytest.mark.parametrize("order", ["short_first", "long_first"])
+def test_read_lengths_that_change_the_evidence_layout_between_pieces(order):
+    """The evidence layout depends on the longest read seen so far (mask words per render record, the kernel
+    instance): a later piece with longer reads makes the library start over; shorter ones do not."""
+    g, b1 = case(n_reads=9000, L=100, seed=21)
+    _, b2 = case(n_reads=9000, L=200, seed=21)        # same genome (same seed), other reads
+    _, b3 = case(n_reads=3000, L=300, seed=21)        # longer than the packed kernel: exact path, text records
+    parts = [b1, b2, b3] if order == "short_first" else [b3, b2, b1]
+    whole = concat(parts)
+    ref = oracle_sv(g, whole)
+    eng = engine.Engine(20, 5000, 2, piece_reads=2000)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        for p in parts:
+            eng.submit(p)
+        assert eng.format_sv(eng.finish()) == ref
+    finally:
+        eng.close()
+
+
+def test_finish_then_more_reads_then_finish():
+    """Appending after a bf_finish: only the new reads are localised, the exact kernel only sees its new list
+    entries, and the result is the oracle's for the union (also with every read on the exact path)."""
+    g, b = case(n_frac=0.003)
+    for flags in (0, BF_FLAG_FORCE_EXACT):
+        eng = engine.Engine(20, 5000, 2, piece_reads=3000, flags=flags)
+        try:
+            eng.set_genome(g.names, g.seqs)
+            cut = [0, 7000, 7001, 15000, b.n]
+            for a, e in zip(cut[:-1], cut[1:]):
+                eng.submit(b.slice(a, e))
+                assert eng.format_sv(eng.finish()) == oracle_sv(g, b.slice(0, e))
+        finally:
+            eng.close()
+
+
+def test_reset_keeps_the_memory_and_reserve_sizes_it():
+    g, b = case()
+    ref = oracle_sv(g, b)
+    eng = engine.Engine(20, 5000, 2, piece_reads=5000)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        eng.reserve(b.n, int(b.seq_off[-1]), int(b.frag_off[-1]))
+        _, bytes0 = eng.stats()
+        pb = eng.pin_batch(b)
+        for _ in range(3):
+            eng.reset()
+            eng.submit(pb)
+            assert eng.format_sv(eng.finish()) == ref
+        eng.reset()
+        half = b.slice(0, b.n // 2)
+        eng.submit(half)
+        assert eng.format_sv(eng.finish()) == oracle_sv(g, half)
+        assert eng.stats()[0] == half.n
+    finally:
+        eng.close()
+
+
+def test_a_rejected_batch_leaves_the_ctx_as_it_was():
+    g, b = case()
+    good = b.slice(0, 10000)
+    ref = oracle_sv(g, good)
+    eng = engine.Engine(20, 5000, 2, piece_reads=1500, host_threads=3)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        eng.submit(good)
+        bad = b.slice(10000, 20000)
+        # an unknown contig id in the batch's last piece: earlier pieces were already uploaded and localised
+        h = bad.hits.copy(); h["contig3"][9000] = 99
+        with pytest.raises(engine.BreakfastError) as e:
+            eng.submit(engine.Batch(bad.seq_bytes, bad.seq_off, bad.frag_bytes, bad.frag_off, h))
+        assert e.value.code == -1 and "read 9000 " in str(e.value)
+        # offsets that run backwards; an anchor position beyond 2^31; a read shorter than 2 * anchor_len
+        so = bad.seq_off.copy(); so[5000] = so[4999] - 1
+        with pytest.raises(engine.BreakfastError) as e:
+            eng.submit(engine.Batch(bad.seq_bytes, so, bad.frag_bytes, bad.frag_off, bad.hits))
+        assert e.value.code == -1 and "monotone" in str(e.value)
+        h = bad.hits.copy(); h["pos5"][3] = 0x80000000
+        with pytest.raises(engine.BreakfastError) as e:
+            eng.submit(engine.Batch(bad.seq_bytes, bad.seq_off, bad.frag_bytes, bad.frag_off, h))
+        assert e.value.code == -5
+        so = bad.seq_off.copy(); so[8001:] -= 100            # read 8000 has 20 bases
+        with pytest.raises(engine.BreakfastError) as e:
+            eng.submit(engine.Batch(bad.seq_bytes, so, bad.frag_bytes, bad.frag_off, bad.hits))
+        assert e.value.code == -5 and "shorter than 2 * anchor_len" in str(e.value)
+        assert eng.stats()[0] == good.n
+        assert eng.format_sv(eng.finish()) == ref
+        # and the ctx still takes the good version of the batch
+        eng.submit(bad)
+        assert eng.format_sv(eng.finish()) == oracle_sv(g, b.slice(0, 20000))
+    finally:
+        eng.close()
+
+
+def test_pageable_batches_may_be_freed_on_return_and_pinned_ones_after_the_wait():
+    g, b = case()
+    ref = oracle_sv(g, b)
+    eng = engine.Engine(20, 5000, 2, piece_reads=4000, host_threads=8)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        half = b.n // 2
+        part = b.slice(0, half)
+        arrs = [np.array(x, copy=True) for x in (part.seq_bytes, part.seq_off, part.frag_bytes, part.frag_off, part.hits)]
+        eng.submit(engine.Batch(*arrs))
+        for a in arrs:                                   # pageable: staged before bf_submit returned
+            a.view(np.uint8)[...] = 0xAB
+        pinned = eng.pin_batch(b.slice(half, b.n))
+        eng.submit(pinned)
+        eng.submit_wait()
+        for a in (pinned.seq_bytes, pinned.frag_bytes):  # pinned: free for reuse once the uploads are through
+            a[...] = 0x21
+        pinned.hits.view(np.uint8)[...] = 0xFF
+        assert eng.format_sv(eng.finish()) == ref
+    finally:
+        eng.close()
