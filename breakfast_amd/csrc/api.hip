@@ -8,6 +8,8 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <ctime>
+#include <unistd.h>
 #include <mutex>
 #include <numeric>
 #include <thread>
@@ -24,6 +26,26 @@ int fail(bf_ctx* ctx, int code, const char* fmt, ...) {
     va_end(ap);
     if (ctx) ctx->err = buf; else g_create_error = buf;
     return code;
+}
+
+bool trace_on() {
+    static const bool on = [] { const char* e = getenv("BREAKFAST_TRACE"); return e && *e && *e != '0'; }();
+    return on;
+}
+void trace_line(const bf_ctx* ctx, const char* what, const char* name, const char* file, int line) {
+    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    const char* base = strrchr(file, '/');
+    fprintf(stderr, "[bf-trace pid=%d rank=%u/%u t=%.6f] %s %s %s:%d\n", (int)getpid(), ctx ? ctx->rank : 0u, ctx ? ctx->n_ranks : 0u,
+            (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec, what, name, base ? base + 1 : file, line);
+    fflush(stderr);
+}
+int traced_sync(bf_ctx* ctx, hipStream_t s, const char* name, const char* file, int line) {
+    const bool t = trace_on();
+    if (t) trace_line(ctx, "wait", name, file, line);
+    const hipError_t e = hipStreamSynchronize(s);
+    if (t) trace_line(ctx, e == hipSuccess ? "done" : "FAILED", name, file, line);
+    if (e != hipSuccess) return fail(ctx, BF_ERR_HIP, "hipStreamSynchronize(%s) failed: %s (%s:%d)", name, hipGetErrorString(e), file, line);
+    return BF_OK;
 }
 
 int ensure(bf_ctx* ctx, DevBuf& b, size_t bytes, bool keep) {
@@ -304,13 +326,14 @@ void bf_ctx_destroy(bf_ctx* ctx) {
 
 int bf_sync(bf_ctx* ctx) {
     if (!ctx) return BF_ERR_INVALID;
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     return BF_OK;
 }
 
 int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint8_t* const* seqs,
                   const uint64_t* lens) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!names || !seqs || !lens || n_contigs == 0) return fail(ctx, BF_ERR_INVALID, "bf_genome_set: null/empty argument");
     if (n_contigs > (1u << kContigBits)) return fail(ctx, BF_ERR_RANGE, "%u contigs; at most %u are supported", n_contigs, 1u << kContigBits);
     if (ctx->n_reads) return fail(ctx, BF_ERR_STATE, "bf_genome_set with resident reads; call bf_reset first");
@@ -353,19 +376,20 @@ int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, con
     BF_HIP(ctx, hipMemsetAsync(ctx->g_exc.p, 0, exc_image_slots(n_blocks) * 8, ctx->stream));
     BF_HIP(ctx, hipMemsetAsync(ctx->g_coarse.p, 0, (n_blocks / 64 + 4) * 8, ctx->stream));
     BF_HIP(ctx, hipMemsetAsync(ctx->g_coarse2.p, 0, (n_blocks / 2048 + 4) * 4, ctx->stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     for (uint32_t i = 0; i < n_contigs; i++)
         if (lens[i]) BF_HIP(ctx, hipMemcpy(ctx->g_raw.as<uint8_t>() + ctx->contig_host[i].goff, seqs[i], lens[i], hipMemcpyHostToDevice));
     BF_HIP(ctx, hipMemcpy(ctx->g_contigs.p, ctx->contig_host.data(), (size_t)n_contigs * sizeof(ContigDev), hipMemcpyHostToDevice));
     BF_TRY(genome_pack(ctx));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     return BF_OK;
 }
 
 int bf_reset(bf_ctx* ctx) {
     if (!ctx) return BF_ERR_INVALID;
-    BF_HIP(ctx, hipStreamSynchronize(ctx->in_stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_TRACE_CALL(ctx);
+    BF_SYNC(ctx, ctx->in_stream);
+    BF_SYNC(ctx, ctx->stream);
     ctx->in_pending = false; ctx->n_localised = 0; ctx->consumed = false;
     ctx->n_reads = 0; ctx->seq_bytes = 0; ctx->frag_bytes = 0;
     ctx->max_len = 0; ctx->min_len = 0xffffffffu; ctx->max_frag = 0;
@@ -485,8 +509,8 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
 static int reserve_input(bf_ctx* ctx, uint64_t reads, uint64_t seq_bytes, uint64_t frag_bytes) {
     if (reads > ctx->cap_reads) BF_TRY(grow_reads(ctx, std::max<uint64_t>({reads, ctx->cap_reads * 2, (uint64_t)1 << 16})));
     if (seq_bytes + 64 > ctx->d_seq.cap || frag_bytes + 64 > ctx->d_frag.cap || !ctx->d_seq.p || !ctx->d_frag.p) {
-        BF_HIP(ctx, hipStreamSynchronize(ctx->in_stream));
-        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BF_SYNC(ctx, ctx->in_stream);
+        BF_SYNC(ctx, ctx->stream);
         if (seq_bytes + 64 > ctx->d_seq.cap || !ctx->d_seq.p) BF_TRY(ensure(ctx, ctx->d_seq, std::max<uint64_t>(seq_bytes + 64, ctx->d_seq.cap * 2), true));
         if (frag_bytes + 64 > ctx->d_frag.cap || !ctx->d_frag.p) BF_TRY(ensure(ctx, ctx->d_frag, std::max<uint64_t>(frag_bytes + 64, ctx->d_frag.cap * 2), true));
     }
@@ -517,7 +541,7 @@ int bf_host_free(bf_ctx* ctx, void* p) {
     if (!p) return BF_OK;
     for (size_t i = 0; i < ctx->pinned.size(); i++)
         if (ctx->pinned[i].first == (const uint8_t*)p) {
-            BF_HIP(ctx, hipStreamSynchronize(ctx->in_stream));       // no upload may still be reading it
+            BF_SYNC(ctx, ctx->in_stream);       // no upload may still be reading it
             (void)hipHostFree(p);
             ctx->pinned.erase(ctx->pinned.begin() + (long)i);
             return BF_OK;
@@ -527,12 +551,14 @@ int bf_host_free(bf_ctx* ctx, void* p) {
 
 int bf_submit_wait(bf_ctx* ctx) {
     if (!ctx) return BF_ERR_INVALID;
-    BF_HIP(ctx, hipStreamSynchronize(ctx->in_stream));
+    BF_TRACE_CALL(ctx);
+    BF_SYNC(ctx, ctx->in_stream);
     return BF_OK;
 }
 
 int bf_submit(bf_ctx* ctx, const bf_batch* b) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!b) return fail(ctx, BF_ERR_INVALID, "bf_submit: null batch");
     if (ctx->n_contigs == 0) return fail(ctx, BF_ERR_STATE, "bf_submit before bf_genome_set");
     const uint64_t m = b->n_reads;
@@ -630,6 +656,7 @@ int bf_submit(bf_ctx* ctx, const bf_batch* b) {
 
 int bf_localise(bf_ctx* ctx) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (ctx->n_contigs == 0) return fail(ctx, BF_ERR_STATE, "bf_localise before bf_genome_set");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     ctx->imported = false;
@@ -716,14 +743,15 @@ static int clusterise_in_groups(bf_ctx* ctx, const OwnerView& v, bool* done) {
         BF_HIP(ctx, hipMemcpyAsync(ctx->out.cjo.p, ctx->c_cjo.p, (cl_base + 1) * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
         ctx->reads_on_device = true;
     }
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    BF_SYNC(ctx, ctx->stream);
+    BF_SYNC(ctx, ctx->copy_stream);
     *done = true;
     return BF_OK;
 }
 
 int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!out) return fail(ctx, BF_ERR_INVALID, "bf_clusterise: null result");
     memset(out, 0, sizeof *out);
     if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_clusterise before bf_localise");
@@ -783,8 +811,8 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
             BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
         }
     }
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));        // the cluster rows went out on it
+    BF_SYNC(ctx, ctx->stream);
+    BF_SYNC(ctx, ctx->copy_stream);        // the cluster rows went out on it
     out->n_evidence = ctx->n_evidence;
     out->n_clusters = ctx->out.n_clusters;
     out->n_reads = nr;
@@ -798,6 +826,7 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
 
 int bf_result_reads(bf_ctx* ctx, bf_result* result) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!result) return fail(ctx, BF_ERR_INVALID, "bf_result_reads: null result");
     if (!ctx->clustered) return fail(ctx, BF_ERR_STATE, "bf_result_reads before bf_clusterise");
     if (result->n_reads != ctx->out.n_reads || result->clusters != ctx->out.clusters.as<bf_cluster>())
@@ -809,7 +838,7 @@ int bf_result_reads(bf_ctx* ctx, bf_result* result) {
         BF_HIP(ctx, hipSetDevice(ctx->device));
         BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
         BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
-        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BF_SYNC(ctx, ctx->stream);
         ctx->reads_on_device = false;
     }
     result->reads = nr ? ctx->out.reads.as<bf_read>() : nullptr;
@@ -818,6 +847,7 @@ int bf_result_reads(bf_ctx* ctx, bf_result* result) {
 
 int bf_finish(bf_ctx* ctx, bf_result* out) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (ctx->n_ranks > 1) return fail(ctx, BF_ERR_STATE, "bf_finish on a multi-rank ctx; use the stage calls");
     BF_TRY(localise_deferred(ctx));
     BF_TRY(bf_clusterise(ctx, out));
@@ -1012,6 +1042,7 @@ int bf_set_rank(bf_ctx* ctx, uint32_t rank, uint32_t n_ranks, uint64_t index_bas
 
 int bf_exchange_local(bf_ctx* ctx, bf_wire_local* out) {
     if (!ctx || !out) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_exchange_local before bf_localise");
     out->max_frag_len_bytes = ctx->max_frag;
     BF_TRY(settle_counts(ctx));
@@ -1022,6 +1053,7 @@ int bf_exchange_local(bf_ctx* ctx, bf_wire_local* out) {
 int bf_exchange_pack(bf_ctx* ctx, const bf_wire_local* agreed, void* dev_send, uint64_t dev_send_bytes, uint64_t* counts,
                      void** dev_out, uint32_t* record_bytes) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!agreed || !counts || !dev_out || !record_bytes) return fail(ctx, BF_ERR_INVALID, "bf_exchange_pack: null argument");
     if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_exchange_pack before bf_localise");
     BF_HIP(ctx, hipSetDevice(ctx->device));
@@ -1030,6 +1062,7 @@ int bf_exchange_pack(bf_ctx* ctx, const bf_wire_local* agreed, void* dev_send, u
 
 int bf_exchange_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts, const uint64_t* src_index_base) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!src_counts || !src_index_base) return fail(ctx, BF_ERR_INVALID, "bf_exchange_import: null argument");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     ctx->src_index_base.assign(src_index_base, src_index_base + ctx->n_ranks);
@@ -1040,6 +1073,7 @@ int bf_exchange_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_co
 
 int bf_result_sources(bf_ctx* ctx, const uint32_t** src_rank, const uint32_t** src_index) {
     if (!ctx || !src_rank || !src_index) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!ctx->imported || !ctx->clustered)
         return fail(ctx, BF_ERR_STATE, "bf_result_sources is only meaningful after bf_exchange_import + bf_clusterise");
     if (ctx->sources_on_device) {
@@ -1047,7 +1081,7 @@ int bf_result_sources(bf_ctx* ctx, const uint32_t** src_rank, const uint32_t** s
         BF_HIP(ctx, hipSetDevice(ctx->device));
         BF_TRY(ensure_host(ctx, ctx->out.src, nr * 8));
         BF_HIP(ctx, hipMemcpyAsync(ctx->out.src.p, ctx->c_rsrc.p, nr * 8, hipMemcpyDeviceToHost, ctx->stream));
-        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BF_SYNC(ctx, ctx->stream);
         ctx->sources_on_device = false;
     }
     *src_rank = ctx->out.src.as<uint32_t>(); *src_index = ctx->out.src.as<uint32_t>() + ctx->out.n_reads;
@@ -1056,6 +1090,7 @@ int bf_result_sources(bf_ctx* ctx, const uint32_t** src_rank, const uint32_t** s
 
 int bf_render_junctions(bf_ctx* ctx, uint64_t n, const uint32_t* local_index, const uint8_t** out_bytes, const uint64_t** out_off) {
     if (!ctx || !out_bytes || !out_off) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_render_junctions before bf_localise");
     if (n && !local_index) return fail(ctx, BF_ERR_INVALID, "bf_render_junctions: null index list");
     for (uint64_t i = 0; i < n; i++)
@@ -1069,7 +1104,7 @@ int bf_render_junctions(bf_ctx* ctx, uint64_t n, const uint32_t* local_index, co
     std::vector<uint8_t> recs(total);
     BF_HIP(ctx, hipMemcpyAsync(roff.data(), ctx->r_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (total) BF_HIP(ctx, hipMemcpyAsync(recs.data(), ctx->r_bytes.p, total, hipMemcpyDeviceToHost, ctx->stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     // this host-side call hands out TEXT (the device-side call hands out records): expand here
     ctx->render_off_host.assign(n + 1, 0);
     for (uint64_t i = 0; i < n; i++) {
@@ -1089,6 +1124,7 @@ int bf_render_junctions(bf_ctx* ctx, uint64_t n, const uint32_t* local_index, co
 
 int bf_result_sources_dev(bf_ctx* ctx, uint32_t* dev_src_rank, uint32_t* dev_src_index) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!ctx->imported || !ctx->clustered)
         return fail(ctx, BF_ERR_STATE, "bf_result_sources_dev is only meaningful after bf_exchange_import + bf_clusterise");
     const uint64_t nr = ctx->out.n_reads;
@@ -1098,13 +1134,14 @@ int bf_result_sources_dev(bf_ctx* ctx, uint32_t* dev_src_rank, uint32_t* dev_src
     const uint32_t* src = ctx->c_rsrc.as<uint32_t>();                  // out_src_rank[nr], out_src_idx[nr]
     BF_HIP(ctx, hipMemcpyAsync(dev_src_rank, src, nr * 4, hipMemcpyDeviceToDevice, ctx->stream));
     BF_HIP(ctx, hipMemcpyAsync(dev_src_index, src + nr, nr * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     return BF_OK;
 }
 
 int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_index, uint64_t* dev_off,
                             uint8_t* dev_bytes, uint64_t dev_bytes_cap, uint64_t* total) {
     if (!ctx || !total) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_render_junctions_dev before bf_localise");
     if (!dev_off || (n && !dev_local_index)) return fail(ctx, BF_ERR_INVALID, "bf_render_junctions_dev: null argument");
     if (((uintptr_t)dev_bytes & 3) || ((uintptr_t)dev_off & 7) || ((uintptr_t)dev_local_index & 3))
@@ -1116,6 +1153,7 @@ int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_i
 int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const uint8_t* dev_bytes, uint64_t size,
                                    bf_result* out) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!out) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junctions_dev: null result");
     if (!ctx->imported || !ctx->clustered)
         return fail(ctx, BF_ERR_STATE, "bf_result_attach_junctions_dev is only meaningful after bf_exchange_import + bf_clusterise");
@@ -1133,7 +1171,7 @@ int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const 
         BF_TRY(ensure_host(ctx, ctx->out.junction, size));
         BF_HIP(ctx, hipMemcpyAsync(ctx->out.junction.p, dev_bytes, size, hipMemcpyDeviceToHost, ctx->stream));
     }
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     ctx->table_attached = true;
     memset(out, 0, sizeof *out);
     out->n_evidence = ctx->n_evidence;
@@ -1152,6 +1190,7 @@ int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const 
 // piece as they arrive; the copies run on the ctx's copy stream behind the caller's next collective.
 int bf_result_junction_sizes_dev(bf_ctx* ctx, uint32_t* dev_len) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!ctx->imported || !ctx->clustered)
         return fail(ctx, BF_ERR_STATE, "bf_result_junction_sizes_dev is only meaningful after bf_exchange_import + bf_clusterise");
     const uint64_t nr = ctx->out.n_reads;
@@ -1159,7 +1198,7 @@ int bf_result_junction_sizes_dev(bf_ctx* ctx, uint32_t* dev_len) {
     if (!dev_len) return fail(ctx, BF_ERR_INVALID, "bf_result_junction_sizes_dev: null output");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     BF_TRY(read_sizes(ctx, dev_len, nr));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     return BF_OK;
 }
 
@@ -1205,19 +1244,21 @@ static int layout_complete(bf_ctx* ctx, uint32_t n_pieces, uint64_t* piece_read_
 
 int bf_result_layout_dev(bf_ctx* ctx, uint32_t n_pieces, uint64_t* piece_read_begin, uint64_t* piece_byte_off) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!ctx->imported || !ctx->clustered)
         return fail(ctx, BF_ERR_STATE, "bf_result_layout_dev is only meaningful after bf_exchange_import + bf_clusterise");
     if (n_pieces == 0 || n_pieces > 64 || !piece_read_begin || !piece_byte_off)
         return fail(ctx, BF_ERR_INVALID, "bf_result_layout_dev: 1..64 pieces and two output arrays");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     BF_TRY(layout_enqueue(ctx, n_pieces, true));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     return layout_complete(ctx, n_pieces, piece_read_begin, piece_byte_off);
 }
 
 int bf_result_requests_dev(bf_ctx* ctx, uint32_t n_pieces, uint32_t* dev_req, uint64_t* counts, uint64_t* bytes,
                            uint64_t* piece_read_begin, uint64_t* piece_byte_off) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!ctx->imported || !ctx->clustered)
         return fail(ctx, BF_ERR_STATE, "bf_result_requests_dev is only meaningful after bf_exchange_import + bf_clusterise");
     if (n_pieces == 0 || n_pieces > 64 || !counts || !bytes || !piece_read_begin || !piece_byte_off)
@@ -1237,7 +1278,7 @@ int bf_result_requests_dev(bf_ctx* ctx, uint32_t n_pieces, uint32_t* dev_req, ui
     }
     uint64_t total_check = 0;
     if (nr) BF_HIP(ctx, hipMemcpyAsync(&total_check, ctx->c_joff.as<uint64_t>() + nr, 8, hipMemcpyDeviceToHost, ctx->stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     // a piece's groups are exactly its reads, so the byte bounds of its first group are the piece's own
     for (uint32_t c = 0; c <= n_pieces && nr; c++) {
         if (start[c * ctx->n_ranks] != ctx->piece_read[c])
@@ -1254,6 +1295,7 @@ int bf_result_requests_dev(bf_ctx* ctx, uint32_t n_pieces, uint32_t* dev_req, ui
 
 int bf_result_attach_records_dev(bf_ctx* ctx, uint32_t piece, const uint8_t* dev_records, uint64_t size, const int64_t* dev_read_pos) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!ctx->imported || !ctx->clustered || !ctx->result_order)
         return fail(ctx, BF_ERR_STATE, "bf_result_attach_records_dev before bf_result_layout_dev");
     if (piece >= ctx->piece_done.size()) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: piece %u of %zu", piece, ctx->piece_done.size());
@@ -1292,14 +1334,15 @@ int bf_result_attach_records_dev(bf_ctx* ctx, uint32_t piece, const uint8_t* dev
 
 int bf_result_attach_finish(bf_ctx* ctx, bf_result* out) {
     if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
     if (!out) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_finish: null result");
     if (!ctx->imported || !ctx->clustered || !ctx->result_order)
         return fail(ctx, BF_ERR_STATE, "bf_result_attach_finish before bf_result_layout_dev");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     uint32_t err = 0;
     if (ctx->out.n_reads) BF_HIP(ctx, hipMemcpyAsync(&err, ctx->c_err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    BF_SYNC(ctx, ctx->stream);
+    BF_SYNC(ctx, ctx->copy_stream);
     if (ctx->out.n_reads == 0) ctx->out.junction_size = 0;
     if (ctx->junction_attached != ctx->out.junction_size)
         return fail(ctx, BF_ERR_STATE, "bf_result_attach_finish: %llu of %llu junction bytes were attached",
@@ -1334,7 +1377,7 @@ int bf_evidence_fetch(bf_ctx* ctx, bf_evidence_view* v) {
     ctx->ev_mask.assign(n * W, 0);
     if (n) {
         std::vector<uint64_t> tmp(n * (W + 1));
-        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BF_SYNC(ctx, ctx->stream);
         BF_HIP(ctx, hipMemcpy(ctx->ev_key.data(), ctx->d_key.p, n * 8, hipMemcpyDeviceToHost));
         BF_HIP(ctx, hipMemcpy(ctx->ev_lpos.data(), ctx->d_lpos.p, n * 4, hipMemcpyDeviceToHost));
         BF_HIP(ctx, hipMemcpy(ctx->ev_rpos.data(), ctx->d_rpos.p, n * 4, hipMemcpyDeviceToHost));
@@ -1352,8 +1395,8 @@ int bf_evidence_fetch(bf_ctx* ctx, bf_evidence_view* v) {
 
 int bf_kernel_times(bf_ctx* ctx, const bf_kernel_time** out, uint32_t* n) {
     if (!ctx || !out || !n) return BF_ERR_INVALID;
-    BF_HIP(ctx, hipStreamSynchronize(ctx->in_stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->in_stream);
+    BF_SYNC(ctx, ctx->stream);
     ctx->timing.clear();
     for (auto& p : pending(ctx)) {
         float ms = 0;

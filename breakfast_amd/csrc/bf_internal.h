@@ -269,6 +269,20 @@ int fail(bf_ctx* ctx, int code, const char* fmt, ...);
         if (r_ != BF_OK) return r_;  \
     } while (0)
 
+// BREAKFAST_TRACE=1: every C-ABI call and every host wait for the GPU writes "enter"/"leave" and "wait"/"done"
+// lines (pid, rank, seconds, call or stream, source line) to stderr, so that a hang names the wait that never
+// returned -- with several ranks sharing one GPU the process that is stuck is not the one whose collective times out.
+bool trace_on();
+void trace_line(const bf_ctx* ctx, const char* what, const char* name, const char* file, int line);
+int traced_sync(bf_ctx* ctx, hipStream_t s, const char* name, const char* file, int line);
+#define BF_SYNC(ctx, s) BF_TRY(bf::traced_sync(ctx, s, #s, __FILE__, __LINE__))
+struct TraceCall {
+    const bf_ctx* ctx; const char* fn;
+    TraceCall(const bf_ctx* c, const char* f) : ctx(c), fn(f) { if (trace_on()) trace_line(ctx, "enter", fn, "", 0); }
+    ~TraceCall() { if (trace_on()) trace_line(ctx, "leave", fn, "", 0); }
+};
+#define BF_TRACE_CALL(ctx) bf::TraceCall trace_call_(ctx, __func__)
+
 int ensure(bf_ctx* ctx, DevBuf& b, size_t bytes, bool keep = false);
 int ensure_host(bf_ctx* ctx, HostBuf& b, size_t bytes);
 void release(bf_ctx* ctx, DevBuf& b);

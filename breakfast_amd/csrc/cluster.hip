@@ -34,7 +34,7 @@ static int sort_pairs(bf_ctx* ctx, const K* kin, K* kout, const uint32_t* vin, u
 
 static int fetch_u64(bf_ctx* ctx, const uint64_t* d, uint64_t* h) {
     BF_HIP(ctx, hipMemcpyAsync(h, d, 8, hipMemcpyDeviceToHost, ctx->stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     return BF_OK;
 }
 
@@ -614,7 +614,7 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
                                 ctx->c_gidx.as<uint32_t>(), n, 0, (unsigned)ctx->contig_bits));
     std::vector<uint64_t> hist(bins + 1);
     BF_HIP(ctx, hipMemcpyAsync(hist.data(), ctx->c_hist.p, (size_t)(bins + 1) * 8, hipMemcpyDeviceToHost, st));
-    BF_HIP(ctx, hipStreamSynchronize(st));
+    BF_SYNC(ctx, st);
     BF_TRY(settle_counts(ctx));                           // the localise counters came along with this synchronisation
     *record_bytes = hist[bins];
     // cut after the rank where the running count passes the next multiple of n / max_groups
@@ -1068,7 +1068,7 @@ int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint
         hipLaunchKernelGGL(pack_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, pv);
     BF_HIP(ctx, hipGetLastError());
     BF_HIP(ctx, hipMemcpyAsync(start.data(), ctx->d_part_tmp.p, (size_t)(R + 1) * 8, hipMemcpyDeviceToHost, st));
-    BF_HIP(ctx, hipStreamSynchronize(st));
+    BF_SYNC(ctx, st);
     // empty buckets keep the sentinel n: a bucket ends where the next non-empty one starts
     uint64_t end = n;
     for (int r = (int)R - 1; r >= 0; r--) {
@@ -1112,7 +1112,7 @@ int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts) {
     else
         hipLaunchKernelGGL(import_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, v);
     BF_HIP(ctx, hipGetLastError());
-    BF_HIP(ctx, hipStreamSynchronize(st));   // dev_recv may be released by the caller on return
+    BF_SYNC(ctx, st);   // dev_recv may be released by the caller on return
     return BF_OK;
 }
 

@@ -1006,7 +1006,7 @@ static void launch_fast(bf_ctx* ctx, const LocaliseArgs& a) {
 
 int settle_counts(bf_ctx* ctx) {
     if (!ctx->counts_pending) return BF_OK;
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     ctx->n_exact = ctx->h_counts[0]; ctx->n_sigx = ctx->h_counts[1]; ctx->n_text_records = ctx->h_counts[2];
     ctx->counts_pending = false;
     return BF_OK;
@@ -1019,8 +1019,8 @@ static inline uint32_t plane_words_for(uint32_t wm) { return wm <= 2 ? 2 : wm ==
 // localised behind their upload -- the evidence the packed kernel wrote for them.  Waits for all queued work.
 int grow_reads(bf_ctx* ctx, uint64_t cap) {
     if (cap <= ctx->cap_reads) return BF_OK;
-    if (ctx->in_stream) BF_HIP(ctx, hipStreamSynchronize(ctx->in_stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->in_stream) BF_SYNC(ctx, ctx->in_stream);
+    BF_SYNC(ctx, ctx->stream);
     BF_TRY(ensure(ctx, ctx->d_seq_off, (cap + 1) * 8, true));
     BF_TRY(ensure(ctx, ctx->d_frag_off, (cap + 1) * 8, true));
     BF_TRY(ensure(ctx, ctx->d_hits, cap * sizeof(bf_hit), true));
@@ -1174,7 +1174,7 @@ int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf&
     uint64_t* d_pick = (uint64_t*)(ctx->c_misc.as<uint8_t>() + ((n * 4 + 15) & ~(size_t)15));
     hipLaunchKernelGGL(pick_offsets_kernel, dim3(1), dim3(64), 0, ctx->stream, d_off.as<uint64_t>(), n, n_chunks, d_pick);
     BF_HIP(ctx, hipMemcpyAsync(chunk_off, d_pick, (size_t)(n_chunks + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     return BF_OK;
 }
 
@@ -1220,7 +1220,7 @@ int render_dev(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint64_t* d
     *total = 0;
     if (n == 0) {
         BF_HIP(ctx, hipMemsetAsync(d_off, 0, 8, ctx->stream));
-        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BF_SYNC(ctx, ctx->stream);
         return BF_OK;
     }
     BF_TRY(ensure(ctx, ctx->r_idx, n * 4 + 16));                      // lengths + the bad-index counter
@@ -1236,7 +1236,7 @@ int render_dev(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint64_t* d
     uint32_t bad = 0;
     BF_HIP(ctx, hipMemcpyAsync(total, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
     BF_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     if (bad) return fail(ctx, BF_ERR_INVALID, "bf_render_junctions_dev: %u of %llu indices are outside the %llu resident reads",
                          bad, (unsigned long long)n, (unsigned long long)ctx->n_reads);
     if (!d_bytes) return BF_OK;
@@ -1247,7 +1247,7 @@ int render_dev(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint64_t* d
         Scope t(ctx, "render");
         BF_TRY(launch_render(ctx, n, d_local_idx, d_off, d_bytes));
     }
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     return BF_OK;
 }
 
@@ -1282,7 +1282,7 @@ static int render_dev_static(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_id
     if (!ctx->scratch || !ctx->h_counts) return fail(ctx, BF_ERR_STATE, "bf_render_junctions_dev_static: the ctx has no scratch pointer");
     if (n == 0) {
         BF_HIP(ctx, hipMemsetAsync(d_off, 0, 8, ctx->stream));
-        BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BF_SYNC(ctx, ctx->stream);
         return BF_OK;
     }
     uint8_t* base = (uint8_t*)ctx->scratch;           // never the array's name
@@ -1299,7 +1299,7 @@ static int render_dev_static(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_id
     volatile uint32_t* hw = ctx->h_counts + 8;
     BF_HIP(ctx, hipMemcpyAsync((void*)(ctx->h_counts + 8), d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
     BF_HIP(ctx, hipMemcpyAsync((void*)(ctx->h_counts + 10), d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     const uint64_t tot = (uint64_t)hw[0] | ((uint64_t)hw[1] << 32);
     const uint32_t bad = hw[2];
     *total = tot;
@@ -1310,7 +1310,7 @@ static int render_dev_static(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_id
         return fail(ctx, BF_ERR_INVALID, "bf_render_junctions_dev_static: buffer of %llu bytes, %llu needed",
                     (unsigned long long)d_bytes_cap, (unsigned long long)tot);
     BF_TRY(launch_render(ctx, n, d_local_idx, d_off, d_bytes));      // no timing scope: events would be created
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     return BF_OK;
 }
 

@@ -394,7 +394,7 @@ int bfx_sort_pairs_u32(bf_ctx* ctx, const uint32_t* kin, uint32_t* kout, const u
     if (!ctx) return BF_ERR_INVALID;
     BF_HIP(ctx, hipSetDevice(ctx->device));
     BF_TRY(bf::radix_sort_pairs(ctx, kin, kout, vin, vout, n, begin_bit, end_bit));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     return BF_OK;
 }
 int bfx_sort_pairs_u64(bf_ctx* ctx, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n,
@@ -402,21 +402,21 @@ int bfx_sort_pairs_u64(bf_ctx* ctx, const uint64_t* kin, uint64_t* kout, const u
     if (!ctx) return BF_ERR_INVALID;
     BF_HIP(ctx, hipSetDevice(ctx->device));
     BF_TRY(bf::radix_sort_pairs(ctx, kin, kout, vin, vout, n, begin_bit, end_bit));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     return BF_OK;
 }
 int bfx_scan_sum(bf_ctx* ctx, const uint32_t* in, uint64_t* out /* n+1 */, uint64_t n) {
     if (!ctx) return BF_ERR_INVALID;
     BF_HIP(ctx, hipSetDevice(ctx->device));
     BF_TRY(bf::scan_u32_to_u64(ctx, in, out, n));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     return BF_OK;
 }
 int bfx_scan_max(bf_ctx* ctx, uint32_t* data, uint64_t n) {
     if (!ctx) return BF_ERR_INVALID;
     BF_HIP(ctx, hipSetDevice(ctx->device));
     BF_TRY(bf::scan_max_u32_inplace(ctx, data, n));
-    BF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BF_SYNC(ctx, ctx->stream);
     return BF_OK;
 }
 }

@@ -173,12 +173,35 @@ class HipStageEngine:
         return out
 
 
+_TRACE = os.environ.get("BREAKFAST_TRACE", "0") not in ("", "0")
+
+
+def _trace(what: str, name: str):
+    """BREAKFAST_TRACE=1: the same enter/leave lines the library writes, for the collectives (a rank that hangs in a
+    library wait makes the OTHER ranks time out inside a collective: the last lines of every rank tell which is which)."""
+    if _TRACE:
+        import sys
+        import time
+        r = dist.get_rank() if dist.is_initialized() else 0
+        w = dist.get_world_size() if dist.is_initialized() else 1
+        print("[bf-trace pid=%d rank=%d/%d t=%.6f] %s %s" % (os.getpid(), r, w, time.monotonic(), what, name),
+              file=sys.stderr, flush=True)
+
+
 def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits: Sequence[int], in_splits: Sequence[int], group=None):
     """all_to_all_single with CPU staging when the backend cannot take the tensors' device."""
+    _trace("enter", "all_to_all %d->%d bytes" % (inp.numel() * inp.element_size(), out.numel() * out.element_size()))
+    try:
+        _a2a_impl(out, inp, out_splits, in_splits, group)
+    finally:
+        _trace("leave", "all_to_all")
+
+
+def _a2a_impl(out: torch.Tensor, inp: torch.Tensor, out_splits: Sequence[int], in_splits: Sequence[int], group=None):
     backend = dist.get_backend(group)
     if backend == "gloo" and inp.is_cuda:
         o = torch.empty(out.shape, dtype=out.dtype)
-        _a2a(o, inp.cpu(), out_splits, in_splits, group)
+        _a2a_impl(o, inp.cpu(), out_splits, in_splits, group)
         out.copy_(o)
         return
     if backend == "gloo":
@@ -271,7 +294,9 @@ class DistributedDetect:
         self._phase("agree")
         mf, sx = st.exchange_local()
         agreed = self._ctl([mf, sx])
+        _trace("enter", "all_reduce(max) of the wire parameters")
         dist.all_reduce(agreed, op=dist.ReduceOp.MAX, group=self.group)
+        _trace("leave", "all_reduce(max)")
         mf, sx = (int(v) for v in agreed.cpu().tolist())
         self._phase("pack")
         send, counts, rec = st.exchange_pack_tensor(mf, sx, W)
