@@ -119,6 +119,55 @@ def _worker(rank, world, port, out_path, uneven, chunks):
         dist.destroy_process_group()
 
 
+def make_skewed_case():
+    """configs[3]-style skew: a third of the reads pile onto two hot junctions (two classes own most of the
+    evidence, so one or two of eight owners get most of it), many QNAME duplicates."""
+    contigs = [("chr1", 90000), ("chr10", 70000), ("chr2", 80000), ("chrX", 60000)]
+    g = synth.make_genome(contigs, seed=51)
+    spec = synth.ReadSpec(n_reads=1600, read_len=80, anchor_len=20, n_events=40, singleton_frac=0.2, mate_frac=0.6,
+                          hot_frac=0.35, hot_events=2, seed=53, margin=300)
+    return g, synth.make_reads(g, spec), 20, 5000, 2
+
+
+def _worker8(rank, world, port, out_path, stats_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        g, b, A, F, E = make_skewed_case()
+        n = b.n
+        # uneven shards, two of them empty (ranks 2 and 5), one holding a single read
+        cuts = [0, n // 3, n // 3 + 1, n // 3 + 1, n // 2, (3 * n) // 4, (3 * n) // 4, (7 * n) // 8, n]
+        lo, hi = cuts[rank], cuts[rank + 1]
+        stage = OracleStage(g.as_dict(), g.names, b, lo, hi, A, F, E)
+        dd = DistributedDetect(stage, rank, world, lo, hi - lo, torch.device("cpu"))
+        dd.junction_chunks = 3
+        res = dd.step()
+        owned = torch.tensor([dd.stats.n_owned], dtype=torch.int64)
+        allo = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allo, owned)
+        merged = dd.gather_result(res, g.names)
+        if rank == 0:
+            open(out_path, "wb").write(format_sv(merged, g.names))
+            open(stats_path, "w").write(" ".join(str(int(x.item())) for x in allo))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_uneven_empty_shards_and_a_hot_class(tmp_path):
+    """World size 8 (what BASELINE configs[2] shards over): owner = hash(class) % 8, arrival order = input order
+    (asserted inside the stand-in's import), merged print order, with empty shards and skewed ownership."""
+    g, b, A, F, E = make_skewed_case()
+    expected = po.detect(g.fasta(), synth.bowtie_lines(b, g.names).split(b"\n")[:-1], A, F, E)
+    assert expected.count(b"\n") > 10
+    out, stats = str(tmp_path / "out.sv"), str(tmp_path / "owned.txt")
+    mp.spawn(_worker8, args=(8, _free_port(), out, stats), nprocs=8, join=True)
+    assert open(out, "rb").read() == expected
+    owned = [int(x) for x in open(stats).read().split()]
+    assert sum(owned) == b.n and max(owned) > 2 * (b.n // 8), owned     # the hot classes make ownership uneven
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 

@@ -237,6 +237,48 @@ def scaled_case():
     return g, synth.make_reads(g, spec), spec.anchor_len
 
 
+def config2_case():
+    """BASELINE configs[2] (100M reads on hg38, sharded over 2/4/8 GPUs), scaled: 400k reads, 1.5 % of the genome."""
+    contigs, gk, spec = synth.config(2, scale=0.004, genome_scale=0.015)
+    spec.margin = 10000 + 2 * spec.read_len + 128
+    g = synth.make_genome(contigs, **gk)
+    return g, synth.make_reads(g, spec), spec.anchor_len
+
+
+def _worker_config2(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g, b, A = config2_case()
+        n = b.n
+        cuts = [n * r // world for r in range(world + 1)]               # contiguous line ranges, as configs[2] says
+        lo, hi = cuts[rank], cuts[rank + 1]
+        dev = torch.device("cuda", 0)
+        eng = engine.Engine(A, 5000, 2, device=0, flags=engine.BF_FLAG_DEVICE_ROUTING)
+        eng.set_genome(g.names, g.seqs)
+        eng.set_rank(rank, world, lo)
+        eng.submit(b.slice(lo, hi))
+        dd = DistributedDetect(HipStageEngine(eng, dev), rank, world, lo, hi - lo, dev)
+        res = dd.step()
+        merged = dd.gather_result(res, g.names)
+        if rank == 0:
+            open(out_path, "wb").write(format_sv(merged, g.names))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_config2_scaled_over_ranks(tmp_path, world):
+    g, b, A = config2_case()
+    ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, A, 5000, 2)
+    assert ref.n_clusters > 2000
+    out = str(tmp_path / "out.sv")
+    mp.spawn(_worker_config2, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert open(out, "rb").read() == ref.sv
+
+
 def test_two_ranks_at_half_a_million_reads(tmp_path):
     g, b, A = scaled_case()
     ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, A, 5000, 2)
