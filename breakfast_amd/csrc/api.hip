@@ -308,6 +308,7 @@ void bf_ctx_destroy(bf_ctx* ctx) {
     if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     if (ctx->in_stream) (void)hipStreamSynchronize(ctx->in_stream);
     drop_pending(ctx);
+    shard_destroy(ctx);
     for (auto& sl : ctx->slots) { if (sl.p) (void)hipHostFree(sl.p); if (sl.ev) (void)hipEventDestroy(sl.ev); }
     ctx->slots.clear();
     for (auto& pr : ctx->pinned) (void)hipHostFree((void*)pr.first);

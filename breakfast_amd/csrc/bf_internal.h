@@ -206,6 +206,7 @@ struct bf_ctx {
     uint32_t* h_counts = nullptr;               // pinned, 64 B (bf_ctx_create): words 0-2 the localise kernels' counters on their way
                                                 // to the three fields above, words 8-11 the read-backs of bf_render_junctions_dev_static
     void* scratch = nullptr;                    // this device's copy of the static scratch array (localise.hip, scratch_setup)
+    void* shard = nullptr;                      // bf::Shard (shard.hip): transport and buffers of the in-library sharded path
     bool counts_pending = false;                // ... not yet read back: settle_counts() after the next synchronisation
     bf::DevBuf d_planes, d_len, d_frag_len, d_fhash;
     bf::DevBuf d_key, d_lpos, d_rpos, d_bp, d_flags, d_mask, d_jrec;   // d_jrec: read_info() words
@@ -319,6 +320,9 @@ int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_o
 
 int render_dev(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint64_t* d_off, uint8_t* d_bytes,
                uint64_t d_bytes_cap, uint64_t* total);
+int render_sizes_checked(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint32_t* d_len, uint32_t* d_bad);   // record bytes per list
+                                                    // entry; entries outside the resident reads are counted in *d_bad, not read
+void shard_destroy(bf_ctx* ctx);                    // shard.hip
 int scratch_setup(bf_ctx* ctx);                     // this device's address of the static scratch array -> ctx->scratch
 
 // cluster.hip -----------------------------------------------------------------------------------

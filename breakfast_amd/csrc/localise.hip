@@ -1212,6 +1212,13 @@ int render_range_at(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local
     return launch_render(ctx, b - a, d_local_idx + a, d_off + a, d_bytes);
 }
 
+int render_sizes_checked(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint32_t* d_len, uint32_t* d_bad) {
+    if (n) hipLaunchKernelGGL(render_len_checked_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
+                              ctx->d_jrec.as<uint64_t>(), ctx->n_reads, d_len, d_bad);
+    BF_HIP(ctx, hipGetLastError());
+    return BF_OK;
+}
+
 // Junction strings for a DEVICE list of local read indices into caller-owned device memory (the
 // multi-GPU route: nothing crosses PCIe here).  d_off receives n+1 offsets; when d_bytes is null only
 // the offsets and *total are produced.

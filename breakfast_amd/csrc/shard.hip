@@ -1,0 +1,593 @@
+// The sharded path inside the library (include/breakfast_hip.h, "the sharded path in one call"; SURVEY.md section
+// 8e; north_star item 4): one ctx per GPU, reads sharded by contiguous input range, ONE exchange of evidence keyed
+// on the breakpoint class, clustering on the owner.  The reference is a single process (detect.rs:76-241); what
+// has to survive the sharding is its order: evidence is sorted stably by (chr, pos) (detect.rs:193-198), so ties
+// fall in input order -- records therefore arrive ordered by (source rank, source order) and ranks hold
+// ascending input ranges.
+//
+// Two transports move device buffers between ranks:
+//   RCCL   grouped ncclSend/ncclRecv on the ctx's stream (xGMI is point to point: every pair has its own link,
+//          an all-to-all uses all seven at once), ncclAllGather for the few control words.  librccl is loaded at
+//          run time, so a one-GPU user of this library never needs it.
+//   host   a POSIX shared-memory segment with a staging slot per rank and a sense-reversing barrier: device ->
+//          slot, barrier, peers' slots -> device.  Threads or processes of one machine; ranks may share a GPU.
+//          (What a one-GPU box can test; also the fallback without RCCL.)
+//
+// Sequences never travel.  After clustering, an owner sends each source rank the list of its surviving reads (a
+// 4-byte index each); the source renders their junction records (detect.rs:155-162) and copies them to its own host
+// memory; the owner's rows carry, per supporting read, (source rank, slot in that source's record list).  Slots are
+// arrival order: requests grouped by owner rank, the owner's result order inside, so every rank can compute them
+// from the W x W matrix of request counts, which all ranks gather.
+
+#include "bf_internal.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <rccl/rccl.h>     // types and prototypes only: the functions are looked up with dlsym
+
+namespace bf {
+
+namespace {
+
+// ---- RCCL, loaded at run time ---------------------------------------------------------------------------
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string why;
+};
+
+Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        // a copy the process already holds (PyTorch ships one) must be the one used: two RCCLs in one process
+        // would each believe they own the GPU's IPC state
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) if ((x.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+        for (const char* n : names) { if (x.lib) break; x.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
+        if (!x.lib) { x.why = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?"); return x; }
+#define BF_SYM(field, name) x.field = (decltype(x.field))dlsym(x.lib, name); if (!x.field) { x.why = std::string("librccl lacks ") + name; x.lib = nullptr; return x; }
+        BF_SYM(GetUniqueId, "ncclGetUniqueId") BF_SYM(CommInitRank, "ncclCommInitRank") BF_SYM(CommDestroy, "ncclCommDestroy")
+        BF_SYM(AllGather, "ncclAllGather") BF_SYM(Send, "ncclSend") BF_SYM(Recv, "ncclRecv")
+        BF_SYM(GroupStart, "ncclGroupStart") BF_SYM(GroupEnd, "ncclGroupEnd") BF_SYM(GetErrorString, "ncclGetErrorString")
+#undef BF_SYM
+        return x;
+    }();
+    return r;
+}
+
+#define BF_NCCL(ctx, expr)                                                                                  \
+    do {                                                                                                    \
+        ncclResult_t r_ = (expr);                                                                           \
+        if (r_ != ncclSuccess)                                                                              \
+            return fail(ctx, BF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, rccl().GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- transports --------------------------------------------------------------------------------------------
+struct Transport {
+    uint32_t rank = 0, n = 1;
+    virtual ~Transport() {}
+    // out[r * k + j] = rank r's in[j]; host values, collective
+    virtual int all_gather(bf_ctx* ctx, const uint64_t* in, uint32_t k, uint64_t* out) = 0;
+    // bytes[s * n + d] = what rank s sends to rank d (every rank passes the same matrix); the send buffer holds the
+    // pieces for ranks 0..n-1 back to back, the receive buffer gets the pieces from ranks 0..n-1 back to back.
+    // Device pointers; queued on (or completed before returning to) the ctx's stream.
+    virtual int all_to_all(bf_ctx* ctx, const uint8_t* d_send, uint8_t* d_recv, const uint64_t* bytes) = 0;
+};
+
+struct RcclTransport : Transport {
+    ncclComm_t comm = nullptr;
+    DevBuf d_ctl;
+    ~RcclTransport() override { if (comm) (void)rccl().CommDestroy(comm); if (d_ctl.p) (void)hipFree(d_ctl.p); }
+    int all_gather(bf_ctx* ctx, const uint64_t* in, uint32_t k, uint64_t* out) override {
+        BF_TRY(ensure(ctx, d_ctl, (size_t)(n + 1) * k * 8));
+        uint64_t* d_in = d_ctl.as<uint64_t>();
+        uint64_t* d_out = d_in + k;
+        BF_HIP(ctx, hipMemcpyAsync(d_in, in, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream));
+        BF_NCCL(ctx, rccl().AllGather(d_in, d_out, k, ncclUint64, comm, ctx->stream));
+        BF_HIP(ctx, hipMemcpyAsync(out, d_out, (size_t)n * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+        BF_SYNC(ctx, ctx->stream);
+        return BF_OK;
+    }
+    int all_to_all(bf_ctx* ctx, const uint8_t* d_send, uint8_t* d_recv, const uint64_t* bytes) override {
+        uint64_t so = 0, ro = 0;
+        std::vector<uint64_t> soff(n), roff(n);
+        for (uint32_t r = 0; r < n; r++) { soff[r] = so; roff[r] = ro; so += bytes[(size_t)rank * n + r]; ro += bytes[(size_t)r * n + rank]; }
+        const uint64_t self = bytes[(size_t)rank * n + rank];
+        if (self) BF_HIP(ctx, hipMemcpyAsync(d_recv + roff[rank], d_send + soff[rank], self, hipMemcpyDeviceToDevice, ctx->stream));
+        if (n > 1) {
+            BF_NCCL(ctx, rccl().GroupStart());
+            for (uint32_t r = 0; r < n; r++) {
+                if (r == rank) continue;
+                const uint64_t sb = bytes[(size_t)rank * n + r], rb = bytes[(size_t)r * n + rank];
+                if (sb) BF_NCCL(ctx, rccl().Send(d_send + soff[r], sb, ncclUint8, (int)r, comm, ctx->stream));
+                if (rb) BF_NCCL(ctx, rccl().Recv(d_recv + roff[r], rb, ncclUint8, (int)r, comm, ctx->stream));
+            }
+            BF_NCCL(ctx, rccl().GroupEnd());
+        }
+        return BF_OK;
+    }
+};
+
+// Shared segment: header, one control row per rank, one staging slot per rank.
+struct ShmHeader {
+    std::atomic<uint32_t> ready;          // kShmMagic once rank 0 has initialised the header
+    std::atomic<uint32_t> arrived, sense; // sense-reversing barrier
+    uint32_t n_ranks; uint64_t slot_bytes, ctl_words;
+};
+constexpr uint32_t kShmMagic = 0xbf5a4d31u;
+constexpr uint64_t kShmCtlWords = 4096;   // u64 per rank for all_gather (n_ranks * k must fit: 64 ranks x 64 words)
+constexpr int kShmTimeoutSec = 180;
+
+struct HostTransport : Transport {
+    std::string name;
+    uint8_t* base = nullptr; size_t size = 0;
+    ShmHeader* hdr = nullptr;
+    uint64_t slot_bytes = 0;
+    uint32_t local_sense = 0;
+    bool owner = false, registered = false;
+    uint64_t* ctl(uint32_t r) const { return (uint64_t*)(base + 4096) + (size_t)r * kShmCtlWords; }
+    uint8_t* slot(uint32_t r) const { return base + 4096 + (size_t)n * kShmCtlWords * 8 + (size_t)r * slot_bytes; }
+    ~HostTransport() override {
+        if (base && registered) (void)hipHostUnregister(base);
+        if (base) munmap(base, size);
+        if (owner) shm_unlink(name.c_str());
+    }
+    int barrier(bf_ctx* ctx, const char* where) {
+        local_sense ^= 1u;
+        if (hdr->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+            hdr->arrived.store(0, std::memory_order_relaxed);
+            hdr->sense.store(local_sense, std::memory_order_release);
+            return BF_OK;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0; hdr->sense.load(std::memory_order_acquire) != local_sense; spins++) {
+            if (spins > 200) std::this_thread::sleep_for(std::chrono::microseconds(50)); else std::this_thread::yield();
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kShmTimeoutSec))
+                return fail(ctx, BF_ERR_STATE, "sharded path: rank %u waited %d s for the other ranks at %s (a rank failed or never called)",
+                            rank, kShmTimeoutSec, where);
+        }
+        return BF_OK;
+    }
+    int all_gather(bf_ctx* ctx, const uint64_t* in, uint32_t k, uint64_t* out) override {
+        if ((uint64_t)k > kShmCtlWords) return fail(ctx, BF_ERR_RANGE, "sharded path: control message of %u words", k);
+        if (trace_on()) trace_line(ctx, "enter", "host all_gather", "", 0);
+        memcpy(ctl(rank), in, (size_t)k * 8);
+        BF_TRY(barrier(ctx, "all_gather (written)"));
+        for (uint32_t r = 0; r < n; r++) memcpy(out + (size_t)r * k, ctl(r), (size_t)k * 8);
+        BF_TRY(barrier(ctx, "all_gather (read)"));
+        if (trace_on()) trace_line(ctx, "leave", "host all_gather", "", 0);
+        return BF_OK;
+    }
+    int all_to_all(bf_ctx* ctx, const uint8_t* d_send, uint8_t* d_recv, const uint64_t* bytes) override {
+        if (trace_on()) trace_line(ctx, "enter", "host all_to_all", "", 0);
+        // rounds: every rank stages at most slot_bytes of its send buffer per round; all ranks run the same number
+        std::vector<uint64_t> total(n, 0), recv_off(n, 0);
+        uint64_t longest = 0, ro = 0;
+        for (uint32_t s = 0; s < n; s++) {
+            for (uint32_t d = 0; d < n; d++) total[s] += bytes[(size_t)s * n + d];
+            longest = std::max(longest, total[s]);
+            recv_off[s] = ro; ro += bytes[(size_t)s * n + rank];
+        }
+        for (uint64_t w0 = 0; w0 < longest; w0 += slot_bytes) {           // window [w0, w0 + slot_bytes) of every send buffer
+            const uint64_t mine = total[rank] > w0 ? std::min(slot_bytes, total[rank] - w0) : 0;
+            if (mine) BF_HIP(ctx, hipMemcpyAsync(slot(rank), d_send + w0, mine, hipMemcpyDeviceToHost, ctx->stream));
+            BF_SYNC(ctx, ctx->stream);
+            BF_TRY(barrier(ctx, "all_to_all (staged)"));
+            for (uint32_t s = 0; s < n; s++) {
+                // rank s's piece for me is [a, b) of its send buffer; the part inside this window
+                uint64_t a = 0;
+                for (uint32_t d = 0; d < rank; d++) a += bytes[(size_t)s * n + d];
+                const uint64_t b = a + bytes[(size_t)s * n + rank];
+                const uint64_t lo = std::max(a, w0), hi = std::min(b, w0 + slot_bytes);
+                if (lo < hi)
+                    BF_HIP(ctx, hipMemcpyAsync(d_recv + recv_off[s] + (lo - a), slot(s) + (lo - w0), hi - lo, hipMemcpyHostToDevice, ctx->stream));
+            }
+            BF_SYNC(ctx, ctx->stream);
+            BF_TRY(barrier(ctx, "all_to_all (taken)"));
+        }
+        if (trace_on()) trace_line(ctx, "leave", "host all_to_all", "", 0);
+        return BF_OK;
+    }
+};
+
+struct Shard {
+    Transport* tr = nullptr;
+    std::vector<uint64_t> bases;                // index_base of every rank
+    DevBuf d_send, d_recv, d_req_out, d_req_in, d_place, d_small, d_roff, d_rbytes;
+    HostBuf h_places, h_roff, h_rbytes;
+    ~Shard() { delete tr; }
+};
+
+Shard* shard_of(bf_ctx* ctx) { return (Shard*)ctx->shard; }
+
+// place[i] = (source rank, slot in that source's record list) of supporting read i: the reads sorted by source rank
+// are position j = order^-1(i); the slot counts from the first request of this owner to that source
+__global__ void place_kernel(bf_place* __restrict__ place, const uint32_t* __restrict__ order, const uint32_t* __restrict__ skey,
+                             const uint64_t* __restrict__ start, const uint64_t* __restrict__ slot_base, uint64_t nr) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nr) return;
+    const uint32_t s = skey[j];
+    place[order[j]] = bf_place{s, (uint32_t)(slot_base[s] + (j - start[s]))};
+}
+
+inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+int shard_attach(bf_ctx* ctx, Transport* tr, uint32_t rank, uint32_t n_ranks, uint64_t index_base) {
+    tr->rank = rank; tr->n = n_ranks;
+    Shard* sh = new Shard();
+    sh->tr = tr;
+    shard_destroy(ctx);
+    ctx->shard = sh;
+    ctx->rank = rank; ctx->n_ranks = n_ranks; ctx->index_base = index_base;
+    ctx->src_index_base.clear(); ctx->imported = false;
+    // every rank learns every rank's first global read index (and that all of them are here)
+    uint64_t mine[2] = {index_base, n_ranks};
+    std::vector<uint64_t> all((size_t)n_ranks * 2);
+    BF_TRY(tr->all_gather(ctx, mine, 2, all.data()));
+    sh->bases.resize(n_ranks);
+    for (uint32_t r = 0; r < n_ranks; r++) {
+        if (all[2 * r + 1] != n_ranks) return fail(ctx, BF_ERR_INVALID, "sharded path: rank %u joined with %llu ranks, this rank with %u", r, (unsigned long long)all[2 * r + 1], n_ranks);
+        sh->bases[r] = all[2 * r];
+        if (r && sh->bases[r] < sh->bases[r - 1])
+            return fail(ctx, BF_ERR_INVALID, "sharded path: ranks must hold ascending input ranges (rank %u starts at %llu, rank %u at %llu): "
+                        "the stable sort's tie-break is the input order, detect.rs:193-198", r - 1, (unsigned long long)sh->bases[r - 1], r, (unsigned long long)sh->bases[r]);
+    }
+    return BF_OK;
+}
+
+}  // namespace
+
+void shard_destroy(bf_ctx* ctx) {
+    Shard* sh = shard_of(ctx);
+    if (!sh) return;
+    DevBuf* bufs[] = {&sh->d_send, &sh->d_recv, &sh->d_req_out, &sh->d_req_in, &sh->d_place, &sh->d_small, &sh->d_roff, &sh->d_rbytes};
+    for (DevBuf* b : bufs) release(ctx, *b);
+    HostBuf* hosts[] = {&sh->h_places, &sh->h_roff, &sh->h_rbytes};
+    for (HostBuf* h : hosts) { if (h->p) (void)hipHostFree(h->p); h->p = nullptr; h->cap = 0; }
+    delete sh;
+    ctx->shard = nullptr;
+}
+
+}  // namespace bf
+
+using namespace bf;
+
+extern "C" {
+
+int bf_shard_unique_id(uint8_t id[128]) {
+    if (!id) return BF_ERR_INVALID;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    if (!rccl().lib) return fail(nullptr, BF_ERR_STATE, "%s", rccl().why.c_str());
+    ncclUniqueId u;
+    const ncclResult_t r = rccl().GetUniqueId(&u);
+    if (r != ncclSuccess) return fail(nullptr, BF_ERR_HIP, "ncclGetUniqueId failed: %s", rccl().GetErrorString(r));
+    memcpy(id, &u, 128);
+    return BF_OK;
+}
+
+int bf_shard_init_rccl(bf_ctx* ctx, uint32_t rank, uint32_t n_ranks, uint64_t index_base, const uint8_t id[128]) {
+    if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
+    if (!id || n_ranks == 0 || n_ranks > 256 || rank >= n_ranks) return fail(ctx, BF_ERR_INVALID, "bf_shard_init_rccl: rank %u of %u", rank, n_ranks);
+    if (!rccl().lib) return fail(ctx, BF_ERR_STATE, "%s", rccl().why.c_str());
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    RcclTransport* tr = new RcclTransport();
+    const ncclResult_t r = rccl().CommInitRank(&tr->comm, (int)n_ranks, u, (int)rank);
+    if (r != ncclSuccess) { tr->comm = nullptr; delete tr; return fail(ctx, BF_ERR_HIP, "ncclCommInitRank failed: %s", rccl().GetErrorString(r)); }
+    return shard_attach(ctx, tr, rank, n_ranks, index_base);
+}
+
+int bf_shard_init_host(bf_ctx* ctx, uint32_t rank, uint32_t n_ranks, uint64_t index_base, const char* name, uint64_t slot_bytes) {
+    if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
+    if (!name || name[0] != '/' || n_ranks == 0 || n_ranks > 64 || rank >= n_ranks)
+        return fail(ctx, BF_ERR_INVALID, "bf_shard_init_host: rank %u of %u (at most 64), name must start with '/'", rank, n_ranks);
+    slot_bytes = std::max<uint64_t>((slot_bytes + 4095) & ~4095ull, 1u << 16);
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    HostTransport* tr = new HostTransport();
+    tr->name = name; tr->slot_bytes = slot_bytes; tr->n = n_ranks; tr->rank = rank;
+    tr->size = 4096 + (size_t)n_ranks * kShmCtlWords * 8 + (size_t)n_ranks * slot_bytes;
+    int fd = -1;
+    if (rank == 0) {
+        shm_unlink(name);                                        // a stale segment of a crashed run
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0 && ftruncate(fd, (off_t)tr->size) != 0) { close(fd); fd = -1; shm_unlink(name); }
+        tr->owner = fd >= 0;
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {                                               // until rank 0 has created and sized it
+            fd = shm_open(name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= tr->size) break;
+            if (fd >= 0) { close(fd); fd = -1; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kShmTimeoutSec)) break;
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+    }
+    if (fd < 0) { delete tr; return fail(ctx, BF_ERR_STATE, "bf_shard_init_host: shared memory segment %s is not available", name); }
+    void* m = mmap(nullptr, tr->size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { delete tr; return fail(ctx, BF_ERR_NOMEM, "bf_shard_init_host: mmap of %zu bytes failed", tr->size); }
+    tr->base = (uint8_t*)m; tr->hdr = (ShmHeader*)m;
+    if (rank == 0) {
+        tr->hdr->arrived.store(0); tr->hdr->sense.store(0);
+        tr->hdr->n_ranks = n_ranks; tr->hdr->slot_bytes = slot_bytes; tr->hdr->ctl_words = kShmCtlWords;
+        tr->hdr->ready.store(kShmMagic, std::memory_order_release);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (tr->hdr->ready.load(std::memory_order_acquire) != kShmMagic) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kShmTimeoutSec)) { delete tr; return fail(ctx, BF_ERR_STATE, "bf_shard_init_host: rank 0 never initialised %s", name); }
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        if (tr->hdr->n_ranks != n_ranks || tr->hdr->slot_bytes != slot_bytes) { delete tr; return fail(ctx, BF_ERR_INVALID, "bf_shard_init_host: ranks disagree about the segment's shape"); }
+    }
+    // pinning the staging slots lets the device copies run at PCIe rate (best effort)
+    tr->registered = hipHostRegister(tr->base, tr->size, hipHostRegisterDefault) == hipSuccess;
+    if (!tr->registered) (void)hipGetLastError();
+    return shard_attach(ctx, tr, rank, n_ranks, index_base);
+}
+
+int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
+    if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
+    if (!out) return fail(ctx, BF_ERR_INVALID, "bf_shard_finish: null result");
+    memset(out, 0, sizeof *out);
+    Shard* sh = shard_of(ctx);
+    if (!sh) return fail(ctx, BF_ERR_STATE, "bf_shard_finish before bf_shard_init_rccl / bf_shard_init_host");
+    if (ctx->n_contigs == 0) return fail(ctx, BF_ERR_STATE, "bf_shard_finish before bf_genome_set");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    Transport* tr = sh->tr;
+    const uint32_t W = tr->n, me = tr->rank;
+    const hipStream_t st = ctx->stream;
+
+    // 1. per-read work on the local shard (detect.rs:105-187); no communication
+    ctx->imported = false;
+    BF_TRY(run_localise(ctx, false, ctx->consumed));
+    const uint64_t n_local = ctx->n_reads;
+
+    // 2. wire parameters every rank must agree on
+    uint64_t mine[2] = {ctx->max_frag, ctx->n_sigx ? 1u : 0u};
+    std::vector<uint64_t> all((size_t)W * std::max<uint32_t>(W, 2));
+    BF_TRY(tr->all_gather(ctx, mine, 2, all.data()));
+    bf_wire_local agreed{0, 0};
+    for (uint32_t r = 0; r < W; r++) {
+        agreed.max_frag_len_bytes = std::max<uint32_t>(agreed.max_frag_len_bytes, (uint32_t)all[2 * r]);
+        agreed.has_exact_sig |= (uint32_t)all[2 * r + 1];
+    }
+
+    // 3. pack by owner = mix64(class key) % W, then the one exchange of evidence
+    const uint32_t rec = (uint32_t)sizeof(WireHeader) + ((agreed.max_frag_len_bytes + 7u) & ~7u) + (agreed.has_exact_sig ? 16u : 0u);
+    BF_TRY(ensure(ctx, sh->d_send, std::max<uint64_t>(n_local, 1) * rec));
+    std::vector<uint64_t> counts(W, 0);
+    void* d_packed = nullptr; uint32_t rec2 = 0;
+    BF_TRY(run_partition(ctx, agreed, sh->d_send.p, sh->d_send.cap, counts.data(), &d_packed, &rec2));
+    if (rec2 != rec) return fail(ctx, BF_ERR_HIP, "sharded path: record size %u, expected %u", rec2, rec);
+    std::vector<uint64_t> cm((size_t)W * W);                        // cm[s * W + d] = records rank s sends to rank d
+    BF_TRY(tr->all_gather(ctx, counts.data(), W, cm.data()));
+    std::vector<uint64_t> bytes((size_t)W * W), src_counts(W);
+    uint64_t n_owned = 0;
+    for (uint32_t s = 0; s < W; s++) {
+        for (uint32_t d = 0; d < W; d++) bytes[(size_t)s * W + d] = cm[(size_t)s * W + d] * rec;
+        src_counts[s] = cm[(size_t)s * W + me];
+        n_owned += src_counts[s];
+    }
+    BF_TRY(ensure(ctx, sh->d_recv, std::max<uint64_t>(n_owned, 1) * rec));
+    {
+        Scope t(ctx, "exchange_alltoall");
+        BF_TRY(tr->all_to_all(ctx, (const uint8_t*)d_packed, sh->d_recv.as<uint8_t>(), bytes.data()));
+    }
+    ctx->src_index_base = sh->bases;
+    BF_TRY(run_import(ctx, sh->d_recv.p, src_counts.data()));
+
+    // 4. the owner's cluster stage (detect.rs:190-231, 247-287)
+    OwnerView v;
+    v.n = ctx->n_imported;
+    v.key = ctx->i_key.as<uint64_t>(); v.lpos = ctx->i_lpos.as<int32_t>(); v.rpos = ctx->i_rpos.as<int32_t>();
+    v.fhash = ctx->i_fhash.as<uint64_t>(); v.bp = ctx->i_bp.as<uint16_t>(); v.len = ctx->i_len.as<uint16_t>();
+    v.flags = ctx->i_flags.as<uint16_t>();
+    v.frag = ctx->i_frag.as<uint8_t>(); v.frag_off = ctx->i_frag_off.as<uint64_t>(); v.frag_len = ctx->i_frag_len.as<uint16_t>();
+    v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
+    v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>();
+    v.info = ctx->i_jrec.as<uint64_t>();
+    ctx->clustered = false; ctx->table_attached = false; ctx->junction_attached = 0; ctx->reads_on_device = false;
+    ctx->result_order = false; ctx->sources_on_device = false;
+    BF_TRY(run_cluster(ctx, v));
+    ctx->clustered = true;
+    const uint64_t nr = ctx->out.n_reads, ncl = ctx->out.n_clusters;
+
+    // 5. which source rank holds each supporting read: requests ordered by source rank (result order inside)
+    std::vector<uint64_t> req_counts(W, 0), start(W + 1, 0);
+    uint64_t* d_start = nullptr; uint64_t* d_gbytes = nullptr;
+    BF_TRY(ensure(ctx, sh->d_req_out, std::max<uint64_t>(nr, 1) * 4));
+    if (nr) {
+        ctx->rsrc_stride = nr;
+        BF_TRY(order_requests(ctx, 1, sh->d_req_out.as<uint32_t>(), &d_start, &d_gbytes));
+        BF_HIP(ctx, hipMemcpyAsync(start.data(), d_start, (size_t)(W + 1) * 8, hipMemcpyDeviceToHost, st));
+        BF_SYNC(ctx, st);
+        for (uint32_t s = 0; s < W; s++) req_counts[s] = start[s + 1] - start[s];
+    }
+    std::vector<uint64_t> rm((size_t)W * W);                        // rm[o * W + s] = requests of owner o to source s
+    BF_TRY(tr->all_gather(ctx, req_counts.data(), W, rm.data()));
+    // slots: a source lists the requests of owner 0, then owner 1, ...: mine start after the earlier owners'
+    std::vector<uint64_t> ctl((size_t)2 * (W + 1));
+    uint64_t n_in = 0;
+    for (uint32_t s = 0; s < W; s++) {
+        uint64_t before = 0;
+        for (uint32_t o = 0; o < me; o++) before += rm[(size_t)o * W + s];
+        ctl[s] = before;
+    }
+    for (uint32_t o = 0; o < W; o++) n_in += rm[(size_t)o * W + me];
+    if (n_in > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "sharded path: %llu junction requests for one rank", (unsigned long long)n_in);
+    BF_TRY(ensure(ctx, sh->d_place, std::max<uint64_t>(nr, 1) * sizeof(bf_place)));
+    if (nr) {
+        BF_TRY(ensure(ctx, sh->d_small, (size_t)(W + 1) * 8));
+        BF_HIP(ctx, hipMemcpyAsync(sh->d_small.p, ctl.data(), (size_t)W * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(place_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, st, sh->d_place.as<bf_place>(), ctx->c_d32.as<uint32_t>(),
+                           ctx->c_b32.as<uint32_t>(), d_start, sh->d_small.as<uint64_t>(), nr);
+        BF_HIP(ctx, hipGetLastError());
+        BF_TRY(ensure_host(ctx, sh->h_places, nr * sizeof(bf_place)));
+        BF_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+        BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[0], 0));
+        BF_HIP(ctx, hipMemcpyAsync(sh->h_places.p, sh->d_place.p, nr * sizeof(bf_place), hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+
+    // 6. the request lists go to the sources (4 bytes a read)
+    for (uint32_t o = 0; o < W; o++) for (uint32_t s = 0; s < W; s++) bytes[(size_t)o * W + s] = rm[(size_t)o * W + s] * 4;
+    BF_TRY(ensure(ctx, sh->d_req_in, std::max<uint64_t>(n_in, 1) * 4));
+    {
+        Scope t(ctx, "request_alltoall");
+        BF_TRY(tr->all_to_all(ctx, sh->d_req_out.as<uint8_t>(), sh->d_req_in.as<uint8_t>(), bytes.data()));
+    }
+
+    // 7. source side: render the requested reads' junction records (detect.rs:155-162) and copy them to THIS
+    //    rank's host memory, chunk by chunk behind the next chunk's render
+    uint64_t rec_total = 0;
+    if (n_in) {
+        constexpr int kMaxChunks = 8;
+        const int nc = n_in >= (1u << 16) ? kMaxChunks : 1;
+        uint64_t off[kMaxChunks + 1];
+        const uint32_t* d_idx = sh->d_req_in.as<uint32_t>();
+        BF_TRY(ensure(ctx, sh->d_roff, (n_in + 1) * 8));
+        BF_TRY(ensure(ctx, ctx->r_idx, n_in * 4 + 16));
+        uint32_t* d_len = ctx->r_idx.as<uint32_t>();
+        uint32_t* d_bad = d_len + n_in;
+        BF_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, st));
+        BF_TRY(render_sizes_checked(ctx, n_in, d_idx, d_len, d_bad));
+        BF_TRY(render_prepare(ctx, n_in, d_idx, sh->d_roff, nc, off, d_len));
+        uint32_t bad = 0;
+        BF_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+        BF_SYNC(ctx, st);
+        if (bad) return fail(ctx, BF_ERR_HIP, "sharded path: %u requested reads are not resident on rank %u", bad, me);
+        rec_total = off[nc];
+        BF_TRY(ensure(ctx, sh->d_rbytes, rec_total ? rec_total : 1));
+        BF_TRY(ensure_host(ctx, sh->h_rbytes, rec_total));
+        BF_TRY(ensure_host(ctx, sh->h_roff, (n_in + 1) * 8));
+        BF_HIP(ctx, hipEventRecord(ctx->ev[9], st));
+        BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[9], 0));
+        BF_HIP(ctx, hipMemcpyAsync(sh->h_roff.p, sh->d_roff.p, (n_in + 1) * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
+        for (int c = 0; c < nc; c++) {
+            BF_TRY(render_range(ctx, n_in * (uint64_t)c / nc, n_in * (uint64_t)(c + 1) / nc, d_idx, sh->d_roff, sh->d_rbytes));
+            if (off[c + 1] > off[c]) {
+                BF_HIP(ctx, hipEventRecord(ctx->ev[1 + c], st));
+                BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[1 + c], 0));
+                BF_HIP(ctx, hipMemcpyAsync(sh->h_rbytes.as<uint8_t>() + off[c], sh->d_rbytes.as<uint8_t>() + off[c], off[c + 1] - off[c],
+                                           hipMemcpyDeviceToHost, ctx->copy_stream));
+            }
+        }
+    }
+    BF_SYNC(ctx, st);
+    BF_SYNC(ctx, ctx->copy_stream);                                  // rows, places and records are in host memory
+    ctx->consumed = true;
+
+    out->n_local = n_local; out->n_evidence = ctx->n_evidence;
+    out->n_clusters = ncl; out->n_reads = nr;
+    out->clusters = ncl ? ctx->out.clusters.as<bf_cluster>() : nullptr;
+    out->places = nr ? sh->h_places.as<bf_place>() : nullptr;
+    out->n_records = n_in;
+    out->record_off = n_in ? sh->h_roff.as<uint64_t>() : nullptr;
+    out->record_bytes = rec_total ? sh->h_rbytes.as<uint8_t>() : nullptr;
+    out->record_size = rec_total;
+    return BF_OK;
+}
+
+static inline unsigned dec_len64(uint64_t v) { unsigned n = 1; while (v >= 10) { v /= 10; n++; } return n; }
+static inline char* put_dec64(char* p, uint64_t v) {
+    char tmp[24]; int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+int64_t bf_shard_format_sv(const bf_ctx* ctx, uint32_t n_ranks, const bf_shard_result* results, char* buf, uint64_t cap) {
+    if (!ctx || !results || n_ranks == 0) return BF_ERR_INVALID;
+    static const char header[] = "CHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tCHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\t"
+                                 "SUPPORTING READS\tSIGNATURE\tNOTES\n";                 // detect.rs:201
+    struct Row { uint32_t rank_; uint64_t idx; };
+    std::vector<Row> rows;
+    for (uint32_t r = 0; r < n_ranks; r++) {
+        const bf_shard_result& x = results[r];
+        if ((x.n_clusters && !x.clusters) || (x.n_reads && !x.places) || (x.n_records && (!x.record_off || (x.record_size && !x.record_bytes))))
+            return BF_ERR_INVALID;
+        for (uint64_t c = 0; c < x.n_clusters; c++) {
+            const bf_cluster& cl = x.clusters[c];
+            if (cl.contig >= ctx->n_contigs || cl.mcontig >= ctx->n_contigs || cl.read_end < cl.read_begin || cl.read_end > x.n_reads) return BF_ERR_INVALID;
+            rows.push_back(Row{r, c});
+        }
+    }
+    // the seed's rank in the reference's sort: (chr by name, pos as the wrapped usize, input index), detect.rs:193-198
+    auto key = [&](const Row& w) -> const bf_cluster& { return results[w.rank_].clusters[w.idx]; };
+    std::sort(rows.begin(), rows.end(), [&](const Row& a, const Row& b) {
+        const bf_cluster& x = key(a); const bf_cluster& y = key(b);
+        const uint32_t rx = ctx->contig_rank[x.contig], ry = ctx->contig_rank[y.contig];
+        if (rx != ry) return rx < ry;
+        if ((uint64_t)x.lpos != (uint64_t)y.lpos) return (uint64_t)x.lpos < (uint64_t)y.lpos;
+        return x.seed_index < y.seed_index;
+    });
+    auto record = [&](const bf_place& p, const uint8_t*& rec, uint64_t& avail) -> bool {
+        if (p.src_rank >= n_ranks) return false;
+        const bf_shard_result& s = results[p.src_rank];
+        if (p.slot >= s.n_records) return false;
+        const uint64_t a = s.record_off[p.slot], b = s.record_off[p.slot + 1];
+        if (a > b || b > s.record_size) return false;
+        rec = s.record_bytes + a; avail = b - a;
+        return true;
+    };
+    uint64_t total = sizeof(header) - 1;
+    for (const Row& w : rows) {
+        const bf_cluster& cl = key(w);
+        total += ctx->contig_names[cl.contig].size() + ctx->contig_names[cl.mcontig].size() + dec_len64((uint64_t)cl.lpos) +
+                 dec_len64((uint64_t)cl.rpos) + 13;
+        const uint64_t k = cl.read_end - cl.read_begin;
+        if (k) total += k - 1;
+        for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
+            const uint8_t* rec; uint64_t avail;
+            if (!record(results[w.rank_].places[i], rec, avail)) return BF_ERR_INVALID;
+            const int64_t tl = junction_decode(rec, avail, nullptr, 0);
+            if (tl < 0) return BF_ERR_INVALID;
+            total += (uint64_t)tl;
+        }
+    }
+    if (!buf || cap < total) return (int64_t)total;
+    char* p = buf;
+    memcpy(p, header, sizeof(header) - 1); p += sizeof(header) - 1;
+    for (const Row& w : rows) {
+        const bf_cluster& cl = key(w);
+        const std::string& n1 = ctx->contig_names[cl.contig];
+        const std::string& n2 = ctx->contig_names[cl.mcontig];
+        memcpy(p, n1.data(), n1.size()); p += n1.size();
+        *p++ = '\t'; *p++ = cl.strand ? '+' : '-'; *p++ = '\t';
+        p = put_dec64(p, (uint64_t)cl.lpos); *p++ = '\t'; *p++ = '\t';
+        memcpy(p, n2.data(), n2.size()); p += n2.size();
+        *p++ = '\t'; *p++ = cl.mstrand ? '+' : '-'; *p++ = '\t';
+        p = put_dec64(p, (uint64_t)cl.rpos); *p++ = '\t'; *p++ = '\t';
+        for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
+            if (i > cl.read_begin) *p++ = ';';
+            const uint8_t* rec; uint64_t avail;
+            record(results[w.rank_].places[i], rec, avail);
+            p += junction_decode(rec, avail, (uint8_t*)p, ~0ull);
+        }
+        *p++ = '\t'; *p++ = '\t'; *p++ = '\n';
+    }
+    return (int64_t)total;
+}
+
+}  // extern "C"

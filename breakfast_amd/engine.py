@@ -57,6 +57,26 @@ class BfWireLocal(C.Structure):
     _fields_ = [("max_frag_len_bytes", C.c_uint32), ("has_exact_sig", C.c_uint32)]
 
 
+class BfShardResult(C.Structure):
+    _fields_ = [("n_local", C.c_uint64), ("n_evidence", C.c_uint64), ("n_clusters", C.c_uint64), ("n_reads", C.c_uint64),
+                ("clusters", C.c_void_p), ("places", C.c_void_p), ("n_records", C.c_uint64), ("record_off", C.c_void_p),
+                ("record_bytes", C.c_void_p), ("record_size", C.c_uint64)]
+
+
+PLACE_DTYPE = np.dtype([("src_rank", "<u4"), ("slot", "<u4")])
+
+
+@dataclass
+class ShardResult:
+    """Copy of a bf_shard_result (numpy arrays own their memory; picklable, so ranks can hand it to the merger)."""
+    n_local: int
+    n_evidence: int
+    clusters: np.ndarray       # CLUSTER_DTYPE, this owner's rows
+    places: np.ndarray         # PLACE_DTYPE per supporting read
+    record_off: np.ndarray     # uint64[n_records + 1], this SOURCE's junction records
+    record_bytes: np.ndarray
+
+
 class BfEvidenceView(C.Structure):
     _fields_ = [("n", C.c_uint64), ("mask_words", C.c_uint32), ("class_key", C.c_void_p),
                 ("lpos", C.c_void_p), ("rpos", C.c_void_p), ("bp", C.c_void_p), ("flags", C.c_void_p),
@@ -77,6 +97,7 @@ ABI_SYMBOLS = [
     "bf_result_junction_sizes_dev", "bf_result_layout_dev", "bf_result_attach_records_dev", "bf_result_requests_dev",
     "bf_result_attach_finish", "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
     "bf_render_junctions_dev_static", "bf_host_alloc", "bf_host_free", "bf_submit_wait", "bf_reserve",
+    "bf_shard_unique_id", "bf_shard_init_rccl", "bf_shard_init_host", "bf_shard_finish", "bf_shard_format_sv",
 ]
 
 _lib = None
@@ -120,6 +141,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_host_free.argtypes = [vp, vp]
     lib.bf_submit_wait.argtypes = [vp]
     lib.bf_reserve.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    lib.bf_shard_unique_id.argtypes = [vp]
+    lib.bf_shard_init_rccl.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp]
+    lib.bf_shard_init_host.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_char_p, C.c_uint64]
+    lib.bf_shard_finish.argtypes = [vp, C.POINTER(BfShardResult)]
+    lib.bf_shard_format_sv.argtypes = [vp, C.c_uint32, C.POINTER(BfShardResult), vp, C.c_uint64]
+    lib.bf_shard_format_sv.restype = C.c_int64
     lib.bf_localise.argtypes = [vp]
     lib.bf_clusterise.argtypes = [vp, C.POINTER(BfResult)]
     lib.bf_finish.argtypes = [vp, C.POINTER(BfResult)]
@@ -460,6 +487,58 @@ class Engine:
         n2 = self.lib.bf_format_sv(self.h, C.byref(r), buf, n)
         self._check(n2)
         return buf.raw[:n]
+
+    # -- the sharded path in one call (bf_shard_*) --
+    @staticmethod
+    def shard_unique_id() -> bytes:
+        lib = load_library()
+        buf = (C.c_uint8 * 128)()
+        rc = lib.bf_shard_unique_id(buf)
+        if rc != 0:
+            raise BreakfastError(rc, (lib.bf_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    def shard_init_rccl(self, rank: int, n_ranks: int, index_base: int, unique_id: bytes) -> None:
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.bf_shard_init_rccl(self.h, rank, n_ranks, index_base, buf))
+        self.n_ranks = n_ranks
+
+    def shard_init_host(self, rank: int, n_ranks: int, index_base: int, name: str, slot_bytes: int = 64 << 20) -> None:
+        self._check(self.lib.bf_shard_init_host(self.h, rank, n_ranks, index_base, name.encode(), slot_bytes))
+        self.n_ranks = n_ranks
+
+    def shard_finish_raw(self) -> BfShardResult:
+        r = BfShardResult()
+        self._check(self.lib.bf_shard_finish(self.h, C.byref(r)))
+        return r
+
+    def shard_finish(self) -> ShardResult:
+        r = self.shard_finish_raw()
+
+        def arr(ptr, n, dt):
+            dt = np.dtype(dt)
+            if not ptr or n == 0:
+                return np.zeros(0, dt)
+            return np.frombuffer((C.c_uint8 * (n * dt.itemsize)).from_address(ptr), dt).copy()
+        return ShardResult(int(r.n_local), int(r.n_evidence), arr(r.clusters, r.n_clusters, CLUSTER_DTYPE),
+                           arr(r.places, r.n_reads, PLACE_DTYPE),
+                           arr(r.record_off, r.n_records + 1 if r.n_records else 0, "<u8"), arr(r.record_bytes, r.record_size, "u1"))
+
+    def shard_format_sv(self, results: Sequence[ShardResult]) -> bytes:
+        """detect.rs:201,233-240 for the results of ALL ranks (rank order); needs only this ctx's contig names."""
+        n = len(results)
+        keep, arr = [], (BfShardResult * n)()
+        for i, x in enumerate(results):
+            cl = np.ascontiguousarray(x.clusters, CLUSTER_DTYPE); pl = np.ascontiguousarray(x.places, PLACE_DTYPE)
+            ro = np.ascontiguousarray(x.record_off, np.uint64); rb = np.ascontiguousarray(x.record_bytes, np.uint8)
+            keep += [cl, pl, ro, rb]
+            arr[i] = BfShardResult(x.n_local, x.n_evidence, cl.shape[0], pl.shape[0], _ptr(cl), _ptr(pl),
+                                   max(ro.shape[0] - 1, 0), _ptr(ro), _ptr(rb), rb.size)
+        size = self.lib.bf_shard_format_sv(self.h, n, arr, None, 0)
+        self._check(size)
+        buf = C.create_string_buffer(int(size) + 1)
+        self._check(self.lib.bf_shard_format_sv(self.h, n, arr, buf, size))
+        return buf.raw[:size]
 
     # -- multi-GPU stage calls --
     def set_rank(self, rank: int, n_ranks: int, index_base: int) -> None:

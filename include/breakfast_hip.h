@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 6
+#define BF_ABI_VERSION 7
 
 enum {
     BF_OK = 0,
@@ -350,6 +350,50 @@ int bf_result_attach_records_dev(bf_ctx* ctx, uint32_t piece, const uint8_t* dev
 int bf_result_attach_finish(bf_ctx* ctx, bf_result* out);
 /* Upper bound of a resident read's junction record in bytes (sizing of bf_render_junctions_dev buffers). */
 uint64_t bf_junction_record_bound(const bf_ctx* ctx);
+
+/* ---- the sharded path in one call (north_star item 4) ------------------ */
+/* The stage calls above leave the all-to-all to the caller.  The calls below run the whole sharded path inside
+ * the library, from C, with no orchestration language in between: one ctx per GPU, each driven by its own thread
+ * or process; the ranks call the same functions in the same order.
+ *
+ *   bf_shard_unique_id      rank 0 makes the 128-byte RCCL id (ncclGetUniqueId); the launcher hands it to every rank
+ *   bf_shard_init_rccl      joins the communicator (ncclCommInitRank): evidence crosses xGMI, device to device.
+ *                           RCCL is loaded at run time (librccl.so.1); one rank per GPU, as RCCL requires
+ *   bf_shard_init_host      a host-staged transport instead: ranks meet in a POSIX shared-memory segment `name`
+ *                           with `slot_bytes` of staging per rank (threads or processes of one machine).  Ranks may
+ *                           share a GPU: what a one-GPU test box can run, and the fallback where RCCL is absent
+ *   bf_shard_finish         the sharded bf_finish.  Every rank: localises its reads (contiguous input range
+ *                           [index_base, index_base + n), detect.rs:105-187); packs the evidence by
+ *                           owner = mix64(class key) % n_ranks; ONE all-to-all brings every class together
+ *                           (records arrive ordered by source rank, then input order, so the stable sort keeps the
+ *                           reference's tie-breaks, detect.rs:193-198); clusters what it owns (detect.rs:190-231,
+ *                           247-287).  The case-marked sequences never travel: an owner sends each source rank the
+ *                           list of its surviving reads (4 bytes each), the source renders their junction records
+ *                           and copies them to ITS host memory, and the owner's `places` say where each supporting
+ *                           read's record lives.  Idempotent like bf_finish.
+ *   bf_shard_format_sv      detect.rs:201,233-240 for the ranks' results together: owners' rows merged by the seed's
+ *                           rank in the reference's sort (contig by name, position as the wrapped usize, input index).
+ *                           Pure host code; `results[r]` = rank r's bf_shard_result (all n_ranks of them).
+ * No counterpart in the reference, which is one process. */
+typedef struct { uint32_t src_rank; uint32_t slot; } bf_place;    /* record = results[src_rank].records[slot] */
+typedef struct {
+    uint64_t          n_local;         /* reads this rank localised (sum over ranks = the count of detect.rs:190) */
+    uint64_t          n_evidence;      /* evidence records this rank owns (clustered here) */
+    /* owner side */
+    uint64_t          n_clusters, n_reads;
+    const bf_cluster* clusters;        /* this owner's rows, in print order among themselves */
+    const bf_place*   places;          /* n_reads: supporting read i of the rows above */
+    /* source side: junction records of this rank's reads that support a row of any owner */
+    uint64_t          n_records;
+    const uint64_t*   record_off;      /* n_records + 1 offsets into record_bytes */
+    const uint8_t*    record_bytes;
+    uint64_t          record_size;
+} bf_shard_result;
+int bf_shard_unique_id(uint8_t id[128]);
+int bf_shard_init_rccl(bf_ctx* ctx, uint32_t rank, uint32_t n_ranks, uint64_t index_base, const uint8_t id[128]);
+int bf_shard_init_host(bf_ctx* ctx, uint32_t rank, uint32_t n_ranks, uint64_t index_base, const char* name, uint64_t slot_bytes);
+int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out);
+int64_t bf_shard_format_sv(const bf_ctx* ctx, uint32_t n_ranks, const bf_shard_result* results, char* buf, uint64_t cap);
 
 /* ---- introspection (tests, bench) ---------------------------------------------------------- */
 

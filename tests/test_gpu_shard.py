@@ -1,0 +1,144 @@
+"""The sharded path inside the library (bf_shard_*, breakfast_amd/csrc/shard.hip): no Python between the stages.
+
+  - RCCL transport with one rank (one GPU cannot host two RCCL ranks): the collectives really go through librccl.
+  - host-staged transport with 2, 3 and 5 ranks sharing the test box's one GPU, as processes and as threads of one
+    process; uneven and empty shards; a staging slot smaller than the exchange (several rounds).
+Every case: the merged .sv (bf_shard_format_sv) equals the oracle's, byte for byte.
+"""
+import os
+import pickle
+import threading
+import uuid
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import oracle_lib as ol
+
+from breakfast_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def make_case(n_reads=30000, n_frac=0.0):
+    contigs = [("chr1", 300000), ("chr10", 200000), ("chr2", 250000)]
+    g = synth.make_genome(contigs, seed=61, n_runs=[(0, 5000, 2000)], lower_runs=[(2, 100000, 30000)])
+    spec = synth.ReadSpec(n_reads=n_reads, read_len=120, anchor_len=20, n_events=300, singleton_frac=0.3, mate_frac=0.4,
+                          seed=63, margin=300, n_rate=n_frac)
+    return g, synth.make_reads(g, spec), 20, 5000, 2
+
+
+def oracle_sv(g, b, A, F, E):
+    return ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, A, F, E).sv
+
+
+def run_rank(rank, world, cuts, name, slot_bytes, transport, uid, steps, out_dir):
+    g, b, A, F, E = make_case()
+    lo, hi = cuts[rank], cuts[rank + 1]
+    eng = engine.Engine(A, F, E, device=0, piece_reads=4000)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        if transport == "rccl":
+            eng.shard_init_rccl(rank, world, lo, uid)
+        else:
+            eng.shard_init_host(rank, world, lo, name, slot_bytes)
+        if hi > lo:
+            eng.submit(b.slice(lo, hi))
+        for _ in range(steps):                                   # idempotent on the resident reads
+            res = eng.shard_finish()
+        assert res.n_local == hi - lo
+        pickle.dump(res, open(os.path.join(out_dir, "rank%d.pkl" % rank), "wb"))
+    finally:
+        eng.close()
+
+
+def _proc(rank, world, cuts, name, slot_bytes, out_dir):
+    run_rank(rank, world, cuts, name, slot_bytes, "host", None, 2, out_dir)
+
+
+def merged_sv(out_dir, world):
+    g, b, A, F, E = make_case()
+    results = [pickle.load(open(os.path.join(out_dir, "rank%d.pkl" % r), "rb")) for r in range(world)]
+    assert sum(x.n_local for x in results) == sum(x.n_evidence for x in results) == b.n
+    eng = engine.Engine(A, F, E, device=0)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        return eng.shard_format_sv(results), results
+    finally:
+        eng.close()
+
+
+def test_one_rank_over_rccl(tmp_path):
+    g, b, A, F, E = make_case()
+    uid = engine.Engine.shard_unique_id()
+    assert len(uid) == 128
+    run_rank(0, 1, [0, b.n], None, 0, "rccl", uid, 3, str(tmp_path))
+    sv, results = merged_sv(str(tmp_path), 1)
+    assert sv == oracle_sv(g, b, A, F, E)
+    # with one rank the places are simply the result order
+    assert np.array_equal(results[0].places["slot"], np.arange(results[0].places.shape[0], dtype=np.uint32))
+
+
+@pytest.mark.parametrize("world,cuts_frac,slot_bytes", [
+    (2, (0, 0.33, 1.0), 64 << 20),
+    (3, (0, 0.25, 0.25, 1.0), 64 << 20),                 # an empty shard in the middle
+    (5, (0, 0.1, 0.5, 0.5, 0.9, 1.0), 1 << 16),          # staging slots far smaller than the exchange: many rounds
+])
+def test_ranks_as_processes_over_the_host_transport(tmp_path, world, cuts_frac, slot_bytes):
+    g, b, A, F, E = make_case()
+    cuts = [int(b.n * f) for f in cuts_frac]
+    name = "/bf_test_%s" % uuid.uuid4().hex[:12]
+    mp.spawn(_proc, args=(world, cuts, name, slot_bytes, str(tmp_path)), nprocs=world, join=True)
+    sv, results = merged_sv(str(tmp_path), world)
+    assert sv == oracle_sv(g, b, A, F, E)
+    assert sum(x.clusters.shape[0] for x in results) == sv.count(b"\n") - 1
+    assert sum(1 for x in results if x.clusters.shape[0]) >= 2            # the classes really spread over the owners
+
+
+def test_ranks_as_threads_of_one_process(tmp_path):
+    """What `breakfast-hip detect --gpus N` does: one thread and one ctx per rank in one process."""
+    g, b, A, F, E = make_case()
+    world = 3
+    cuts = [0, b.n // 2, b.n // 2 + 1, b.n]
+    name = "/bf_test_%s" % uuid.uuid4().hex[:12]
+    errors = []
+
+    def work(rank):
+        try:
+            run_rank(rank, world, cuts, name, 1 << 20, "host", None, 1, str(tmp_path))
+        except Exception as e:                                   # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not errors, errors
+    sv, _ = merged_sv(str(tmp_path), world)
+    assert sv == oracle_sv(g, b, A, F, E)
+
+
+def test_descending_input_ranges_are_refused():
+    g, b, A, F, E = make_case(n_reads=2000)
+    name = "/bf_test_%s" % uuid.uuid4().hex[:12]
+    out = {}
+
+    def work(rank):
+        eng = engine.Engine(A, F, E, device=0)
+        try:
+            eng.set_genome(g.names, g.seqs)
+            eng.shard_init_host(rank, 2, 1000 if rank == 0 else 0, name, 1 << 16)
+            out[rank] = "joined"
+        except engine.BreakfastError as e:
+            out[rank] = str(e)
+        finally:
+            eng.close()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert all("ascending input ranges" in out[r] for r in range(2)), out
