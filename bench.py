@@ -41,7 +41,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from breakfast_amd import engine, synth  # noqa: E402
-from breakfast_amd.distributed import DistributedDetect, HipStageEngine, bind_to_gpu_numa_node, init_from_env  # noqa: E402
+from breakfast_amd.distributed import bind_to_gpu_numa_node, init_from_env  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -78,12 +78,10 @@ def main():
                     help="A/B of the localise stage: fused encode+localise (shipped), separate encode kernel, "
                          "separate encode + cooperative LDS-staged gather, every read through the byte-exact kernel")
     ap.add_argument("--exchange", action="store_true",
-                    help="with one GPU: run the sharded code path anyway (pack -> RCCL all-to-all with itself -> import -> "
-                         "device junction routing), to time what the exchange adds per rank")
+                    help="with one GPU: run the sharded code path anyway (bf_shard_finish over RCCL with one rank: pack -> "
+                         "all-to-all with itself -> import -> cluster -> request lists -> source-side records), to time "
+                         "what the exchange adds per rank")
     ap.add_argument("--groups", type=int, default=0, help="contig groups of the cluster stage (0 = library default, 1 = one go)")
-    ap.add_argument("--junction-chunks", type=int, default=0, help="sharded path: pieces the junction records come in (0 = default)")
-    ap.add_argument("--phases", action="store_true", help="sharded path: synchronise after every phase and report phase_ms "
-                                                           "(diagnostic: the extra synchronisation slows the step)")
     ap.add_argument("--soft-mask", type=float, default=0.0,
                     help="fraction of the genome in lowercase (soft-masked repeats, as in UCSC hg38.fa), in runs of 300-30000 "
                          "bases; 0 = the all-uppercase genome of BASELINE's config (diagnostic for the byte-exact path)")
@@ -94,11 +92,6 @@ def main():
 
     rank, world, local = init_from_env()
     forced = args.exchange and world == 1
-    if forced:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", rank=0, world_size=1)
     if world != args.gpus:
         log(rank, "note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -137,15 +130,19 @@ def main():
     log(rank, "reads: %d x %d bp per rank in %.1fs" % (n_local, L, time.time() - t1))
 
     # ---- resident inputs -------------------------------------------------------------------------
-    routing = engine.BF_FLAG_DEVICE_ROUTING if (world > 1 or forced) else 0
-    eng = engine.Engine(A, 5000, 2, device=local, groups=args.groups, host_threads=args.host_threads, flags=routing | {"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER,
+    eng = engine.Engine(A, 5000, 2, device=local, groups=args.groups, host_threads=args.host_threads, flags=0 | {"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER,
                                                                                "exact": engine.BF_FLAG_FORCE_EXACT}[args.variant])
     t2 = time.time()
     eng.set_genome(genome.names, genome.seqs)
     log(rank, "genome packed into HBM in %.1fs" % (time.time() - t2))
     t3 = time.time()
     if world > 1 or forced:
-        eng.set_rank(rank, world, rank * n_local)
+        # the sharded path runs inside the library (bf_shard_*): rank 0 makes the RCCL id, the launcher's process
+        # group only carries those 128 bytes
+        box = [engine.Engine.shard_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        eng.shard_init_rccl(rank, world, rank * n_local, box[0])
     chunk = 1 << 21
     for a in range(0, n_local, chunk):
         eng.submit(batch.slice(a, min(n_local, a + chunk)))
@@ -154,16 +151,7 @@ def main():
     log(rank, "reads resident in HBM in %.2fs (first hand-over, buffers still growing: %.2f GB/s)" %
         (time.time() - t3, in_bytes / 1e9 / max(time.time() - t3, 1e-9)))
 
-    if world > 1 or forced:
-        stage = HipStageEngine(eng, dev)
-        stage.fetch_reads = False     # as on one GPU: the read table stays on the device until bf_result_reads asks
-        dd = DistributedDetect(stage, rank, world, rank * n_local, n_local, dev)
-        dd.profile = args.phases
-        if args.junction_chunks:
-            dd.junction_chunks = args.junction_chunks
-        step = dd.step
-    else:
-        step = eng.finish_raw
+    step = eng.shard_finish_raw if (world > 1 or forced) else eng.finish_raw
 
     sharded_run = world > 1 or forced
 
@@ -176,8 +164,6 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.kernel_times()                                # drop warm-up timings
-    if sharded_run:
-        dd.phase_ms = {}
     barrier()
     t_start = time.perf_counter()
     last = None
@@ -191,7 +177,7 @@ def main():
         elapsed = float(t.item())
     ktimes = eng.kernel_times()
     sharded = world > 1 or forced
-    n_clusters = int(last.clusters.shape[0]) if sharded else int(last.n_clusters)
+    n_clusters = int(last.n_clusters)
     n_support = int(last.n_reads)
     if world > 1:                                      # totals over all owner ranks
         t = torch.tensor([n_clusters, n_support], dtype=torch.int64, device=dev)
@@ -287,13 +273,12 @@ def main():
             "result": {"clusters": n_clusters, "supporting_reads": n_support},
             "stage_ms": stages, "roofline": roofline, "cpu_baseline": cpu, "host_to_host": h2h,
             "pipeline": pipeline_headline(n_local, L, ms_per_step),
-            **({"phase_ms": {k: round(v / args.steps, 3) for k, v in dd.phase_ms.items()}} if sharded_run and args.phases else {}),
             "published_reference": "~40M BAM reads/min/core whole-file scan (README.md:6), a different stage",
         }
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     eng.close()
-    if world > 1 or forced:
+    if world > 1:
         dist.destroy_process_group()
 
 

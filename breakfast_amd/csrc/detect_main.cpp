@@ -8,6 +8,10 @@
 //     --anchor-len=N --anchor-mm=N --max-frag-len=N --min-evidence=N     (as the reference)
 //     --anchor-hits=FILE   read bowtie's output (the 4-column `--suppress 5,6,7,8` lines) from FILE
 //                          ("-" = stdin) instead of spawning bowtie on <bam_file>.
+//     --gpus=N             shard the reads over GPUs 0..N-1 (contiguous input ranges, one thread + one ctx per GPU,
+//                          evidence exchanged over RCCL inside the library: bf_shard_*)
+//     --devices=a,b,...    the same with an explicit device list; a device named twice makes the ranks meet through
+//                          the library's host-staged transport instead (RCCL wants one rank per GPU): test boxes
 //     --threads=N          host worker threads: BGZF inflate, FASTA load, anchor-hit parsing [default: 8]
 //     --timing             print the wall time of every host/GPU stage on stderr (TIMING lines)
 //   breakfast-hip hits [--threads=N] [--block-bytes=N] <hits_file> <genome>
@@ -73,6 +77,8 @@ static const char* USAGE =
     "  --max-frag-len=N     Maximum fragment length [default: 5000]\n"
     "  --min-evidence=N     Minimum number of supporting DNA fragments [default: 2]\n"
     "  --anchor-hits=FILE   Read Bowtie's anchor alignments from FILE instead of running Bowtie\n"
+    "  --gpus=N             Shard the reads over N GPUs [default: 1]\n"
+    "  --devices=LIST       Comma-separated GPU ordinals, one rank each (instead of --gpus)\n"
     "  --threads=N          Host worker threads [default: 8]\n"
     "  --timing             Print stage wall times on stderr\n";
 
@@ -263,6 +269,94 @@ static void write_all(int fd, const char* p, size_t n) {
     }
 }
 
+// `breakfast-hip detect --gpus=N`: the reads are parsed into host memory, cut into N contiguous input ranges (the
+// reference's tie-breaks are input order, detect.rs:193-198, so rank r must hold the reads before rank r+1's), and
+// every range is driven by its own thread and ctx through the library's sharded path.  Rows are merged for printing
+// by bf_shard_format_sv.
+static int detect_sharded(const bf_config& cfg0, const std::vector<int>& devices, const std::string& genome_path, int in_fd,
+                          const hits::Options& popt, int threads, Timing& timing) {
+    const uint32_t W = (uint32_t)devices.size();
+    bool shared_gpu = false;
+    for (uint32_t a = 0; a < W; a++) for (uint32_t b = a + 1; b < W; b++) shared_gpu = shared_gpu || devices[a] == devices[b];
+    uint8_t uid[128] = {0};
+    if (!shared_gpu && bf_shard_unique_id(uid) != BF_OK) error("%s", bf_last_error(nullptr));
+    char shm_name[64];
+    snprintf(shm_name, sizeof shm_name, "/breakfast_hip_%d", (int)getpid());
+
+    Fasta fa = read_fasta(genome_path + ".fa", threads);
+    fprintf(stderr, "Reading reference genome into memory...\n");
+    timing.lap("fasta_load");
+    hits::ContigIndex contigs;
+    std::vector<const char*> names; std::vector<const uint8_t*> seqs;
+    for (size_t i = 0; i < fa.names.size(); i++) {
+        names.push_back(fa.names[i].c_str());
+        seqs.push_back((const uint8_t*)fa.seqs[i].get());
+        contigs.add(fa.names[i], (uint32_t)i);
+    }
+    if (names.empty()) error("Genome FASTA file %s.fa holds no sequences.", genome_path.c_str());
+    contigs.build();
+
+    fprintf(stderr, "Splitting unaligned reads into %u bp anchors and aligning against the genome...\n", cfg0.anchor_len);
+    std::vector<hits::Batch> all;
+    uint64_t n_total = 0;
+    try {
+        hits::parse_stream(in_fd, contigs, genome_path, popt, [&](hits::Batch& b) {
+            n_total += b.n();
+            all.emplace_back();
+            std::swap(all.back(), b);
+        });
+    } catch (const std::exception& e) { error("%s", e.what()); }
+    if (in_fd > 0) close(in_fd);
+    timing.lap("parse");
+
+    std::vector<uint64_t> first(all.size() + 1, 0);               // global index of every batch's first read
+    for (size_t k = 0; k < all.size(); k++) first[k + 1] = first[k] + all[k].n();
+    std::vector<bf_ctx*> ctxs(W, nullptr);
+    std::vector<bf_shard_result> results(W);
+    std::vector<std::string> errors(W);
+    std::vector<std::thread> pool;
+    for (uint32_t r = 0; r < W; r++) {
+        pool.emplace_back([&, r] {
+            bf_config cfg = cfg0;
+            cfg.device = devices[r];
+            if (bf_ctx_create(&cfg, &ctxs[r]) != BF_OK) { errors[r] = bf_last_error(nullptr); return; }
+            bf_ctx* ctx = ctxs[r];
+            auto check = [&](int rc) { if (rc != BF_OK && errors[r].empty()) errors[r] = bf_last_error(ctx); return rc == BF_OK; };
+            if (!check(bf_genome_set(ctx, (uint32_t)names.size(), names.data(), seqs.data(), fa.lens.data()))) return;
+            const uint64_t lo = n_total * r / W, hi = n_total * (r + 1) / W;
+            if (!check(shared_gpu ? bf_shard_init_host(ctx, r, W, lo, shm_name, 64u << 20) : bf_shard_init_rccl(ctx, r, W, lo, uid))) return;
+            for (size_t k = 0; k < all.size(); k++) {                // the parts of the parsed batches inside [lo, hi)
+                const uint64_t a = std::max(lo, first[k]), b = std::min(hi, first[k + 1]);
+                if (a >= b) continue;
+                const hits::Batch& src = all[k];
+                bf_batch bb;
+                bb.n_reads = b - a;
+                bb.seq_bytes = (const uint8_t*)src.seq.data(); bb.seq_off = src.seq_off.data() + (a - first[k]);
+                bb.frag_bytes = (const uint8_t*)src.frag.data(); bb.frag_off = src.frag_off.data() + (a - first[k]);
+                bb.hits = src.hits.data() + (a - first[k]);
+                if (!check(bf_submit(ctx, &bb))) return;
+            }
+            check(bf_shard_finish(ctx, &results[r]));
+        });
+    }
+    for (auto& th : pool) th.join();
+    for (uint32_t r = 0; r < W; r++) if (!errors[r].empty()) error("rank %u: %s", r, errors[r].c_str());
+    timing.lap("gpu_sharded_detect");
+    fprintf(stderr, "Found %llu rearrangement supporting reads.\n", (unsigned long long)n_total);
+    fprintf(stderr, "Sorting rearrangement supporting reads by position...\n");
+    fprintf(stderr, "Identifying rearrangements based on clusters of discordant reads...\n");
+    const int64_t size = bf_shard_format_sv(ctxs[0], W, results.data(), nullptr, 0);
+    if (size < 0) error("could not render the result");
+    std::unique_ptr<char[]> out(new char[(size_t)size + 1]);
+    if (bf_shard_format_sv(ctxs[0], W, results.data(), out.get(), (uint64_t)size) != size) error("could not render the result");
+    timing.lap("format_sv");
+    fflush(stdout);
+    write_all(1, out.get(), (size_t)size);
+    timing.lap("write_stdout");
+    for (bf_ctx* c : ctxs) bf_ctx_destroy(c);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc >= 2 && strcmp(argv[1], "filter") == 0) return filter_main(argc, argv);        // main.rs:26
     if (argc >= 2 && strcmp(argv[1], "annotate") == 0) return annotate_main(argc, argv);    // main.rs:27
@@ -280,6 +374,7 @@ int main(int argc, char** argv) {
     cfg.anchor_len = 30; cfg.max_frag_len = 5000; cfg.min_evidence = 2; cfg.device = -1;
     std::string hits_path;
     int threads = 8;
+    std::vector<int> devices;                     // empty: one GPU, the current device
     hits::Options popt;
     Timing timing;
     std::vector<std::string> pos;
@@ -298,6 +393,19 @@ int main(int argc, char** argv) {
         else if (val("--min-evidence=", v)) cfg.min_evidence = (uint32_t)std::min<uint64_t>(v, 0xffffffffu);
         else if (val("--threads=", v)) threads = (int)std::min<uint64_t>(std::max<uint64_t>(v, 1), 64);
         else if (val("--block-bytes=", v)) popt.block_bytes = (size_t)std::max<uint64_t>(v, 1);
+        else if (val("--gpus=", v)) { devices.clear(); for (uint64_t d = 0; d < std::min<uint64_t>(std::max<uint64_t>(v, 1), 64); d++) devices.push_back((int)d); }
+        else if (a.compare(0, 10, "--devices=") == 0) {
+            devices.clear();
+            std::string_view list = std::string_view(a).substr(10);
+            while (!list.empty()) {
+                const size_t c = list.find(',');
+                uint64_t d;
+                if (!parse_u64(list.substr(0, c), d) || d > 1023) error("Invalid arguments.\n%s", USAGE);
+                devices.push_back((int)d);
+                list = c == std::string_view::npos ? std::string_view() : list.substr(c + 1);
+            }
+            if (devices.empty() || devices.size() > 64) error("Invalid arguments.\n%s", USAGE);
+        }
         else if (a == "--timing") timing.on = true;
         else if (a.compare(0, 14, "--anchor-hits=") == 0) hits_path = a.substr(14);
         else if (a.size() > 1 && a[0] == '-' && a != "-") error("Invalid arguments.\n%s", USAGE);
@@ -365,6 +473,14 @@ int main(int argc, char** argv) {
     }
     timing.lap("start_up");
 
+    if (devices.size() > 1) {
+        const int rc = detect_sharded(cfg, devices, genome_path, in_fd, popt, threads, timing);
+        if (producer.joinable()) producer.join();
+        if (child.pid > 0) { int st = 0; waitpid(child.pid, &st, 0); }
+        timing.print();
+        return rc;
+    }
+    if (devices.size() == 1) cfg.device = devices[0];
     bf_ctx* ctx = nullptr;
     if (bf_ctx_create(&cfg, &ctx) != BF_OK) error("%s", bf_last_error(nullptr));
     timing.lap("gpu_context");

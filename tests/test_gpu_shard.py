@@ -142,3 +142,23 @@ def test_descending_input_ranges_are_refused():
     for t in ts:
         t.join(timeout=120)
     assert all("ascending input ranges" in out[r] for r in range(2)), out
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_command_line_sharded_over_one_gpu(tmp_path, devices):
+    """`breakfast-hip detect --devices=0,0`: the C++ driver's sharded mode (threads, the library's sharded path, the
+    host-staged transport because the ranks share the GPU), from files on disk to the .sv bytes."""
+    import subprocess
+    import detect_oracle as po
+    g, b, A, F, E = make_case(n_reads=12000)
+    prefix = str(tmp_path / "g")
+    open(prefix + ".fa", "wb").write(g.fasta())
+    hits = str(tmp_path / "hits.txt")
+    text = synth.bowtie_lines(b, g.names)
+    open(hits, "wb").write(text)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "breakfast_amd", "csrc", "breakfast-hip")
+    p = subprocess.run([exe, "detect", "--anchor-len=%d" % A, "--devices=" + devices, "--block-bytes=200000",
+                        "--anchor-hits=" + hits, "unused.bam", prefix], capture_output=True, timeout=200)
+    assert p.returncode == 0, p.stderr.decode()
+    assert p.stdout == po.detect(g.fasta(), text.split(b"\n")[:-1], A, F, E)
+    assert b"Found 12000 rearrangement supporting reads." in p.stderr
