@@ -86,6 +86,8 @@ def main():
                     help="fraction of the genome in lowercase (soft-masked repeats, as in UCSC hg38.fa), in runs of 300-30000 "
                          "bases; 0 = the all-uppercase genome of BASELINE's config (diagnostic for the byte-exact path)")
     ap.add_argument("--check", action="store_true", help="also compare the GPU .sv with the oracle's on the sample")
+    ap.add_argument("--one-stream", action="store_true", help="profiling: all kernels and copies of the library on one stream "
+                                                               "(a kernel trace then shows each kernel's own duration)")
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host loops (resident-input value only)")
     ap.add_argument("--host-threads", type=int, default=0, help="staging threads of bf_submit (0 = library default)")
     args = ap.parse_args()
@@ -130,7 +132,7 @@ def main():
     log(rank, "reads: %d x %d bp per rank in %.1fs" % (n_local, L, time.time() - t1))
 
     # ---- resident inputs -------------------------------------------------------------------------
-    eng = engine.Engine(A, 5000, 2, device=local, groups=args.groups, host_threads=args.host_threads, flags=0 | {"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER,
+    eng = engine.Engine(A, 5000, 2, device=local, groups=args.groups, host_threads=args.host_threads, flags=(engine.BF_FLAG_ONE_STREAM if args.one_stream else 0) | {"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER,
                                                                                "exact": engine.BF_FLAG_FORCE_EXACT}[args.variant])
     t2 = time.time()
     eng.set_genome(genome.names, genome.seqs)

@@ -280,9 +280,14 @@ int bf_ctx_create(const bf_config* cfg, bf_ctx** out) {
         delete ctx;
         return fail(nullptr, BF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
-    bool ok = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = true;
+    if (cfg->flags & BF_FLAG_ONE_STREAM) {
+        ctx->copy_stream = ctx->side_stream = ctx->in_stream = ctx->stream;
+    } else {
+        ok = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking) == hipSuccess;
+    }
     ok = ok && hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) == hipSuccess;
     {
         const unsigned hw = std::thread::hardware_concurrency();
@@ -314,11 +319,11 @@ void bf_ctx_destroy(bf_ctx* ctx) {
     for (auto& pr : ctx->pinned) (void)hipHostFree((void*)pr.first);
     ctx->pinned.clear();
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
-    if (ctx->in_stream) (void)hipStreamDestroy(ctx->in_stream);
+    if (ctx->in_stream && ctx->in_stream != ctx->stream) (void)hipStreamDestroy(ctx->in_stream);
     free_all(ctx);
     for (auto& e2 : ctx->ev) if (e2) (void)hipEventDestroy(e2);
-    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
-    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->copy_stream && ctx->copy_stream != ctx->stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->side_stream && ctx->side_stream != ctx->stream) (void)hipStreamDestroy(ctx->side_stream);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     delete reinterpret_cast<std::vector<PendingEvent>*>(ctx->timing_pending);
@@ -392,6 +397,7 @@ int bf_reset(bf_ctx* ctx) {
     BF_SYNC(ctx, ctx->in_stream);
     BF_SYNC(ctx, ctx->stream);
     ctx->in_pending = false; ctx->n_localised = 0; ctx->consumed = false;
+    ctx->rank_hist.assign(ctx->n_contigs, 0);
     ctx->n_reads = 0; ctx->seq_bytes = 0; ctx->frag_bytes = 0;
     ctx->max_len = 0; ctx->min_len = 0xffffffffu; ctx->max_frag = 0;
     ctx->localised = false; ctx->imported = false; ctx->clustered = false; ctx->n_imported = 0; ctx->n_exact = 0;
@@ -432,6 +438,7 @@ struct SubmitShared {
     std::mutex mu;
     uint64_t err_read = ~0ull; int err_code = BF_OK; std::string err_msg;
     uint32_t mx = 0, mn = 0xffffffffu, mf = 0;
+    std::vector<uint64_t> hist;        // reads per left contig rank (this batch)
     void error(uint64_t read, int code, const char* fmt, ...) {
         char buf[512];
         va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -456,6 +463,7 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
     if (hipSetDevice(ctx->device) != hipSuccess) { sh->error(0, BF_ERR_HIP, "hipSetDevice failed in a staging thread"); return; }
     bf_ctx::StageSlot& sl = ctx->slots[slot_id];
     uint32_t mx = 0, mn = 0xffffffffu, mf = 0;
+    std::vector<uint64_t> hist(ctx->n_contigs, 0);
     for (size_t j; (j = sh->next.fetch_add(1)) < sh->jobs.size();) {
         const SubmitJob& job = sh->jobs[j];
         if (!slot_ready(ctx, sl)) { sh->error(job.a, BF_ERR_NOMEM, "pinned staging memory is not available"); return; }
@@ -483,6 +491,7 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
                     ok = false; break;
                 }
                 if (h.pos5 >= 0x80000000u || h.pos3 >= 0x80000000u) { sh->error(i, BF_ERR_RANGE, "read %llu: anchor position >= 2^31", (unsigned long long)i); ok = false; break; }
+                hist[std::min(ctx->contig_rank[h.contig5], ctx->contig_rank[h.contig3])]++;     // `chr` after detect.rs:108-113
                 so[i - job.a] = sh->seq0 + (sa - s0);
                 fo[i - job.a] = sh->frag0 + (fa - f0);
                 if (!sh->hits_direct) hh[i - job.a] = h;
@@ -505,6 +514,7 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
     }
     std::lock_guard<std::mutex> g(sh->mu);
     sh->mx = std::max(sh->mx, mx); sh->mn = std::min(sh->mn, mn); sh->mf = std::max(sh->mf, mf);
+    for (uint32_t r = 0; r < ctx->n_contigs; r++) sh->hist[r] += hist[r];
 }
 
 static int reserve_input(bf_ctx* ctx, uint64_t reads, uint64_t seq_bytes, uint64_t frag_bytes) {
@@ -592,6 +602,7 @@ int bf_submit(bf_ctx* ctx, const bf_batch* b) {
     SubmitShared sh;
     sh.ctx = ctx; sh.bat = b; sh.n0 = ctx->n_reads; sh.seq0 = ctx->seq_bytes; sh.frag0 = ctx->frag_bytes;
     sh.hits_direct = is_pinned(ctx, b->hits, m * sizeof(bf_hit));
+    sh.hist.assign(ctx->n_contigs, 0);
     if (ctx->slots.size() < ctx->host_threads) ctx->slots.resize(ctx->host_threads);
     // (the A/B variants of the localise stage keep their one launch over the whole set)
     const bool eager = !(ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE));
@@ -647,6 +658,8 @@ int bf_submit(bf_ctx* ctx, const bf_batch* b) {
     ctx->n_reads += m; ctx->seq_bytes += sb; ctx->frag_bytes += fb;
     ctx->max_len = mx; ctx->min_len = mn; ctx->max_frag = mf;
     ctx->localised = false; ctx->imported = false; ctx->consumed = false;
+    if (ctx->rank_hist.size() != ctx->n_contigs) ctx->rank_hist.assign(ctx->n_contigs, 0);
+    for (uint32_t r = 0; r < ctx->n_contigs; r++) ctx->rank_hist[r] += sh.hist[r];
     timer.ok = true;
     BF_HIP(ctx, hipEventRecord(ctx->ev_in, ctx->in_stream));
     ctx->in_pending = true;

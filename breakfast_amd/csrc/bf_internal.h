@@ -189,6 +189,9 @@ struct bf_ctx {
     uint32_t host_threads = 0;                  // bf_config.reserved[1], or chosen from the machine
     uint64_t cap_reads = 0;                     // capacity of every per-read array below (inputs and evidence)
     uint64_t n_localised = 0;                   // reads [0, n_localised) have evidence under (plane_words, mask_words)
+    std::vector<uint64_t> rank_hist;            // resident reads per left contig rank after the reorient step (detect.rs:108-113:
+                                                // the smaller of the two anchors' ranks), counted by bf_submit's staging threads:
+                                                // the cluster stage cuts its contig groups from it without asking the GPU
     bool consumed = false;                      // a bf_finish has clustered exactly this read set: the next one without
                                                 // new reads runs the whole path again (bf_finish is idempotent)
 

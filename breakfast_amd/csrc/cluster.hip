@@ -574,54 +574,43 @@ __global__ void __launch_bounds__(256) emit_kernel(const EmitView e, uint64_t ns
 // ranks at a time and the results appended; api.hip copies a group's records to the host while the next group
 // is clustered.  rank32[i] = left contig rank of record i, hist[r] = records of rank r, hist[bins] = sum of all
 // records' junction record bytes (the bound the output buffers are sized with).
-constexpr uint32_t kMaxRankBins = 4096;
-__global__ void __launch_bounds__(256) rank_histogram_kernel(const uint64_t* __restrict__ key, const uint64_t* __restrict__ info,
-                                                             uint64_t n, int shift, uint32_t bins, uint32_t* __restrict__ rank32,
-                                                             unsigned long long* hist) {
-    extern __shared__ uint32_t s_hist[];
-    for (uint32_t b = threadIdx.x; b < bins; b += 256) s_hist[b] = 0;
-    __syncthreads();
+// Sum of the records' junction record bytes (the bound the output buffers are sized with): one atomic per wave.
+__global__ void __launch_bounds__(256) record_bytes_kernel(const uint64_t* __restrict__ info, uint64_t n, unsigned long long* sum) {
     unsigned long long bytes = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-        const uint32_t r = (uint32_t)(key[i] >> shift) & (bins - 1);
-        rank32[i] = r;
-        atomicAdd(&s_hist[r], 1u);
-        bytes += info_jrec(info[i]);
-    }
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) bytes += info_jrec(info[i]);
     for (int d = 32; d; d >>= 1) bytes += __shfl_down(bytes, d);
-    if ((threadIdx.x & 63) == 0 && bytes) atomicAdd(&hist[bins], bytes);
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < bins; b += 256)
-        if (s_hist[b]) atomicAdd(&hist[b], (unsigned long long)s_hist[b]);
+    if ((threadIdx.x & 63) == 0 && bytes) atomicAdd(sum, bytes);
 }
 // -> bounds: positions in c_gidx (record ids ordered by contig rank, input order inside) where the groups start;
-// one group (bounds = {0, n}) when there is nothing to gain.
+// one group (bounds = {0, n}) when there is nothing to gain.  The reads per left contig rank are known on the host
+// (bf_submit's staging threads count them from the hits: the rank after the reorient step is the smaller of the two
+// anchors' ranks), so the cut costs the GPU one radix pass on the rank bits of the class keys and a sum.
 int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::vector<uint64_t>& bounds, uint64_t* record_bytes) {
     const uint64_t n = v.n;
     const hipStream_t st = ctx->stream;
-    const uint32_t bins = 1u << ctx->contig_bits;
     bounds.assign(1, 0); bounds.push_back(n);
     *record_bytes = 0;
-    if (max_groups < 2 || bins > kMaxRankBins || n == 0) return BF_OK;
-    BF_TRY(ensure(ctx, ctx->c_gidx, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_hist, (size_t)(bins + 1) * 8, false));
-    BF_TRY(ensure(ctx, ctx->c_a32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_b32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_c32, n * 4, false));
-    BF_HIP(ctx, hipMemsetAsync(ctx->c_hist.p, 0, (size_t)(bins + 1) * 8, st));
-    hipLaunchKernelGGL(rank_histogram_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, 256), 2048)), dim3(256), bins * 4, st,
-                       v.key, v.info, n, key_rank_shift(ctx->contig_bits), bins, ctx->c_b32.as<uint32_t>(),
+    if (max_groups < 2 || n == 0 || v.src_rank || ctx->rank_hist.size() != ctx->n_contigs) return BF_OK;
+    uint64_t counted = 0;
+    for (uint64_t c : ctx->rank_hist) counted += c;
+    if (counted != n) return fail(ctx, BF_ERR_STATE, "contig histogram of %llu reads for %llu evidence records", (unsigned long long)counted, (unsigned long long)n);
+    BF_TRY(ensure(ctx, ctx->c_gidx, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_hist, 64, false));
+    BF_TRY(ensure(ctx, ctx->c_c32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_k64a, n * 8, false));
+    BF_HIP(ctx, hipMemsetAsync(ctx->c_hist.p, 0, 8, st));
+    hipLaunchKernelGGL(record_bytes_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, 256), 2048)), dim3(256), 0, st, v.info, n,
                        (unsigned long long*)ctx->c_hist.p);
+    BF_HIP(ctx, hipMemcpyAsync(record_bytes, ctx->c_hist.p, 8, hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, ctx->c_c32.as<uint32_t>(), n);
-    BF_TRY(sort_pairs<uint32_t>(ctx, ctx->c_b32.as<uint32_t>(), ctx->c_a32.as<uint32_t>(), ctx->c_c32.as<uint32_t>(),
-                                ctx->c_gidx.as<uint32_t>(), n, 0, (unsigned)ctx->contig_bits));
-    std::vector<uint64_t> hist(bins + 1);
-    BF_HIP(ctx, hipMemcpyAsync(hist.data(), ctx->c_hist.p, (size_t)(bins + 1) * 8, hipMemcpyDeviceToHost, st));
+    const unsigned shift = (unsigned)key_rank_shift(ctx->contig_bits);
+    BF_TRY(sort_pairs<uint64_t>(ctx, v.key, ctx->c_k64a.as<uint64_t>(), ctx->c_c32.as<uint32_t>(), ctx->c_gidx.as<uint32_t>(), n,
+                                shift, shift + (unsigned)ctx->contig_bits));
     BF_SYNC(ctx, st);
     BF_TRY(settle_counts(ctx));                           // the localise counters came along with this synchronisation
-    *record_bytes = hist[bins];
     // cut after the rank where the running count passes the next multiple of n / max_groups
     bounds.assign(1, 0);
     uint64_t run = 0;
-    for (uint32_t r = 0; r < bins; r++) {
-        run += hist[r];
+    for (uint32_t r = 0; r < ctx->n_contigs; r++) {
+        run += ctx->rank_hist[r];
         if (run >= n * bounds.size() / max_groups && run > bounds.back() && run < n) bounds.push_back(run);
     }
     bounds.push_back(n);

@@ -327,9 +327,11 @@ __global__ void __launch_bounds__(256) scan_carry_kernel(uint64_t* __restrict__ 
 
 // Inclusive scan of in[0..n) into out[0..n); Out may be wider than the input, and out may be in.
 template <class Op, class Out>
-__global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, Out* out, uint64_t n, const uint64_t* __restrict__ tile_before) {
+__global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, Out* out, uint64_t n, const uint64_t* __restrict__ tile_before,
+                                                         Out* zero_at) {
     __shared__ uint64_t s_wave[4];
     const int t = threadIdx.x;
+    if (zero_at && blockIdx.x == 0 && t == 0) *zero_at = 0;      // the exclusive scan's leading zero (saves a memset launch)
     const uint64_t first = (uint64_t)blockIdx.x * kScanTile + (uint64_t)t * kScanItems;
     uint64_t v[kScanItems];
     load_tile_items<Op>(in, first, n, v);
@@ -352,8 +354,11 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, Out
 
 // `tot`: workspace of scan_workspace_bytes(n) bytes (one total per tile); nullptr = the ctx's own (c_tmp, grown on demand)
 template <class Op, class Out>
-static int scan_impl(bf_ctx* ctx, const uint32_t* in, Out* out, uint64_t n, uint64_t* tot = nullptr) {
-    if (n == 0) return BF_OK;
+static int scan_impl(bf_ctx* ctx, const uint32_t* in, Out* out, uint64_t n, uint64_t* tot = nullptr, Out* zero_at = nullptr) {
+    if (n == 0) {
+        if (zero_at) BF_HIP(ctx, hipMemsetAsync(zero_at, 0, sizeof(Out), ctx->stream));
+        return BF_OK;
+    }
     const uint64_t tiles = (n + kScanTile - 1) / kScanTile;
     if (!tot) {
         BF_TRY(ensure(ctx, ctx->c_tmp, tiles * 8 + 256, false));
@@ -361,22 +366,20 @@ static int scan_impl(bf_ctx* ctx, const uint32_t* in, Out* out, uint64_t n, uint
     }
     hipLaunchKernelGGL((scan_totals_kernel<Op>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, in, n, tot);
     hipLaunchKernelGGL((scan_carry_kernel<Op>), dim3(1), dim3(256), 0, ctx->stream, tot, tiles);
-    hipLaunchKernelGGL((scan_apply_kernel<Op, Out>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, in, out, n, tot);
+    hipLaunchKernelGGL((scan_apply_kernel<Op, Out>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, in, out, n, tot, zero_at);
     BF_HIP(ctx, hipGetLastError());
     return BF_OK;
 }
 
 // exclusive scan with total: out[0] = 0, out[i+1] = in[0] + ... + in[i]
 int scan_u32_to_u64(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n) {
-    BF_HIP(ctx, hipMemsetAsync(out, 0, 8, ctx->stream));
-    return scan_impl<OpSumU64, uint64_t>(ctx, in, out + 1, n);
+    return scan_impl<OpSumU64, uint64_t>(ctx, in, out + 1, n, nullptr, out);
 }
 
 // the same with the tile totals in caller-provided device memory: allocates nothing
 uint64_t scan_workspace_bytes(uint64_t n) { return ((n + kScanTile - 1) / kScanTile) * 8 + 256; }
 int scan_u32_to_u64_ws(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* workspace) {
-    BF_HIP(ctx, hipMemsetAsync(out, 0, 8, ctx->stream));
-    return scan_impl<OpSumU64, uint64_t>(ctx, in, out + 1, n, workspace);
+    return scan_impl<OpSumU64, uint64_t>(ctx, in, out + 1, n, workspace, out);
 }
 
 // data[i] = max(data[0..i]), in place (a tile reads its elements before it writes them; tiles are disjoint)
