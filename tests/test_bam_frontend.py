@@ -99,3 +99,27 @@ def test_corrupt_block_is_an_error(tmp_path):
         (tmp_path / "bad.bam").write_bytes(bytes(bad))
         p = subprocess.run([EXE, "anchors", "--anchor-len=20", str(tmp_path / "bad.bam")], capture_output=True, timeout=60)
         assert p.returncode == 255 and b"ERROR: " in p.stderr
+
+
+# ---- a BAM file assembled byte by byte from the specification ----------------------------------------------
+# tests/golden/spec_bytes.bam is written by tests/golden/make_bam_fixture.py field by field from SAMv1 sections
+# 4.1-4.2 with STORED deflate blocks -- not by tests/bamtools.py, whose writer shares its understanding of the format
+# with the reader under test.  The expected anchor FASTA is written out by hand from detect.rs:290-338.
+SPEC_BAM_ANCHORS = (
+    b">5p:1:\nACGTACGTAC\n>3p:1:q_1_a:ACGTACGTACGTACGTACGTAC:\nACGTACGTAC\n"
+    b">5p:2:\nTTTTTTTTTT\n>3p:2:clip_lead:TTTTTTTTTTTTGGGGGGGGGGGGGGGGGG:\nGGGGGGGGGG\n"
+    b">5p:3:\n=ACMGRSVTW\n>3p:3:clip_trail:=ACMGRSVTWYHKDBNACGTACGTACGTAC:\nACGTACGTAC\n"
+    b">5p:4:\nCCCCCCCCCC\n>3p:4:hard_soft:CCCCCCCCCCCAAAAAAAAAAAAAAAAAAA:\nAAAAAAAAAA\n"
+    b">5p:5:\nGATTACAGAT\n>3p:5:odd:GATTACAGATTACAGATTACA:\nACAGATTACA\n")
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_bam_written_byte_by_byte_from_the_specification(threads):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spec_bytes.bam")
+    raw = open(path, "rb").read()
+    # the committed file is what the builder writes (28-byte EOF marker at its end, two data blocks before it)
+    assert raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    p = subprocess.run([EXE, "anchors", "--anchor-len=10", "--threads=%d" % threads, path], capture_output=True, timeout=60)
+    assert p.returncode == 0, p.stderr.decode()
+    assert p.stdout == SPEC_BAM_ANCHORS
+    assert do.dispatch_reads_to_bowtie(raw, 10) == SPEC_BAM_ANCHORS

@@ -1,0 +1,114 @@
+"""Both restatements of detect.rs (oracle/detect_oracle.py, oracle/detect_oracle.cpp) and the GPU against per-read
+tables derived without either of them (tests/golden/derive_tables.py -> tests/golden/hand_tables.json: whole-slice
+flanks, position-by-position mismatch vectors, the closed form of mm[k]; one row entirely by hand).
+
+The reference holds no vectors, so parity stays "unpinned by the reference"; these tables are what this repository
+can add: a third derivation that shares no code with the two oracles it checks.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import detect_oracle as po
+import oracle_lib as ol
+from conftest import GOLDEN, load_golden
+
+TABLES = json.load(open(os.path.join(GOLDEN, "hand_tables.json")))
+SV_HEADER = (b"CHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tCHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\t"
+             b"SUPPORTING READS\tSIGNATURE\tNOTES\n")
+
+
+def test_tables_are_what_the_script_derives():
+    """The committed JSON is the script's output (so the literal numbers cannot drift from their derivation)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("derive_tables", os.path.join(GOLDEN, "derive_tables.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert {n: mod.derive(n) for n in mod.FIXTURES} == TABLES
+    hand = mod.HAND_ROW
+    row = TABLES[hand["fixture"]]["reads"][hand["read"]]
+    assert all(row[k] == hand[k] for k in ("swapped", "bp", "lpos", "rpos", "junction", "signature"))
+    assert row["mm"][:len(hand["mm"])] == hand["mm"]
+
+
+@pytest.mark.parametrize("name", sorted(TABLES))
+def test_python_restatement_against_the_tables(name):
+    fa, lines, (A, F, E), _ = load_golden(name)
+    ev = po.consume_lines(po.parse_fasta(fa), lines.split(b"\n")[:-1], A)
+    rows = TABLES[name]["reads"]
+    assert len(ev) == len(rows)
+    for e, r in zip(ev, rows):
+        assert (e.swapped, e.bp, e.pos, e.mpos) == (r["swapped"], r["bp"], r["lpos"], r["rpos"])
+        assert (e.strand, e.mstrand, e.chr, e.mchr) == (r["strand"], r["mstrand"], r["chr"].encode(), r["mchr"].encode())
+        assert e.sequence == r["junction"].encode() and e.signature == r["signature"].encode()
+        assert min(r["mm"]) == r["mm"][0 if r["bp"] == A else r["bp"] - A] and r["mm"].index(min(r["mm"])) == r["bp"] - A
+
+
+@pytest.mark.parametrize("name", sorted(TABLES))
+def test_cpp_restatement_against_the_tables(name):
+    fa, lines, (A, F, E), _ = load_golden(name)
+    run = ol.detect_text(ol.OracleGenome.from_fasta(fa), lines, A, F, E, keep=True)
+    rows = TABLES[name]["reads"]
+    assert run.n_evidence == len(rows)
+    assert run.bp.tolist() == [r["bp"] for r in rows]
+    assert (run.flags & 4).astype(bool).tolist() == [r["swapped"] for r in rows]
+    assert (run.flags & 1).astype(bool).tolist() == [r["strand"] for r in rows]
+    assert (run.flags & 2).astype(bool).tolist() == [r["mstrand"] for r in rows]
+    assert run.lpos.tolist() == [r["lpos"] for r in rows] and run.rpos.tolist() == [r["rpos"] for r in rows]
+    assert [bytes(s) for s in run.signature] == [r["signature"].encode() for r in rows]
+    assert [run.junction_of(i) for i in range(len(rows))] == [r["junction"].encode() for r in rows]
+
+
+def expected_dedup_sv():
+    """The .sv of hz_dedup_min_evidence written out from the table's clusters (seed coordinates, surviving reads)."""
+    t = TABLES["hz_dedup_min_evidence"]
+    out = [SV_HEADER]
+    for c in t["clusters"]:
+        s = t["reads"][c["seed"]]
+        out.append(b"%s\t%s\t%d\t\t%s\t%s\t%d\t\t%s\t\t\n" % (
+            s["chr"].encode(), b"+" if s["strand"] else b"-", s["lpos"], s["mchr"].encode(), b"+" if s["mstrand"] else b"-", s["rpos"],
+            b";".join(t["reads"][k]["junction"].encode() for k in c["kept"])))
+    return b"".join(out)
+
+
+def test_dedup_choice_against_the_table():
+    """remove_frag_id_duplicates (detect.rs:247-287) and the double min_evidence test: which reads survive, in which
+    slot, derived from fragment ids and scores alone."""
+    fa, lines, (A, F, E), sv = load_golden("hz_dedup_min_evidence")
+    want = expected_dedup_sv()
+    assert sv == want
+    assert po.detect(fa, lines.split(b"\n")[:-1], A, F, E) == want
+    assert ol.detect_text(ol.OracleGenome.from_fasta(fa), lines, A, F, E).sv == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(TABLES))
+def test_gpu_against_the_tables(name):
+    from breakfast_amd import engine
+    fa, lines, (A, F, E), sv = load_golden(name)
+    rows = TABLES[name]["reads"]
+    g = po.parse_fasta(fa)
+    names = list(g.keys())
+    for flags in (0, engine.BF_FLAG_FORCE_EXACT):
+        eng = engine.Engine(A, F, E, flags=flags | engine.BF_FLAG_KEEP_EVIDENCE)
+        try:
+            eng.set_genome(names, [np.frombuffer(g[n], np.uint8) for n in names])
+            b = engine.parse_bowtie_lines(lines.split(b"\n")[:-1], eng.contig_id)
+            eng.submit(b)
+            res = eng.finish()
+            ev = eng.evidence()
+            assert ev["bp"].tolist() == [r["bp"] for r in rows]
+            assert ((ev["flags"] & 4) != 0).tolist() == [r["swapped"] for r in rows]
+            assert ((ev["flags"] & 1) != 0).tolist() == [r["strand"] for r in rows]
+            assert ((ev["flags"] & 2) != 0).tolist() == [r["mstrand"] for r in rows]
+            assert ev["lpos"].astype(np.int64).astype(np.uint64).tolist() == [r["lpos"] for r in rows]
+            assert ev["rpos"].astype(np.int64).astype(np.uint64).tolist() == [r["rpos"] for r in rows]
+            by, off = eng.render_junctions(np.arange(b.n, dtype=np.uint32))
+            text = by.tobytes()
+            assert [text[int(off[i]):int(off[i + 1])] for i in range(b.n)] == [r["junction"].encode() for r in rows]
+            if name == "hz_dedup_min_evidence":
+                assert eng.format_sv(res) == expected_dedup_sv()
+        finally:
+            eng.close()
