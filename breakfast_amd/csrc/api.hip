@@ -316,6 +316,8 @@ void bf_ctx_destroy(bf_ctx* ctx) {
     shard_destroy(ctx);
     for (auto& sl : ctx->slots) { if (sl.p) (void)hipHostFree(sl.p); if (sl.ev) (void)hipEventDestroy(sl.ev); }
     ctx->slots.clear();
+    for (auto& sl : ctx->gslots) { if (sl.p) (void)hipHostFree(sl.p); if (sl.ev) (void)hipEventDestroy(sl.ev); }
+    ctx->gslots.clear();
     for (auto& pr : ctx->pinned) (void)hipHostFree((void*)pr.first);
     ctx->pinned.clear();
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
@@ -336,15 +338,23 @@ int bf_sync(bf_ctx* ctx) {
     return BF_OK;
 }
 
-int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint8_t* const* seqs,
-                  const uint64_t* lens) {
+// ---- the genome, detect.rs:48-56 ------------------------------------------------------------------------------
+// bf_genome_begin sizes and clears the device images and fixes the contig table (after it bf_submit may already
+// stage reads: it only needs the contig ids); bf_genome_write stages any piece of any contig through pinned slots
+// onto the copy-in stream, from any thread, so that a FASTA loader can upload while it is still reading; bf_genome_end
+// waits for the pieces and packs the images.  bf_genome_set is the three in one call.
+constexpr size_t kStageSlotBytes = 8u << 20;         // pinned staging slots of bf_submit and bf_genome_write
+constexpr uint32_t kGenomeSlots = 16;
+
+int bf_genome_begin(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint64_t* lens) {
     if (!ctx) return BF_ERR_INVALID;
     BF_TRACE_CALL(ctx);
-    if (!names || !seqs || !lens || n_contigs == 0) return fail(ctx, BF_ERR_INVALID, "bf_genome_set: null/empty argument");
+    if (!names || !lens || n_contigs == 0) return fail(ctx, BF_ERR_INVALID, "bf_genome_begin: null/empty argument");
     if (n_contigs > (1u << kContigBits)) return fail(ctx, BF_ERR_RANGE, "%u contigs; at most %u are supported", n_contigs, 1u << kContigBits);
-    if (ctx->n_reads) return fail(ctx, BF_ERR_STATE, "bf_genome_set with resident reads; call bf_reset first");
+    if (ctx->n_reads) return fail(ctx, BF_ERR_STATE, "the genome cannot change under resident reads; call bf_reset first");
     BF_HIP(ctx, hipSetDevice(ctx->device));
-    ctx->n_contigs = n_contigs;
+    ctx->genome_ready = false;
+    ctx->n_contigs = 0;
     ctx->contig_bits = 1;
     while ((1u << ctx->contig_bits) < n_contigs) ctx->contig_bits++;
     ctx->contig_names.assign(names, names + n_contigs);
@@ -377,18 +387,103 @@ int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, con
     BF_TRY(ensure(ctx, ctx->g_coarse, (n_blocks / 64 + 4) * 8));
     BF_TRY(ensure(ctx, ctx->g_coarse2, (n_blocks / 2048 + 4) * 4));
     BF_TRY(ensure(ctx, ctx->g_contigs, (size_t)n_contigs * sizeof(ContigDev)));
-    BF_HIP(ctx, hipMemsetAsync(ctx->g_raw.p, 'A', total + 4096, ctx->stream));   // padding is never compared
-    BF_HIP(ctx, hipMemsetAsync(ctx->g_blocks.p, 0, block_image_slots(n_blocks) * sizeof(GenomeBlock), ctx->stream));
-    BF_HIP(ctx, hipMemsetAsync(ctx->g_exc.p, 0, exc_image_slots(n_blocks) * 8, ctx->stream));
-    BF_HIP(ctx, hipMemsetAsync(ctx->g_coarse.p, 0, (n_blocks / 64 + 4) * 8, ctx->stream));
-    BF_HIP(ctx, hipMemsetAsync(ctx->g_coarse2.p, 0, (n_blocks / 2048 + 4) * 4, ctx->stream));
-    BF_SYNC(ctx, ctx->stream);
-    for (uint32_t i = 0; i < n_contigs; i++)
-        if (lens[i]) BF_HIP(ctx, hipMemcpy(ctx->g_raw.as<uint8_t>() + ctx->contig_host[i].goff, seqs[i], lens[i], hipMemcpyHostToDevice));
-    BF_HIP(ctx, hipMemcpy(ctx->g_contigs.p, ctx->contig_host.data(), (size_t)n_contigs * sizeof(ContigDev), hipMemcpyHostToDevice));
+    // on the copy-in stream, so that the pieces written behind them land on cleared memory
+    const hipStream_t is = ctx->in_stream;
+    BF_HIP(ctx, hipMemsetAsync(ctx->g_raw.p, 'A', total + 4096, is));   // padding is never compared
+    BF_HIP(ctx, hipMemsetAsync(ctx->g_blocks.p, 0, block_image_slots(n_blocks) * sizeof(GenomeBlock), is));
+    BF_HIP(ctx, hipMemsetAsync(ctx->g_exc.p, 0, exc_image_slots(n_blocks) * 8, is));
+    BF_HIP(ctx, hipMemsetAsync(ctx->g_coarse.p, 0, (n_blocks / 64 + 4) * 8, is));
+    BF_HIP(ctx, hipMemsetAsync(ctx->g_coarse2.p, 0, (n_blocks / 2048 + 4) * 4, is));
+    BF_HIP(ctx, hipMemcpyAsync(ctx->g_contigs.p, ctx->contig_host.data(), (size_t)n_contigs * sizeof(ContigDev), hipMemcpyHostToDevice, is));
+    if (ctx->gslots.size() != kGenomeSlots) ctx->gslots = std::vector<bf_ctx::GenomeSlot>(kGenomeSlots);
+    { std::lock_guard<std::mutex> g(ctx->genome_mu); ctx->genome_err.clear(); ctx->genome_err_code = 0; }
+    ctx->rank_hist.assign(n_contigs, 0);
+    ctx->n_contigs = n_contigs;
+    return BF_OK;
+}
+
+// Thread-safe; reports through its return value only (the message is kept for bf_genome_end).
+int bf_genome_write(bf_ctx* ctx, uint32_t contig, uint64_t offset, const uint8_t* bytes, uint64_t n) {
+    if (!ctx) return BF_ERR_INVALID;
+    auto bad = [&](int code, const char* msg) {
+        std::lock_guard<std::mutex> g(ctx->genome_mu);
+        if (!ctx->genome_err_code) { ctx->genome_err_code = code; ctx->genome_err = msg; }
+        return code;
+    };
+    if (ctx->n_contigs == 0 || ctx->genome_ready) return bad(BF_ERR_STATE, "bf_genome_write outside bf_genome_begin .. bf_genome_end");
+    if (contig >= ctx->n_contigs || offset > ctx->contig_host[contig].len || n > ctx->contig_host[contig].len - offset)
+        return bad(BF_ERR_RANGE, "bf_genome_write: piece outside its contig");
+    if (n == 0) return BF_OK;
+    if (!bytes) return bad(BF_ERR_INVALID, "bf_genome_write: null bytes");
+    if (hipSetDevice(ctx->device) != hipSuccess) return bad(BF_ERR_HIP, "hipSetDevice failed");
+    uint8_t* dst = ctx->g_raw.as<uint8_t>() + ctx->contig_host[contig].goff + offset;
+    for (uint64_t a = 0; a < n; a += kStageSlotBytes) {
+        const uint64_t len = std::min<uint64_t>(kStageSlotBytes, n - a);
+        bf_ctx::GenomeSlot& sl = ctx->gslots[ctx->gslot_next.fetch_add(1) % kGenomeSlots];
+        std::lock_guard<std::mutex> g(sl.mu);
+        if (!sl.p) {
+            if (hipHostMalloc((void**)&sl.p, kStageSlotBytes, hipHostMallocDefault) != hipSuccess) { sl.p = nullptr; return bad(BF_ERR_NOMEM, "pinned staging memory is not available"); }
+            if (hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) return bad(BF_ERR_HIP, "hipEventCreate failed");
+        }
+        if (sl.used && hipEventSynchronize(sl.ev) != hipSuccess) return bad(BF_ERR_HIP, "hipEventSynchronize failed");
+        memcpy(sl.p, bytes + a, len);
+        if (hipMemcpyAsync(dst + a, sl.p, len, hipMemcpyHostToDevice, ctx->in_stream) != hipSuccess ||
+            hipEventRecord(sl.ev, ctx->in_stream) != hipSuccess)
+            return bad(BF_ERR_HIP, "genome upload failed");
+        sl.used = true;
+    }
+    return BF_OK;
+}
+
+int bf_genome_end(bf_ctx* ctx) {
+    if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
+    if (ctx->n_contigs == 0) return fail(ctx, BF_ERR_STATE, "bf_genome_end before bf_genome_begin");
+    if (ctx->genome_ready) return BF_OK;
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        std::lock_guard<std::mutex> g(ctx->genome_mu);
+        if (ctx->genome_err_code) return fail(ctx, ctx->genome_err_code, "%s", ctx->genome_err.c_str());
+    }
+    // the pack kernel runs on the main stream behind every piece
+    BF_HIP(ctx, hipEventRecord(ctx->ev_in, ctx->in_stream));
+    BF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));
     BF_TRY(genome_pack(ctx));
     BF_SYNC(ctx, ctx->stream);
+    ctx->genome_ready = true;
+    // reads that arrived while the genome was still on its way
+    if (ctx->n_reads > ctx->n_localised && !(ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE))) {
+        BF_HIP(ctx, hipEventRecord(ctx->ev_in, ctx->in_stream));
+        ctx->in_pending = true;
+        BF_TRY(localise_uploaded(ctx, ctx->n_reads, ctx->max_len));
+    }
     return BF_OK;
+}
+
+int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint8_t* const* seqs,
+                  const uint64_t* lens) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!names || !seqs || !lens || n_contigs == 0) return fail(ctx, BF_ERR_INVALID, "bf_genome_set: null/empty argument");
+    BF_TRY(bf_genome_begin(ctx, n_contigs, names, lens));
+    // pieces of up to 8 MB, staged by a few host threads (one thread copies at ~10 GB/s, PCIe takes 55)
+    struct Piece { uint32_t c; uint64_t off, n; };
+    std::vector<Piece> pieces;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_contigs; i++) {
+        if (lens[i] && !seqs[i]) return fail(ctx, BF_ERR_INVALID, "bf_genome_set: contig %u has no bytes", i);
+        for (uint64_t a = 0; a < lens[i]; a += kStageSlotBytes) pieces.push_back(Piece{i, a, std::min<uint64_t>(kStageSlotBytes, lens[i] - a)});
+        total += lens[i];
+    }
+    const size_t nt = total < (4u << 20) ? 1 : std::min<size_t>(ctx->host_threads, pieces.size());
+    std::atomic<size_t> next{0};
+    auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < pieces.size();) if (bf_genome_write(ctx, pieces[k].c, pieces[k].off, seqs[pieces[k].c] + pieces[k].off, pieces[k].n) != BF_OK) return; };
+    if (nt <= 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < nt; t++) pool.emplace_back(work);
+        for (auto& th : pool) th.join();
+    }
+    return bf_genome_end(ctx);
 }
 
 int bf_reset(bf_ctx* ctx) {
@@ -412,7 +507,6 @@ int bf_reset(bf_ctx* ctx) {
 // host threads fill (a single thread copies at ~10 GB/s, PCIe takes 55) -- and the packed kernel for the piece is
 // queued behind its upload, so that the reads of piece k are localised while piece k+1 is still on PCIe.
 // bf_finish is then left with the last piece, the exact kernel and the cluster stage.
-constexpr size_t kStageSlotBytes = 8u << 20;
 constexpr uint64_t kPieceReads = 1u << 20;        // also the granularity of the eager localise launches
 constexpr uint64_t kEagerReads = 1u << 18;        // smaller submits are gathered up to this many before a launch
 constexpr uint64_t kInlineBytes = 1u << 20;       // pieces below this are staged by the calling thread
@@ -605,7 +699,7 @@ int bf_submit(bf_ctx* ctx, const bf_batch* b) {
     sh.hist.assign(ctx->n_contigs, 0);
     if (ctx->slots.size() < ctx->host_threads) ctx->slots.resize(ctx->host_threads);
     // (the A/B variants of the localise stage keep their one launch over the whole set)
-    const bool eager = !(ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE));
+    const bool eager = ctx->genome_ready && !(ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE));
     // reads per offsets job: two offset arrays (+1 entry each) and the hits share one slot
     const uint64_t per_job = (kStageSlotBytes - 64) / (8 + 8 + sizeof(bf_hit)) - 2;
     uint32_t mx = ctx->max_len, mn = ctx->min_len, mf = ctx->max_frag;
@@ -619,10 +713,14 @@ int bf_submit(bf_ctx* ctx, const bf_batch* b) {
         if ((se < sa || se > sb || fe < fa || fe > fb) && p0) ctx->n_localised = 0;
         if (se < sa || se > sb || fe < fa || fe > fb) return fail(ctx, BF_ERR_INVALID, "bf_submit: offsets not monotone near read %llu", (unsigned long long)p0);
         sh.jobs.clear(); sh.next = 0;
-        for (uint64_t a = p0; a < p1; a += per_job) sh.jobs.push_back(SubmitJob{0, a, std::min(p1, a + per_job)});
-        if (!seq_direct) for (uint64_t a = sa; a < se; a += kStageSlotBytes) sh.jobs.push_back(SubmitJob{1, a, std::min(se, a + kStageSlotBytes)});
-        if (!frag_direct) for (uint64_t a = fa; a < fe; a += kStageSlotBytes) sh.jobs.push_back(SubmitJob{2, a, std::min(fe, a + kStageSlotBytes)});
+        // jobs of about staged / threads bytes (at least 1 MB, at most a slot), so that a batch of a few dozen MB still
+        // keeps every staging thread busy
         const uint64_t staged = (p1 - p0) * 32 + (seq_direct ? 0 : se - sa) + (frag_direct ? 0 : fe - fa);
+        const uint64_t job_bytes = std::min<uint64_t>(kStageSlotBytes, std::max<uint64_t>(1u << 20, staged / std::max(1u, ctx->host_threads)));
+        const uint64_t job_reads = std::min<uint64_t>(per_job, std::max<uint64_t>(job_bytes / 32, 1));
+        for (uint64_t a = p0; a < p1; a += job_reads) sh.jobs.push_back(SubmitJob{0, a, std::min(p1, a + job_reads)});
+        if (!seq_direct) for (uint64_t a = sa; a < se; a += job_bytes) sh.jobs.push_back(SubmitJob{1, a, std::min(se, a + job_bytes)});
+        if (!frag_direct) for (uint64_t a = fa; a < fe; a += job_bytes) sh.jobs.push_back(SubmitJob{2, a, std::min(fe, a + job_bytes)});
         const size_t nt = staged < kInlineBytes ? 1 : std::min<size_t>(ctx->host_threads, sh.jobs.size());
         if (nt <= 1) submit_worker(&sh, 0);
         else {
@@ -671,7 +769,7 @@ int bf_submit(bf_ctx* ctx, const bf_batch* b) {
 int bf_localise(bf_ctx* ctx) {
     if (!ctx) return BF_ERR_INVALID;
     BF_TRACE_CALL(ctx);
-    if (ctx->n_contigs == 0) return fail(ctx, BF_ERR_STATE, "bf_localise before bf_genome_set");
+    if (ctx->n_contigs == 0 || !ctx->genome_ready) return fail(ctx, BF_ERR_STATE, "bf_localise before bf_genome_set / bf_genome_end");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     ctx->imported = false;
     return run_localise(ctx, false, true);
@@ -680,7 +778,7 @@ int bf_localise(bf_ctx* ctx) {
 // bf_finish: the host does not wait for the localise kernels' counters, the cluster stage's first
 // synchronisation brings them along
 static int localise_deferred(bf_ctx* ctx) {
-    if (ctx->n_contigs == 0) return fail(ctx, BF_ERR_STATE, "bf_localise before bf_genome_set");
+    if (ctx->n_contigs == 0 || !ctx->genome_ready) return fail(ctx, BF_ERR_STATE, "bf_finish before bf_genome_set / bf_genome_end");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     ctx->imported = false;
     // reads bf_submit localised behind their upload are done; when nothing has arrived since the last bf_finish the

@@ -2,8 +2,10 @@
 // Device data layout is documented in DESIGN.md ("Data layout in HBM").
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -194,6 +196,14 @@ struct bf_ctx {
                                                 // the cluster stage cuts its contig groups from it without asking the GPU
     bool consumed = false;                      // a bf_finish has clustered exactly this read set: the next one without
                                                 // new reads runs the whole path again (bf_finish is idempotent)
+
+    // genome hand-over in pieces (bf_genome_begin / bf_genome_write / bf_genome_end): any thread may write
+    bool genome_ready = false;                  // bf_genome_end (or bf_genome_set) has packed the image: kernels may read it
+    struct GenomeSlot { uint8_t* p = nullptr; hipEvent_t ev = nullptr; bool used = false; std::mutex mu; };
+    std::vector<GenomeSlot> gslots;
+    std::atomic<uint32_t> gslot_next{0};
+    std::mutex genome_mu;                       // guards genome_err
+    std::string genome_err; int genome_err_code = 0;
 
     // source-side resident reads
     uint64_t n_reads = 0;

@@ -34,9 +34,12 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <string_view>
@@ -120,58 +123,21 @@ static bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c ==
 // bio::io::fasta::Reader semantics (detect.rs:48-56): id = header up to the first whitespace, sequence
 // lines right-trimmed and concatenated, case preserved; a repeated id replaces the earlier record
 // (HashMap::insert).  The file is mapped and cut into pieces at line boundaries; the pieces are
-// measured, then copied, by `threads` workers.
-static Fasta read_fasta(const std::string& path, int threads) {
-    const int fd = open(path.c_str(), O_RDONLY);
-    if (fd < 0) error("Genome FASTA file %s could not be read.", path.c_str());
-    struct stat st;
-    if (fstat(fd, &st) != 0) error("Genome FASTA file %s could not be read.", path.c_str());
-    Fasta fa;
-    const size_t size = (size_t)st.st_size;
-    if (size == 0) { close(fd); return fa; }
-    std::string fallback;
-    const char* data = nullptr;
-    void* map = S_ISREG(st.st_mode) ? mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
-    size_t n = size;
-    if (map != MAP_FAILED) {
-        data = (const char*)map;
-        (void)madvise(map, size, MADV_WILLNEED);
-    } else {                                            // not mappable (a pipe): read it whole
-        char buf[1 << 16];
-        ssize_t r;
-        while ((r = read(fd, buf, sizeof buf)) > 0) fallback.append(buf, (size_t)r);
-        data = fallback.data(); n = fallback.size();
-    }
-    // record starts: '>' at the beginning of a line
+// measured by `threads` workers (FastaScan), then either copied into one buffer per contig (load) or handed
+// out piece by piece (stream: the GPU upload runs while the file is still being read).
+struct FastaScan {
     struct Rec { size_t head, body, end; };
-    std::vector<Rec> recs;
-    for (const char* p = data; p < data + n;) {
-        const char* q = (const char*)memchr(p, '>', (size_t)(data + n - p));
-        if (!q) break;
-        if (q == data || q[-1] == '\n') {
-            if (!recs.empty()) recs.back().end = (size_t)(q - data);
-            const char* eol = (const char*)memchr(q, '\n', (size_t)(data + n - q));
-            recs.push_back(Rec{(size_t)(q - data), eol ? (size_t)(eol - data) + 1 : n, n});
-        }
-        p = q + 1;
-    }
-    // pieces of record bodies, cut at line boundaries
     struct Piece { size_t rec, a, b, out; uint64_t len; };
+    const char* data = nullptr; size_t n = 0;
+    void* map = MAP_FAILED; size_t map_size = 0;
+    std::string fallback;
+    std::vector<Rec> recs;
     std::vector<Piece> pieces;
-    const size_t kPiece = 16u << 20;
-    for (size_t r = 0; r < recs.size(); r++) {
-        size_t a = recs[r].body;
-        while (a < recs[r].end) {
-            size_t b = std::min(recs[r].end, a + kPiece);
-            if (b < recs[r].end) {
-                const char* nl = (const char*)memchr(data + b, '\n', recs[r].end - b);
-                b = nl ? (size_t)(nl - data) + 1 : recs[r].end;
-            }
-            pieces.push_back(Piece{r, a, b, 0, 0});
-            a = b;
-        }
-    }
-    auto each_line = [&](const Piece& pc, auto&& fn) {
+    std::vector<std::string> names;            // by slot (first appearance of an id)
+    std::vector<uint64_t> lens;
+    std::vector<long> rec_slot;                // record -> slot, -1 when a later record of the same id supersedes it
+    ~FastaScan() { if (map != MAP_FAILED) munmap(map, map_size); }
+    template <class F> void each_line(const Piece& pc, F&& fn) const {
         const char* s = data + pc.a;
         const char* end = data + pc.b;
         while (s < end) {
@@ -181,14 +147,75 @@ static Fasta read_fasta(const std::string& path, int threads) {
             fn(s, (size_t)(e - s));
             s = nl ? nl + 1 : end;
         }
-    };
-    parallel_for(pieces.size(), threads, [&](size_t i) {
+    }
+};
+
+static std::unique_ptr<FastaScan> scan_fasta(const std::string& path, int threads) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) error("Genome FASTA file %s could not be read.", path.c_str());
+    struct stat st;
+    if (fstat(fd, &st) != 0) error("Genome FASTA file %s could not be read.", path.c_str());
+    auto fs = std::make_unique<FastaScan>();
+    const size_t size = (size_t)st.st_size;
+    if (size == 0) { close(fd); return fs; }
+    fs->map = S_ISREG(st.st_mode) ? mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+    fs->n = size;
+    if (fs->map != MAP_FAILED) {
+        fs->map_size = size;
+        fs->data = (const char*)fs->map;
+        (void)madvise(fs->map, size, MADV_WILLNEED);
+    } else {                                            // not mappable (a pipe): read it whole
+        char buf[1 << 16];
+        ssize_t r;
+        while ((r = read(fd, buf, sizeof buf)) > 0) fs->fallback.append(buf, (size_t)r);
+        fs->data = fs->fallback.data(); fs->n = fs->fallback.size();
+    }
+    close(fd);
+    const char* data = fs->data;
+    const size_t n = fs->n;
+    // record starts: '>' at the beginning of a line; the file is searched in slices by several threads
+    {
+        const size_t slices = std::max<size_t>(1, std::min<size_t>((size_t)threads * 4, n >> 24));
+        std::vector<std::vector<size_t>> found(slices);
+        parallel_for(slices, threads, [&](size_t k) {
+            const char* p = data + n * k / slices;
+            const char* end = data + n * (k + 1) / slices;
+            while (p < end) {
+                const char* q = (const char*)memchr(p, '>', (size_t)(end - p));
+                if (!q) break;
+                if (q == data || q[-1] == '\n') found[k].push_back((size_t)(q - data));
+                p = q + 1;
+            }
+        });
+        for (auto& f : found)
+            for (size_t h : f) {
+                if (!fs->recs.empty()) fs->recs.back().end = h;
+                const char* eol = (const char*)memchr(data + h, '\n', n - h);
+                fs->recs.push_back(FastaScan::Rec{h, eol ? (size_t)(eol - data) + 1 : n, n});
+            }
+    }
+    auto& recs = fs->recs;
+    // pieces of record bodies, cut at line boundaries
+    const size_t kPiece = 8u << 20;
+    for (size_t r = 0; r < recs.size(); r++) {
+        size_t a = recs[r].body;
+        while (a < recs[r].end) {
+            size_t b = std::min(recs[r].end, a + kPiece);
+            if (b < recs[r].end) {
+                const char* nl = (const char*)memchr(data + b, '\n', recs[r].end - b);
+                b = nl ? (size_t)(nl - data) + 1 : recs[r].end;
+            }
+            fs->pieces.push_back(FastaScan::Piece{r, a, b, 0, 0});
+            a = b;
+        }
+    }
+    parallel_for(fs->pieces.size(), threads, [&](size_t i) {
         uint64_t len = 0;
-        each_line(pieces[i], [&](const char*, size_t l) { len += l; });
-        pieces[i].len = len;
+        fs->each_line(fs->pieces[i], [&](const char*, size_t l) { len += l; });
+        fs->pieces[i].len = len;
     });
     std::vector<uint64_t> rec_len(recs.size(), 0);
-    for (auto& pc : pieces) { pc.out = rec_len[pc.rec]; rec_len[pc.rec] += pc.len; }
+    for (auto& pc : fs->pieces) { pc.out = rec_len[pc.rec]; rec_len[pc.rec] += pc.len; }
     // ids; a repeated id keeps its first slot and takes the later record's sequence
     std::unordered_map<std::string, size_t> index;
     std::vector<size_t> slot_rec;                        // slot -> record that supplies the sequence
@@ -199,26 +226,41 @@ static Fasta read_fasta(const std::string& path, int threads) {
         while (e < hend && !is_space(*e)) e++;
         std::string id(h, (size_t)(e - h));
         auto it = index.find(id);
-        if (it == index.end()) { index[id] = fa.names.size(); fa.names.push_back(id); slot_rec.push_back(r); }
+        if (it == index.end()) { index[id] = fs->names.size(); fs->names.push_back(id); slot_rec.push_back(r); }
         else slot_rec[it->second] = r;
     }
-    std::vector<long> rec_slot(recs.size(), -1);
-    for (size_t sl = 0; sl < slot_rec.size(); sl++) rec_slot[slot_rec[sl]] = (long)sl;
+    fs->rec_slot.assign(recs.size(), -1);
+    for (size_t sl = 0; sl < slot_rec.size(); sl++) fs->rec_slot[slot_rec[sl]] = (long)sl;
+    fs->lens.resize(fs->names.size());
+    for (size_t sl = 0; sl < slot_rec.size(); sl++) fs->lens[sl] = rec_len[slot_rec[sl]];
+    return fs;
+}
+
+static Fasta read_fasta(const std::string& path, int threads) {
+    auto fs = scan_fasta(path, threads);
+    Fasta fa;
+    fa.names = fs->names; fa.lens = fs->lens;
     fa.seqs.resize(fa.names.size());
-    fa.lens.resize(fa.names.size());
-    for (size_t sl = 0; sl < slot_rec.size(); sl++) {
-        fa.lens[sl] = rec_len[slot_rec[sl]];
-        fa.seqs[sl].reset(new char[std::max<uint64_t>(fa.lens[sl], 1)]);
-    }
-    parallel_for(pieces.size(), threads, [&](size_t i) {
-        const long sl = rec_slot[pieces[i].rec];
+    for (size_t sl = 0; sl < fa.names.size(); sl++) fa.seqs[sl].reset(new char[std::max<uint64_t>(fa.lens[sl], 1)]);
+    parallel_for(fs->pieces.size(), threads, [&](size_t i) {
+        const long sl = fs->rec_slot[fs->pieces[i].rec];
         if (sl < 0) return;                              // superseded by a later record of the same id
-        char* out = fa.seqs[(size_t)sl].get() + pieces[i].out;
-        each_line(pieces[i], [&](const char* s, size_t l) { memcpy(out, s, l); out += l; });
+        char* out = fa.seqs[(size_t)sl].get() + fs->pieces[i].out;
+        fs->each_line(fs->pieces[i], [&](const char* s, size_t l) { memcpy(out, s, l); out += l; });
     });
-    if (map != MAP_FAILED) munmap(map, size);
-    close(fd);
     return fa;
+}
+
+// Every piece of every contig to `sink(contig slot, offset inside the contig, bytes, n)`, from `threads` workers.
+static void stream_fasta(const FastaScan& fs, int threads, const std::function<void(uint32_t, uint64_t, const uint8_t*, uint64_t)>& sink) {
+    parallel_for(fs.pieces.size(), threads, [&](size_t i) {
+        const long sl = fs.rec_slot[fs.pieces[i].rec];
+        if (sl < 0 || fs.pieces[i].len == 0) return;
+        std::unique_ptr<char[]> buf(new char[fs.pieces[i].len]);
+        char* out = buf.get();
+        fs.each_line(fs.pieces[i], [&](const char* s, size_t l) { memcpy(out, s, l); out += l; });
+        sink((uint32_t)sl, fs.pieces[i].out, (const uint8_t*)buf.get(), fs.pieces[i].len);
+    });
 }
 
 struct Child { pid_t pid = -1; int to_child = -1, from_child = -1; };
@@ -485,65 +527,123 @@ int main(int argc, char** argv) {
     if (bf_ctx_create(&cfg, &ctx) != BF_OK) error("%s", bf_last_error(nullptr));
     timing.lap("gpu_context");
 
-    Fasta fa = read_fasta(genome_path + ".fa", threads);
+    // The FASTA is measured (names, lengths), then its pieces go to the GPU from a few threads WHILE the main thread
+    // already parses Bowtie's output: the parser only needs the contig names, and bf_submit accepts reads from
+    // bf_genome_begin on (their kernels wait for bf_genome_end).
+    auto fs = scan_fasta(genome_path + ".fa", threads);
     fprintf(stderr, "Reading reference genome into memory...\n");
-    timing.lap("fasta_load");
+    timing.lap("fasta_scan");
     hits::ContigIndex contigs;
     {
-        std::vector<const char*> names; std::vector<const uint8_t*> seqs;
-        for (size_t i = 0; i < fa.names.size(); i++) {
-            names.push_back(fa.names[i].c_str());
-            seqs.push_back((const uint8_t*)fa.seqs[i].get());
-            contigs.add(fa.names[i], (uint32_t)i);
-        }
+        std::vector<const char*> names;
+        for (size_t i = 0; i < fs->names.size(); i++) { names.push_back(fs->names[i].c_str()); contigs.add(fs->names[i], (uint32_t)i); }
         if (names.empty()) error("Genome FASTA file %s.fa holds no sequences.", genome_path.c_str());
-        if (bf_genome_set(ctx, (uint32_t)names.size(), names.data(), seqs.data(), fa.lens.data()) != BF_OK)
-            error("%s", bf_last_error(ctx));
+        if (bf_genome_begin(ctx, (uint32_t)names.size(), names.data(), fs->lens.data()) != BF_OK) error("%s", bf_last_error(ctx));
         contigs.build();
     }
-    for (auto& s : fa.seqs) s.reset();                         // the genome now lives in HBM
-    timing.lap("genome_to_hbm");
+    const int g_threads = std::max(1, threads / 2);
+    if (const char* e = getenv("BREAKFAST_HIP_PARSER_THREADS")) popt.threads = std::max(1, atoi(e));
+    double genome_s = 0;
+    std::thread genome_thread([&] {
+        const auto t0 = std::chrono::steady_clock::now();
+        stream_fasta(*fs, g_threads, [&](uint32_t c, uint64_t off, const uint8_t* p, uint64_t n) { (void)bf_genome_write(ctx, c, off, p, n); });
+        genome_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    });
 
     fprintf(stderr, "Splitting unaligned reads into %u bp anchors and aligning against the genome...\n", cfg.anchor_len);
 
+    // parsed batches go to a submit thread through a short queue (in input order: one producer, one consumer), so that
+    // the thread that pairs lines across block boundaries is not held up while a batch is staged for the GPU
     double submit_s = 0;
-    try {
-        hits::parse_stream(in_fd, contigs, genome_path, popt, [&](hits::Batch& b) {
-            const auto t0 = std::chrono::steady_clock::now();
-            bf_batch bb;
-            bb.n_reads = b.n();
-            bb.seq_bytes = (const uint8_t*)b.seq.data(); bb.seq_off = b.seq_off.data();
-            bb.frag_bytes = (const uint8_t*)b.frag.data(); bb.frag_off = b.frag_off.data();
-            bb.hits = b.hits.data();
-            if (bf_submit(ctx, &bb) != BF_OK) error("%s", bf_last_error(ctx));
-            submit_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!getenv("BREAKFAST_HIP_PARSER_THREADS")) popt.threads = std::max(1, threads - g_threads);
+    {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<hits::Batch> queue;
+        bool done = false;
+        std::thread submitter([&] {
+            for (;;) {
+                hits::Batch b;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return done || !queue.empty(); });
+                    if (queue.empty()) return;
+                    b = std::move(queue.front());
+                    queue.pop_front();
+                    cv.notify_all();
+                }
+                const auto t0 = std::chrono::steady_clock::now();
+                bf_batch bb;
+                bb.n_reads = b.n();
+                bb.seq_bytes = (const uint8_t*)b.seq.data(); bb.seq_off = b.seq_off.data();
+                bb.frag_bytes = (const uint8_t*)b.frag.data(); bb.frag_off = b.frag_off.data();
+                bb.hits = b.hits.data();
+                if (bf_submit(ctx, &bb) != BF_OK) error("%s", bf_last_error(ctx));
+                submit_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
         });
-    } catch (const std::exception& e) { error("%s", e.what()); }
+        try {
+            hits::parse_stream(in_fd, contigs, genome_path, popt, [&](hits::Batch& b) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return queue.size() < 4; });
+                queue.emplace_back();
+                std::swap(queue.back(), b);
+                cv.notify_all();
+            });
+        } catch (const std::exception& e) { error("%s", e.what()); }
+        { std::lock_guard<std::mutex> g(mu); done = true; cv.notify_all(); }
+        submitter.join();
+    }
     if (in_fd > 0) close(in_fd);
     if (producer.joinable()) producer.join();
     if (child.pid > 0) { int st = 0; waitpid(child.pid, &st, 0); }     // the reference never checks it either
     timing.lap("parse_and_submit");
     timing.add("  of_which_bf_submit", submit_s);
+    genome_thread.join();
+    if (bf_genome_end(ctx) != BF_OK) error("%s", bf_last_error(ctx));
+    fs.reset();                                                 // the genome now lives in HBM
+    timing.lap("genome_to_hbm_tail");
+    timing.add("  genome_stream_beside_the_parser", genome_s);
 
     bf_result res;
-    if (bf_localise(ctx) != BF_OK) error("%s", bf_last_error(ctx));
     uint64_t n_reads = 0;
     bf_stats(ctx, &n_reads, nullptr);
     fprintf(stderr, "Found %llu rearrangement supporting reads.\n", (unsigned long long)n_reads);
     fprintf(stderr, "Sorting rearrangement supporting reads by position...\n");
     fprintf(stderr, "Identifying rearrangements based on clusters of discordant reads...\n");
-    if (bf_clusterise(ctx, &res) != BF_OK) error("%s", bf_last_error(ctx));
+    if (bf_finish(ctx, &res) != BF_OK) error("%s", bf_last_error(ctx));
     timing.lap("gpu_localise_clusterise");
-    const int64_t size = bf_format_sv(ctx, &res, nullptr, 0);
-    if (size < 0) error("could not render the result");
-    std::unique_ptr<char[]> out(new char[(size_t)size + 1]);
-    if (bf_format_sv(ctx, &res, out.get(), (uint64_t)size) != size) error("could not render the result");
-    timing.lap("format_sv");
+    // the rows are rendered a slice of clusters at a time while the previous slice is being written
     fflush(stdout);
-    write_all(1, out.get(), (size_t)size);
-    timing.lap("write_stdout");
-    bf_ctx_destroy(ctx);
-    timing.lap("teardown");
+    {
+        const uint64_t nc = res.n_clusters;
+        const int slices = nc >= 4096 ? 8 : 1;
+        const size_t hdr = strlen("CHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tCHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tSUPPORTING READS\tSIGNATURE\tNOTES\n");
+        std::vector<std::unique_ptr<char[]>> bufs((size_t)slices);
+        std::vector<int64_t> sizes((size_t)slices, 0);
+        std::thread writer;
+        for (int k = 0; k < slices; k++) {
+            bf_result part = res;
+            const uint64_t c0 = nc * (uint64_t)k / slices, c1 = nc * (uint64_t)(k + 1) / slices;
+            part.n_clusters = c1 - c0;
+            part.clusters = res.clusters ? res.clusters + c0 : nullptr;
+            part.cluster_junction_off = res.cluster_junction_off ? res.cluster_junction_off + c0 : nullptr;
+            const int64_t size = bf_format_sv(ctx, &part, nullptr, 0);
+            if (size < 0) error("could not render the result");
+            bufs[k].reset(new char[(size_t)size + 1]);
+            if (bf_format_sv(ctx, &part, bufs[k].get(), (uint64_t)size) != size) error("could not render the result");
+            sizes[k] = size;
+            if (writer.joinable()) writer.join();
+            const char* p = bufs[k].get() + (k ? hdr : 0);       // every slice starts with the header line: once is enough
+            const size_t len = (size_t)size - (k ? hdr : 0);
+            writer = std::thread([p, len] { write_all(1, p, len); });
+        }
+        if (writer.joinable()) writer.join();
+    }
+    timing.lap("format_and_write");
+    if (getenv("BREAKFAST_HIP_TEARDOWN")) { bf_ctx_destroy(ctx); timing.lap("teardown"); }
     timing.print();
-    return 0;
+    // everything is written: the process ends here and the driver reclaims the GPU memory
+    fflush(stderr);
+    _exit(0);
 }

@@ -353,7 +353,7 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
     memset(out, 0, sizeof *out);
     Shard* sh = shard_of(ctx);
     if (!sh) return fail(ctx, BF_ERR_STATE, "bf_shard_finish before bf_shard_init_rccl / bf_shard_init_host");
-    if (ctx->n_contigs == 0) return fail(ctx, BF_ERR_STATE, "bf_shard_finish before bf_genome_set");
+    if (ctx->n_contigs == 0 || !ctx->genome_ready) return fail(ctx, BF_ERR_STATE, "bf_shard_finish before bf_genome_set / bf_genome_end");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     Transport* tr = sh->tr;
     const uint32_t W = tr->n, me = tr->rank;

@@ -98,6 +98,7 @@ ABI_SYMBOLS = [
     "bf_result_junction_sizes_dev", "bf_result_layout_dev", "bf_result_attach_records_dev", "bf_result_requests_dev",
     "bf_result_attach_finish", "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
     "bf_render_junctions_dev_static", "bf_host_alloc", "bf_host_free", "bf_submit_wait", "bf_reserve",
+    "bf_genome_begin", "bf_genome_write", "bf_genome_end",
     "bf_shard_unique_id", "bf_shard_init_rccl", "bf_shard_init_host", "bf_shard_finish", "bf_shard_format_sv",
 ]
 
@@ -137,6 +138,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_last_error.argtypes = [vp]
     lib.bf_last_error.restype = C.c_char_p
     lib.bf_genome_set.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(vp), u64p]
+    lib.bf_genome_begin.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), u64p]
+    lib.bf_genome_write.argtypes = [vp, C.c_uint32, C.c_uint64, vp, C.c_uint64]
+    lib.bf_genome_end.argtypes = [vp]
     lib.bf_submit.argtypes = [vp, C.POINTER(BfBatch)]
     lib.bf_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     lib.bf_host_free.argtypes = [vp, vp]

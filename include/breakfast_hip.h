@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 7
+#define BF_ABI_VERSION 8
 
 enum {
     BF_OK = 0,
@@ -174,6 +174,13 @@ int bf_abi_version(void);
  * (Rust String Ord, detect.rs:108,194) is derived here.  Inputs may be freed on return. */
 int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names,
                   const uint8_t* const* seqs, const uint64_t* lens);
+/* The same in pieces, for a FASTA loader that uploads while it is still reading (detect.rs:48-56 reads the file
+ * record by record): bf_genome_begin fixes names and lengths (from then on bf_submit accepts reads; their kernels
+ * wait for the genome), bf_genome_write hands over any piece of any contig -- from ANY thread, in any order;
+ * bytes may be freed on return; its errors are returned and repeated by bf_genome_end --, bf_genome_end packs. */
+int bf_genome_begin(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint64_t* lens);
+int bf_genome_write(bf_ctx* ctx, uint32_t contig, uint64_t offset, const uint8_t* bytes, uint64_t n);
+int bf_genome_end(bf_ctx* ctx);
 
 /* ---- the hot path -------------------------------------------------------------------------- */
 
