@@ -522,8 +522,14 @@ struct SubmitJob {
     uint64_t a, b;
 };
 
+struct BatchView {          // bf_batch or bf_packed_batch
+    uint64_t n_reads;
+    const uint8_t* seq_bytes; const uint64_t* seq_off; const uint16_t* seq_len;     // seq_len: 4-bit reads only
+    const uint8_t* frag_bytes; const uint64_t* frag_off; const bf_hit* hits;
+};
+
 struct SubmitShared {
-    bf_ctx* ctx; const bf_batch* bat;
+    bf_ctx* ctx; const BatchView* bat;
     uint64_t r_base;       // first read of the piece inside the batch
     uint64_t n0, seq0, frag0;          // resident reads / bytes before the BATCH
     bool hits_direct;
@@ -553,7 +559,7 @@ static bool slot_ready(bf_ctx* ctx, bf_ctx::StageSlot& sl) {
 
 static void submit_worker(SubmitShared* sh, int slot_id) {
     bf_ctx* ctx = sh->ctx;
-    const bf_batch* b = sh->bat;
+    const BatchView* b = sh->bat;
     if (hipSetDevice(ctx->device) != hipSuccess) { sh->error(0, BF_ERR_HIP, "hipSetDevice failed in a staging thread"); return; }
     bf_ctx::StageSlot& sl = ctx->slots[slot_id];
     uint32_t mx = 0, mn = 0xffffffffu, mf = 0;
@@ -569,12 +575,23 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
             uint64_t* so = (uint64_t*)sl.p;
             uint64_t* fo = so + (cnt + 1);
             bf_hit* hh = (bf_hit*)(fo + (cnt + 1));
+            uint16_t* ll = (uint16_t*)(hh + cnt);                // lengths of 4-bit reads
             const uint64_t s0 = b->seq_off[0], f0 = b->frag_off[0];
             bool ok = true;
             for (uint64_t i = job.a; i < job.b; i++) {
                 const uint64_t sa = b->seq_off[i], sb = b->seq_off[i + 1], fa = b->frag_off[i], fb = b->frag_off[i + 1];
                 if (sb < sa || fb < fa) { sh->error(i, BF_ERR_INVALID, "bf_submit: offsets not monotone at read %llu", (unsigned long long)i); ok = false; break; }
-                const uint64_t L = sb - sa, fl = fb - fa;
+                uint64_t L = sb - sa;
+                const uint64_t fl = fb - fa;
+                if (b->seq_len) {                                // 4-bit codes: ceil(L / 2) bytes hold the L bases
+                    L = b->seq_len[i];
+                    if (sb - sa != (L + 1) / 2) {
+                        sh->error(i, BF_ERR_INVALID, "bf_submit_packed: read %llu has %llu bases in %llu bytes (expected %llu)", (unsigned long long)i,
+                                  (unsigned long long)L, (unsigned long long)(sb - sa), (unsigned long long)((L + 1) / 2));
+                        ok = false; break;
+                    }
+                    ll[i - job.a] = (uint16_t)L;
+                }
                 if (L > 65535) { sh->error(i, BF_ERR_RANGE, "read %llu has %llu bases; at most 65535 are supported", (unsigned long long)i, (unsigned long long)L); ok = false; break; }
                 if (fl > 65535) { sh->error(i, BF_ERR_RANGE, "fragment id of read %llu has %llu bytes; at most 65535", (unsigned long long)i, (unsigned long long)fl); ok = false; break; }
                 mx = std::max<uint32_t>(mx, (uint32_t)L); mn = std::min<uint32_t>(mn, (uint32_t)L); mf = std::max<uint32_t>(mf, (uint32_t)fl);
@@ -596,6 +613,8 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
             if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_frag_off.as<uint64_t>() + sh->n0 + job.a, fo, n_off * 8, hipMemcpyHostToDevice, ctx->in_stream);
             if (e == hipSuccess && !sh->hits_direct)
                 e = hipMemcpyAsync(ctx->d_hits.as<bf_hit>() + sh->n0 + job.a, hh, cnt * sizeof(bf_hit), hipMemcpyHostToDevice, ctx->in_stream);
+            if (e == hipSuccess && b->seq_len)
+                e = hipMemcpyAsync(ctx->d_len.as<uint16_t>() + sh->n0 + job.a, ll, cnt * 2, hipMemcpyHostToDevice, ctx->in_stream);
         } else {
             const uint8_t* src = job.kind == 1 ? b->seq_bytes + b->seq_off[0] : b->frag_bytes + b->frag_off[0];
             uint8_t* dst = job.kind == 1 ? ctx->d_seq.as<uint8_t>() + sh->seq0 : ctx->d_frag.as<uint8_t>() + sh->frag0;
@@ -613,6 +632,11 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
 
 static int reserve_input(bf_ctx* ctx, uint64_t reads, uint64_t seq_bytes, uint64_t frag_bytes) {
     if (reads > ctx->cap_reads) BF_TRY(grow_reads(ctx, std::max<uint64_t>({reads, ctx->cap_reads * 2, (uint64_t)1 << 16})));
+    if (ctx->packed_reads && ctx->d_len.cap < ctx->cap_reads * 2) {      // capacity reserved before the ctx took 4-bit reads
+        BF_SYNC(ctx, ctx->in_stream);
+        BF_SYNC(ctx, ctx->stream);
+        BF_TRY(ensure(ctx, ctx->d_len, ctx->cap_reads * 2, true));
+    }
     if (seq_bytes + 64 > ctx->d_seq.cap || frag_bytes + 64 > ctx->d_frag.cap || !ctx->d_seq.p || !ctx->d_frag.p) {
         BF_SYNC(ctx, ctx->in_stream);
         BF_SYNC(ctx, ctx->stream);
@@ -661,14 +685,34 @@ int bf_submit_wait(bf_ctx* ctx) {
     return BF_OK;
 }
 
+static int submit_impl(bf_ctx* ctx, const BatchView* b);
+
 int bf_submit(bf_ctx* ctx, const bf_batch* b) {
     if (!ctx) return BF_ERR_INVALID;
-    BF_TRACE_CALL(ctx);
     if (!b) return fail(ctx, BF_ERR_INVALID, "bf_submit: null batch");
+    if (ctx->n_reads && ctx->packed_reads && b->n_reads) return fail(ctx, BF_ERR_STATE, "bf_submit after bf_submit_packed: a ctx holds its reads in one form; call bf_reset first");
+    const BatchView v{b->n_reads, b->seq_bytes, b->seq_off, nullptr, b->frag_bytes, b->frag_off, b->hits};
+    return submit_impl(ctx, &v);
+}
+
+int bf_submit_packed(bf_ctx* ctx, const bf_packed_batch* b) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!b) return fail(ctx, BF_ERR_INVALID, "bf_submit_packed: null batch");
+    if (b->n_reads && !b->seq_len) return fail(ctx, BF_ERR_INVALID, "bf_submit_packed: null seq_len");
+    if (ctx->n_reads && !ctx->packed_reads && b->n_reads) return fail(ctx, BF_ERR_STATE, "bf_submit_packed after bf_submit: a ctx holds its reads in one form; call bf_reset first");
+    if (ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE))
+        return fail(ctx, BF_ERR_STATE, "the A/B variants with a separate encode kernel read ASCII reads only (bf_submit)");
+    const BatchView v{b->n_reads, b->seq_nibbles, b->seq_off, b->seq_len, b->frag_bytes, b->frag_off, b->hits};
+    return submit_impl(ctx, &v);
+}
+
+static int submit_impl(bf_ctx* ctx, const BatchView* b) {
+    BF_TRACE_CALL(ctx);
     if (ctx->n_contigs == 0) return fail(ctx, BF_ERR_STATE, "bf_submit before bf_genome_set");
     const uint64_t m = b->n_reads;
     if (m == 0) return BF_OK;
     if (!b->seq_bytes || !b->seq_off || !b->frag_off || !b->hits) return fail(ctx, BF_ERR_INVALID, "bf_submit: null array");
+    if (ctx->n_reads == 0) ctx->packed_reads = b->seq_len != nullptr;
     if (ctx->n_reads + m > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "more than 2^32-16 reads in one ctx");
     if (b->seq_off[m] < b->seq_off[0] || b->frag_off[m] < b->frag_off[0]) return fail(ctx, BF_ERR_INVALID, "bf_submit: offsets not monotone");
     const uint64_t sb = b->seq_off[m] - b->seq_off[0], fb = b->frag_off[m] - b->frag_off[0];
@@ -701,7 +745,7 @@ int bf_submit(bf_ctx* ctx, const bf_batch* b) {
     // (the A/B variants of the localise stage keep their one launch over the whole set)
     const bool eager = ctx->genome_ready && !(ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE));
     // reads per offsets job: two offset arrays (+1 entry each) and the hits share one slot
-    const uint64_t per_job = (kStageSlotBytes - 64) / (8 + 8 + sizeof(bf_hit)) - 2;
+    const uint64_t per_job = (kStageSlotBytes - 64) / (8 + 8 + sizeof(bf_hit) + 2) - 2;
     uint32_t mx = ctx->max_len, mn = ctx->min_len, mf = ctx->max_frag;
     const uint64_t piece_reads = ctx->cfg.reserved[2] ? ctx->cfg.reserved[2] : kPieceReads;
     for (uint64_t p0 = 0; p0 < m; p0 += piece_reads) {
@@ -717,7 +761,7 @@ int bf_submit(bf_ctx* ctx, const bf_batch* b) {
         // keeps every staging thread busy
         const uint64_t staged = (p1 - p0) * 32 + (seq_direct ? 0 : se - sa) + (frag_direct ? 0 : fe - fa);
         const uint64_t job_bytes = std::min<uint64_t>(kStageSlotBytes, std::max<uint64_t>(1u << 20, staged / std::max(1u, ctx->host_threads)));
-        const uint64_t job_reads = std::min<uint64_t>(per_job, std::max<uint64_t>(job_bytes / 32, 1));
+        const uint64_t job_reads = std::min<uint64_t>(per_job, std::max<uint64_t>(job_bytes / 34, 1));
         for (uint64_t a = p0; a < p1; a += job_reads) sh.jobs.push_back(SubmitJob{0, a, std::min(p1, a + job_reads)});
         if (!seq_direct) for (uint64_t a = sa; a < se; a += job_bytes) sh.jobs.push_back(SubmitJob{1, a, std::min(se, a + job_bytes)});
         if (!frag_direct) for (uint64_t a = fa; a < fe; a += job_bytes) sh.jobs.push_back(SubmitJob{2, a, std::min(fe, a + job_bytes)});

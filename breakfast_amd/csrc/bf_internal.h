@@ -206,6 +206,7 @@ struct bf_ctx {
     std::string genome_err; int genome_err_code = 0;
 
     // source-side resident reads
+    bool packed_reads = false;                  // d_seq holds 4-bit base codes (bf_submit_packed), d_len came with them
     uint64_t n_reads = 0;
     uint64_t seq_bytes = 0, frag_bytes = 0;
     uint32_t max_len = 0, min_len = 0xffffffffu, max_frag = 0;

@@ -21,6 +21,16 @@ __constant__ uint8_t kComp[256] = {
 };
 
 __device__ __forceinline__ uint8_t comp_byte(uint8_t c) { return kComp[c]; }
+
+// Reads may be resident as BAM 4-bit base codes (bf_submit_packed; SAMv1 4.2: "=ACMGRSVTWYHKDBN", two bases per
+// byte, high nibble first, every read starting on a byte) instead of ASCII: half the bytes on PCIe and in every
+// kernel that touches a read.  base_at() is the byte the reference would see (detect.rs:91 decodes the same table).
+__constant__ uint8_t kNibbleBase[16] = {'=', 'A', 'C', 'M', 'G', 'R', 'S', 'V', 'T', 'W', 'Y', 'H', 'K', 'D', 'B', 'N'};
+__device__ __forceinline__ uint8_t base_at(const uint8_t* __restrict__ seq, uint64_t so, int k, bool packed) {
+    if (!packed) return seq[so + (uint64_t)k];
+    const uint8_t b = seq[so + (uint64_t)(k >> 1)];
+    return kNibbleBase[(k & 1) ? (b & 15) : (b >> 4)];
+}
 __device__ __forceinline__ bool is_acgt(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
 
 // ---------------------------------------------------------------------------------------------
@@ -126,10 +136,10 @@ __global__ void __launch_bounds__(256) read_meta_kernel(uint64_t r0, uint64_t n,
                                                         const uint64_t* __restrict__ frag_off,
                                                         uint16_t* __restrict__ len,
                                                         uint16_t* __restrict__ frag_len,
-                                                        uint64_t* __restrict__ fhash) {
+                                                        uint64_t* __restrict__ fhash, bool packed) {
     const uint64_t r = r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;     // reads [r0, n)
     if (r >= n) return;
-    len[r] = (uint16_t)(seq_off[r + 1] - seq_off[r]);
+    if (!packed) len[r] = (uint16_t)(seq_off[r + 1] - seq_off[r]);                // (4-bit reads bring their lengths along)
     const uint64_t o = frag_off[r];
     const uint32_t fl = (uint32_t)(frag_off[r + 1] - o);
     frag_len[r] = (uint16_t)fl;
@@ -329,6 +339,68 @@ __device__ __forceinline__ void encode_ascii(const uint8_t* __restrict__ seq, ui
     }
 }
 
+// The same three planes from 4-bit base codes.  One dword = 8 bases; the two nibbles of every byte are swapped first
+// so that nibble j of the dword is base j; then lo = "C or G" = bit1|bit2, hi = "G or T" = bit2|bit3 of the one-hot
+// code (A=1 C=2 G=4 T=8 -> 2-bit codes A0 C1 T2 G3 as in the genome image), exception = the nibble's popcount is not 1.
+__device__ __forceinline__ uint32_t gather_nibble_bits(uint32_t t) {     // bits 0,4,...,28 -> bits 0..7
+    uint32_t y = (t | (t >> 3)) & 0x03030303u;
+    y = (y | (y >> 6)) & 0x000f000fu;
+    return (y | (y >> 12)) & 0xffu;
+}
+
+template <int W>
+__device__ __forceinline__ void encode_nibbles(const uint8_t* __restrict__ seq, uint64_t o, int L,
+                                               uint64_t (&lo)[W], uint64_t (&hi)[W], uint64_t (&ex)[W]) {
+    constexpr int ND = 8 * W;                               // dwords of 8 bases
+    const uint32_t sh8 = (uint32_t)(o & 3);
+    const U4A* __restrict__ src = (const U4A*)(seq + (o - sh8));
+    const int need = (int)((sh8 + (uint32_t)((L + 1) >> 1) + 3u) >> 2);   // aligned dwords holding the read
+    uint32_t d[ND + 4];
+#pragma unroll
+    for (int g = 0; g <= ND / 4; g++) {
+        U4A v{0, 0, 0, 0};
+        if (4 * g < need) v = src[g];
+        d[4 * g] = v.x; d[4 * g + 1] = v.y; d[4 * g + 2] = v.z; d[4 * g + 3] = v.w;
+    }
+    uint32_t plo[2 * W], phi[2 * W], pex[2 * W];
+#pragma unroll
+    for (int i = 0; i < 2 * W; i++) plo[i] = phi[i] = pex[i] = 0;
+#pragma unroll
+    for (int g = 0; g < ND / 4; g++) {
+        if (__any(4 * g < need)) {                          // wave-uniform skip of the unused tail
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int j = 4 * g + q;                    // dword j = bases [8j, 8j + 8)
+                const uint32_t x = __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh8);
+                const uint32_t n = ((x & 0x0f0f0f0fu) << 4) | ((x >> 4) & 0x0f0f0f0fu);
+                const uint32_t blo = gather_nibble_bits(((n >> 1) | (n >> 2)) & 0x11111111u);
+                const uint32_t bhi = gather_nibble_bits(((n >> 2) | (n >> 3)) & 0x11111111u);
+                uint32_t c = (n & 0x55555555u) + ((n >> 1) & 0x55555555u);
+                c = (c & 0x33333333u) + ((c >> 2) & 0x33333333u);          // popcount of every nibble
+                const uint32_t e = c ^ 0x11111111u;                           // zero where exactly one bit is set
+                const uint32_t bex = gather_nibble_bits((e | (e >> 1) | (e >> 2) | (e >> 3)) & 0x11111111u);
+                const int slot = j >> 2, bit = 8 * (j & 3);
+                plo[slot] |= blo << bit;
+                phi[slot] |= bhi << bit;
+                pex[slot] |= bex << bit;
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const uint64_t vm = low_mask(min(max(L - 64 * w, 0), 64));
+        lo[w] = (((uint64_t)plo[2 * w + 1] << 32) | plo[2 * w]) & vm;
+        hi[w] = (((uint64_t)phi[2 * w + 1] << 32) | phi[2 * w]) & vm;
+        ex[w] = (((uint64_t)pex[2 * w + 1] << 32) | pex[2 * w]) & vm;
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void encode_read(const uint8_t* __restrict__ seq, uint64_t o, int L, bool packed,
+                                            uint64_t (&lo)[W], uint64_t (&hi)[W], uint64_t (&ex)[W]) {
+    if (packed) encode_nibbles<W>(seq, o, L, lo, hi, ex); else encode_ascii<W>(seq, o, L, lo, hi, ex);
+}
+
 struct LocaliseArgs {
     uint64_t r0, n;          // this launch covers reads [r0, n): bf_submit localises every uploaded piece on its own
     int A;
@@ -338,8 +410,9 @@ struct LocaliseArgs {
     const uint16_t* len;          // separate-encode variant: read lengths (input)
     uint16_t* len_out;            // fused variant: read lengths (output)
     const uint64_t* planes;       // separate-encode variant
-    const uint8_t* seq;           // fused variant: ASCII reads
-    const uint64_t* seq_off;
+    const uint8_t* seq;           // fused variant: the reads, ASCII or 4-bit codes
+    const uint64_t* seq_off;      // ... and where each starts (bytes)
+    uint32_t packed;              // 1: 4-bit codes, lengths in `len`
     const ContigDev* contigs;
     const GenomeBlock* blocks;
     const uint64_t* coarse;
@@ -393,7 +466,7 @@ __device__ __forceinline__ uint64_t make_key(const Oriented& o, bool sigx, uint3
 
 // (No occupancy attribute here: at W=3 the kernel takes 102 VGPRs = 4 waves/SIMD; forcing 5, 6 or 8 waves
 // spills and measured 1.12, 1.45 and 2.30 ms against 1.07 ms.)
-template <int W, bool COOP, bool FUSED>
+template <int W, bool COOP, bool FUSED, bool PACKED = false>
 __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a) {
     __shared__ uint4 lds[COOP ? 4 * 2 * CoopGeom<W>::WAVE_U4 : 1];
     const uint64_t r_raw = a.r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -404,8 +477,8 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
     int L;
     if (FUSED) {
         so = a.seq_off[r];
-        L = (int)(a.seq_off[r + 1] - so);
-        a.len_out[r] = (uint16_t)L;
+        if (PACKED) L = a.len[r];
+        else { L = (int)(a.seq_off[r + 1] - so); a.len_out[r] = (uint16_t)L; }
     } else {
         L = a.len[r];
     }
@@ -426,7 +499,7 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
         // read bases are requested first and the flank windows right after, so the encode arithmetic
         // runs while the window gathers are still in flight (vmcnt retires in issue order)
         if (L <= 64 * W) {
-            encode_ascii<W>(a.seq, so, L, rlo, rhi, rex);
+            if (PACKED) encode_nibbles<W>(a.seq, so, L, rlo, rhi, rex); else encode_ascii<W>(a.seq, so, L, rlo, rhi, rex);
         } else {
 #pragma unroll
             for (int w = 0; w < W; w++) rlo[w] = rhi[w] = rex[w] = 0;
@@ -625,6 +698,8 @@ struct ExactArgs {
     const bf_hit* hits;
     const uint8_t* seq;
     const uint64_t* seq_off;
+    const uint16_t* len;     // read lengths when the reads are 4-bit codes
+    uint32_t packed;
     const ContigDev* contigs;
     const uint8_t* raw;
     uint64_t* key;
@@ -641,11 +716,12 @@ struct ExactArgs {
 };
 
 struct ExactRead {
-    const uint8_t* seq; int L; bool swapped;
+    const uint8_t* seq; uint64_t so; bool packed; int L; bool swapped;
+    __device__ __forceinline__ uint8_t raw_base(int k) const { return base_at(seq, so, k, packed); }
     const uint8_t* lraw; int64_t llen; int64_t lbase; bool lfwd;
     const uint8_t* rraw; int64_t rlen; int64_t rbase; bool rfwd;
     __device__ __forceinline__ uint8_t s(int k) const {
-        return swapped ? comp_byte(seq[L - 1 - k]) : seq[k];
+        return swapped ? comp_byte(raw_base(L - 1 - k)) : raw_base(k);
     }
     __device__ __forceinline__ uint8_t left(int k) const {
         const int64_t i = lfwd ? lbase + k : lbase - k;
@@ -675,8 +751,8 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
     const Oriented o = orient(h, a.contigs);
     const int A = a.A;
     ExactRead x;
-    x.seq = a.seq + a.seq_off[r];
-    x.L = (int)(a.seq_off[r + 1] - a.seq_off[r]);
+    x.seq = a.seq; x.so = a.seq_off[r]; x.packed = a.packed != 0;
+    x.L = a.packed ? (int)a.len[r] : (int)(a.seq_off[r + 1] - a.seq_off[r]);
     x.swapped = o.swapped;
     const int L = x.L;
     x.lraw = a.raw + o.c.goff; x.llen = o.c.len; x.lfwd = o.strand;
@@ -701,7 +777,7 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
         const uint64_t lowA = low(A - 64 * c);
         mm += __popcll(ml & lowA) + __popcll(mr & ~lowA);
         const int k = 64 * c + lane;
-        n_exc += (uint32_t)__popcll(__ballot(k < L && !is_acgt(x.seq[k])));
+        n_exc += (uint32_t)__popcll(__ballot(k < L && !is_acgt(x.raw_base(k))));
     }
     n_exc = min(n_exc, 0xffffu);
     // candidates k in [A+1, L-A): mm[k] = mm[k-1] + ml[k-1] - mr[k-1]; j = k-1 runs over [A, L-A-2]
@@ -892,6 +968,42 @@ render_kernel(uint64_t n, const uint32_t* __restrict__ idx,
     }
 }
 
+// Text records of reads that are resident as 4-bit codes: 16 lanes per read, a byte at a time (such records are rare:
+// reads above the packed kernel's 256 bases, or with more than one base in eight outside ACGT).
+__global__ void __launch_bounds__(256) render_text_nibbles_kernel(uint64_t n, const uint32_t* __restrict__ idx,
+                                                                  const uint64_t* __restrict__ joff,
+                                                                  const uint8_t* __restrict__ seq,
+                                                                  const uint64_t* __restrict__ seq_off,
+                                                                  const uint64_t* __restrict__ meta, int meta_stride,
+                                                                  uint32_t max_packed, uint8_t* __restrict__ out) {
+    const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    const uint64_t i = (uint64_t)blockIdx.x * 16 + g;
+    if (i >= n) return;
+    const uint32_t r = idx[i];
+    const uint64_t so = seq_off[r];
+    const uint64_t* rec = meta + (uint64_t)r * meta_stride;
+    const uint64_t tail = rec[meta_stride - 1];
+    const int bp = (int)(tail & 0xffff), L = (int)((tail >> 32) & 0xffff);
+    const bool swapped = ((tail >> 16) & kEvSwapped) != 0;
+    if (junction_packable((uint32_t)L, (uint32_t)(tail >> 48), max_packed)) return;      // render_packed_kernel's
+    uint8_t* o = out + joff[i];
+    if (l16 == 0) {
+        uint16_t* hd = (uint16_t*)o;
+        hd[0] = (uint16_t)L; hd[1] = (uint16_t)bp; hd[2] = (uint16_t)kJunctionText;
+        hd[3] = (uint16_t)(swapped ? kJunctionSwapped : 0u);
+        for (int q = 8 + L + 1; q & 3; q++) o[q] = 0;                                    // padding
+    }
+    for (int q = l16; q <= L; q += 16) {                                                 // L + 1 output bytes
+        uint32_t c = '|';
+        if (q != bp) {
+            const int k = q < bp ? q : q - 1;
+            c = swapped ? comp_byte(base_at(seq, so, L - 1 - k, true)) : base_at(seq, so, k, true);
+            if (((rec[k >> 6] >> (k & 63)) & 1) && c >= 'A' && c <= 'Z') c += 32;          // to_ascii_lowercase
+        }
+        o[8 + q] = (uint8_t)c;
+    }
+}
+
 // Packed junction records: one lane per surviving read whose record is packable (at most 64*W bases, few
 // bases outside ACGT).  The lane re-encodes its read from the ASCII bases exactly as the localise kernel did
 // (same function, so the exception count in the render record is the one found here), re-orients it when the
@@ -908,7 +1020,7 @@ __global__ void __launch_bounds__(256) render_packed_kernel(uint64_t n, const ui
                                                             const uint8_t* __restrict__ seq,
                                                             const uint64_t* __restrict__ seq_off,
                                                             const uint64_t* __restrict__ meta, int meta_stride,
-                                                            uint8_t* __restrict__ out) {
+                                                            uint8_t* __restrict__ out, bool packed) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t r = idx[i];
@@ -920,7 +1032,7 @@ __global__ void __launch_bounds__(256) render_packed_kernel(uint64_t n, const ui
     const bool swapped = ((tail >> 16) & kEvSwapped) != 0;
     const uint64_t so = seq_off[r];
     uint64_t lo[W], hi[W], ex[W], cs[W];
-    encode_ascii<W>(seq, so, L, lo, hi, ex);
+    encode_read<W>(seq, so, L, packed, lo, hi, ex);
 #pragma unroll
     for (int w = 0; w < W; w++) cs[w] = w < meta_stride - 1 ? rec[w] : 0ull;
     if (swapped) {
@@ -970,7 +1082,7 @@ __global__ void __launch_bounds__(256) render_packed_kernel(uint64_t n, const ui
                 const int b = __builtin_ctzll(m);
                 m &= m - 1;
                 const int k = 64 * w + b;
-                uint32_t c = swapped ? comp_byte(seq[so + (uint64_t)(L - 1 - k)]) : seq[so + (uint64_t)k];
+                uint32_t c = swapped ? comp_byte(base_at(seq, so, L - 1 - k, packed)) : base_at(seq, so, k, packed);
                 if (((cs[w] >> b) & 1) && c >= 'A' && c <= 'Z') c += 32;  // to_ascii_lowercase, detect.rs:157,161
                 xo[e++] = (uint32_t)k | (c << 16);
             }
@@ -1000,6 +1112,8 @@ static void launch_fast(bf_ctx* ctx, const LocaliseArgs& a) {
         hipLaunchKernelGGL((localise_fast_kernel<W, true, false>), g, b, 0, ctx->stream, a);
     else if (ctx->cfg.flags & BF_FLAG_SEPARATE_ENCODE)
         hipLaunchKernelGGL((localise_fast_kernel<W, false, false>), g, b, 0, ctx->stream, a);
+    else if (a.packed)
+        hipLaunchKernelGGL((localise_fast_kernel<W, false, true, true>), g, b, 0, ctx->stream, a);
     else
         hipLaunchKernelGGL((localise_fast_kernel<W, false, true>), g, b, 0, ctx->stream, a);
 }
@@ -1024,6 +1138,7 @@ int grow_reads(bf_ctx* ctx, uint64_t cap) {
     BF_TRY(ensure(ctx, ctx->d_seq_off, (cap + 1) * 8, true));
     BF_TRY(ensure(ctx, ctx->d_frag_off, (cap + 1) * 8, true));
     BF_TRY(ensure(ctx, ctx->d_hits, cap * sizeof(bf_hit), true));
+    if (ctx->packed_reads) BF_TRY(ensure(ctx, ctx->d_len, cap * 2, true));      // input in this mode: the lengths came with the reads
     if (ctx->n_localised) {
         const uint64_t stride = (uint64_t)ctx->mask_words + 1;
         BF_TRY(ensure(ctx, ctx->d_len, cap * 2, true)); BF_TRY(ensure(ctx, ctx->d_frag_len, cap * 2, true));
@@ -1053,7 +1168,7 @@ int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len) {
     const bool keep = r0 > 0;
     const uint64_t cap = std::max<uint64_t>(ctx->cap_reads, n);
     ctx->plane_words = W; ctx->mask_words = Wm;
-    BF_TRY(ensure(ctx, ctx->d_len, cap * 2, keep)); BF_TRY(ensure(ctx, ctx->d_frag_len, cap * 2, keep));
+    BF_TRY(ensure(ctx, ctx->d_len, cap * 2, keep || ctx->packed_reads)); BF_TRY(ensure(ctx, ctx->d_frag_len, cap * 2, keep));
     BF_TRY(ensure(ctx, ctx->d_fhash, cap * 8, keep)); BF_TRY(ensure(ctx, ctx->d_key, cap * 8, keep));
     BF_TRY(ensure(ctx, ctx->d_lpos, cap * 4, keep)); BF_TRY(ensure(ctx, ctx->d_rpos, cap * 4, keep));
     BF_TRY(ensure(ctx, ctx->d_bp, cap * 2, keep)); BF_TRY(ensure(ctx, ctx->d_flags, cap * 2, keep));
@@ -1069,6 +1184,8 @@ int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len) {
     }
 
     const bool separate = (ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE)) != 0;
+    if (separate && ctx->packed_reads)
+        return fail(ctx, BF_ERR_STATE, "the A/B variants with a separate encode kernel read ASCII reads only (bf_submit, not bf_submit_packed)");
     if (separate) {                                        // A/B variants: always the whole set (run_localise sees to it)
         BF_TRY(ensure(ctx, ctx->d_planes, (size_t)3 * W * n * 8));
         Scope t(ctx, "encode_reads");
@@ -1085,7 +1202,7 @@ int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len) {
         hipLaunchKernelGGL(read_meta_kernel, dim3(grid_for(n - r0, 256)), dim3(256), 0, ctx->stream, r0, n,
                            ctx->d_seq_off.as<uint64_t>(), ctx->d_frag.as<uint8_t>(),
                            ctx->d_frag_off.as<uint64_t>(), ctx->d_len.as<uint16_t>(),
-                           ctx->d_frag_len.as<uint16_t>(), ctx->d_fhash.as<uint64_t>());
+                           ctx->d_frag_len.as<uint16_t>(), ctx->d_fhash.as<uint64_t>(), ctx->packed_reads);
     }
     BF_HIP(ctx, hipGetLastError());
 
@@ -1094,6 +1211,7 @@ int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len) {
     a.hits = ctx->d_hits.as<bf_hit>(); a.len = ctx->d_len.as<uint16_t>();
     a.planes = ctx->d_planes.as<uint64_t>(); a.len_out = ctx->d_len.as<uint16_t>();
     a.seq = ctx->d_seq.as<uint8_t>(); a.seq_off = ctx->d_seq_off.as<uint64_t>(); a.contigs = ctx->g_contigs.as<ContigDev>();
+    a.packed = ctx->packed_reads ? 1u : 0u;
     a.blocks = ctx->g_blocks.as<GenomeBlock>(); a.coarse = ctx->g_coarse.as<uint64_t>();
     a.coarse2 = ctx->g_coarse2.as<uint32_t>();
     a.exc = ctx->g_exc.as<uint64_t>(); a.raw = ctx->g_raw.as<uint8_t>();
@@ -1131,6 +1249,7 @@ int run_localise(bf_ctx* ctx, bool defer_counts, bool all) {
         e.n_total = n; e.A = (int)A; e.cb = ctx->contig_bits; e.exact_list = ctx->d_exact_list.as<uint32_t>();
         e.counters = ctx->d_counters.as<uint32_t>(); e.hits = ctx->d_hits.as<bf_hit>();
         e.seq = ctx->d_seq.as<uint8_t>(); e.seq_off = ctx->d_seq_off.as<uint64_t>();
+        e.len = ctx->d_len.as<uint16_t>(); e.packed = ctx->packed_reads ? 1u : 0u;
         e.contigs = ctx->g_contigs.as<ContigDev>(); e.raw = ctx->g_raw.as<uint8_t>();
         e.key = ctx->d_key.as<uint64_t>(); e.lpos = ctx->d_lpos.as<int32_t>(); e.rpos = ctx->d_rpos.as<int32_t>();
         e.bp = ctx->d_bp.as<uint16_t>(); e.flags = ctx->d_flags.as<uint16_t>(); e.meta = ctx->d_mask.as<uint64_t>();
@@ -1187,11 +1306,15 @@ static int launch_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_idx, const u
     const uint8_t* seq = ctx->d_seq.as<uint8_t>();
     const uint64_t* so = ctx->d_seq_off.as<uint64_t>();
     const uint64_t* meta = ctx->d_mask.as<uint64_t>();
-    if (W == 2) hipLaunchKernelGGL(render_packed_kernel<2>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes);
-    else if (W == 3) hipLaunchKernelGGL(render_packed_kernel<3>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes);
-    else hipLaunchKernelGGL(render_packed_kernel<4>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes);
+    const bool packed = ctx->packed_reads;
+    if (W == 2) hipLaunchKernelGGL(render_packed_kernel<2>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes, packed);
+    else if (W == 3) hipLaunchKernelGGL(render_packed_kernel<3>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes, packed);
+    else hipLaunchKernelGGL(render_packed_kernel<4>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes, packed);
     BF_TRY(settle_counts(ctx));
-    if (ctx->n_text_records)
+    if (ctx->n_text_records && packed)
+        hipLaunchKernelGGL(render_text_nibbles_kernel, dim3(grid_for(n * 16, 256)), dim3(256), 0, ctx->stream, n, d_idx, d_off, seq, so,
+                           meta, stride, 64u * W, d_bytes);
+    else if (ctx->n_text_records)
         hipLaunchKernelGGL(render_kernel, dim3(grid_for(n * 16, 256)), dim3(256), 0, ctx->stream, n, d_idx, d_off, seq, so, meta,
                            stride, 64u * W, d_bytes);
     BF_HIP(ctx, hipGetLastError());

@@ -48,6 +48,11 @@ class BfBatch(C.Structure):
                 ("frag_bytes", C.c_void_p), ("frag_off", C.c_void_p), ("hits", C.c_void_p)]
 
 
+class BfPackedBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("seq_nibbles", C.c_void_p), ("seq_off", C.c_void_p), ("seq_len", C.c_void_p),
+                ("frag_bytes", C.c_void_p), ("frag_off", C.c_void_p), ("hits", C.c_void_p)]
+
+
 class BfResult(C.Structure):
     _fields_ = [("n_evidence", C.c_uint64), ("n_clusters", C.c_uint64), ("n_reads", C.c_uint64),
                 ("clusters", C.c_void_p), ("reads", C.c_void_p), ("junction_bytes", C.c_void_p),
@@ -98,7 +103,7 @@ ABI_SYMBOLS = [
     "bf_result_junction_sizes_dev", "bf_result_layout_dev", "bf_result_attach_records_dev", "bf_result_requests_dev",
     "bf_result_attach_finish", "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
     "bf_render_junctions_dev_static", "bf_host_alloc", "bf_host_free", "bf_submit_wait", "bf_reserve",
-    "bf_genome_begin", "bf_genome_write", "bf_genome_end",
+    "bf_genome_begin", "bf_genome_write", "bf_genome_end", "bf_submit_packed",
     "bf_shard_unique_id", "bf_shard_init_rccl", "bf_shard_init_host", "bf_shard_finish", "bf_shard_format_sv",
 ]
 
@@ -142,6 +147,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_genome_write.argtypes = [vp, C.c_uint32, C.c_uint64, vp, C.c_uint64]
     lib.bf_genome_end.argtypes = [vp]
     lib.bf_submit.argtypes = [vp, C.POINTER(BfBatch)]
+    lib.bf_submit_packed.argtypes = [vp, C.POINTER(BfPackedBatch)]
     lib.bf_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     lib.bf_host_free.argtypes = [vp, vp]
     lib.bf_submit_wait.argtypes = [vp]
@@ -214,6 +220,62 @@ class Batch:
 
     def frag(self, i: int) -> bytes:
         return self.frag_bytes[int(self.frag_off[i]):int(self.frag_off[i + 1])].tobytes()
+
+
+NIBBLE_CODES = b"=ACMGRSVTWYHKDBN"            # SAMv1 4.2
+
+
+@dataclass
+class PackedBatch:
+    """A Batch with the reads as BAM 4-bit base codes = bf_packed_batch (two bases per byte, high nibble first; every
+    read starts on a byte)."""
+    seq_nibbles: np.ndarray  # uint8
+    seq_off: np.ndarray      # uint64 byte offsets, n+1
+    seq_len: np.ndarray      # uint16, n
+    frag_bytes: np.ndarray
+    frag_off: np.ndarray
+    hits: np.ndarray
+
+    @property
+    def n(self) -> int:
+        return int(self.hits.shape[0])
+
+
+def pack_batch(b: Batch, chunk: int = 1 << 20) -> PackedBatch:
+    """ASCII reads -> 4-bit codes (what a parser that packs while it copies would produce).  Raises ValueError when a
+    read holds a byte outside "=ACMGRSVTWYHKDBN" (such batches go through bf_submit as ASCII)."""
+    lut = np.full(256, 255, np.uint8)
+    lut[np.frombuffer(NIBBLE_CODES, np.uint8)] = np.arange(16, dtype=np.uint8)
+    so = np.ascontiguousarray(b.seq_off, np.uint64).astype(np.int64)
+    lens = np.diff(so)
+    if lens.size and int(lens.max()) > 65535:
+        raise ValueError("a read longer than 65535 bases")
+    nbytes = (lens + 1) // 2
+    boff = np.zeros(b.n + 1, np.int64)
+    np.cumsum(nbytes, out=boff[1:])
+    out = np.zeros(int(boff[-1]), np.uint8)
+    seq = np.ascontiguousarray(b.seq_bytes, np.uint8)
+    for a in range(0, b.n, chunk):
+        e = min(b.n, a + chunk)
+        codes = lut[seq[int(so[a]):int(so[e])]]
+        if codes.size and int(codes.max()) == 255:
+            raise ValueError("a read holds a byte outside BAM's base alphabet %r" % NIBBLE_CODES)
+        ln = lens[a:e]
+        if ln.size and int(ln.min()) == int(ln.max()):                 # one length: a plain reshape
+            L = int(ln[0])
+            m = codes.reshape(e - a, L)
+            if L & 1:
+                m = np.concatenate([m, np.zeros((e - a, 1), np.uint8)], axis=1)
+            out[int(boff[a]):int(boff[e])] = ((m[:, 0::2] << 4) | m[:, 1::2]).reshape(-1)
+        else:
+            read = np.repeat(np.arange(e - a, dtype=np.int64), ln)
+            k = np.arange(codes.size, dtype=np.int64) - np.repeat(so[a:e] - so[a], ln)
+            byte = boff[a:e][read] + (k >> 1)
+            hi = (k & 1) == 0
+            out[byte[hi]] = codes[hi] << 4
+            out[byte[~hi]] |= codes[~hi]
+    return PackedBatch(out, boff.astype(np.uint64), lens.astype(np.uint16), np.ascontiguousarray(b.frag_bytes, np.uint8),
+                       np.ascontiguousarray(b.frag_off, np.uint64), np.ascontiguousarray(b.hits, HIT_DTYPE))
 
 
 @dataclass
@@ -391,12 +453,21 @@ class Engine:
         return {n: i for i, n in enumerate(self.contig_names)}
 
     # -- hot path --
-    def submit(self, b: Batch) -> None:
+    def submit(self, b) -> None:
+        if isinstance(b, PackedBatch):
+            return self.submit_packed(b)
         arrs = [np.ascontiguousarray(b.seq_bytes, np.uint8), np.ascontiguousarray(b.seq_off, np.uint64),
                 np.ascontiguousarray(b.frag_bytes, np.uint8), np.ascontiguousarray(b.frag_off, np.uint64),
                 np.ascontiguousarray(b.hits, HIT_DTYPE)]
         cb = BfBatch(b.n, *[a.ctypes.data for a in arrs])
         self._check(self.lib.bf_submit(self.h, C.byref(cb)))
+
+    def submit_packed(self, b: PackedBatch) -> None:
+        arrs = [np.ascontiguousarray(b.seq_nibbles, np.uint8), np.ascontiguousarray(b.seq_off, np.uint64),
+                np.ascontiguousarray(b.seq_len, np.uint16), np.ascontiguousarray(b.frag_bytes, np.uint8),
+                np.ascontiguousarray(b.frag_off, np.uint64), np.ascontiguousarray(b.hits, HIT_DTYPE)]
+        cb = BfPackedBatch(b.n, *[a.ctypes.data for a in arrs])
+        self._check(self.lib.bf_submit_packed(self.h, C.byref(cb)))
 
     def host_alloc(self, nbytes: int, dtype=np.uint8) -> np.ndarray:
         """A numpy array over bf_host_alloc memory (pinned; owned by the ctx, valid until close())."""
@@ -414,6 +485,9 @@ class Engine:
             out = self.host_alloc(a.nbytes, dt)
             out[...] = a
             return out
+        if isinstance(b, PackedBatch):
+            return PackedBatch(pin(b.seq_nibbles, np.uint8), pin(b.seq_off, np.uint64), pin(b.seq_len, np.uint16),
+                               pin(b.frag_bytes, np.uint8), pin(b.frag_off, np.uint64), pin(b.hits, HIT_DTYPE))
         return Batch(pin(b.seq_bytes, np.uint8), pin(b.seq_off, np.uint64), pin(b.frag_bytes, np.uint8),
                      pin(b.frag_off, np.uint64), pin(b.hits, HIT_DTYPE))
 
@@ -673,13 +747,15 @@ class Engine:
 
 
 def detect(fasta: Dict[bytes, bytes], bowtie_lines: Iterable[bytes], anchor_len: int = 30,
-           max_frag_len: int = 5000, min_evidence: int = 2, flags: int = 0) -> bytes:
-    """`breakfast detect` on one GPU: genome dict + bowtie's stdout lines -> .sv bytes."""
+           max_frag_len: int = 5000, min_evidence: int = 2, flags: int = 0, packed: bool = False) -> bytes:
+    """`breakfast detect` on one GPU: genome dict + bowtie's stdout lines -> .sv bytes (packed: the reads handed over as
+    4-bit base codes, bf_submit_packed)."""
     eng = Engine(anchor_len, max_frag_len, min_evidence, flags=flags)
     try:
         names = list(fasta.keys())
         eng.set_genome(names, [np.frombuffer(fasta[n], np.uint8) for n in names])
-        eng.submit(parse_bowtie_lines(bowtie_lines, eng.contig_id))
+        b = parse_bowtie_lines(bowtie_lines, eng.contig_id)
+        eng.submit(pack_batch(b) if packed else b)
         return eng.format_sv(eng.finish())
     finally:
         eng.close()

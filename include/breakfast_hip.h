@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 8
+#define BF_ABI_VERSION 9
 
 enum {
     BF_OK = 0,
@@ -196,6 +196,23 @@ int bf_genome_end(bf_ctx* ctx);
  *     uploaded from where they are, without a copy: they must stay untouched until bf_submit_wait, bf_finish or
  *     bf_localise returns.  Each of the five arrays is looked at on its own. */
 int bf_submit(bf_ctx* ctx, const bf_batch* batch);
+
+/* The same with the reads as BAM 4-bit base codes instead of ASCII (SAMv1 4.2: "=ACMGRSVTWYHKDBN" -> 0..15, two bases
+ * per byte, high nibble first; every read starts on a byte and takes ceil(len / 2) bytes: seq_off are BYTE offsets,
+ * seq_len the bases).  The reads of detect.rs:91 come from a BAM file, whose decoder (detect.rs:321, rust-htslib) emits
+ * exactly these sixteen letters, so the packing loses nothing; it halves what crosses PCIe and what every kernel that
+ * touches a read has to fetch.  A caller whose reads hold other bytes (lower case, ...) uses bf_submit.  A ctx holds
+ * its reads in one form: mixing the two calls without bf_reset is BF_ERR_STATE. */
+typedef struct {
+    uint64_t        n_reads;
+    const uint8_t*  seq_nibbles;
+    const uint64_t* seq_off;     /* n_reads+1 byte offsets into seq_nibbles */
+    const uint16_t* seq_len;     /* n_reads: bases per read */
+    const uint8_t*  frag_bytes;
+    const uint64_t* frag_off;
+    const bf_hit*   hits;
+} bf_packed_batch;
+int bf_submit_packed(bf_ctx* ctx, const bf_packed_batch* batch);
 
 /* Pinned host memory for batches (bf_submit uploads from it without staging).  Owned by the ctx: freed by
  * bf_host_free or bf_ctx_destroy.  No counterpart in the reference (its reads never leave host memory). */

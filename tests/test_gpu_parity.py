@@ -16,14 +16,29 @@ from breakfast_amd.engine import (BF_FLAG_COOP_GATHER, BF_FLAG_FORCE_EXACT, BF_F
 pytestmark = pytest.mark.gpu
 
 
-def run_gpu_text(fa, lines, A, F, E, flags=0):
-    return engine.detect(po.parse_fasta(fa), lines.split(b"\n")[:-1], A, F, E, flags=flags)
+def run_gpu_text(fa, lines, A, F, E, flags=0, packed=False):
+    return engine.detect(po.parse_fasta(fa), lines.split(b"\n")[:-1], A, F, E, flags=flags, packed=packed)
 
 
 @pytest.mark.parametrize("name", golden_names())
 def test_golden_fixture(name):
     fa, lines, (A, F, E), sv = load_golden(name)
     assert run_gpu_text(fa, lines, A, F, E) == sv
+
+
+@pytest.mark.parametrize("flags", [0, BF_FLAG_FORCE_EXACT, BF_FLAG_GROUPS_ALWAYS])
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fixture_with_reads_as_4bit_codes(name, flags):
+    # bf_submit_packed: the reads as BAM 4-bit base codes (odd lengths, '=' and IUPAC letters, reads above 256 bases)
+    fa, lines, (A, F, E), sv = load_golden(name)
+    try:
+        out = run_gpu_text(fa, lines, A, F, E, flags=flags, packed=True)
+    except ValueError:
+        # hz_ref_alphabet's reads were cut out of a soft-masked genome: lower-case letters are outside BAM's
+        # alphabet, such reads go through bf_submit as ASCII (engine.pack_batch refuses them)
+        assert name == "hz_ref_alphabet"
+        pytest.skip("reads with bytes outside =ACMGRSVTWYHKDBN are handed over as ASCII")
+    assert out == sv
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -51,13 +66,13 @@ def pack_sig(sig17: np.ndarray) -> np.ndarray:
     return out
 
 
-def check_against_oracle(g, b, A, F=5000, E=2, flags=0, expect_exact=None):
+def check_against_oracle(g, b, A, F=5000, E=2, flags=0, expect_exact=None, packed=False):
     og = ol.OracleGenome(g.names, g.seqs)
     ref = ol.detect_batch(og, g.names, b, A, F, E, keep=True)
     eng = engine.Engine(A, F, E, flags=flags | BF_FLAG_KEEP_EVIDENCE)
     try:
         eng.set_genome(g.names, g.seqs)
-        eng.submit(b)
+        eng.submit(engine.pack_batch(b) if packed else b)
         # what bf_finish itself brings to the host: rows, records, one offset per cluster; no read table
         bare = eng.finish(reads=False)
         assert bare.reads.shape[0] == 0
@@ -104,6 +119,64 @@ def test_scaled_baseline_config(cfg, scale, gscale):
     b = synth.make_reads(g, spec)
     res, ref = check_against_oracle(g, b, spec.anchor_len)
     assert ref.n_clusters > 0
+
+
+@pytest.mark.parametrize("flags", [0, BF_FLAG_FORCE_EXACT])
+@pytest.mark.parametrize("cfg,scale,gscale", [(0, 0.05, 0.02), (1, 0.004, 0.002), (3, 0.001, 0.002), (4, 0.002, 0.002)])
+def test_scaled_baseline_config_with_reads_as_4bit_codes(cfg, scale, gscale, flags):
+    """Every per-read value, every junction string and the .sv with the reads resident as 4-bit codes
+    (bf_submit_packed): configs[4] brings 1 % N bases, the exact kernel reads its bytes through the code table."""
+    contigs, gk, spec = synth.config(cfg, scale=scale, genome_scale=gscale)
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    b.seq_bytes = b.seq_bytes & np.uint8(0xDF)     # a sequencer's reads are upper case whatever the reference's case is
+    res, ref = check_against_oracle(g, b, spec.anchor_len, flags=flags, packed=True)
+    assert ref.n_clusters > 0
+
+
+def test_long_and_odd_reads_as_4bit_codes():
+    contigs = [("c%d" % i, 120000) for i in range(3)]
+    g = synth.make_genome(contigs, seed=19, lower_runs=[(1, 30000, 20000)])
+    for L in (51, 129, 257, 701):
+        spec = synth.ReadSpec(n_reads=900, read_len=L, anchor_len=25, n_events=15, singleton_frac=0.3, seed=300 + L,
+                              margin=1300, subst_rate=0.02, n_rate=0.01)
+        b = synth.make_reads(g, spec)
+        b.seq_bytes = b.seq_bytes & np.uint8(0xDF)
+        check_against_oracle(g, b, 25, packed=True)
+
+
+def test_one_form_of_reads_per_ctx_and_packed_validation():
+    contigs, gk, spec = synth.config(1, scale=0.001, genome_scale=0.002)
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    pb = engine.pack_batch(b)
+    eng = engine.Engine(spec.anchor_len, 5000, 2)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        eng.submit(pb)
+        with pytest.raises(engine.BreakfastError) as e:
+            eng.submit(b)                                   # ASCII after 4-bit
+        assert e.value.code == -4
+        ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, spec.anchor_len, 5000, 2)
+        assert eng.format_sv(eng.finish()) == ref.sv
+        eng.reset()
+        eng.submit(b)                                       # after a reset either form is fine
+        with pytest.raises(engine.BreakfastError) as e:
+            eng.submit(pb)
+        assert e.value.code == -4
+        assert eng.format_sv(eng.finish()) == ref.sv
+        eng.reset()
+        bad = engine.PackedBatch(pb.seq_nibbles, pb.seq_off, pb.seq_len.copy(), pb.frag_bytes, pb.frag_off, pb.hits)
+        bad.seq_len[7] += 2                                 # bases and bytes disagree
+        with pytest.raises(engine.BreakfastError) as e:
+            eng.submit(bad)
+        assert e.value.code == -1 and "read 7 " in str(e.value)
+        eng.submit(pb)
+        assert eng.format_sv(eng.finish()) == ref.sv
+    finally:
+        eng.close()
+    with pytest.raises(ValueError):
+        engine.pack_batch(engine.make_batch([b"ACGTacgt" * 6], [b"f"], [(1, 100, 0, 0, 3)]))
 
 
 @pytest.mark.parametrize("flag", [BF_FLAG_COOP_GATHER, BF_FLAG_SEPARATE_ENCODE])
