@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--check", action="store_true", help="also compare the GPU .sv with the oracle's on the sample")
     ap.add_argument("--one-stream", action="store_true", help="profiling: all kernels and copies of the library on one stream "
                                                                "(a kernel trace then shows each kernel's own duration)")
+    ap.add_argument("--reads", choices=["packed", "ascii"], default="packed",
+                    help="how the reads are handed over and kept resident: BAM 4-bit base codes (bf_submit_packed: what the "
+                         "command line's parser produces, the shipped path) or ASCII (bf_submit)")
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host loops (resident-input value only)")
     ap.add_argument("--host-threads", type=int, default=0, help="staging threads of bf_submit (0 = library default)")
     args = ap.parse_args()
@@ -129,7 +132,14 @@ def main():
     if args.soft_mask > 0:
         batch.seq_bytes &= np.uint8(0xDF)              # sequencer reads are upper case whatever the reference's case
     n_local = batch.n
+    ascii_batch = batch
     log(rank, "reads: %d x %d bp per rank in %.1fs" % (n_local, L, time.time() - t1))
+    if args.reads == "packed" and args.variant in ("fused", "exact"):
+        t1 = time.time()
+        batch = engine.pack_batch(ascii_batch)
+        log(rank, "reads packed to 4-bit codes in %.1fs (the parser's job on the command line)" % (time.time() - t1))
+    else:
+        args.reads = "ascii"
 
     # ---- resident inputs -------------------------------------------------------------------------
     eng = engine.Engine(A, 5000, 2, device=local, groups=args.groups, host_threads=args.host_threads, flags=(engine.BF_FLAG_ONE_STREAM if args.one_stream else 0) | {"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER,
@@ -145,11 +155,12 @@ def main():
         if world > 1:
             dist.broadcast_object_list(box, src=0)
         eng.shard_init_rccl(rank, world, rank * n_local, box[0])
-    chunk = 1 << 21
-    for a in range(0, n_local, chunk):
-        eng.submit(batch.slice(a, min(n_local, a + chunk)))
+    eng.submit(batch)
     eng.submit_wait()
-    in_bytes = sum(x.nbytes for x in (batch.seq_bytes, batch.seq_off, batch.frag_bytes, batch.frag_off, batch.hits))
+
+    def nbytes(b):
+        return sum(getattr(b, f).nbytes for f in b.__dataclass_fields__)
+    in_bytes = nbytes(batch)
     log(rank, "reads resident in HBM in %.2fs (first hand-over, buffers still growing: %.2f GB/s)" %
         (time.time() - t3, in_bytes / 1e9 / max(time.time() - t3, 1e-9)))
 
@@ -217,12 +228,36 @@ def main():
         t4 = time.time()
         pinned = eng.pin_batch(batch)
         log(rank, "batch copied into bf_host_alloc memory in %.1fs" % (time.time() - t4))
-        h2h = timed(pinned, "host-to-host, pinned batches")
-        h2h["input"] = "the whole batch in bf_host_alloc (pinned) memory, one bf_submit per step"
+        h2h = timed(pinned, "host-to-host, pinned batches, %s reads" % args.reads)
+        h2h["input"] = "the whole batch (%s reads) in bf_host_alloc (pinned) memory, one bf_submit per step" % args.reads
         h2h["input_bytes"] = int(in_bytes)
         h2h["pcie_bound_ms"] = round(in_bytes / 55e9 * 1e3, 2)       # ~55 GB/s achievable on PCIe 5.0 x16
-        h2h["pageable"] = timed(batch, "host-to-host, pageable batches")
+        h2h["pageable"] = timed(batch, "host-to-host, pageable batches, %s reads" % args.reads)
         h2h["pageable"]["input"] = "the same batch in ordinary numpy arrays, staged by the library's host threads"
+        if args.reads == "packed":
+            # the same with ASCII reads (bf_submit): a caller that does not pack
+            in_bytes_ascii = nbytes(ascii_batch)
+            del pinned
+            pinned = eng.pin_batch(ascii_batch)
+            keep_in = in_bytes
+            in_bytes = in_bytes_ascii
+            h2h["ascii_reads"] = timed(pinned, "host-to-host, pinned batches, ascii reads")
+            h2h["ascii_reads"]["input_bytes"] = int(in_bytes_ascii)
+            # ... and the resident-input step on them
+            for _ in range(args.warmup):
+                eng.finish_raw()
+            eng.kernel_times()
+            barrier()
+            t0_ = time.perf_counter()
+            for _ in range(args.steps):
+                eng.finish_raw()
+            barrier()
+            dt = (time.perf_counter() - t0_) / args.steps
+            kt = eng.kernel_times()
+            h2h["ascii_reads"]["resident_step"] = {"value": round(n_local / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+                                                   "localise_ms": round(kt.get("localise", (0, 1))[0] / max(kt.get("localise", (0, 1))[1], 1), 4)}
+            log(rank, "ascii reads, resident step: %.3f ms, localise %.3f ms" % (dt * 1e3, h2h["ascii_reads"]["resident_step"]["localise_ms"]))
+            in_bytes = keep_in
 
     # ---- roofline of the dominant kernel -----------------------------------------------------------
     loc_ms, loc_n = ktimes.get("localise", (0.0, 0))
@@ -241,7 +276,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         import oracle_lib as ol
         ns = min(args.cpu_sample, n_local)
-        sample = batch.slice(0, ns)
+        sample = ascii_batch.slice(0, ns)
         og = ol.OracleGenome(genome.names, genome.seqs)
         tc = time.perf_counter()
         ref = ol.detect_batch(og, genome.names, sample, A, 5000, 2, stage=3)
@@ -271,6 +306,7 @@ def main():
             "config": {"workload": "configs[%d]: %d unaligned 2x%d bp reads per GPU with anchor hits on a %.2f Gb genome, anchor length %d"
                        % (args.config, n_local, L, sum(l for _, l in contigs) / 1e9, A),
                        "reads_per_gpu": n_local, "read_len": L, "anchor_len": A, "max_frag_len": 5000, "min_evidence": 2,
+                       "reads_as": {"packed": "BAM 4-bit base codes (bf_submit_packed)", "ascii": "ASCII (bf_submit)"}[args.reads],
                        "parallelism": "shard%d+alltoall" % world if sharded else "single"},
             "result": {"clusters": n_clusters, "supporting_reads": n_support},
             "stage_ms": stages, "roofline": roofline, "cpu_baseline": cpu, "host_to_host": h2h,
@@ -301,7 +337,7 @@ def pmc_traffic(args, n_local, L):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
-            want = "config=%d reads=%d len=%d variant=%s" % (args.config, n_local, L, args.variant)
+            want = "config=%d reads=%d len=%d variant=%s reads_as=%s" % (args.config, n_local, L, args.variant, args.reads)
             if want in d.get("workload", ""):
                 for k, v in d["kernels"].items():
                     if "localise_fast_kernel" in k:

@@ -316,6 +316,7 @@ void bf_ctx_destroy(bf_ctx* ctx) {
     shard_destroy(ctx);
     for (auto& sl : ctx->slots) { if (sl.p) (void)hipHostFree(sl.p); if (sl.ev) (void)hipEventDestroy(sl.ev); }
     ctx->slots.clear();
+    for (auto& w : ctx->wide) { if (w.p) (void)hipHostFree(w.p); if (w.ev) (void)hipEventDestroy(w.ev); w = bf_ctx::WideSlot{}; }
     for (auto& sl : ctx->gslots) { if (sl.p) (void)hipHostFree(sl.p); if (sl.ev) (void)hipEventDestroy(sl.ev); }
     ctx->gslots.clear();
     for (auto& pr : ctx->pinned) (void)hipHostFree((void*)pr.first);
@@ -533,6 +534,8 @@ struct SubmitShared {
     uint64_t r_base;       // first read of the piece inside the batch
     uint64_t n0, seq0, frag0;          // resident reads / bytes before the BATCH
     bool hits_direct;
+    uint8_t* wide = nullptr;           // piece-wide pinned buffer for the rebased offsets (batches in bf_host_alloc memory)
+    uint64_t p0 = 0, p1 = 0;           // the piece
     std::vector<SubmitJob> jobs;
     std::atomic<size_t> next{0};
     std::mutex mu;
@@ -566,7 +569,8 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
     std::vector<uint64_t> hist(ctx->n_contigs, 0);
     for (size_t j; (j = sh->next.fetch_add(1)) < sh->jobs.size();) {
         const SubmitJob& job = sh->jobs[j];
-        if (!slot_ready(ctx, sl)) { sh->error(job.a, BF_ERR_NOMEM, "pinned staging memory is not available"); return; }
+        const bool wide = job.kind == 0 && sh->wide;
+        if (!wide && !slot_ready(ctx, sl)) { sh->error(job.a, BF_ERR_NOMEM, "pinned staging memory is not available"); return; }
         hipError_t e = hipSuccess;
         if (job.kind == 0) {
             // offsets rebased onto the resident arrays, lengths and hits validated on the way (detect.rs:92, :115)
@@ -576,6 +580,13 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
             uint64_t* fo = so + (cnt + 1);
             bf_hit* hh = (bf_hit*)(fo + (cnt + 1));
             uint16_t* ll = (uint16_t*)(hh + cnt);                // lengths of 4-bit reads
+            if (wide) {                                          // this job's part of the piece-wide arrays; the caller uploads them
+                const uint64_t pc = sh->p1 - sh->p0;
+                so = (uint64_t*)sh->wide + (job.a - sh->p0);
+                fo = (uint64_t*)sh->wide + (pc + 1) + (job.a - sh->p0);
+                hh = (bf_hit*)((uint64_t*)sh->wide + 2 * (pc + 1)) + (job.a - sh->p0);
+                ll = (uint16_t*)((bf_hit*)((uint64_t*)sh->wide + 2 * (pc + 1)) + pc) + (job.a - sh->p0);
+            }
             const uint64_t s0 = b->seq_off[0], f0 = b->frag_off[0];
             bool ok = true;
             for (uint64_t i = job.a; i < job.b; i++) {
@@ -609,6 +620,7 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
             }
             if (!ok) return;
             so[cnt] = sh->seq0 + (b->seq_off[job.b] - s0); fo[cnt] = sh->frag0 + (b->frag_off[job.b] - f0);
+            if (wide) continue;
             e = hipMemcpyAsync(ctx->d_seq_off.as<uint64_t>() + sh->n0 + job.a, so, n_off * 8, hipMemcpyHostToDevice, ctx->in_stream);
             if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_frag_off.as<uint64_t>() + sh->n0 + job.a, fo, n_off * 8, hipMemcpyHostToDevice, ctx->in_stream);
             if (e == hipSuccess && !sh->hits_direct)
@@ -757,14 +769,41 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
         if ((se < sa || se > sb || fe < fa || fe > fb) && p0) ctx->n_localised = 0;
         if (se < sa || se > sb || fe < fa || fe > fb) return fail(ctx, BF_ERR_INVALID, "bf_submit: offsets not monotone near read %llu", (unsigned long long)p0);
         sh.jobs.clear(); sh.next = 0;
+        // arrays in bf_host_alloc memory go first, straight from where they lie: the DMA engine works on them while
+        // the host threads below check this piece's offsets and hits.  (Nothing of a batch is resident before its
+        // last piece has passed: these copies only touch memory beyond n_reads.)
+        if (seq_direct && se > sa)
+            BF_HIP(ctx, hipMemcpyAsync(ctx->d_seq.as<uint8_t>() + sh.seq0 + sa, b->seq_bytes + b->seq_off[0] + sa, se - sa, hipMemcpyHostToDevice, ctx->in_stream));
+        if (frag_direct && fe > fa)
+            BF_HIP(ctx, hipMemcpyAsync(ctx->d_frag.as<uint8_t>() + sh.frag0 + fa, b->frag_bytes + b->frag_off[0] + fa, fe - fa, hipMemcpyHostToDevice, ctx->in_stream));
+        if (sh.hits_direct)
+            BF_HIP(ctx, hipMemcpyAsync(ctx->d_hits.as<bf_hit>() + sh.n0 + p0, b->hits + p0, (p1 - p0) * sizeof(bf_hit), hipMemcpyHostToDevice, ctx->in_stream));
         // jobs of about staged / threads bytes (at least 1 MB, at most a slot), so that a batch of a few dozen MB still
-        // keeps every staging thread busy
+        // keeps every staging thread busy; when only offsets are staged, one job per thread
         const uint64_t staged = (p1 - p0) * 32 + (seq_direct ? 0 : se - sa) + (frag_direct ? 0 : fe - fa);
         const uint64_t job_bytes = std::min<uint64_t>(kStageSlotBytes, std::max<uint64_t>(1u << 20, staged / std::max(1u, ctx->host_threads)));
-        const uint64_t job_reads = std::min<uint64_t>(per_job, std::max<uint64_t>(job_bytes / 34, 1));
+        uint64_t job_reads = std::min<uint64_t>(per_job, std::max<uint64_t>(job_bytes / 34, 1));
+        if (seq_direct && frag_direct)
+            job_reads = std::min<uint64_t>(per_job, std::max<uint64_t>((p1 - p0 + ctx->host_threads - 1) / std::max(1u, ctx->host_threads), 1u << 15));
         for (uint64_t a = p0; a < p1; a += job_reads) sh.jobs.push_back(SubmitJob{0, a, std::min(p1, a + job_reads)});
         if (!seq_direct) for (uint64_t a = sa; a < se; a += job_bytes) sh.jobs.push_back(SubmitJob{1, a, std::min(se, a + job_bytes)});
         if (!frag_direct) for (uint64_t a = fa; a < fe; a += job_bytes) sh.jobs.push_back(SubmitJob{2, a, std::min(fe, a + job_bytes)});
+        // a batch wholly in bf_host_alloc memory: the threads write one piece-wide set of arrays, uploaded in four copies
+        sh.wide = nullptr; sh.p0 = p0; sh.p1 = p1;
+        bf_ctx::WideSlot* ws = nullptr;
+        if (seq_direct && frag_direct) {
+            ws = &ctx->wide[ctx->wide_next++ & 1];
+            const size_t need = (p1 - p0 + 1) * 16 + (p1 - p0) * (sizeof(bf_hit) + 2) + 64;
+            if (ws->used) { BF_HIP(ctx, hipEventSynchronize(ws->ev)); ws->used = false; }
+            if (ws->cap < need) {
+                if (ws->p) (void)hipHostFree(ws->p);
+                ws->p = nullptr; ws->cap = 0;
+                if (hipHostMalloc((void**)&ws->p, need, hipHostMallocDefault) != hipSuccess) { ws->p = nullptr; return fail(ctx, BF_ERR_NOMEM, "pinned staging memory is not available"); }
+                ws->cap = need;
+            }
+            if (!ws->ev) BF_HIP(ctx, hipEventCreateWithFlags(&ws->ev, hipEventDisableTiming));
+            sh.wide = ws->p;
+        }
         const size_t nt = staged < kInlineBytes ? 1 : std::min<size_t>(ctx->host_threads, sh.jobs.size());
         if (nt <= 1) submit_worker(&sh, 0);
         else {
@@ -778,16 +817,21 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
             if (p0) ctx->n_localised = 0;
             return fail(ctx, sh.err_code, "%s", sh.err_msg.c_str());
         }
+        if (ws) {
+            const uint64_t pc = p1 - p0;
+            uint64_t* so = (uint64_t*)ws->p; uint64_t* fo = so + (pc + 1);
+            bf_hit* hh = (bf_hit*)(fo + (pc + 1)); uint16_t* ll = (uint16_t*)(hh + pc);
+            BF_HIP(ctx, hipMemcpyAsync(ctx->d_seq_off.as<uint64_t>() + sh.n0 + p0, so, (pc + 1) * 8, hipMemcpyHostToDevice, ctx->in_stream));
+            BF_HIP(ctx, hipMemcpyAsync(ctx->d_frag_off.as<uint64_t>() + sh.n0 + p0, fo, (pc + 1) * 8, hipMemcpyHostToDevice, ctx->in_stream));
+            if (!sh.hits_direct) BF_HIP(ctx, hipMemcpyAsync(ctx->d_hits.as<bf_hit>() + sh.n0 + p0, hh, pc * sizeof(bf_hit), hipMemcpyHostToDevice, ctx->in_stream));
+            if (b->seq_len) BF_HIP(ctx, hipMemcpyAsync(ctx->d_len.as<uint16_t>() + sh.n0 + p0, ll, pc * 2, hipMemcpyHostToDevice, ctx->in_stream));
+            BF_HIP(ctx, hipEventRecord(ws->ev, ctx->in_stream));
+            ws->used = true;
+        }
         mx = std::max(mx, sh.mx); mn = std::min(mn, sh.mn); mf = std::max(mf, sh.mf);
         if (mn < 2 * ctx->cfg.anchor_len && p0) ctx->n_localised = 0;
         if (mn < 2 * ctx->cfg.anchor_len)
             return fail(ctx, BF_ERR_RANGE, "a read of length %u is shorter than 2 * anchor_len = %u (detect.rs:311 never emits such reads)", mn, 2 * ctx->cfg.anchor_len);
-        if (seq_direct && se > sa)
-            BF_HIP(ctx, hipMemcpyAsync(ctx->d_seq.as<uint8_t>() + sh.seq0 + sa, b->seq_bytes + b->seq_off[0] + sa, se - sa, hipMemcpyHostToDevice, ctx->in_stream));
-        if (frag_direct && fe > fa)
-            BF_HIP(ctx, hipMemcpyAsync(ctx->d_frag.as<uint8_t>() + sh.frag0 + fa, b->frag_bytes + b->frag_off[0] + fa, fe - fa, hipMemcpyHostToDevice, ctx->in_stream));
-        if (sh.hits_direct)
-            BF_HIP(ctx, hipMemcpyAsync(ctx->d_hits.as<bf_hit>() + sh.n0 + p0, b->hits + p0, (p1 - p0) * sizeof(bf_hit), hipMemcpyHostToDevice, ctx->in_stream));
         if (p1 < m && eager) {
             // a finished piece in the middle of a large batch: localise it behind its upload.  (The batch becomes
             // resident only when its last piece has been checked; a rejected batch drops the evidence again.)

@@ -187,6 +187,9 @@ struct bf_ctx {
     bool in_pending = false;                    // ... and `stream` has not been told to wait for it yet
     struct StageSlot { uint8_t* p = nullptr; hipEvent_t ev = nullptr; bool used = false; };
     std::vector<StageSlot> slots;               // one per host thread, kStageSlotBytes each (allocated on first use)
+    struct WideSlot { uint8_t* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
+    WideSlot wide[2];                           // piece-wide offset staging for batches in bf_host_alloc memory, used in turn
+    uint32_t wide_next = 0;
     std::vector<std::pair<const uint8_t*, size_t>> pinned;   // bf_host_alloc ranges
     uint32_t host_threads = 0;                  // bf_config.reserved[1], or chosen from the machine
     uint64_t cap_reads = 0;                     // capacity of every per-read array below (inputs and evidence)

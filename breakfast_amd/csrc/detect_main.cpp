@@ -311,6 +311,31 @@ static void write_all(int fd, const char* p, size_t n) {
     }
 }
 
+// One parsed batch (or reads [a, b) of it) to the library, in the form the parser produced it
+static int submit_parsed(bf_ctx* ctx, const hits::Batch& src, uint64_t a, uint64_t b) {
+    if (src.packed) {
+        bf_packed_batch pb;
+        pb.n_reads = b - a;
+        pb.seq_nibbles = (const uint8_t*)src.seq.data(); pb.seq_off = src.seq_off.data() + a; pb.seq_len = src.seq_len.data() + a;
+        pb.frag_bytes = (const uint8_t*)src.frag.data(); pb.frag_off = src.frag_off.data() + a;
+        pb.hits = src.hits.data() + a;
+        return bf_submit_packed(ctx, &pb);
+    }
+    bf_batch bb;
+    bb.n_reads = b - a;
+    bb.seq_bytes = (const uint8_t*)src.seq.data(); bb.seq_off = src.seq_off.data() + a;
+    bb.frag_bytes = (const uint8_t*)src.frag.data(); bb.frag_off = src.frag_off.data() + a;
+    bb.hits = src.hits.data() + a;
+    return bf_submit(ctx, &bb);
+}
+
+// Reads go to the GPU as BAM 4-bit codes when they are known to be in BAM's alphabet (they come out of this program's
+// own BAM reader) or when the hit list is a file that can be read again as ASCII should a read turn out otherwise.
+static bool can_reread(int fd) {
+    struct stat st;
+    return fd > 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+}
+
 // `breakfast-hip detect --gpus=N`: the reads are parsed into host memory, cut into N contiguous input ranges (the
 // reference's tie-breaks are input order, detect.rs:193-198, so rank r must hold the reads before rank r+1's), and
 // every range is driven by its own thread and ctx through the library's sharded path.  Rows are merged for printing
@@ -341,13 +366,20 @@ static int detect_sharded(const bf_config& cfg0, const std::vector<int>& devices
     fprintf(stderr, "Splitting unaligned reads into %u bp anchors and aligning against the genome...\n", cfg0.anchor_len);
     std::vector<hits::Batch> all;
     uint64_t n_total = 0;
-    try {
-        hits::parse_stream(in_fd, contigs, genome_path, popt, [&](hits::Batch& b) {
-            n_total += b.n();
-            all.emplace_back();
-            std::swap(all.back(), b);
-        });
-    } catch (const std::exception& e) { error("%s", e.what()); }
+    hits::Options opt = popt;
+    for (;;) {
+        try {
+            hits::parse_stream(in_fd, contigs, genome_path, opt, [&](hits::Batch& b) {
+                n_total += b.n();
+                all.emplace_back();
+                std::swap(all.back(), b);
+            });
+            break;
+        } catch (const hits::Unpackable& e) {                      // once more, as ASCII
+            if (!can_reread(in_fd) || lseek(in_fd, 0, SEEK_SET) != 0) error("%s", e.what());
+            opt.pack = false; all.clear(); n_total = 0;
+        } catch (const std::exception& e) { error("%s", e.what()); }
+    }
     if (in_fd > 0) close(in_fd);
     timing.lap("parse");
 
@@ -370,13 +402,7 @@ static int detect_sharded(const bf_config& cfg0, const std::vector<int>& devices
             for (size_t k = 0; k < all.size(); k++) {                // the parts of the parsed batches inside [lo, hi)
                 const uint64_t a = std::max(lo, first[k]), b = std::min(hi, first[k + 1]);
                 if (a >= b) continue;
-                const hits::Batch& src = all[k];
-                bf_batch bb;
-                bb.n_reads = b - a;
-                bb.seq_bytes = (const uint8_t*)src.seq.data(); bb.seq_off = src.seq_off.data() + (a - first[k]);
-                bb.frag_bytes = (const uint8_t*)src.frag.data(); bb.frag_off = src.frag_off.data() + (a - first[k]);
-                bb.hits = src.hits.data() + (a - first[k]);
-                if (!check(bf_submit(ctx, &bb))) return;
+                if (!check(submit_parsed(ctx, all[k], a - first[k], b - first[k]))) return;
             }
             check(bf_shard_finish(ctx, &results[r]));
         });
@@ -418,6 +444,7 @@ int main(int argc, char** argv) {
     int threads = 8;
     std::vector<int> devices;                     // empty: one GPU, the current device
     hits::Options popt;
+    int reads_form = -1;                          // -1: chosen from where the reads come from; 0 ASCII; 1 BAM 4-bit codes
     Timing timing;
     std::vector<std::string> pos;
     for (int i = 2; i < argc; i++) {
@@ -449,6 +476,8 @@ int main(int argc, char** argv) {
             if (devices.empty() || devices.size() > 64) error("Invalid arguments.\n%s", USAGE);
         }
         else if (a == "--timing") timing.on = true;
+        else if (a == "--ascii-reads") reads_form = 0;
+        else if (a == "--packed-reads") reads_form = 1;
         else if (a.compare(0, 14, "--anchor-hits=") == 0) hits_path = a.substr(14);
         else if (a.size() > 1 && a[0] == '-' && a != "-") error("Invalid arguments.\n%s", USAGE);
         else pos.push_back(a);
@@ -472,13 +501,18 @@ int main(int argc, char** argv) {
         contigs.build();
         const int fd = pos[0] == "-" ? 0 : open(pos[0].c_str(), O_RDONLY);
         if (fd < 0) error("Cannot open file %s for reading.", pos[0].c_str());
+        popt.pack = reads_form == 1;
         try {
             hits::parse_stream(fd, contigs, pos[1], popt, [&](hits::Batch& b) {
                 for (size_t i = 0; i < b.n(); i++) {
                     const bf_hit& h = b.hits[i];
                     fwrite(b.frag.data() + b.frag_off[i], 1, b.frag_off[i + 1] - b.frag_off[i], stdout);
                     fputc('\t', stdout);
-                    fwrite(b.seq.data() + b.seq_off[i], 1, b.seq_off[i + 1] - b.seq_off[i], stdout);
+                    if (b.packed) {                                 // --packed-reads: the 4-bit codes, spelled out again
+                        const uint8_t* q = (const uint8_t*)b.seq.data() + b.seq_off[i];
+                        for (uint32_t k = 0; k < b.seq_len[i]; k++) fputc("=ACMGRSVTWYHKDBN"[(q[k >> 1] >> ((~k & 1) * 4)) & 15], stdout);
+                    } else
+                        fwrite(b.seq.data() + b.seq_off[i], 1, b.seq_off[i + 1] - b.seq_off[i], stdout);
                     fprintf(stdout, "\t%u\t%u\t%u\t%u\t%u\n", h.strands, h.contig5, h.pos5, h.contig3, h.pos3);
                 }
             });
@@ -514,6 +548,7 @@ int main(int argc, char** argv) {
         if (in_fd < 0) error("Cannot open file %s for reading.", hits_path.c_str());
     }
     timing.lap("start_up");
+    popt.pack = reads_form >= 0 ? reads_form == 1 : (hits_path.empty() || can_reread(in_fd));
 
     if (devices.size() > 1) {
         const int rc = detect_sharded(cfg, devices, genome_path, in_fd, popt, threads, timing);
@@ -524,86 +559,104 @@ int main(int argc, char** argv) {
     }
     if (devices.size() == 1) cfg.device = devices[0];
     bf_ctx* ctx = nullptr;
-    if (bf_ctx_create(&cfg, &ctx) != BF_OK) error("%s", bf_last_error(nullptr));
-    timing.lap("gpu_context");
+    double genome_s = 0, submit_s = 0;
+    // one attempt at "genome + reads into the GPU"; false when the reads have to be taken as ASCII after all
+    bool announce = true;
+    auto load_inputs = [&]() -> bool {
+        if (bf_ctx_create(&cfg, &ctx) != BF_OK) error("%s", bf_last_error(nullptr));
+        timing.lap("gpu_context");
 
-    // The FASTA is measured (names, lengths), then its pieces go to the GPU from a few threads WHILE the main thread
-    // already parses Bowtie's output: the parser only needs the contig names, and bf_submit accepts reads from
-    // bf_genome_begin on (their kernels wait for bf_genome_end).
-    auto fs = scan_fasta(genome_path + ".fa", threads);
-    fprintf(stderr, "Reading reference genome into memory...\n");
-    timing.lap("fasta_scan");
-    hits::ContigIndex contigs;
-    {
-        std::vector<const char*> names;
-        for (size_t i = 0; i < fs->names.size(); i++) { names.push_back(fs->names[i].c_str()); contigs.add(fs->names[i], (uint32_t)i); }
-        if (names.empty()) error("Genome FASTA file %s.fa holds no sequences.", genome_path.c_str());
-        if (bf_genome_begin(ctx, (uint32_t)names.size(), names.data(), fs->lens.data()) != BF_OK) error("%s", bf_last_error(ctx));
-        contigs.build();
-    }
-    const int g_threads = std::max(1, threads / 2);
-    if (const char* e = getenv("BREAKFAST_HIP_PARSER_THREADS")) popt.threads = std::max(1, atoi(e));
-    double genome_s = 0;
-    std::thread genome_thread([&] {
-        const auto t0 = std::chrono::steady_clock::now();
-        stream_fasta(*fs, g_threads, [&](uint32_t c, uint64_t off, const uint8_t* p, uint64_t n) { (void)bf_genome_write(ctx, c, off, p, n); });
-        genome_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    });
-
-    fprintf(stderr, "Splitting unaligned reads into %u bp anchors and aligning against the genome...\n", cfg.anchor_len);
-
-    // parsed batches go to a submit thread through a short queue (in input order: one producer, one consumer), so that
-    // the thread that pairs lines across block boundaries is not held up while a batch is staged for the GPU
-    double submit_s = 0;
-    if (!getenv("BREAKFAST_HIP_PARSER_THREADS")) popt.threads = std::max(1, threads - g_threads);
-    {
-        std::mutex mu;
-        std::condition_variable cv;
-        std::deque<hits::Batch> queue;
-        bool done = false;
-        std::thread submitter([&] {
-            for (;;) {
-                hits::Batch b;
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return done || !queue.empty(); });
-                    if (queue.empty()) return;
-                    b = std::move(queue.front());
-                    queue.pop_front();
-                    cv.notify_all();
-                }
-                const auto t0 = std::chrono::steady_clock::now();
-                bf_batch bb;
-                bb.n_reads = b.n();
-                bb.seq_bytes = (const uint8_t*)b.seq.data(); bb.seq_off = b.seq_off.data();
-                bb.frag_bytes = (const uint8_t*)b.frag.data(); bb.frag_off = b.frag_off.data();
-                bb.hits = b.hits.data();
-                if (bf_submit(ctx, &bb) != BF_OK) error("%s", bf_last_error(ctx));
-                submit_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            }
+        // The FASTA is measured (names, lengths), then its pieces go to the GPU from a few threads WHILE the main thread
+        // already parses Bowtie's output: the parser only needs the contig names, and bf_submit accepts reads from
+        // bf_genome_begin on (their kernels wait for bf_genome_end).
+        auto fs = scan_fasta(genome_path + ".fa", threads);
+        if (announce) fprintf(stderr, "Reading reference genome into memory...\n");
+        timing.lap("fasta_scan");
+        hits::ContigIndex contigs;
+        {
+            std::vector<const char*> names;
+            for (size_t i = 0; i < fs->names.size(); i++) { names.push_back(fs->names[i].c_str()); contigs.add(fs->names[i], (uint32_t)i); }
+            if (names.empty()) error("Genome FASTA file %s.fa holds no sequences.", genome_path.c_str());
+            if (bf_genome_begin(ctx, (uint32_t)names.size(), names.data(), fs->lens.data()) != BF_OK) error("%s", bf_last_error(ctx));
+            contigs.build();
+        }
+        const int g_threads = std::max(1, threads / 2);
+        if (const char* e = getenv("BREAKFAST_HIP_PARSER_THREADS")) popt.threads = std::max(1, atoi(e));
+        genome_s = 0;
+        std::thread genome_thread([&] {
+            const auto t0 = std::chrono::steady_clock::now();
+            stream_fasta(*fs, g_threads, [&](uint32_t c, uint64_t off, const uint8_t* p, uint64_t n) { (void)bf_genome_write(ctx, c, off, p, n); });
+            genome_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         });
-        try {
-            hits::parse_stream(in_fd, contigs, genome_path, popt, [&](hits::Batch& b) {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return queue.size() < 4; });
-                queue.emplace_back();
-                std::swap(queue.back(), b);
-                cv.notify_all();
+
+        if (announce) fprintf(stderr, "Splitting unaligned reads into %u bp anchors and aligning against the genome...\n", cfg.anchor_len);
+        announce = false;
+
+        // parsed batches go to a submit thread through a short queue (in input order: one producer, one consumer), so that
+        // the thread that pairs lines across block boundaries is not held up while a batch is staged for the GPU
+        submit_s = 0;
+        if (!getenv("BREAKFAST_HIP_PARSER_THREADS")) popt.threads = std::max(1, threads - g_threads);
+        {
+            std::mutex mu;
+            std::condition_variable cv;
+            std::deque<hits::Batch> queue;
+            bool done = false;
+            std::thread submitter([&] {
+                for (;;) {
+                    hits::Batch b;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return done || !queue.empty(); });
+                        if (queue.empty()) return;
+                        b = std::move(queue.front());
+                        queue.pop_front();
+                        cv.notify_all();
+                    }
+                    const auto t0 = std::chrono::steady_clock::now();
+                    if (submit_parsed(ctx, b, 0, b.n()) != BF_OK) error("%s", bf_last_error(ctx));
+                    submit_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                }
             });
-        } catch (const std::exception& e) { error("%s", e.what()); }
-        { std::lock_guard<std::mutex> g(mu); done = true; cv.notify_all(); }
-        submitter.join();
+            try {
+                hits::parse_stream(in_fd, contigs, genome_path, popt, [&](hits::Batch& b) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return queue.size() < 4; });
+                    queue.emplace_back();
+                    std::swap(queue.back(), b);
+                    cv.notify_all();
+                });
+            } catch (const hits::Unpackable& e) {
+                // a read outside BAM's alphabet: everything once more with ASCII reads (only offered for a hit list that
+                // can be read again; such reads do not come out of a BAM file)
+                if (!can_reread(in_fd) || lseek(in_fd, 0, SEEK_SET) != 0) error("%s", e.what());
+                { std::lock_guard<std::mutex> g(mu); queue.clear(); done = true; cv.notify_all(); }
+                submitter.join();
+                genome_thread.join();
+                bf_ctx_destroy(ctx);
+                ctx = nullptr;
+                return false;
+            } catch (const std::exception& e) { error("%s", e.what()); }
+            { std::lock_guard<std::mutex> g(mu); done = true; cv.notify_all(); }
+            submitter.join();
+        }
+        if (in_fd > 0) close(in_fd);
+        if (producer.joinable()) producer.join();
+        if (child.pid > 0) { int st = 0; waitpid(child.pid, &st, 0); }     // the reference never checks it either
+        timing.lap("parse_and_submit");
+        timing.add("  of_which_bf_submit", submit_s);
+        genome_thread.join();
+        if (bf_genome_end(ctx) != BF_OK) error("%s", bf_last_error(ctx));
+        fs.reset();                                                 // the genome now lives in HBM
+        timing.lap("genome_to_hbm_tail");
+        timing.add("  genome_stream_beside_the_parser", genome_s);
+
+        return true;
+    };
+    if (!load_inputs()) {
+        popt.pack = false;
+        popt.threads = threads;
+        if (!load_inputs()) error("could not read the anchor hits");
     }
-    if (in_fd > 0) close(in_fd);
-    if (producer.joinable()) producer.join();
-    if (child.pid > 0) { int st = 0; waitpid(child.pid, &st, 0); }     // the reference never checks it either
-    timing.lap("parse_and_submit");
-    timing.add("  of_which_bf_submit", submit_s);
-    genome_thread.join();
-    if (bf_genome_end(ctx) != BF_OK) error("%s", bf_last_error(ctx));
-    fs.reset();                                                 // the genome now lives in HBM
-    timing.lap("genome_to_hbm_tail");
-    timing.add("  genome_stream_beside_the_parser", genome_s);
 
     bf_result res;
     uint64_t n_reads = 0;

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <thread>
 
+#include <immintrin.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -28,6 +29,67 @@ void ContigIndex::build() {
 int ContigIndex::find(std::string_view name) const {
     auto it = map_.find(name);
     return it == map_.end() ? -1 : (int)it->second;
+}
+
+namespace {
+
+// BAM's base codes (SAM specification section 4.2.3: "=ACMGRSVTWYHKDBN" -> 0..15)
+struct CodeTable {
+    uint8_t t[256];
+    CodeTable() {
+        memset(t, 0xff, sizeof t);
+        const char* a = "=ACMGRSVTWYHKDBN";
+        for (int i = 0; i < 16; i++) t[(uint8_t)a[i]] = (uint8_t)i;
+    }
+};
+const CodeTable kCodes;
+
+bool pack_scalar(const char* s, size_t n, uint8_t* out) {
+    unsigned bad = 0;
+    size_t i = 0;
+    for (; i + 1 < n; i += 2) {
+        const uint8_t a = kCodes.t[(uint8_t)s[i]], b = kCodes.t[(uint8_t)s[i + 1]];
+        bad |= (a | b) & 0x80;
+        out[i >> 1] = (uint8_t)((a << 4) | (b & 15));
+    }
+    if (i < n) {
+        const uint8_t a = kCodes.t[(uint8_t)s[i]];
+        bad |= a & 0x80;
+        out[i >> 1] = (uint8_t)(a << 4);
+    }
+    return bad == 0;
+}
+
+// 16 bases a step: the code of a letter is looked up by its low five bits (two 16-entry tables), checked by decoding
+// it again (any other character decodes to something else), and the 16 codes are folded into 8 bytes.
+__attribute__((target("ssse3"))) bool pack_ssse3(const char* s, size_t n, uint8_t* out) {
+    //                                 idx:  0  A  B   C  D   E  F  G  H   I  J  K   L  M  N   O
+    const __m128i lo = _mm_setr_epi8(0, 1, 14, 2, 13, 0, 0, 4, 11, 0, 0, 12, 0, 3, 15, 0);
+    //                                 idx:  P  Q  R  S  T  U  V  W  X  Y   Z  [  \  =  ^  _
+    const __m128i hi = _mm_setr_epi8(0, 0, 5, 6, 8, 0, 7, 9, 0, 10, 0, 0, 0, 0, 0, 0);
+    const __m128i dec = _mm_setr_epi8('=', 'A', 'C', 'M', 'G', 'R', 'S', 'V', 'T', 'W', 'Y', 'H', 'K', 'D', 'B', 'N');
+    const __m128i m0f = _mm_set1_epi8(0x0f), m10 = _mm_set1_epi8(0x10), fold = _mm_set1_epi16(0x0110);
+    __m128i ok = _mm_set1_epi8((char)0xff);
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        const __m128i v = _mm_loadu_si128((const __m128i*)(s + i));
+        const __m128i ix = _mm_and_si128(v, m0f);
+        const __m128i upper = _mm_cmpeq_epi8(_mm_and_si128(v, m10), m10);
+        const __m128i code = _mm_or_si128(_mm_andnot_si128(upper, _mm_shuffle_epi8(lo, ix)), _mm_and_si128(upper, _mm_shuffle_epi8(hi, ix)));
+        ok = _mm_and_si128(ok, _mm_cmpeq_epi8(_mm_shuffle_epi8(dec, code), v));
+        const __m128i w = _mm_maddubs_epi16(code, fold);            // code[2k] * 16 + code[2k+1]
+        _mm_storel_epi64((__m128i*)(out + (i >> 1)), _mm_packus_epi16(w, w));
+    }
+    const bool head_ok = _mm_movemask_epi8(ok) == 0xffff;
+    return pack_scalar(s + i, n - i, out + (i >> 1)) && head_ok;
+}
+
+const bool kHaveSsse3 = __builtin_cpu_supports("ssse3");
+
+}  // namespace
+
+bool pack_bases(const char* bases, size_t n, uint8_t* out) {
+    return kHaveSsse3 ? pack_ssse3(bases, n, out) : pack_scalar(bases, n, out);
 }
 
 namespace {
@@ -73,6 +135,7 @@ uint64_t read_number(std::string_view line) {
 struct PairParser {
     const ContigIndex& contigs;
     const std::string& genome_path;
+    bool pack = false;
     int contig(std::string_view name) const {
         const int id = contigs.find(name);
         if (id < 0)
@@ -97,7 +160,18 @@ struct PairParser {
         h.contig5 = (uint16_t)c5; h.contig3 = (uint16_t)c3;
         h.strands = (uint8_t)((c[1] == "+" ? 1 : 0) | (m[1] == "+" ? 2 : 0));
         out.hits.push_back(h);
-        out.seq.append(a[3]); out.seq_off.push_back(out.seq.size());
+        if (pack) {
+            const size_t L = a[3].size(), at = out.seq.size();
+            if (L > 65535) throw Unpackable("a read of more than 65535 bases");
+            out.seq.resize(at + (L + 1) / 2);
+            if (!pack_bases(a[3].data(), L, (uint8_t*)out.seq.data() + at))
+                throw Unpackable("a read holds a character outside BAM's base alphabet: " + std::string(a[3].substr(0, 200)));
+            out.seq_len.push_back((uint16_t)L);
+            out.packed = true;
+        } else {
+            out.seq.append(a[3]);
+        }
+        out.seq_off.push_back(out.seq.size());
         out.frag.append(a[2]); out.frag_off.push_back(out.frag.size());
     }
 };
@@ -118,6 +192,7 @@ struct Parsed {
     std::string last5;
     uint64_t last5_num = 0;
     std::string error;
+    bool unpackable = false;
     uint64_t lines = 0, bytes = 0;
 };
 
@@ -127,7 +202,8 @@ void parse_block(const Block& b, const PairParser& pair, Parsed& out) {
     std::string_view prev;
     uint64_t prev_num = 0;
     out.bytes = b.n;
-    out.batch.seq.reserve(b.n * 3 / 4);
+    out.batch.seq.reserve(pair.pack ? b.n * 3 / 8 : b.n * 3 / 4);
+    out.batch.packed = pair.pack;
     out.batch.frag.reserve(b.n / 8);
     try {
         while (s < end) {
@@ -145,6 +221,8 @@ void parse_block(const Block& b, const PairParser& pair, Parsed& out) {
             if (is3 && num != prev_num) continue;                                      // detect.rs:85-87
             pair(prev, line, out.batch);
         }
+    } catch (const Unpackable& ex) {
+        out.error = ex.what(); out.unpackable = true;
     } catch (const std::exception& ex) {
         out.error = ex.what();
     }
@@ -266,11 +344,11 @@ Stats parse_stream(int fd, const ContigIndex& contigs, const std::string& genome
         pl.cv_done.notify_all();
     });
 
-    const PairParser proto{contigs, genome_path};
+    const PairParser proto{contigs, genome_path, opt.pack};
     std::vector<std::thread> workers;
     for (int w = 0; w < n_workers; w++) {
         workers.emplace_back([&] {
-            PairParser pair{contigs, genome_path};
+            PairParser pair{contigs, genome_path, opt.pack};
             for (;;) {
                 Block b;
                 {
@@ -320,10 +398,12 @@ Stats parse_stream(int fd, const ContigIndex& contigs, const std::string& genome
             }
             // the block's lines before its first 5p line, against the stream's state (detect.rs:85-103)
             lead_batch.clear();
+            lead_batch.packed = opt.pack;
             for (const Lead& l : p->lead) {
                 if (l.is3p && l.read_num != prev_num) continue;
                 proto(prev, l.line, lead_batch);
             }
+            if (p->unpackable) throw Unpackable(p->error);
             if (!p->error.empty()) throw ParseError(p->error);
             if (lead_batch.n()) { stats.pairs += lead_batch.n(); sink(lead_batch); }
             if (p->batch.n()) { stats.pairs += p->batch.n(); sink(p->batch); }

@@ -23,15 +23,24 @@
 
 namespace hits {
 
-struct Batch {                           // one bf_batch worth of parsed anchor-hit pairs
-    std::string seq, frag;
+struct Batch {                           // one bf_batch (or, with Options::pack, bf_packed_batch) worth of parsed pairs
+    std::string seq, frag;               // seq: ASCII bases, or BAM 4-bit codes (two bases a byte, every read byte-aligned)
     std::vector<uint64_t> seq_off{0}, frag_off{0};
+    std::vector<uint16_t> seq_len;       // bases per read (4-bit codes only)
     std::vector<bf_hit> hits;
+    bool packed = false;
     size_t n() const { return hits.size(); }
-    void clear() { seq.clear(); frag.clear(); seq_off.assign(1, 0); frag_off.assign(1, 0); hits.clear(); }
+    void clear() { seq.clear(); frag.clear(); seq_off.assign(1, 0); frag_off.assign(1, 0); seq_len.clear(); hits.clear(); }
 };
 
 struct ParseError : std::runtime_error { using std::runtime_error::runtime_error; };
+// Options::pack only: a read holds a character outside BAM's alphabet "=ACMGRSVTWYHKDBN" (lower case, '.', ...), or
+// more than 65535 bases.  Nothing of the stream is lost for a caller that can read it again as ASCII.
+struct Unpackable : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// `n` ASCII bases -> ceil(n / 2) bytes of BAM 4-bit codes at `out` (high nibble first, a trailing low nibble 0);
+// false when a base is outside the alphabet.  (SSSE3 where the CPU has it.)
+bool pack_bases(const char* bases, size_t n, uint8_t* out);
 
 class ContigIndex {                      // contig name -> id (index in the arrays given to bf_genome_set)
 public:
@@ -48,6 +57,7 @@ private:
 struct Options {
     int threads = 8;                     // parser workers (>= 1)
     size_t block_bytes = 32u << 20;      // nominal block size; blocks end on a line boundary
+    bool pack = false;                   // reads as BAM 4-bit codes (for bf_submit_packed); throws Unpackable where they cannot be
 };
 
 struct Stats { uint64_t bytes = 0, lines = 0, pairs = 0, blocks = 0; };

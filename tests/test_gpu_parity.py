@@ -381,9 +381,13 @@ def test_read_table_on_request():
         eng.close()
 
 
-@pytest.mark.parametrize("name", ["kat_survey", "hz_contig_order", "hz_ref_alphabet", "hz_pairing", "hz_wrapped_coords"])
-def test_cli_driver_reproduces_golden(name, tmp_path):
-    """`breakfast-hip detect` (the C++ host driver over the C ABI): same argv shape and stdout as the reference."""
+@pytest.mark.parametrize("form", ["file", "file --ascii-reads", "pipe", "pipe --packed-reads", "file --devices=0,0"])
+@pytest.mark.parametrize("name", ["kat_survey", "hz_contig_order", "hz_ref_alphabet", "hz_pairing", "hz_wrapped_coords",
+                                  "hz_read_n_iupac", "hz_mixed_lengths", "hz_dedup_min_evidence", "hz_empty"])
+def test_cli_driver_reproduces_golden(name, form, tmp_path):
+    """`breakfast-hip detect` (the C++ host driver over the C ABI): same argv shape and stdout as the reference.
+    A hit list in a file goes to the GPU as 4-bit base codes, and once more as ASCII when a read is outside BAM's
+    alphabet (hz_ref_alphabet's lower-case reads); a pipe is taken as ASCII unless --packed-reads promises the alphabet."""
     import os
     import subprocess
     from conftest import GOLDEN, ROOT
@@ -391,11 +395,19 @@ def test_cli_driver_reproduces_golden(name, tmp_path):
     assert os.path.exists(exe), "build the CLI driver first (__graft_entry__.build)"
     fa, lines, (A, F, E), sv = load_golden(name)
     prefix = os.path.join(GOLDEN, name)          # the driver opens <genome>.fa like detect.rs:48
-    p = subprocess.run([exe, "detect", "--anchor-len=%d" % A, "--max-frag-len=%d" % F, "--min-evidence=%d" % E,
-                        "--anchor-hits=%s.bowtie" % prefix, "unused.bam", prefix], capture_output=True, timeout=120)
+    source, *flags = form.split()
+    reads = [l.split(b":")[3] for l in lines.split(b"\n") if l.startswith(b"3p:") and l.count(b":") >= 4]
+    lower = any(c not in b"=ACMGRSVTWYHKDBN" for r in reads for c in r)
+    p = subprocess.run([exe, "detect", "--anchor-len=%d" % A, "--max-frag-len=%d" % F, "--min-evidence=%d" % E] + flags +
+                       ["--anchor-hits=" + ("%s.bowtie" % prefix if source == "file" else "-"), "unused.bam", prefix],
+                       input=lines if source == "pipe" else None, capture_output=True, timeout=120)
+    if lower and form == "pipe --packed-reads":                    # the promise does not hold: an error, never a wrong table
+        assert p.returncode == 255 and b"outside BAM's base alphabet" in p.stderr
+        return
     assert p.returncode == 0, p.stderr.decode()
     assert p.stdout == sv
     assert b"Found " in p.stderr and b"rearrangement supporting reads." in p.stderr
+    assert p.stderr.count(b"Reading reference genome into memory...") == 1
 
 
 def test_cli_driver_error_convention(tmp_path):

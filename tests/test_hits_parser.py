@@ -15,10 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "breakfast_amd", "csrc", "breakfast-hip")
 
 
-def run_hits(tmp_path, fasta: bytes, text: bytes, block=None, threads=3, stdin=False):
+def run_hits(tmp_path, fasta: bytes, text: bytes, block=None, threads=3, stdin=False, packed=False):
     (tmp_path / "g.fa").write_bytes(fasta)
     (tmp_path / "hits.txt").write_bytes(text)
-    cmd = [EXE, "hits", "--threads=%d" % threads]
+    cmd = [EXE, "hits", "--threads=%d" % threads] + (["--packed-reads"] if packed else [])
     if block:
         cmd.append("--block-bytes=%d" % block)
     if stdin:
@@ -129,3 +129,43 @@ def test_fasta_loader_semantics(tmp_path):
     p = run_hits(tmp_path, fa, text)
     assert p.returncode == 0, p.stderr.decode()
     assert p.stdout == b"f\tACGTACGT\t1\t1\t1\t0\t3\n"
+
+
+def alphabet_text(seed: int, n_reads: int = 400):
+    """Hit lines whose reads use all of BAM's sixteen base letters, in every length from 1 to 70 (so every tail of
+    the 16-bases-a-step packer is taken, odd and even)."""
+    rng = random.Random(seed)
+    out = []
+    for i in range(n_reads):
+        L = 1 + i % 70
+        seq = "".join(rng.choice("=ACMGRSVTWYHKDBN") for _ in range(L))
+        out.append("5p:%d:\t+\tchr1\t%d\n3p:%d:frag%d:%s:\t-\tchr2\t%d\n" % (i + 1, 1 + i, i + 1, i, seq, 3 + i))
+    return "".join(out).encode()
+
+
+@pytest.mark.parametrize("block", [1, 333, None])
+def test_reads_as_4bit_codes_spell_the_same_reads(tmp_path, block):
+    """--packed-reads: the parser hands the reads over as BAM 4-bit codes (for bf_submit_packed); spelled out again they
+    are the reads of the ASCII parse."""
+    fa, _, _, _ = load_golden("kat_survey")
+    text = alphabet_text(3)
+    want = expected(text, fasta_names(fa))
+    for stdin in (False, True):
+        p = run_hits(tmp_path, fa, text, block=block, stdin=stdin, packed=True)
+        assert p.returncode == 0, p.stderr.decode()
+        assert p.stdout == want
+    g, lossy = lossy_text(11)
+    up = lossy.upper().replace(b"5P:", b"5p:").replace(b"3P:", b"3p:").replace(b"CHR", b"chr")
+    p = run_hits(tmp_path, g.fasta(), up, block=block, packed=True)
+    assert p.returncode == 0, p.stderr.decode()
+    assert p.stdout == expected(up, g.names)
+
+
+@pytest.mark.parametrize("seq", [b"ACGTacgt", b"ACGTNNNNACGTNNNNACGTNNNNACGx", b"ACG.T", b"ACGTACGTACGTACGTACGTACGTACGTACG\x80"])
+def test_a_read_outside_the_alphabet_cannot_be_packed(tmp_path, seq):
+    fa, _, _, _ = load_golden("kat_survey")
+    text = b"5p:1:\t+\tchr1\t27\n3p:1:f:" + seq + b":\t+\tchr2\t5\n"
+    p = run_hits(tmp_path, fa, text, packed=True)
+    assert p.returncode == 255 and b"outside BAM's base alphabet" in p.stderr
+    p = run_hits(tmp_path, fa, text)
+    assert p.returncode == 0 and seq in p.stdout

@@ -11,4 +11,4 @@ python tools/kernel_stats_md.py $src/trace1 profiles/${tag}_kernel_stats_cfg1_10
 grep -h '^{"metric"' $src/trace.log > profiles/${tag}_bench_cfg1_under_rocprofv3.json || true
 grep -h '^{"metric"' $src/trace1.log > profiles/${tag}_bench_cfg1_under_rocprofv3_one_stream.json || true
 python tools/pmc_traffic.py $src/pmc_fetch $src/pmc_write profiles/${tag}_pmc_traffic.json \
-  "config=1 reads=10000000 len=150 variant=fused (bench.py --steps 2 --warmup 1), $tag"
+  "config=1 reads=10000000 len=150 variant=fused reads_as=packed (bench.py --steps 2 --warmup 1), $tag"

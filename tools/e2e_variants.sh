@@ -1,18 +1,21 @@
+# Variants of the command line on the files tests/e2e_cli.py left in /tmp/bf_e2e (run that first, in the same gpurun call)
 set -u
 D=/tmp/bf_e2e
 EXE=breakfast_amd/csrc/breakfast-hip
-run() { # label, env...
-  label=$1; shift
+run() { # label, extra flag ("-" for none), env...
+  label=$1; flag=$2; shift 2
+  [ "$flag" = "-" ] && flag=
   for i in 1 2 3; do
     s=$(date +%s%N)
-    env "$@" $EXE detect --anchor-len=20 --anchor-hits=$D/hits.txt --threads=16 --timing unused.bam $D/g > $D/out.sv 2> $D/err.txt
+    env "$@" $EXE detect --anchor-len=20 --anchor-hits=$D/hits.txt --threads=16 --timing $flag unused.bam $D/g > $D/out.sv 2> $D/err.txt
     e=$(date +%s%N)
-    echo "$label run $i wall_ms $(( (e - s) / 1000000 )) total $(grep 'TIMING.total' $D/err.txt | cut -f3) parse $(grep 'parse_and_submit' $D/err.txt | cut -f3) fw $(grep 'format_and_write' $D/err.txt | cut -f3)"
+    echo "$label run $i wall_ms $(( (e - s) / 1000000 )) total $(grep 'TIMING.total' $D/err.txt | cut -f3) parse $(grep 'parse_and_submit' $D/err.txt | cut -f3) submit $(grep 'of_which_bf_submit' $D/err.txt | cut -f3) gpu $(grep 'gpu_localise' $D/err.txt | cut -f3) fw $(grep 'format_and_write' $D/err.txt | cut -f3) sha $(sha256sum $D/out.sv | cut -c1-12)"
   done
 }
-run default X=1
-run teardown BREAKFAST_HIP_TEARDOWN=1
-run parser12 BREAKFAST_HIP_PARSER_THREADS=12
+run packed-reads - X=1
+run ascii-reads --ascii-reads X=1
+run teardown - BREAKFAST_HIP_TEARDOWN=1
+run parser12 - BREAKFAST_HIP_PARSER_THREADS=12
 s=$(date +%s%N); $EXE hits /dev/null $D/g > /dev/null 2>&1; e=$(date +%s%N); echo "hits-only (fasta load, no gpu) wall_ms $(( (e - s) / 1000000 ))"
 s=$(date +%s%N); $EXE anchors /dev/null > /dev/null 2>&1; e=$(date +%s%N); echo "trivial process (library load only) wall_ms $(( (e - s) / 1000000 ))"
-sha256sum $D/out.sv $D/gpu.sv
+sha256sum $D/gpu.sv | cut -c1-12
