@@ -284,6 +284,9 @@ int bf_ctx_create(const bf_config* cfg, bf_ctx** out) {
     if (cfg->flags & BF_FLAG_ONE_STREAM) {
         ctx->copy_stream = ctx->side_stream = ctx->in_stream = ctx->stream;
     } else {
+        // Default priority on purpose.  With a high-priority copy / side stream, three processes sharing one GPU stopped
+        // inside bf_clusterise (round 1): a high-priority queue waiting for an event can be kept on the hardware while the
+        // normal-priority queue that has to signal it is not scheduled.
         ok = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking) == hipSuccess;

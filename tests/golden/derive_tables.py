@@ -11,7 +11,7 @@ pencil-and-paper method of that derivation written down once, for fixtures too l
     positions outside the contig -> 'N'), the mismatch vectors ML / MR are compared position by position, and
     mm[k] is the CLOSED FORM of SURVEY.md section 3.3 item 4 -- |ML below k| + |MR from k on| -- not the
     reference's running sum (detect.rs:147-153); bp = lowest k of the minimum over k in [A, L-A-1];
-  * one read (hz_contig_ends read 1) was also derived entirely by hand from detect.rs:105-187 and the FASTA text
+  * one read (hz_contig_ends read 0) was also derived entirely by hand from detect.rs:105-187 and the FASTA text
     (DESIGN.md section 2 shows the work); the script must reproduce that row, see HAND_ROW below.
 
 Output: tests/golden/hand_tables.json -- literal numbers and strings per read (input order of the paired reads):

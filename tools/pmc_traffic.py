@@ -4,6 +4,7 @@
   python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [workload note]
 
 FETCH_SIZE and WRITE_SIZE are collected in SEPARATE passes (TCC counter slots), both in KiB.
+Per kernel only the launches with its largest grid count (the launches over the whole resident input).
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-byte requests at 64 bytes, so
 the read side is doubled; calibrated in this repo on genome_pack_kernel (3.088 GB read: FETCH_SIZE
 says 1.544 GB, TCC_EA0_RDREQ_128B x 128 B says 3.088 GB; every request of these kernels is a
@@ -21,8 +22,14 @@ def per_kernel(d, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return acc
+            acc[r["Kernel_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+    # a kernel that also ran on pieces of the input (the per-piece launches behind bf_submit's uploads) is reported
+    # for its launches over the WHOLE input only: those with the kernel's largest grid
+    out = {}
+    for k, v in acc.items():
+        g = max(x[0] for x in v)
+        out[k] = [x[1] for x in v if x[0] == g]
+    return out
 
 
 def main():
