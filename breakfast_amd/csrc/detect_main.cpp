@@ -503,8 +503,11 @@ int main(int argc, char** argv) {
         if (fd < 0) error("Cannot open file %s for reading.", pos[0].c_str());
         popt.pack = reads_form == 1;
         try {
+            uint64_t counted = 0;
+            const bool count_only = getenv("BREAKFAST_HIP_COUNT_ONLY") != nullptr;     // parser timing: no text
             hits::parse_stream(fd, contigs, pos[1], popt, [&](hits::Batch& b) {
-                for (size_t i = 0; i < b.n(); i++) {
+                counted += b.n();
+                for (size_t i = 0; i < (count_only ? 0 : b.n()); i++) {
                     const bf_hit& h = b.hits[i];
                     fwrite(b.frag.data() + b.frag_off[i], 1, b.frag_off[i + 1] - b.frag_off[i], stdout);
                     fputc('\t', stdout);
@@ -516,6 +519,7 @@ int main(int argc, char** argv) {
                     fprintf(stdout, "\t%u\t%u\t%u\t%u\t%u\n", h.strands, h.contig5, h.pos5, h.contig3, h.pos3);
                 }
             });
+            if (count_only) fprintf(stderr, "%llu pairs\n", (unsigned long long)counted);
         } catch (const std::exception& e) { error("%s", e.what()); }
         fflush(stdout);
         return 0;
@@ -558,32 +562,66 @@ int main(int argc, char** argv) {
         return rc;
     }
     if (devices.size() == 1) cfg.device = devices[0];
+    cfg.reserved[1] = (uint32_t)std::max(2, threads / 5);              // staging threads of bf_submit: the copies are light
+    if (const char* e = getenv("BREAKFAST_HIP_STAGE_THREADS")) cfg.reserved[1] = (uint32_t)std::max(1, atoi(e));
     bf_ctx* ctx = nullptr;
     double genome_s = 0, submit_s = 0;
     // one attempt at "genome + reads into the GPU"; false when the reads have to be taken as ASCII after all
     bool announce = true;
     auto load_inputs = [&]() -> bool {
-        if (bf_ctx_create(&cfg, &ctx) != BF_OK) error("%s", bf_last_error(nullptr));
-        timing.lap("gpu_context");
-
-        // The FASTA is measured (names, lengths), then its pieces go to the GPU from a few threads WHILE the main thread
-        // already parses Bowtie's output: the parser only needs the contig names, and bf_submit accepts reads from
-        // bf_genome_begin on (their kernels wait for bf_genome_end).
+        // The GPU context comes up on a thread of its own (most of that is the driver) while the FASTA is measured
+        // (names, lengths) and the main thread ALREADY parses Bowtie's output: the parser only needs the contig names.
+        // The same thread then sends the FASTA's pieces to the GPU from a few workers; bf_submit accepts reads from
+        // bf_genome_begin on (their kernels wait for bf_genome_end): the submit thread below waits for that moment.
+        std::string ctx_error;
+        std::thread ctx_thread([&] { if (bf_ctx_create(&cfg, &ctx) != BF_OK) ctx_error = bf_last_error(nullptr); });
         auto fs = scan_fasta(genome_path + ".fa", threads);
         if (announce) fprintf(stderr, "Reading reference genome into memory...\n");
         timing.lap("fasta_scan");
         hits::ContigIndex contigs;
-        {
-            std::vector<const char*> names;
-            for (size_t i = 0; i < fs->names.size(); i++) { names.push_back(fs->names[i].c_str()); contigs.add(fs->names[i], (uint32_t)i); }
-            if (names.empty()) error("Genome FASTA file %s.fa holds no sequences.", genome_path.c_str());
-            if (bf_genome_begin(ctx, (uint32_t)names.size(), names.data(), fs->lens.data()) != BF_OK) error("%s", bf_last_error(ctx));
-            contigs.build();
-        }
-        const int g_threads = std::max(1, threads / 2);
+        std::vector<const char*> names;
+        for (size_t i = 0; i < fs->names.size(); i++) { names.push_back(fs->names[i].c_str()); contigs.add(fs->names[i], (uint32_t)i); }
+        if (names.empty()) error("Genome FASTA file %s.fa holds no sequences.", genome_path.c_str());
+        contigs.build();
+        // the parser is what the wall clock waits for: it gets four fifths of the threads, the genome stream the rest
+        int g_threads = std::max(1, threads / 5);
+        if (const char* e = getenv("BREAKFAST_HIP_GENOME_THREADS")) g_threads = std::max(1, atoi(e));
         if (const char* e = getenv("BREAKFAST_HIP_PARSER_THREADS")) popt.threads = std::max(1, atoi(e));
         genome_s = 0;
+        std::mutex gpu_mu;
+        std::condition_variable gpu_cv;
+        bool gpu_ready = false;
         std::thread genome_thread([&] {
+            ctx_thread.join();
+            if (!ctx) error("%s", ctx_error.c_str());
+            if (bf_genome_begin(ctx, (uint32_t)names.size(), names.data(), fs->lens.data()) != BF_OK) error("%s", bf_last_error(ctx));
+            // a hit list in a file: the resident arrays are sized once from a sample of its first lines (growing them
+            // later waits for all queued work and copies what is there)
+            struct stat hst;
+            std::vector<char> sample(1 << 16);
+            ssize_t got = 0;
+            if (can_reread(in_fd) && fstat(in_fd, &hst) == 0 && hst.st_size > (off_t)sample.size() && (got = pread(in_fd, sample.data(), sample.size(), 0)) > 0) {
+                uint64_t lines = 0, seq = 0, frag = 0;
+                for (const char* q = sample.data(); q < sample.data() + got;) {
+                    const char* nl = (const char*)memchr(q, '\n', (size_t)(sample.data() + got - q));
+                    if (!nl) break;
+                    if (nl - q > 3 && q[0] == '3' && q[1] == 'p') {        // 3p:<number>:<fragment id>:<sequence>:
+                        const char* c1 = (const char*)memchr(q + 3, ':', (size_t)(nl - q - 3));
+                        const char* c2 = c1 ? (const char*)memchr(c1 + 1, ':', (size_t)(nl - c1 - 1)) : nullptr;
+                        const char* c3 = c2 ? (const char*)memchr(c2 + 1, ':', (size_t)(nl - c2 - 1)) : nullptr;
+                        if (c3) { frag += (uint64_t)(c2 - c1 - 1); seq += (uint64_t)(c3 - c2 - 1); }
+                    }
+                    lines++; q = nl + 1;
+                }
+                if (lines >= 2) {
+                    const double scale = (double)hst.st_size / (double)got * 1.03;
+                    const uint64_t n_est = (uint64_t)((double)(lines / 2 + 1) * scale) + 4096;
+                    const uint64_t seq_est = (uint64_t)((double)(popt.pack ? seq / 2 + lines : seq) * scale) + (1u << 20);
+                    (void)bf_reserve(ctx, n_est, seq_est, (uint64_t)((double)frag * scale) + (1u << 20));   // an estimate: failing is not fatal
+                }
+            }
+            { std::lock_guard<std::mutex> g(gpu_mu); gpu_ready = true; }
+            gpu_cv.notify_all();
             const auto t0 = std::chrono::steady_clock::now();
             stream_fasta(*fs, g_threads, [&](uint32_t c, uint64_t off, const uint8_t* p, uint64_t n) { (void)bf_genome_write(ctx, c, off, p, n); });
             genome_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -600,8 +638,10 @@ int main(int argc, char** argv) {
             std::mutex mu;
             std::condition_variable cv;
             std::deque<hits::Batch> queue;
+            std::vector<hits::Batch> spent;           // submitted batches: their buffers go back to the parser
             bool done = false;
             std::thread submitter([&] {
+                { std::unique_lock<std::mutex> lk(gpu_mu); gpu_cv.wait(lk, [&] { return gpu_ready; }); }
                 for (;;) {
                     hits::Batch b;
                     {
@@ -615,13 +655,16 @@ int main(int argc, char** argv) {
                     const auto t0 = std::chrono::steady_clock::now();
                     if (submit_parsed(ctx, b, 0, b.n()) != BF_OK) error("%s", bf_last_error(ctx));
                     submit_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    std::lock_guard<std::mutex> g(mu);      // pageable arrays are staged when bf_submit returns
+                    spent.push_back(std::move(b));
                 }
             });
             try {
                 hits::parse_stream(in_fd, contigs, genome_path, popt, [&](hits::Batch& b) {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return queue.size() < 4; });
+                    cv.wait(lk, [&] { return queue.size() < 8; });
                     queue.emplace_back();
+                    if (!spent.empty()) { queue.back() = std::move(spent.back()); spent.pop_back(); }
                     std::swap(queue.back(), b);
                     cv.notify_all();
                 });
@@ -674,13 +717,17 @@ int main(int argc, char** argv) {
         const size_t hdr = strlen("CHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tCHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tSUPPORTING READS\tSIGNATURE\tNOTES\n");
         std::vector<std::unique_ptr<char[]>> bufs((size_t)slices);
         std::vector<int64_t> sizes((size_t)slices, 0);
-        std::thread writer;
-        for (int k = 0; k < slices; k++) {
+        auto slice = [&](int k) {
             bf_result part = res;
             const uint64_t c0 = nc * (uint64_t)k / slices, c1 = nc * (uint64_t)(k + 1) / slices;
             part.n_clusters = c1 - c0;
             part.clusters = res.clusters ? res.clusters + c0 : nullptr;
             part.cluster_junction_off = res.cluster_junction_off ? res.cluster_junction_off + c0 : nullptr;
+            return part;
+        };
+        std::thread writer;
+        for (int k = 0; k < slices; k++) {
+            const bf_result part = slice(k);
             const int64_t size = bf_format_sv(ctx, &part, nullptr, 0);
             if (size < 0) error("could not render the result");
             bufs[k].reset(new char[(size_t)size + 1]);

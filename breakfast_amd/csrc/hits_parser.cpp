@@ -3,8 +3,12 @@
 #include "hits_parser.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -19,16 +23,35 @@
 
 namespace hits {
 
+// Open addressing on FNV-1a of the name: contig names are a handful of bytes, and the parser looks two of them up per
+// read (std::unordered_map's hash and bucket walk were a fifth of its time).
+static inline uint64_t name_hash(std::string_view s) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (unsigned char c : s) h = (h ^ c) * 0x100000001b3ull;
+    return h ^ (h >> 29);
+}
+
 void ContigIndex::build() {
-    map_.clear();
-    map_.reserve(names_.size() * 2);
-    for (size_t i = 0; i < names_.size(); i++) map_[std::string_view(names_[i])] = ids_[i];   // last record of a name wins
+    size_t cap = 16;
+    while (cap < names_.size() * 4) cap *= 2;
+    slots_.assign(cap, 0);
+    for (size_t i = 0; i < names_.size(); i++) {
+        size_t at = name_hash(names_[i]) & (cap - 1);
+        while (slots_[at] && names_[slots_[at] - 1] != names_[i]) at = (at + 1) & (cap - 1);
+        slots_[at] = (uint32_t)i + 1;                         // last record of a name wins
+    }
     built_ = true;
 }
 
 int ContigIndex::find(std::string_view name) const {
-    auto it = map_.find(name);
-    return it == map_.end() ? -1 : (int)it->second;
+    if (slots_.empty()) return -1;
+    const size_t mask = slots_.size() - 1;
+    for (size_t at = name_hash(name) & mask;; at = (at + 1) & mask) {
+        const uint32_t s = slots_[at];
+        if (!s) return -1;
+        const std::string& n = names_[s - 1];
+        if (n.size() == name.size() && memcmp(n.data(), name.data(), name.size()) == 0) return (int)ids_[s - 1];
+    }
 }
 
 namespace {
@@ -97,6 +120,14 @@ namespace {
 bool parse_u64(std::string_view s, uint64_t& v) {
     if (s.empty()) return false;
     v = 0;
+    if (s.size() <= 19) {                                     // cannot overflow: no check per digit
+        for (char c : s) {
+            const unsigned d = (unsigned)(c - '0');
+            if (d > 9) return false;
+            v = v * 10 + d;
+        }
+        return true;
+    }
     for (char c : s) {
         if (c < '0' || c > '9') return false;
         if (v > (0xffffffffffffffffull - (uint64_t)(c - '0')) / 10) return false;    // usize::parse overflows -> Err
@@ -238,6 +269,7 @@ struct Pipeline {
     bool eof = false, abort = false;
     std::string reader_error;
     size_t max_in_flight = 4;
+    std::vector<Batch> spare;             // batches whose buffers are kept for the next block (no allocator churn, no fresh pages)
 };
 
 void push_block(Pipeline& pl, Block&& b) {
@@ -249,10 +281,13 @@ void push_block(Pipeline& pl, Block&& b) {
     pl.cv_work.notify_one();
 }
 
-void read_mapped(Pipeline& pl, const char* base, size_t size, size_t block_bytes) {
+void read_mapped(Pipeline& pl, const char* base, size_t size, size_t block_bytes, size_t n_workers) {
     size_t pos = 0;
     while (pos < size) {
-        size_t end = std::min(size, pos + block_bytes);
+        // towards the end the blocks get smaller, so that the workers finish together
+        const size_t left = size - pos;
+        const size_t want = left < block_bytes * n_workers ? std::max<size_t>(block_bytes / 8, std::min<size_t>(block_bytes, 1u << 20)) : block_bytes;
+        size_t end = std::min(size, pos + want);
         if (end < size) {
             const void* back = memrchr(base + pos, '\n', end - pos);
             if (back) end = (size_t)((const char*)back - base) + 1;
@@ -332,7 +367,7 @@ Stats parse_stream(int fd, const ContigIndex& contigs, const std::string& genome
 
     std::thread reader([&] {
         try {
-            if (map_base) read_mapped(pl, map_base, map_size, block_bytes);
+            if (map_base) read_mapped(pl, map_base, map_size, block_bytes, (size_t)n_workers);
             else read_stream(pl, fd, block_bytes);
         } catch (const std::exception& ex) {
             std::lock_guard<std::mutex> g(pl.mu);
@@ -345,6 +380,8 @@ Stats parse_stream(int fd, const ContigIndex& contigs, const std::string& genome
     });
 
     const PairParser proto{contigs, genome_path, opt.pack};
+    std::atomic<uint64_t> worker_ns{0};
+    const auto t_begin = std::chrono::steady_clock::now();
     std::vector<std::thread> workers;
     for (int w = 0; w < n_workers; w++) {
         workers.emplace_back([&] {
@@ -359,7 +396,14 @@ Stats parse_stream(int fd, const ContigIndex& contigs, const std::string& genome
                     pl.work.pop_front();
                 }
                 auto out = std::make_unique<Parsed>();
+                {
+                    std::lock_guard<std::mutex> g(pl.mu);
+                    if (!pl.spare.empty()) { out->batch = std::move(pl.spare.back()); pl.spare.pop_back(); }
+                }
+                out->batch.clear();
+                const auto t0 = std::chrono::steady_clock::now();
                 parse_block(b, pair, *out);
+                worker_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
                 std::lock_guard<std::mutex> g(pl.mu);
                 pl.done[b.seq] = std::move(out);
                 pl.cv_done.notify_all();
@@ -409,6 +453,11 @@ Stats parse_stream(int fd, const ContigIndex& contigs, const std::string& genome
             if (p->batch.n()) { stats.pairs += p->batch.n(); sink(p->batch); }
             if (p->has5) { prev = std::move(p->last5); prev_num = p->last5_num; }
             stats.bytes += p->bytes; stats.lines += p->lines; stats.blocks++;
+            {
+                // whatever the sink left in the batch (its own spent buffers, if it swapped) serves the next block
+                std::lock_guard<std::mutex> g(pl.mu);
+                if (pl.spare.size() < pl.max_in_flight + 8) pl.spare.push_back(std::move(p->batch));
+            }
             p.reset();
             {
                 std::lock_guard<std::mutex> g(pl.mu);
@@ -421,6 +470,10 @@ Stats parse_stream(int fd, const ContigIndex& contigs, const std::string& genome
         throw;
     }
     shut_down(false);
+    if (getenv("BREAKFAST_HIP_PARSER_TIMING"))
+        fprintf(stderr, "parser: wall %.3f s, workers busy %.3f s in total (%d threads), %llu blocks\n",
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), worker_ns.load() * 1e-9, n_workers,
+                (unsigned long long)stats.blocks);
     return stats;
 }
 

@@ -50,7 +50,7 @@ public:
 private:
     std::vector<std::string> names_;
     std::vector<uint32_t> ids_;
-    std::unordered_map<std::string_view, uint32_t> map_;
+    std::vector<uint32_t> slots_;        // open addressing: index into names_ + 1, 0 = empty
     bool built_ = false;
 };
 
@@ -63,7 +63,8 @@ struct Options {
 struct Stats { uint64_t bytes = 0, lines = 0, pairs = 0, blocks = 0; };
 
 // Reads `fd` to its end (a regular file is memory-mapped, anything else is read()), parses it and
-// calls sink(batch) on the calling thread, batch after batch in input order.  Throws ParseError for
+// calls sink(batch) on the calling thread, batch after batch in input order.  A sink that keeps a batch swaps it
+// away; whatever it leaves in `batch` (best: a batch it is done with) has its buffers reused for a later block.  Throws ParseError for
 // what makes the reference panic (malformed line, unknown contig); the message names the line.
 Stats parse_stream(int fd, const ContigIndex& contigs, const std::string& genome_path, const Options& opt,
                    const std::function<void(Batch&)>& sink);

@@ -12,10 +12,18 @@ run() { # label, extra flag ("-" for none), env...
     echo "$label run $i wall_ms $(( (e - s) / 1000000 )) total $(grep 'TIMING.total' $D/err.txt | cut -f3) parse $(grep 'parse_and_submit' $D/err.txt | cut -f3) submit $(grep 'of_which_bf_submit' $D/err.txt | cut -f3) gpu $(grep 'gpu_localise' $D/err.txt | cut -f3) fw $(grep 'format_and_write' $D/err.txt | cut -f3) sha $(sha256sum $D/out.sv | cut -c1-12)"
   done
 }
-run packed-reads - X=1
-run ascii-reads --ascii-reads X=1
+run default - BREAKFAST_HIP_PARSER_TIMING=1
+grep parser: $D/err.txt
+run b16M --block-bytes=16000000 BREAKFAST_HIP_PARSER_TIMING=1
+grep parser: $D/err.txt
+run g2-p14 - BREAKFAST_HIP_GENOME_THREADS=2 BREAKFAST_HIP_PARSER_THREADS=14 BREAKFAST_HIP_PARSER_TIMING=1
+grep parser: $D/err.txt
+run s6 - BREAKFAST_HIP_STAGE_THREADS=6 BREAKFAST_HIP_PARSER_TIMING=1
+grep parser: $D/err.txt
+run ascii --ascii-reads BREAKFAST_HIP_PARSER_TIMING=1
+grep parser: $D/err.txt
 run teardown - BREAKFAST_HIP_TEARDOWN=1
-run parser12 - BREAKFAST_HIP_PARSER_THREADS=12
+grep TIMING $D/err.txt
 s=$(date +%s%N); $EXE hits /dev/null $D/g > /dev/null 2>&1; e=$(date +%s%N); echo "hits-only (fasta load, no gpu) wall_ms $(( (e - s) / 1000000 ))"
 s=$(date +%s%N); $EXE anchors /dev/null > /dev/null 2>&1; e=$(date +%s%N); echo "trivial process (library load only) wall_ms $(( (e - s) / 1000000 ))"
 sha256sum $D/gpu.sv | cut -c1-12
