@@ -253,7 +253,7 @@ struct bf_ctx {
     // cluster stage scratch + results
     bf::DevBuf c_tmp, c_a32, c_b32, c_c32, c_d32, c_k64a, c_k64b, c_slpos, c_srpos, c_reported,
         c_csize, c_flag, c_scan, c_qseed, c_qsize, c_qoff, c_members, c_leader, c_rep, c_qnrep,
-        c_ctl, c_sel, c_ord, c_clusters, c_reads, c_misc, c_pos2, c_joff, c_jbytes, c_rsrc, c_tables, c_mkey_s, c_slot, c_big, c_cjo, c_aoff, c_err, c_tmp2, c_qord, c_gidx, c_hist;
+        c_ctl, c_sel, c_ord, c_clusters, c_reads, c_misc, c_pos2, c_joff, c_jbytes, c_rsrc, c_tables, c_mkey_s, c_slot, c_big, c_cjo, c_aoff, c_err, c_tmp2, c_qord, c_gidx, c_hist, c_comp, c_bstart, c_chunk;
     bf::ClusterOut out;
     std::vector<uint64_t> render_off_host;
     std::vector<uint8_t> render_bytes_host;
@@ -362,6 +362,9 @@ int radix_sort_pairs(bf_ctx* ctx, const uint32_t* kin, uint32_t* kout, const uin
                      unsigned begin_bit, unsigned end_bit);
 int radix_sort_pairs(bf_ctx* ctx, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n,
                      unsigned begin_bit, unsigned end_bit);
+struct RsV3 { uint32_t a, b, c; };
+int radix_sort_kv3(bf_ctx* ctx, const uint64_t* kin, uint64_t* kout, const RsV3* vin, RsV3* vout, uint64_t n,
+                   unsigned begin_bit, unsigned end_bit);
 int scan_u32_to_u64(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n);  // exclusive, out has n+1
 uint64_t scan_workspace_bytes(uint64_t n);
 int scan_u32_to_u64_ws(bf_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* workspace);   // allocates nothing

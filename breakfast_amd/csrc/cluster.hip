@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256) sweep_big_kernel(const SweepView v, uint8
 
 // flag[i] = val[i] >= thr, and the sums the host needs to size what follows, so that they come along with the
 // fetch of the flag count instead of costing a synchronisation each: sums[0] += the flagged values, sums[1] +=
-// those above wave_max.  Fixed grid: one atomic per wave with something to add.
+// those above wave_max.  Fixed grid: one atomic per block with something to add.
 constexpr unsigned kFlagGrid = 1024;
 __global__ void __launch_bounds__(256) flag_ge_kernel(uint32_t* flag, const uint32_t* __restrict__ val, uint32_t thr, uint64_t n,
                                                       uint32_t wave_max, unsigned long long* sums,
@@ -231,7 +231,14 @@ __global__ void __launch_bounds__(256) flag_ge_kernel(uint32_t* flag, const uint
         if (f) { s_all += c; if (c > wave_max) s_big += c; }
     }
     for (int d = 32; d; d >>= 1) { s_all += __shfl_down(s_all, d); s_big += __shfl_down(s_big, d); }
-    if ((threadIdx.x & 63) == 0) {
+    // one pair of atomics per BLOCK: they all hit the same two words and are served one after the other (with one pair
+    // per wave the 8192 atomics of a launch, not its 40 MB of traffic, set the kernel's time: 75 us for 5M records)
+    __shared__ unsigned long long w_all[4], w_big[4];
+    if ((threadIdx.x & 63) == 0) { w_all[threadIdx.x >> 6] = s_all; w_big[threadIdx.x >> 6] = s_big; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_all = w_all[0] + w_all[1] + w_all[2] + w_all[3];
+        s_big = w_big[0] + w_big[1] + w_big[2] + w_big[3];
         if (s_all) atomicAdd(&sums[0], s_all);
         if (s_big) atomicAdd(&sums[1], s_big);
     }
@@ -574,12 +581,20 @@ __global__ void __launch_bounds__(256) emit_kernel(const EmitView e, uint64_t ns
 // ranks at a time and the results appended; api.hip copies a group's records to the host while the next group
 // is clustered.  rank32[i] = left contig rank of record i, hist[r] = records of rank r, hist[bins] = sum of all
 // records' junction record bytes (the bound the output buffers are sized with).
-// Sum of the records' junction record bytes (the bound the output buffers are sized with): one atomic per wave.
+// Sum of the records' junction record bytes (the bound the output buffers are sized with): one atomic per block.
 __global__ void __launch_bounds__(256) record_bytes_kernel(const uint64_t* __restrict__ info, uint64_t n, unsigned long long* sum) {
     unsigned long long bytes = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) bytes += info_jrec(info[i]);
     for (int d = 32; d; d >>= 1) bytes += __shfl_down(bytes, d);
-    if ((threadIdx.x & 63) == 0 && bytes) atomicAdd(sum, bytes);
+    __shared__ unsigned long long w[4];                    // one atomic per block: they all hit one word
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = bytes;
+    __syncthreads();
+    if (threadIdx.x == 0 && w[0] + w[1] + w[2] + w[3]) atomicAdd(sum, w[0] + w[1] + w[2] + w[3]);
+}
+__global__ void group_id_kernel(uint32_t* __restrict__ gid, const uint64_t* __restrict__ key, const uint8_t* __restrict__ group_of_rank,
+                                int shift, uint32_t mask, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) gid[i] = group_of_rank[(uint32_t)(key[i] >> shift) & mask];
 }
 // -> bounds: positions in c_gidx (record ids ordered by contig rank, input order inside) where the groups start;
 // one group (bounds = {0, n}) when there is nothing to gain.  The reads per left contig rank are known on the host
@@ -594,26 +609,46 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
     uint64_t counted = 0;
     for (uint64_t c : ctx->rank_hist) counted += c;
     if (counted != n) return fail(ctx, BF_ERR_STATE, "contig histogram of %llu reads for %llu evidence records", (unsigned long long)counted, (unsigned long long)n);
-    BF_TRY(ensure(ctx, ctx->c_gidx, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_hist, 64, false));
-    BF_TRY(ensure(ctx, ctx->c_c32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_k64a, n * 8, false));
-    BF_HIP(ctx, hipMemsetAsync(ctx->c_hist.p, 0, 8, st));
-    hipLaunchKernelGGL(record_bytes_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, 256), 2048)), dim3(256), 0, st, v.info, n,
-                       (unsigned long long*)ctx->c_hist.p);
-    BF_HIP(ctx, hipMemcpyAsync(record_bytes, ctx->c_hist.p, 8, hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, ctx->c_c32.as<uint32_t>(), n);
-    const unsigned shift = (unsigned)key_rank_shift(ctx->contig_bits);
-    BF_TRY(sort_pairs<uint64_t>(ctx, v.key, ctx->c_k64a.as<uint64_t>(), ctx->c_c32.as<uint32_t>(), ctx->c_gidx.as<uint32_t>(), n,
-                                shift, shift + (unsigned)ctx->contig_bits));
-    BF_SYNC(ctx, st);
-    BF_TRY(settle_counts(ctx));                           // the localise counters came along with this synchronisation
     // cut after the rank where the running count passes the next multiple of n / max_groups
     bounds.assign(1, 0);
     uint64_t run = 0;
+    std::vector<uint8_t> group_of(ctx->n_contigs, 0);
     for (uint32_t r = 0; r < ctx->n_contigs; r++) {
+        group_of[r] = (uint8_t)(bounds.size() - 1);
         run += ctx->rank_hist[r];
-        if (run >= n * bounds.size() / max_groups && run > bounds.back() && run < n) bounds.push_back(run);
+        if (run >= n * bounds.size() / max_groups && run > bounds.back() && run < n && bounds.size() < 255) bounds.push_back(run);
     }
     bounds.push_back(n);
+    const bool lsd = (ctx->cfg.flags & BF_FLAG_LSD_SORT) != 0;
+    BF_TRY(ensure(ctx, ctx->c_gidx, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_hist, 64 + ctx->n_contigs, false));
+    BF_TRY(ensure(ctx, ctx->c_c32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_k64a, n * 8, false));
+    BF_HIP(ctx, hipMemsetAsync(ctx->c_hist.p, 0, 8, st));
+    hipLaunchKernelGGL(record_bytes_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, 256), 1024)), dim3(256), 0, st, v.info, n,
+                       (unsigned long long*)ctx->c_hist.p);
+    BF_HIP(ctx, hipMemcpyAsync(record_bytes, ctx->c_hist.p, 8, hipMemcpyDeviceToHost, st));
+    if (bounds.size() > 2) {
+        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, ctx->c_c32.as<uint32_t>(), n);
+        const unsigned shift = (unsigned)key_rank_shift(ctx->contig_bits);
+        if (lsd) {
+            // round 1's cut: record ids ordered by contig rank, input order inside
+            BF_TRY(sort_pairs<uint64_t>(ctx, v.key, ctx->c_k64a.as<uint64_t>(), ctx->c_c32.as<uint32_t>(), ctx->c_gidx.as<uint32_t>(), n,
+                                        shift, shift + (unsigned)ctx->contig_bits));
+        } else {
+            // record ids ordered by GROUP, input order inside: a group's ids ascend, so what reads the records through them
+            // walks memory once (ordered by rank, a group was a dozen interleaved walks: 835 MB fetched for 60 MB used)
+            BF_TRY(ensure(ctx, ctx->c_a32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_b32, n * 4, false));
+            uint8_t* d_tab = ctx->c_hist.as<uint8_t>() + 64;
+            BF_HIP(ctx, hipMemcpyAsync(d_tab, group_of.data(), ctx->n_contigs, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(group_id_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, ctx->c_b32.as<uint32_t>(), v.key, d_tab, (int)shift,
+                               (1u << ctx->contig_bits) - 1, n);
+            unsigned gbits = 1;
+            while ((1u << gbits) < bounds.size() - 1) gbits++;
+            BF_TRY(sort_pairs<uint32_t>(ctx, ctx->c_b32.as<uint32_t>(), ctx->c_a32.as<uint32_t>(), ctx->c_c32.as<uint32_t>(),
+                                        ctx->c_gidx.as<uint32_t>(), n, 0, gbits));
+        }
+    }
+    BF_SYNC(ctx, st);                                     // (group_of is read by the copy above until here)
+    BF_TRY(settle_counts(ctx));                           // the localise counters came along with this synchronisation
     return BF_OK;
 }
 // sort keys and record ids of a group
@@ -625,6 +660,160 @@ __global__ void group_keys_kernel(uint32_t* __restrict__ key, uint32_t* __restri
 __global__ void zip_pos_kernel(int2* __restrict__ pos2, const int32_t* __restrict__ lpos, const int32_t* __restrict__ rpos, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) pos2[i] = make_int2(lpos[i], rpos[i]);
+}
+
+// ---- sorted space without a full sort: class partition + chunk sort ----------------------------------
+// What the sweep needs (detect.rs:193-227 restricted to one class, see the header comment of this file) is: the records
+// of one signature side by side, inside a signature in (lpos as u32, input index) order.  The ORDER OF THE SIGNATURES
+// among themselves is never used (the print order is computed from the seeds, cluster_keys_kernel).  So instead of
+// eight LSD radix passes over (lpos, signature) followed by three gathers through the permutation:
+//   1. comp[j] = signature << 32 | lpos, val[j] = {record id, rpos, key >> 32}    (one streaming kernel)
+//   2. two (three from 16M records on) stable radix passes on the low signature bits: 65536 buckets (2^20), each
+//      holding whole signatures, in input order inside
+//   3. bucket starts from the partitioned array (no histogram, no atomics), chunks of whole buckets of about
+//      kChunkBase records (a bucket belongs to the chunk its start lies in)
+//   4. one workgroup per chunk sorts it in LDS (bitonic on (comp, position in the chunk): input order breaks ties,
+//      as the stable sort of the reference does) and writes the sorted-space arrays; a record's id, rpos and upper
+//      key bits travelled with it through the partition passes (three words of payload), so nothing is gathered
+//   5. chunks too large for LDS (a signature with more records than fit: duplicate-heavy input) are set aside, sorted
+//      together by the radix sort on all 64 bits of comp and placed after the others.
+constexpr uint32_t kChunkBase = 320;            // chunk c = the buckets that start in [c * 320, (c + 1) * 320)
+constexpr uint32_t kChunkCap = 1024;            // records a workgroup sorts in LDS
+
+__global__ void comp_build_kernel(uint64_t* __restrict__ comp, RsV3* __restrict__ val, const uint32_t* __restrict__ idx,
+                                  const uint64_t* __restrict__ key, const int32_t* __restrict__ lpos, const int32_t* __restrict__ rpos, uint64_t m) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t i = idx ? idx[j] : (uint32_t)j;
+    const uint64_t k = key[i];
+    comp[j] = (k << 32) | (uint32_t)lpos[i];
+    val[j] = RsV3{i, (uint32_t)rpos[i], (uint32_t)(k >> 32)};       // what the sorted space needs besides comp: carried along, not fetched later
+}
+// bstart[b] = first position of bucket b in the partitioned array (= the next bucket's start when b is empty),
+// bstart[n_buckets] = m.  Every entry is written by exactly one thread: the one at the first record of the next
+// non-empty bucket (or the last record).
+__global__ void bucket_start_kernel(uint32_t* __restrict__ bstart, const uint64_t* __restrict__ comp, uint64_t m, int bits) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t mask = (1u << bits) - 1;
+    const uint32_t b = (uint32_t)(comp[j] >> 32) & mask;
+    const int64_t pb = j ? (int64_t)((uint32_t)(comp[j - 1] >> 32) & mask) : -1;
+    for (int64_t x = pb + 1; x <= (int64_t)b; x++) bstart[x] = (uint32_t)j;
+    if (j == m - 1) for (uint32_t x = b + 1; x <= mask + 1; x++) bstart[x] = (uint32_t)m;
+}
+// cstart[c] = where chunk c begins (c <= n_chunks; cstart[n_chunks] = m); osize[c] = its size if it is too large for LDS
+__global__ void chunk_table_kernel(uint32_t* __restrict__ cstart, uint32_t* __restrict__ osize, const uint32_t* __restrict__ bstart,
+                                   uint32_t n_buckets, uint32_t n_chunks, uint32_t m) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_chunks) return;
+    auto first_at_or_after = [&](uint64_t pos) -> uint32_t {      // start of the first bucket that starts at or after pos
+        if (pos >= m) return m;
+        uint32_t lo = 0, hi = n_buckets;                           // bstart is non-decreasing, bstart[n_buckets] = m
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (bstart[mid] >= pos) hi = mid; else lo = mid + 1; }
+        return bstart[lo];
+    };
+    const uint32_t s = first_at_or_after((uint64_t)c * kChunkBase);
+    cstart[c] = s;
+    if (c < n_chunks) {
+        const uint32_t e = first_at_or_after((uint64_t)(c + 1) * kChunkBase);
+        osize[c] = e - s > kChunkCap ? e - s : 0u;
+    }
+}
+struct SortedOut { uint64_t* skey; int32_t* slpos; int32_t* srpos; uint32_t* perm; };
+__device__ __forceinline__ void put_sorted(const SortedOut& o, uint64_t at, uint64_t comp, const RsV3& x) {
+    o.skey[at] = ((uint64_t)x.c << 32) | (comp >> 32);
+    o.slpos[at] = (int32_t)(uint32_t)comp;
+    o.srpos[at] = (int32_t)x.b;
+    o.perm[at] = x.a;
+}
+__global__ void __launch_bounds__(256) chunk_sort_kernel(const uint32_t* __restrict__ cstart, const uint64_t* __restrict__ obefore,
+                                                         const uint64_t* __restrict__ comp, const RsV3* __restrict__ val, SortedOut out,
+                                                         uint64_t* __restrict__ side_comp, RsV3* __restrict__ side_val) {
+    __shared__ uint64_t s_comp[kChunkCap];
+    __shared__ uint32_t s_li[kChunkCap];
+    __shared__ RsV3 s_v[kChunkCap];
+    const uint32_t c = blockIdx.x, t = threadIdx.x;
+    const uint32_t s = cstart[c], size = cstart[c + 1] - s;
+    if (size == 0) return;
+    const uint64_t ob = obefore[c];
+    if (size > kChunkCap) {                                      // set aside, in order (stable)
+        for (uint32_t r = t; r < size; r += 256) { side_comp[ob + r] = comp[s + r]; side_val[ob + r] = val[s + r]; }
+        return;
+    }
+    uint32_t P = 64;
+    while (P < size) P <<= 1;
+    for (uint32_t r = t; r < P; r += 256) {
+        const bool in = r < size;
+        s_comp[r] = in ? comp[s + r] : ~0ull;
+        s_li[r] = in ? r : 0xffffffffu;
+        if (in) s_v[r] = val[s + r];
+    }
+    // Bitonic network, pair p of a step with stride j: elements i = (p / j) * 2j + p % j and i + j.  Thread t takes the
+    // pairs t, t + 256, ...: with j <= 64 a wave's 64 pairs lie in 128 consecutive elements that no other wave
+    // touches, so only the steps with a longer stride (and the step after one) need the whole block to wait.
+    bool wide_before = true;                                     // the loads above came from every wave
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const bool wide = j > 64;
+            if (wide || wide_before) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            wide_before = wide;
+            for (uint32_t p = t; p < P / 2; p += 256) {
+                const uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i + j;
+                const uint64_t a = s_comp[i], b = s_comp[l];
+                const uint32_t ai = s_li[i], bi = s_li[l];
+                const bool gt = a > b || (a == b && ai > bi);
+                const bool asc = (i & k) == 0;
+                if (gt == asc) { s_comp[i] = b; s_comp[l] = a; s_li[i] = bi; s_li[l] = ai; }
+            }
+        }
+    }
+    __syncthreads();
+    const uint64_t base = (uint64_t)s - ob;
+    for (uint32_t r = t; r < size; r += 256) put_sorted(out, base + r, s_comp[r], s_v[s_li[r]]);
+}
+__global__ void side_write_kernel(const uint64_t* __restrict__ comp, const RsV3* __restrict__ val, SortedOut out, uint64_t base, uint64_t n) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) put_sorted(out, base + r, comp[r], val[r]);
+}
+
+// records [0, m) of the group (idx: their ids, or null = all of the view) -> sorted space
+static int class_order(bf_ctx* ctx, const OwnerView& v, const uint32_t* idx, uint64_t m, const SortedOut& out) {
+    const hipStream_t st = ctx->stream;
+    const unsigned B = 256;
+    int bits = m > (16u << 20) ? 20 : 16;
+    if (const char* e = getenv("BREAKFAST_HIP_BUCKET_BITS")) bits = std::min(20, std::max(1, atoi(e)));      // tests: few buckets = chunks that overflow
+    const uint32_t n_buckets = 1u << bits;
+    const uint32_t n_chunks = (uint32_t)((m + kChunkBase - 1) / kChunkBase);
+    // chunk table: cstart u32[n_chunks + 1] | osize u32[n_chunks] | obefore u64[n_chunks + 1]
+    const size_t off_osize = ((size_t)(n_chunks + 1) * 4 + 255) & ~(size_t)255;
+    const size_t off_obefore = (off_osize + (size_t)n_chunks * 4 + 255) & ~(size_t)255;
+    const size_t comp_bytes = (m * 8 + 255) & ~(size_t)255;
+    BF_TRY(ensure(ctx, ctx->c_chunk, off_obefore + (size_t)(n_chunks + 1) * 8, false));
+    BF_TRY(ensure(ctx, ctx->c_bstart, (size_t)(n_buckets + 1) * 4, false));
+    BF_TRY(ensure(ctx, ctx->c_comp, comp_bytes + m * sizeof(RsV3), false));       // partitioned: comp, then the payload
+    BF_TRY(ensure(ctx, ctx->c_pos2, m * sizeof(RsV3), false));
+    uint64_t* comp_in = ctx->c_k64a.as<uint64_t>(); RsV3* val_in = ctx->c_pos2.as<RsV3>();
+    uint64_t* comp_s = ctx->c_comp.as<uint64_t>(); RsV3* val_s = (RsV3*)(ctx->c_comp.as<uint8_t>() + comp_bytes);
+    uint32_t* cstart = ctx->c_chunk.as<uint32_t>();
+    uint32_t* osize = (uint32_t*)(ctx->c_chunk.as<uint8_t>() + off_osize);
+    uint64_t* obefore = (uint64_t*)(ctx->c_chunk.as<uint8_t>() + off_obefore);
+    hipLaunchKernelGGL(comp_build_kernel, dim3(grid_for(m, B)), dim3(B), 0, st, comp_in, val_in, idx, v.key, v.lpos, v.rpos, m);
+    BF_TRY(radix_sort_kv3(ctx, comp_in, comp_s, val_in, val_s, m, 32, 32 + (unsigned)bits));
+    hipLaunchKernelGGL(bucket_start_kernel, dim3(grid_for(m, B)), dim3(B), 0, st, ctx->c_bstart.as<uint32_t>(), comp_s, m, bits);
+    hipLaunchKernelGGL(chunk_table_kernel, dim3(grid_for(n_chunks + 1, B)), dim3(B), 0, st, cstart, osize, ctx->c_bstart.as<uint32_t>(),
+                       n_buckets, n_chunks, (uint32_t)m);
+    BF_TRY(scan_u32_to_u64(ctx, osize, obefore, n_chunks));
+    hipLaunchKernelGGL(chunk_sort_kernel, dim3(n_chunks), dim3(256), 0, st, cstart, obefore, comp_s, val_s, out, comp_in, val_in);
+    BF_HIP(ctx, hipGetLastError());
+    uint64_t n_over = 0;
+    BF_TRY(fetch_u64(ctx, obefore + n_chunks, &n_over));
+    if (n_over) {
+        if (n_over > m) return fail(ctx, BF_ERR_HIP, "class order: %llu records set aside out of %llu", (unsigned long long)n_over, (unsigned long long)m);
+        BF_TRY(radix_sort_kv3(ctx, comp_in, comp_s, val_in, val_s, n_over, 0, 64));
+        hipLaunchKernelGGL(side_write_kernel, dim3(grid_for(n_over, B)), dim3(B), 0, st, comp_s, val_s, out, m - n_over, n_over);
+        BF_HIP(ctx, hipGetLastError());
+    }
+    return BF_OK;
 }
 
 // ---- the cluster stage -----------------------------------------------------------------------
@@ -650,7 +839,11 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
     BF_TRY(ensure(ctx, ctx->c_slpos, n * 4)); BF_TRY(ensure(ctx, ctx->c_srpos, n * 4));
     BF_TRY(ensure(ctx, ctx->c_pos2, v.n * 8));
     uint32_t* perm = ctx->c_a32.as<uint32_t>();
-    {
+    if (!(ctx->cfg.flags & BF_FLAG_LSD_SORT)) {
+        Scope t(ctx, "sort");
+        const SortedOut so{ctx->c_k64b.as<uint64_t>(), ctx->c_slpos.as<int32_t>(), ctx->c_srpos.as<int32_t>(), perm};
+        BF_TRY(class_order(ctx, v, grp ? grp->idx : nullptr, n, so));
+    } else {
         Scope t(ctx, "sort");
         const uint32_t* keys1 = (const uint32_t*)v.lpos;
         if (!grp) {

@@ -28,8 +28,7 @@ constexpr int kRsBins = 256;
 #ifndef RS_ITEMS
 #define RS_ITEMS 16
 #endif
-constexpr int kRsItems = RS_ITEMS;                   // pairs per thread
-constexpr int kRsTile = kRsThreads * kRsItems;       // 4096 pairs per tile
+// pairs per thread: RS_ITEMS (tiles of 4096 pairs) for one word of payload, 8 for three
 constexpr uint32_t kRsFewTiles = 64;                 // up to here the downsweep scans the tile counts itself
 
 // ---- radix sort --------------------------------------------------------------------------------------
@@ -48,9 +47,10 @@ __device__ __forceinline__ uint64_t same_digit_lanes(uint32_t d) {
 // upsweep: counts[d * tiles + tile] = keys of the tile with digit d.  Plain LDS atomics: with spread-out digits
 // they cost a few cycles per 64 keys, and with the few-valued upper digits of the class keys (contig ranks,
 // strands) no more than matching the lanes with ballots first would (measured: 30 -> 14 us per 10M keys).
-template <class K>
+template <class K, int kRsItems>
 __global__ void __launch_bounds__(256) rs_upsweep_kernel(const K* __restrict__ kin, uint64_t n, int shift, uint32_t digit_mask,
                                                          uint32_t* __restrict__ counts, uint32_t tiles) {
+    constexpr int kRsTile = kRsThreads * kRsItems;
     __shared__ uint32_t h[kRsBins];
     const int t = threadIdx.x;
     h[t] = 0;
@@ -97,17 +97,18 @@ __global__ void __launch_bounds__(256) rs_tilescan_kernel(uint32_t* __restrict__
     if (t == 0) totals[blockIdx.x] = s_carry;
 }
 
-template <class K>
+template <class K, class V, int kRsItems>
 __global__ void __launch_bounds__(256) rs_downsweep_kernel(const K* __restrict__ kin, K* __restrict__ kout,
-                                                           const uint32_t* __restrict__ vin, uint32_t* __restrict__ vout,
+                                                           const V* __restrict__ vin, V* __restrict__ vout,
                                                            uint64_t n, int shift, uint32_t digit_mask,
                                                            const uint32_t* __restrict__ tile_before /* [256][tiles] */,
                                                            const uint32_t* __restrict__ totals /* [256] */, uint32_t tiles) {
+    constexpr int kRsTile = kRsThreads * kRsItems;
     __shared__ uint32_t s_cnt[kRsWaves][kRsBins];    // per wave: running digit counts, later the wave's start inside the tile
     __shared__ uint32_t s_gofs[kRsBins];             // global position of a digit's run minus its start inside the tile
     __shared__ uint32_t s_scan[kRsWaves], s_scan2[kRsWaves];
     __shared__ K s_keys[kRsTile];
-    __shared__ uint32_t s_vals[kRsTile];
+    __shared__ V s_vals[kRsTile];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     for (int i = t; i < kRsWaves * kRsBins; i += 256) (&s_cnt[0][0])[i] = 0;
     __syncthreads();
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(256) rs_downsweep_kernel(const K* __restrict__
         const uint32_t pos = s_cnt[w][d] + rank[i];
         const uint64_t idx = wbase + (uint64_t)i * 64 + lane;
         s_keys[pos] = key[i];
-        s_vals[pos] = idx < n ? vin[idx] : 0u;
+        s_vals[pos] = idx < n ? vin[idx] : V{};
     }
     __syncthreads();
 #pragma unroll
@@ -192,38 +193,39 @@ __global__ void __launch_bounds__(256) rs_downsweep_kernel(const K* __restrict__
     }
 }
 
-template <class K>
-static int radix_sort_pairs_impl(bf_ctx* ctx, const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, uint64_t n,
+template <class K, class V, int kItems>
+static int radix_sort_pairs_impl(bf_ctx* ctx, const K* kin, K* kout, const V* vin, V* vout, uint64_t n,
                                  unsigned begin_bit, unsigned end_bit) {
+    constexpr int kTile = kRsThreads * kItems;
     if (n == 0) return BF_OK;
     if (n > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "radix sort of %llu pairs (limit 2^32-16)", (unsigned long long)n);
     hipStream_t st = ctx->stream;
     if (end_bit <= begin_bit) {                      // nothing to sort by: a stable sort is the identity
         BF_HIP(ctx, hipMemcpyAsync(kout, kin, n * sizeof(K), hipMemcpyDeviceToDevice, st));
-        BF_HIP(ctx, hipMemcpyAsync(vout, vin, n * 4, hipMemcpyDeviceToDevice, st));
+        BF_HIP(ctx, hipMemcpyAsync(vout, vin, n * sizeof(V), hipMemcpyDeviceToDevice, st));
         return BF_OK;
     }
     const int passes = (int)(end_bit - begin_bit + 7) / 8;          // <= 8
-    const uint32_t tiles = (uint32_t)((n + kRsTile - 1) / kRsTile);
+    const uint32_t tiles = (uint32_t)((n + kTile - 1) / kTile);
     // workspace: [digit totals 256 u32][tile counts 256 * tiles u32][tmp keys][tmp values]; all of it is written before it is read
     const size_t ctl_bytes = ((size_t)kRsBins * 4 + (size_t)kRsBins * tiles * 4 + 255) & ~(size_t)255;
     const size_t keys_bytes = (n * sizeof(K) + 255) & ~(size_t)255;
-    BF_TRY(ensure(ctx, ctx->c_tmp, ctl_bytes + keys_bytes + n * 4 + 256, false));
+    BF_TRY(ensure(ctx, ctx->c_tmp, ctl_bytes + keys_bytes + n * sizeof(V) + 256, false));
     uint8_t* ws = ctx->c_tmp.as<uint8_t>();
     uint32_t* totals = (uint32_t*)ws;
     uint32_t* counts = totals + kRsBins;
     K* ktmp = (K*)(ws + ctl_bytes);
-    uint32_t* vtmp = (uint32_t*)(ws + ctl_bytes + keys_bytes);
-    const K* src_k = kin; const uint32_t* src_v = vin;
+    V* vtmp = (V*)(ws + ctl_bytes + keys_bytes);
+    const K* src_k = kin; const V* src_v = vin;
     for (int p = 0; p < passes; p++) {
         const bool to_out = ((passes - 1 - p) & 1) == 0;             // the last pass lands in the caller's output
-        K* dst_k = to_out ? kout : ktmp; uint32_t* dst_v = to_out ? vout : vtmp;
+        K* dst_k = to_out ? kout : ktmp; V* dst_v = to_out ? vout : vtmp;
         const int sh = (int)begin_bit + 8 * p;
         const uint32_t mask = (1u << std::min(8, (int)end_bit - sh)) - 1;
-        hipLaunchKernelGGL(rs_upsweep_kernel<K>, dim3(tiles), dim3(256), 0, st, src_k, n, sh, mask, counts, tiles);
+        hipLaunchKernelGGL((rs_upsweep_kernel<K, kItems>), dim3(tiles), dim3(256), 0, st, src_k, n, sh, mask, counts, tiles);
         const bool few = tiles <= kRsFewTiles;
         if (!few) hipLaunchKernelGGL(rs_tilescan_kernel, dim3(kRsBins), dim3(256), 0, st, counts, tiles, totals);
-        hipLaunchKernelGGL(rs_downsweep_kernel<K>, dim3(tiles), dim3(256), 0, st, src_k, dst_k, src_v, dst_v, n, sh, mask,
+        hipLaunchKernelGGL((rs_downsweep_kernel<K, V, kItems>), dim3(tiles), dim3(256), 0, st, src_k, dst_k, src_v, dst_v, n, sh, mask,
                            counts, few ? (const uint32_t*)nullptr : totals, tiles);
         src_k = dst_k; src_v = dst_v;
     }
@@ -233,11 +235,17 @@ static int radix_sort_pairs_impl(bf_ctx* ctx, const K* kin, K* kout, const uint3
 
 int radix_sort_pairs(bf_ctx* ctx, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n,
                      unsigned begin_bit, unsigned end_bit) {
-    return radix_sort_pairs_impl<uint32_t>(ctx, kin, kout, vin, vout, n, begin_bit, end_bit);
+    return radix_sort_pairs_impl<uint32_t, uint32_t, RS_ITEMS>(ctx, kin, kout, vin, vout, n, begin_bit, end_bit);
 }
 int radix_sort_pairs(bf_ctx* ctx, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n,
                      unsigned begin_bit, unsigned end_bit) {
-    return radix_sort_pairs_impl<uint64_t>(ctx, kin, kout, vin, vout, n, begin_bit, end_bit);
+    return radix_sort_pairs_impl<uint64_t, uint32_t, RS_ITEMS>(ctx, kin, kout, vin, vout, n, begin_bit, end_bit);
+}
+// 64-bit keys with three words of payload (the class partition of the cluster stage carries a record's id, right
+// position and upper key bits along instead of fetching them through the id afterwards): tiles of 2048, 44 KB of LDS
+int radix_sort_kv3(bf_ctx* ctx, const uint64_t* kin, uint64_t* kout, const RsV3* vin, RsV3* vout, uint64_t n,
+                   unsigned begin_bit, unsigned end_bit) {
+    return radix_sort_pairs_impl<uint64_t, RsV3, 8>(ctx, kin, kout, vin, vout, n, begin_bit, end_bit);
 }
 
 // ---- scans -------------------------------------------------------------------------------------------

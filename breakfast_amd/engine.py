@@ -27,6 +27,7 @@ BF_FLAG_WEAK_DEDUP_HASH = 64
 BF_FLAG_ONE_GROUP = 128
 BF_FLAG_GROUPS_ALWAYS = 256
 BF_FLAG_ONE_STREAM = 512
+BF_FLAG_LSD_SORT = 1024
 BF_EV_STRAND, BF_EV_MSTRAND, BF_EV_SWAPPED, BF_EV_EXACT, BF_EV_SIGX = 1, 2, 4, 8, 16
 
 HIT_DTYPE = np.dtype([("pos5", "<u4"), ("pos3", "<u4"), ("contig5", "<u2"), ("contig3", "<u2"),

@@ -70,6 +70,8 @@ typedef struct {
 #define BF_FLAG_ONE_GROUP    128u   /* A/B + tests: cluster all contigs in one go instead of a few contig ranks at a time with
                                       each group's records copied to the host behind the next group's kernels */
 #define BF_FLAG_GROUPS_ALWAYS 256u  /* tests: the groups even for inputs below the size where they pay (4M reads) */
+#define BF_FLAG_LSD_SORT    1024u   /* A/B + tests: the cluster stage orders its records with the eight-pass LSD radix sort and three
+                                       gathers of round 1 instead of the class partition + chunk sort */
 #define BF_FLAG_ONE_STREAM   512u   /* profiling: every kernel and copy of the ctx on ONE stream, nothing overlaps (a kernel trace then
                                       shows each kernel's own duration, not its share of a GPU it has to share with the result copy) */
 #define BF_FLAG_DEVICE_ROUTING 16u /* multi-rank: bf_clusterise leaves the read table on the device (result.reads

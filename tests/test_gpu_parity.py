@@ -233,6 +233,38 @@ def test_dedup_over_cluster_sizes(n_reads, n_events):
     check_against_oracle(g, b, 20, flags=BF_FLAG_WEAK_DEDUP_HASH)
 
 
+@pytest.mark.parametrize("cfg,scale,gscale", [(0, 0.05, 0.02), (1, 0.004, 0.002), (3, 0.001, 0.002), (4, 0.002, 0.002)])
+def test_scaled_baseline_config_lsd_sort(cfg, scale, gscale):
+    """The round-1 ordering of the cluster stage (eight LSD radix passes + gathers), kept for A/B."""
+    contigs, gk, spec = synth.config(cfg, scale=scale, genome_scale=gscale)
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    check_against_oracle(g, b, spec.anchor_len, flags=engine.BF_FLAG_LSD_SORT)
+    check_against_oracle(g, b, spec.anchor_len, flags=engine.BF_FLAG_LSD_SORT | BF_FLAG_GROUPS_ALWAYS)
+
+
+@pytest.mark.parametrize("bits", [None, "20", "9", "1"])
+def test_class_order_chunks_that_overflow(bits, monkeypatch):
+    """Class partition + chunk sort: signatures with thousands of records (chunks too large for LDS are set aside and
+    sorted by the radix sort), beside thousands of small ones; and the same with 2^20, 512 and 2 buckets (test hook):
+    with two buckets EVERY chunk overflows."""
+    if bits:
+        monkeypatch.setenv("BREAKFAST_HIP_BUCKET_BITS", bits)
+    contigs = [("chr1", 300000), ("chr10", 200000), ("chr2", 250000)]
+    g = synth.make_genome(contigs, seed=15)
+    heavy = synth.make_reads(g, synth.ReadSpec(n_reads=12000, read_len=100, anchor_len=20, n_events=5, singleton_frac=0.0, mate_frac=0.3,
+                                               seed=77, margin=300))
+    light = synth.make_reads(g, synth.ReadSpec(n_reads=20000, read_len=100, anchor_len=20, n_events=2500, singleton_frac=0.4, mate_frac=0.2,
+                                               seed=78, margin=300, frag_base=12000))
+    import test_gpu_submit as tgs
+    b = tgs.concat([heavy.slice(0, 5000), light, heavy.slice(5000, heavy.n)])
+    res, ref = check_against_oracle(g, b, 20)
+    sizes = (res.clusters["read_end"] - res.clusters["read_begin"]).astype(np.int64)
+    assert sizes.max() > 1024
+    check_against_oracle(g, b, 20, flags=BF_FLAG_GROUPS_ALWAYS)
+    check_against_oracle(g, b, 20, flags=BF_FLAG_FORCE_EXACT)
+
+
 def test_scaled_config_exact_kernel_only():
     contigs, gk, spec = synth.config(1, scale=0.0005, genome_scale=0.002)
     g = synth.make_genome(contigs, **gk)
