@@ -351,7 +351,9 @@ struct ClusterGroup {
     uint64_t cl_base, rd_base, cap;
     uint64_t ns = 0, nr = 0;           // out: clusters and supporting reads this group added
 };
-int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::vector<uint64_t>& bounds, uint64_t* record_bytes);
+int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::vector<uint64_t>& bounds, uint64_t* record_bytes,
+                   const std::vector<uint64_t>* view_hist = nullptr);   // view_hist: records per left contig rank of an imported view
+int rank_histogram(bf_ctx* ctx, const OwnerView& v, std::vector<uint64_t>& hist);
 int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* g = nullptr);   // fills ctx->out (without junction text)
 int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint64_t dev_send_bytes, uint64_t* counts,
                   void** dev_out, uint32_t* record_bytes);
@@ -373,6 +375,7 @@ int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
 int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n, uint64_t rd_base = 0, uint64_t byte_base = 0);
 int cluster_record_offsets(bf_ctx* ctx, const uint64_t* d_joff, uint64_t* d_out, uint64_t n_clusters, uint64_t byte_base = 0);
 int order_requests(bf_ctx* ctx, uint32_t K, uint32_t* d_req, uint64_t** d_start, uint64_t** d_bytes);
+int order_requests_range(bf_ctx* ctx, uint64_t rd_base, uint64_t nr, uint32_t* d_req, uint64_t** d_start);
 int scatter_ordered(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_records, uint64_t size);
 int scatter_records(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_records, uint64_t size, const int64_t* d_pos);
 int read_sizes(bf_ctx* ctx, uint32_t* d_out, uint64_t n);

@@ -600,14 +600,42 @@ __global__ void group_id_kernel(uint32_t* __restrict__ gid, const uint64_t* __re
 // one group (bounds = {0, n}) when there is nothing to gain.  The reads per left contig rank are known on the host
 // (bf_submit's staging threads count them from the hits: the rank after the reorient step is the smaller of the two
 // anchors' ranks), so the cut costs the GPU one radix pass on the rank bits of the class keys and a sum.
-int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::vector<uint64_t>& bounds, uint64_t* record_bytes) {
+// Records per left contig rank of an IMPORTED view (the sharded path: what arrived is not what bf_submit counted):
+// block histograms in LDS, one atomic per non-empty bin and block.  Up to 4096 contigs.
+constexpr uint32_t kRankHistMax = 4096;
+__global__ void __launch_bounds__(256) rank_hist_kernel(unsigned long long* __restrict__ hist, const uint64_t* __restrict__ key, int shift,
+                                                        uint32_t mask, uint32_t bins, uint64_t n) {
+    __shared__ uint32_t h[kRankHistMax];
+    for (uint32_t b = threadIdx.x; b < bins; b += 256) h[b] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        atomicAdd(&h[min((uint32_t)(key[i] >> shift) & mask, bins - 1)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < bins; b += 256) if (h[b]) atomicAdd(&hist[b], (unsigned long long)h[b]);
+}
+int rank_histogram(bf_ctx* ctx, const OwnerView& v, std::vector<uint64_t>& hist) {
+    hist.assign(ctx->n_contigs, 0);
+    if (v.n == 0 || ctx->n_contigs > kRankHistMax) return BF_OK;
+    const hipStream_t st = ctx->stream;
+    BF_TRY(ensure(ctx, ctx->c_bstart, std::max<size_t>((size_t)ctx->n_contigs * 8, 64), false));
+    BF_HIP(ctx, hipMemsetAsync(ctx->c_bstart.p, 0, (size_t)ctx->n_contigs * 8, st));
+    hipLaunchKernelGGL(rank_hist_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(v.n, 256), 512)), dim3(256), 0, st,
+                       (unsigned long long*)ctx->c_bstart.p, v.key, key_rank_shift(ctx->contig_bits), (1u << ctx->contig_bits) - 1, ctx->n_contigs, v.n);
+    BF_HIP(ctx, hipMemcpyAsync(hist.data(), ctx->c_bstart.p, (size_t)ctx->n_contigs * 8, hipMemcpyDeviceToHost, st));
+    BF_SYNC(ctx, st);
+    return BF_OK;
+}
+
+int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::vector<uint64_t>& bounds, uint64_t* record_bytes,
+                   const std::vector<uint64_t>* view_hist) {
     const uint64_t n = v.n;
     const hipStream_t st = ctx->stream;
     bounds.assign(1, 0); bounds.push_back(n);
     *record_bytes = 0;
-    if (max_groups < 2 || n == 0 || v.src_rank || ctx->rank_hist.size() != ctx->n_contigs) return BF_OK;
+    const std::vector<uint64_t>& rank_hist = view_hist ? *view_hist : ctx->rank_hist;
+    if (max_groups < 2 || n == 0 || (v.src_rank && !view_hist) || rank_hist.size() != ctx->n_contigs) return BF_OK;
     uint64_t counted = 0;
-    for (uint64_t c : ctx->rank_hist) counted += c;
+    for (uint64_t c : rank_hist) counted += c;
     if (counted != n) return fail(ctx, BF_ERR_STATE, "contig histogram of %llu reads for %llu evidence records", (unsigned long long)counted, (unsigned long long)n);
     // cut after the rank where the running count passes the next multiple of n / max_groups
     bounds.assign(1, 0);
@@ -615,7 +643,7 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
     std::vector<uint8_t> group_of(ctx->n_contigs, 0);
     for (uint32_t r = 0; r < ctx->n_contigs; r++) {
         group_of[r] = (uint8_t)(bounds.size() - 1);
-        run += ctx->rank_hist[r];
+        run += rank_hist[r];
         if (run >= n * bounds.size() / max_groups && run > bounds.back() && run < n && bounds.size() < 255) bounds.push_back(run);
     }
     bounds.push_back(n);
@@ -692,7 +720,7 @@ __global__ void comp_build_kernel(uint64_t* __restrict__ comp, RsV3* __restrict_
 // bstart[b] = first position of bucket b in the partitioned array (= the next bucket's start when b is empty),
 // bstart[n_buckets] = m.  Every entry is written by exactly one thread: the one at the first record of the next
 // non-empty bucket (or the last record).
-__global__ void bucket_start_kernel(uint32_t* __restrict__ bstart, const uint64_t* __restrict__ comp, uint64_t m, int bits) {
+__global__ void class_bucket_start_kernel(uint32_t* __restrict__ bstart, const uint64_t* __restrict__ comp, uint64_t m, int bits) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const uint32_t mask = (1u << bits) - 1;
@@ -799,7 +827,7 @@ static int class_order(bf_ctx* ctx, const OwnerView& v, const uint32_t* idx, uin
     uint64_t* obefore = (uint64_t*)(ctx->c_chunk.as<uint8_t>() + off_obefore);
     hipLaunchKernelGGL(comp_build_kernel, dim3(grid_for(m, B)), dim3(B), 0, st, comp_in, val_in, idx, v.key, v.lpos, v.rpos, m);
     BF_TRY(radix_sort_kv3(ctx, comp_in, comp_s, val_in, val_s, m, 32, 32 + (unsigned)bits));
-    hipLaunchKernelGGL(bucket_start_kernel, dim3(grid_for(m, B)), dim3(B), 0, st, ctx->c_bstart.as<uint32_t>(), comp_s, m, bits);
+    hipLaunchKernelGGL(class_bucket_start_kernel, dim3(grid_for(m, B)), dim3(B), 0, st, ctx->c_bstart.as<uint32_t>(), comp_s, m, bits);
     hipLaunchKernelGGL(chunk_table_kernel, dim3(grid_for(n_chunks + 1, B)), dim3(B), 0, st, cstart, osize, ctx->c_bstart.as<uint32_t>(),
                        n_buckets, n_chunks, (uint32_t)m);
     BF_TRY(scan_u32_to_u64(ctx, osize, obefore, n_chunks));
@@ -1436,6 +1464,34 @@ int order_requests(bf_ctx* ctx, uint32_t K, uint32_t* d_req, uint64_t** d_start,
                        ctx->c_b32.as<uint32_t>(), aoff, nr, groups);
     BF_HIP(ctx, hipGetLastError());
     *d_start = start; *d_bytes = bytes;
+    return BF_OK;
+}
+// The same for supporting reads [rd_base, rd_base + nr) of a result that is appended group by group (one piece):
+// d_req[j] = source index of the j-th request in (source rank, result order); start[s] = first request to rank s.
+// Leaves the order in c_d32 and the sorted source ranks in c_b32 (place_kernel reads them).
+int order_requests_range(bf_ctx* ctx, uint64_t rd_base, uint64_t nr, uint32_t* d_req, uint64_t** d_start) {
+    const uint32_t W = ctx->n_ranks;
+    const uint64_t stride = ctx->rsrc_stride;
+    const hipStream_t st = ctx->stream;
+    BF_TRY(ensure(ctx, ctx->c_a32, nr * 4, false)); BF_TRY(ensure(ctx, ctx->c_b32, nr * 4, false));
+    BF_TRY(ensure(ctx, ctx->c_c32, nr * 4, false)); BF_TRY(ensure(ctx, ctx->c_d32, nr * 4, false));
+    BF_TRY(ensure(ctx, ctx->c_aoff, (nr + 1) * 8 + (size_t)(W + 1) * 16 + nr * 4 + 16));
+    uint64_t* aoff = ctx->c_aoff.as<uint64_t>();
+    uint64_t* start = aoff + nr + 1; uint64_t* bytes = start + W + 1;
+    uint32_t* len = (uint32_t*)(bytes + W + 1);
+    const uint32_t* src = ctx->c_rsrc.as<uint32_t>() + rd_base;     // out_src_rank, out_src_idx, out_rec, out_jrec: `stride` apart
+    hipLaunchKernelGGL(request_keys_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, st, ctx->c_a32.as<uint32_t>(),
+                       ctx->c_c32.as<uint32_t>(), src, nr, 1u, W);
+    unsigned bits = 1; while ((1u << bits) < W) bits++;
+    BF_TRY(sort_pairs<uint32_t>(ctx, ctx->c_a32.as<uint32_t>(), ctx->c_b32.as<uint32_t>(), ctx->c_c32.as<uint32_t>(),
+                                ctx->c_d32.as<uint32_t>(), nr, 0, bits));
+    hipLaunchKernelGGL(request_gather_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, st, d_req, len, ctx->c_d32.as<uint32_t>(),
+                       src + stride, src + 3 * stride, nr);
+    BF_TRY(scan_u32_to_u64(ctx, len, aoff, nr));
+    hipLaunchKernelGGL(request_bounds_kernel, dim3(grid_for(W + 1, 256)), dim3(256), 0, st, start, bytes,
+                       ctx->c_b32.as<uint32_t>(), aoff, nr, W);
+    BF_HIP(ctx, hipGetLastError());
+    *d_start = start;
     return BF_OK;
 }
 int scatter_ordered(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_records, uint64_t size) {

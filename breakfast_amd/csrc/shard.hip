@@ -210,12 +210,32 @@ struct HostTransport : Transport {
 struct Shard {
     Transport* tr = nullptr;
     std::vector<uint64_t> bases;                // index_base of every rank
-    DevBuf d_send, d_recv, d_req_out, d_req_in, d_place, d_small, d_roff, d_rbytes;
+    DevBuf d_send, d_recv, d_req_out, d_req_in, d_place, d_small, d_roff, d_roff_g, d_rbytes;
     HostBuf h_places, h_roff, h_rbytes;
     ~Shard() { delete tr; }
 };
 
 Shard* shard_of(bf_ctx* ctx) { return (Shard*)ctx->shard; }
+
+
+// a group's record offsets (n + 1 of them, from 0) appended to the rank's list, shifted by the bytes before them
+__global__ void offsets_append_kernel(uint64_t* __restrict__ all, const uint64_t* __restrict__ part, uint64_t byte_base, uint64_t n) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) all[k] = part[k] + byte_base;
+}
+// pinned host buffer that keeps its first `used` bytes when it has to grow (copies into it may be in flight)
+static int grow_host_keep(bf_ctx* ctx, HostBuf& b, size_t used, size_t need) {
+    if (need <= b.cap && b.p) return BF_OK;
+    BF_SYNC(ctx, ctx->stream);
+    BF_SYNC(ctx, ctx->copy_stream);
+    void* p = nullptr;
+    const size_t cap = std::max<size_t>(need + need / 2, 4096);
+    const hipError_t e = hipHostMalloc(&p, cap, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, BF_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+    if (b.p) { if (used) memcpy(p, b.p, std::min(used, b.cap)); (void)hipHostFree(b.p); }
+    b.p = p; b.cap = cap;
+    return BF_OK;
+}
 
 // place[i] = (source rank, slot in that source's record list) of supporting read i: the reads sorted by source rank
 // are position j = order^-1(i); the slot counts from the first request of this owner to that source
@@ -257,7 +277,7 @@ int shard_attach(bf_ctx* ctx, Transport* tr, uint32_t rank, uint32_t n_ranks, ui
 void shard_destroy(bf_ctx* ctx) {
     Shard* sh = shard_of(ctx);
     if (!sh) return;
-    DevBuf* bufs[] = {&sh->d_send, &sh->d_recv, &sh->d_req_out, &sh->d_req_in, &sh->d_place, &sh->d_small, &sh->d_roff, &sh->d_rbytes};
+    DevBuf* bufs[] = {&sh->d_send, &sh->d_recv, &sh->d_req_out, &sh->d_req_in, &sh->d_place, &sh->d_small, &sh->d_roff, &sh->d_roff_g, &sh->d_rbytes};
     for (DevBuf* b : bufs) release(ctx, *b);
     HostBuf* hosts[] = {&sh->h_places, &sh->h_roff, &sh->h_rbytes};
     for (HostBuf* h : hosts) { if (h->p) (void)hipHostFree(h->p); h->p = nullptr; h->cap = 0; }
@@ -398,7 +418,11 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
     ctx->src_index_base = sh->bases;
     BF_TRY(run_import(ctx, sh->d_recv.p, src_counts.data()));
 
-    // 4. the owner's cluster stage (detect.rs:190-231, 247-287)
+    // 4.-7. the owner's cluster stage (detect.rs:190-231, 247-287), a few contig ranks at a time like bf_finish on one
+    //       GPU: when a group is clustered its supporting reads are requested from their source ranks, and the sources
+    //       render and copy those records to their host memory WHILE the owners cluster the next group.  Every rank
+    //       runs the same number of groups (agreed from the exchange counts every rank knows; a rank whose records
+    //       cut into fewer groups takes part in the remaining rounds with nothing to ask for).
     OwnerView v;
     v.n = ctx->n_imported;
     v.key = ctx->i_key.as<uint64_t>(); v.lpos = ctx->i_lpos.as<int32_t>(); v.rpos = ctx->i_rpos.as<int32_t>();
@@ -410,89 +434,137 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
     v.info = ctx->i_jrec.as<uint64_t>();
     ctx->clustered = false; ctx->table_attached = false; ctx->junction_attached = 0; ctx->reads_on_device = false;
     ctx->result_order = false; ctx->sources_on_device = false;
-    BF_TRY(run_cluster(ctx, v));
-    ctx->clustered = true;
-    const uint64_t nr = ctx->out.n_reads, ncl = ctx->out.n_clusters;
+    ctx->out.n_clusters = ctx->out.n_reads = 0; ctx->n_evidence = v.n;
 
-    // 5. which source rank holds each supporting read: requests ordered by source rank (result order inside)
-    std::vector<uint64_t> req_counts(W, 0), start(W + 1, 0);
-    uint64_t* d_start = nullptr; uint64_t* d_gbytes = nullptr;
-    BF_TRY(ensure(ctx, sh->d_req_out, std::max<uint64_t>(nr, 1) * 4));
-    if (nr) {
-        ctx->rsrc_stride = nr;
-        BF_TRY(order_requests(ctx, 1, sh->d_req_out.as<uint32_t>(), &d_start, &d_gbytes));
-        BF_HIP(ctx, hipMemcpyAsync(start.data(), d_start, (size_t)(W + 1) * 8, hipMemcpyDeviceToHost, st));
-        BF_SYNC(ctx, st);
-        for (uint32_t s = 0; s < W; s++) req_counts[s] = start[s + 1] - start[s];
+    uint64_t max_owned = 0;
+    for (uint32_t d = 0; d < W; d++) {
+        uint64_t owned = 0;
+        for (uint32_t s2 = 0; s2 < W; s2++) owned += cm[(size_t)s2 * W + d];
+        max_owned = std::max(max_owned, owned);
     }
-    std::vector<uint64_t> rm((size_t)W * W);                        // rm[o * W + s] = requests of owner o to source s
-    BF_TRY(tr->all_gather(ctx, req_counts.data(), W, rm.data()));
-    // slots: a source lists the requests of owner 0, then owner 1, ...: mine start after the earlier owners'
-    std::vector<uint64_t> ctl((size_t)2 * (W + 1));
-    uint64_t n_in = 0;
-    for (uint32_t s = 0; s < W; s++) {
-        uint64_t before = 0;
-        for (uint32_t o = 0; o < me; o++) before += rm[(size_t)o * W + s];
-        ctl[s] = before;
+    uint32_t G = 1;                                                  // the same on every rank: flags and config must agree
+    if (ctx->cfg.flags & BF_FLAG_ONE_GROUP) G = 1;
+    else if (ctx->cfg.reserved[0]) G = std::min<uint32_t>(ctx->cfg.reserved[0], 64u);
+    else if (ctx->cfg.flags & BF_FLAG_GROUPS_ALWAYS) G = 2;
+    // (by itself the stage runs in one go: measured on one MI355X through RCCL, configs[1], two groups 9.19 ms per step
+    //  against 9.24, three 9.57, four 9.96 -- a group costs some sixty launches and five host round trips, and the step is
+    //  bound by the host's launch rate before the first byte leaves and by PCIe afterwards, so the overlap buys nothing)
+    (void)max_owned;
+    std::vector<uint64_t> gb{0, v.n};
+    if (G > 1 && v.n) {
+        std::vector<uint64_t> hist;
+        uint64_t unused = 0;
+        BF_TRY(rank_histogram(ctx, v, hist));
+        BF_TRY(cluster_groups(ctx, v, G, gb, &unused, &hist));
     }
-    for (uint32_t o = 0; o < W; o++) n_in += rm[(size_t)o * W + me];
-    if (n_in > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "sharded path: %llu junction requests for one rank", (unsigned long long)n_in);
-    BF_TRY(ensure(ctx, sh->d_place, std::max<uint64_t>(nr, 1) * sizeof(bf_place)));
-    if (nr) {
-        BF_TRY(ensure(ctx, sh->d_small, (size_t)(W + 1) * 8));
-        BF_HIP(ctx, hipMemcpyAsync(sh->d_small.p, ctl.data(), (size_t)W * 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(place_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, st, sh->d_place.as<bf_place>(), ctx->c_d32.as<uint32_t>(),
-                           ctx->c_b32.as<uint32_t>(), d_start, sh->d_small.as<uint64_t>(), nr);
-        BF_HIP(ctx, hipGetLastError());
-        BF_TRY(ensure_host(ctx, sh->h_places, nr * sizeof(bf_place)));
-        BF_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-        BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[0], 0));
-        BF_HIP(ctx, hipMemcpyAsync(sh->h_places.p, sh->d_place.p, nr * sizeof(bf_place), hipMemcpyDeviceToHost, ctx->copy_stream));
-    }
+    const size_t my_groups = gb.size() - 1;
 
-    // 6. the request lists go to the sources (4 bytes a read)
-    for (uint32_t o = 0; o < W; o++) for (uint32_t s = 0; s < W; s++) bytes[(size_t)o * W + s] = rm[(size_t)o * W + s] * 4;
-    BF_TRY(ensure(ctx, sh->d_req_in, std::max<uint64_t>(n_in, 1) * 4));
-    {
-        Scope t(ctx, "request_alltoall");
-        BF_TRY(tr->all_to_all(ctx, sh->d_req_out.as<uint8_t>(), sh->d_req_in.as<uint8_t>(), bytes.data()));
-    }
-
-    // 7. source side: render the requested reads' junction records (detect.rs:155-162) and copy them to THIS
-    //    rank's host memory, chunk by chunk behind the next chunk's render
-    uint64_t rec_total = 0;
-    if (n_in) {
-        constexpr int kMaxChunks = 8;
-        const int nc = n_in >= (1u << 16) ? kMaxChunks : 1;
-        uint64_t off[kMaxChunks + 1];
-        const uint32_t* d_idx = sh->d_req_in.as<uint32_t>();
-        BF_TRY(ensure(ctx, sh->d_roff, (n_in + 1) * 8));
-        BF_TRY(ensure(ctx, ctx->r_idx, n_in * 4 + 16));
-        uint32_t* d_len = ctx->r_idx.as<uint32_t>();
-        uint32_t* d_bad = d_len + n_in;
-        BF_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, st));
-        BF_TRY(render_sizes_checked(ctx, n_in, d_idx, d_len, d_bad));
-        BF_TRY(render_prepare(ctx, n_in, d_idx, sh->d_roff, nc, off, d_len));
-        uint32_t bad = 0;
-        BF_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
-        BF_SYNC(ctx, st);
-        if (bad) return fail(ctx, BF_ERR_HIP, "sharded path: %u requested reads are not resident on rank %u", bad, me);
-        rec_total = off[nc];
-        BF_TRY(ensure(ctx, sh->d_rbytes, rec_total ? rec_total : 1));
-        BF_TRY(ensure_host(ctx, sh->h_rbytes, rec_total));
-        BF_TRY(ensure_host(ctx, sh->h_roff, (n_in + 1) * 8));
-        BF_HIP(ctx, hipEventRecord(ctx->ev[9], st));
-        BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[9], 0));
-        BF_HIP(ctx, hipMemcpyAsync(sh->h_roff.p, sh->d_roff.p, (n_in + 1) * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
-        for (int c = 0; c < nc; c++) {
-            BF_TRY(render_range(ctx, n_in * (uint64_t)c / nc, n_in * (uint64_t)(c + 1) / nc, d_idx, sh->d_roff, sh->d_rbytes));
-            if (off[c + 1] > off[c]) {
-                BF_HIP(ctx, hipEventRecord(ctx->ev[1 + c], st));
-                BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[1 + c], 0));
-                BF_HIP(ctx, hipMemcpyAsync(sh->h_rbytes.as<uint8_t>() + off[c], sh->d_rbytes.as<uint8_t>() + off[c], off[c + 1] - off[c],
-                                           hipMemcpyDeviceToHost, ctx->copy_stream));
+    std::vector<uint64_t> req_counts(W), start(W + 1), rm((size_t)W * W), ctl(W), recv_before(W, 0);
+    uint64_t cl_base = 0, rd_base = 0, n_in = 0, rec_total = 0;
+    for (uint32_t g = 0; g < G; g++) {
+        // the owner's side: cluster the group
+        uint64_t nr_g = 0, ns_g = 0;
+        if (g < my_groups && gb[g + 1] > gb[g]) {
+            if (G == 1) {
+                BF_TRY(run_cluster(ctx, v));
+                nr_g = ctx->out.n_reads; ns_g = ctx->out.n_clusters;
+            } else {
+                ClusterGroup grp{ctx->c_gidx.as<uint32_t>() + gb[g], gb[g + 1] - gb[g], cl_base, rd_base, v.n};
+                BF_TRY(run_cluster(ctx, v, &grp));
+                nr_g = grp.nr; ns_g = grp.ns;
             }
         }
+        // which source rank holds each of its supporting reads: requests ordered by source rank (result order inside)
+        std::fill(req_counts.begin(), req_counts.end(), 0);
+        uint64_t* d_start = nullptr;
+        BF_TRY(ensure(ctx, sh->d_req_out, std::max<uint64_t>(nr_g, 1) * 4));
+        if (nr_g) {
+            BF_TRY(order_requests_range(ctx, rd_base, nr_g, sh->d_req_out.as<uint32_t>(), &d_start));
+            BF_HIP(ctx, hipMemcpyAsync(start.data(), d_start, (size_t)(W + 1) * 8, hipMemcpyDeviceToHost, st));
+            BF_SYNC(ctx, st);
+            for (uint32_t s2 = 0; s2 < W; s2++) req_counts[s2] = start[s2 + 1] - start[s2];
+        }
+        BF_TRY(tr->all_gather(ctx, req_counts.data(), W, rm.data()));   // rm[o * W + s] = requests of owner o to source s
+        // slots: a source lists what it was asked in earlier groups, then this group's requests of owner 0, owner 1, ...
+        uint64_t n_in_g = 0;
+        for (uint32_t s2 = 0; s2 < W; s2++) {
+            uint64_t before = recv_before[s2];
+            for (uint32_t o = 0; o < me; o++) before += rm[(size_t)o * W + s2];
+            ctl[s2] = before;
+        }
+        for (uint32_t o = 0; o < W; o++) n_in_g += rm[(size_t)o * W + me];
+        if (n_in + n_in_g > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "sharded path: %llu junction requests for one rank", (unsigned long long)(n_in + n_in_g));
+        if (nr_g) {
+            BF_TRY(ensure(ctx, sh->d_place, (rd_base + nr_g) * sizeof(bf_place), true));
+            BF_TRY(ensure(ctx, sh->d_small, (size_t)(W + 1) * 8));
+            BF_HIP(ctx, hipMemcpyAsync(sh->d_small.p, ctl.data(), (size_t)W * 8, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(place_kernel, dim3(grid_for(nr_g, 256)), dim3(256), 0, st, sh->d_place.as<bf_place>() + rd_base,
+                               ctx->c_d32.as<uint32_t>(), ctx->c_b32.as<uint32_t>(), d_start, sh->d_small.as<uint64_t>(), nr_g);
+            BF_HIP(ctx, hipGetLastError());
+            BF_SYNC(ctx, st);                                        // (ctl is reused by the next group)
+        }
+        // the request lists go to the sources (4 bytes a read), appended to what came in earlier groups
+        for (uint32_t o = 0; o < W; o++) for (uint32_t s2 = 0; s2 < W; s2++) bytes[(size_t)o * W + s2] = rm[(size_t)o * W + s2] * 4;
+        BF_TRY(ensure(ctx, sh->d_req_in, std::max<uint64_t>(n_in + n_in_g, 1) * 4, true));
+        {
+            Scope t(ctx, "request_alltoall");
+            BF_TRY(tr->all_to_all(ctx, sh->d_req_out.as<uint8_t>(), sh->d_req_in.as<uint8_t>() + n_in * 4, bytes.data()));
+        }
+        // the source's side: render the requested reads' junction records (detect.rs:155-162) and copy them to THIS rank's
+        // host memory, chunk by chunk behind the next chunk's render (and behind the owners' next group)
+        if (n_in_g) {
+            constexpr int kMaxChunks = 8;
+            const int nc = n_in_g >= (1u << 16) ? (G > 1 ? 2 : kMaxChunks) : 1;
+            uint64_t off[kMaxChunks + 1];
+            const uint32_t* d_idx = sh->d_req_in.as<uint32_t>() + n_in;
+            BF_TRY(ensure(ctx, ctx->r_idx, n_in_g * 4 + 16));
+            uint32_t* d_len = ctx->r_idx.as<uint32_t>();
+            uint32_t* d_bad = d_len + n_in_g;
+            BF_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, st));
+            BF_TRY(render_sizes_checked(ctx, n_in_g, d_idx, d_len, d_bad));
+            BF_TRY(render_prepare(ctx, n_in_g, d_idx, sh->d_roff_g, nc, off, d_len));
+            uint32_t bad = 0;
+            BF_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+            BF_SYNC(ctx, st);
+            if (bad) return fail(ctx, BF_ERR_HIP, "sharded path: %u requested reads are not resident on rank %u", bad, me);
+            const uint64_t total_g = off[nc];
+            BF_TRY(ensure(ctx, sh->d_rbytes, std::max<uint64_t>(rec_total + total_g, 1), true));
+            BF_TRY(grow_host_keep(ctx, sh->h_rbytes, rec_total, rec_total + total_g));
+            BF_TRY(ensure(ctx, sh->d_roff, (n_in + n_in_g + 1) * 8, true));
+            hipLaunchKernelGGL(offsets_append_kernel, dim3(grid_for(n_in_g + 1, 256)), dim3(256), 0, st, sh->d_roff.as<uint64_t>() + n_in,
+                               sh->d_roff_g.as<uint64_t>(), rec_total, n_in_g + 1);
+            for (int c = 0; c < nc; c++) {
+                BF_TRY(render_range_at(ctx, n_in_g * (uint64_t)c / nc, n_in_g * (uint64_t)(c + 1) / nc, d_idx, sh->d_roff_g.as<uint64_t>(),
+                                       sh->d_rbytes.as<uint8_t>() + rec_total));
+                if (off[c + 1] > off[c]) {
+                    BF_HIP(ctx, hipEventRecord(ctx->ev[1 + c], st));
+                    BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[1 + c], 0));
+                    BF_HIP(ctx, hipMemcpyAsync(sh->h_rbytes.as<uint8_t>() + rec_total + off[c], sh->d_rbytes.as<uint8_t>() + rec_total + off[c],
+                                               off[c + 1] - off[c], hipMemcpyDeviceToHost, ctx->copy_stream));
+                }
+            }
+            rec_total += total_g;
+        }
+        for (uint32_t s2 = 0; s2 < W; s2++) for (uint32_t o = 0; o < W; o++) recv_before[s2] += rm[(size_t)o * W + s2];
+        cl_base += ns_g; rd_base += nr_g; n_in += n_in_g;
+    }
+    const uint64_t nr = rd_base, ncl = cl_base;
+    ctx->out.n_clusters = ncl; ctx->out.n_reads = nr;
+    ctx->clustered = true;
+    // rows (when groups appended them: the one-go path has copied them itself), places and record offsets -> host
+    BF_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[0], 0));
+    if (G > 1 && ncl) {
+        BF_TRY(ensure_host(ctx, ctx->out.clusters, ncl * sizeof(bf_cluster)));
+        BF_HIP(ctx, hipMemcpyAsync(ctx->out.clusters.p, ctx->c_clusters.p, ncl * sizeof(bf_cluster), hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+    if (nr) {
+        BF_TRY(ensure_host(ctx, sh->h_places, nr * sizeof(bf_place)));
+        BF_HIP(ctx, hipMemcpyAsync(sh->h_places.p, sh->d_place.p, nr * sizeof(bf_place), hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+    if (n_in) {
+        BF_TRY(ensure_host(ctx, sh->h_roff, (n_in + 1) * 8));
+        BF_HIP(ctx, hipMemcpyAsync(sh->h_roff.p, sh->d_roff.p, (n_in + 1) * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
     }
     BF_SYNC(ctx, st);
     BF_SYNC(ctx, ctx->copy_stream);                                  // rows, places and records are in host memory

@@ -33,10 +33,10 @@ def oracle_sv(g, b, A, F, E):
     return ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, A, F, E).sv
 
 
-def run_rank(rank, world, cuts, name, slot_bytes, transport, uid, steps, out_dir):
+def run_rank(rank, world, cuts, name, slot_bytes, transport, uid, steps, out_dir, flags=0):
     g, b, A, F, E = make_case()
     lo, hi = cuts[rank], cuts[rank + 1]
-    eng = engine.Engine(A, F, E, device=0, piece_reads=4000)
+    eng = engine.Engine(A, F, E, device=0, piece_reads=4000, flags=flags)
     try:
         eng.set_genome(g.names, g.seqs)
         if transport == "rccl":
@@ -53,8 +53,8 @@ def run_rank(rank, world, cuts, name, slot_bytes, transport, uid, steps, out_dir
         eng.close()
 
 
-def _proc(rank, world, cuts, name, slot_bytes, out_dir):
-    run_rank(rank, world, cuts, name, slot_bytes, "host", None, 2, out_dir)
+def _proc(rank, world, cuts, name, slot_bytes, out_dir, flags=0):
+    run_rank(rank, world, cuts, name, slot_bytes, "host", None, 2, out_dir, flags)
 
 
 def merged_sv(out_dir, world):
@@ -69,14 +69,15 @@ def merged_sv(out_dir, world):
         eng.close()
 
 
-def test_one_rank_over_rccl(tmp_path):
+@pytest.mark.parametrize("flags", [0, engine.BF_FLAG_GROUPS_ALWAYS])
+def test_one_rank_over_rccl(tmp_path, flags):
     g, b, A, F, E = make_case()
     uid = engine.Engine.shard_unique_id()
     assert len(uid) == 128
-    run_rank(0, 1, [0, b.n], None, 0, "rccl", uid, 3, str(tmp_path))
+    run_rank(0, 1, [0, b.n], None, 0, "rccl", uid, 3, str(tmp_path), flags)
     sv, results = merged_sv(str(tmp_path), 1)
     assert sv == oracle_sv(g, b, A, F, E)
-    # with one rank the places are simply the result order
+    # with one rank the places are simply the result order (group after group when the cluster stage runs in groups)
     assert np.array_equal(results[0].places["slot"], np.arange(results[0].places.shape[0], dtype=np.uint32))
 
 
@@ -85,11 +86,14 @@ def test_one_rank_over_rccl(tmp_path):
     (3, (0, 0.25, 0.25, 1.0), 64 << 20),                 # an empty shard in the middle
     (5, (0, 0.1, 0.5, 0.5, 0.9, 1.0), 1 << 16),          # staging slots far smaller than the exchange: many rounds
 ])
-def test_ranks_as_processes_over_the_host_transport(tmp_path, world, cuts_frac, slot_bytes):
+@pytest.mark.parametrize("flags", [0, engine.BF_FLAG_GROUPS_ALWAYS])
+def test_ranks_as_processes_over_the_host_transport(tmp_path, world, cuts_frac, slot_bytes, flags):
+    """flags = BF_FLAG_GROUPS_ALWAYS: the owners' cluster stage a few contig ranks at a time, the sources rendering and
+    copying a group's records while the next group is clustered (what large inputs do by themselves)."""
     g, b, A, F, E = make_case()
     cuts = [int(b.n * f) for f in cuts_frac]
     name = "/bf_test_%s" % uuid.uuid4().hex[:12]
-    mp.spawn(_proc, args=(world, cuts, name, slot_bytes, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_proc, args=(world, cuts, name, slot_bytes, str(tmp_path), flags), nprocs=world, join=True)
     sv, results = merged_sv(str(tmp_path), world)
     assert sv == oracle_sv(g, b, A, F, E)
     assert sum(x.clusters.shape[0] for x in results) == sv.count(b"\n") - 1
