@@ -78,6 +78,12 @@ def useful_bytes(n, m, s, c, L):
         "emit_kernel": s * (4 + 8 + 16) + c * 56,
         "render_packed_kernel<3>": s * (4 + 8 + lb + 32 + 52),   # index, offset, the read's codes, its render record in; ~52 B record out
         "record_bytes_kernel": n * 8,
+        # class partition + chunk sort: 20 B per record (comp 8 + {id, rpos, upper key bits} 12) in and out of every step
+        "comp_build_kernel": n * (4 + 8 + 4 + 4 + 20),        # id, key, lpos, rpos in; the 20 B out
+        "rs_upsweep_kernel<unsigned long, 8>": 2 * n * 8,     # two partition passes: the keys
+        "rs_downsweep_kernel<unsigned long, RsV3, 8>": 2 * n * 40,
+        "chunk_sort_kernel": n * (20 + 20),                   # partitioned records in; skey 8, lpos 4, rpos 4, perm 4 out
+        "group_id_kernel": n * (8 + 4),
     }
 
 
@@ -106,7 +112,7 @@ def main():
                 continue
             hb = fetch.get(k, 0.0) + write.get(k, 0.0)
             rate = hb / (us * 1e-6) / 1e9 if us else 0
-            u = useful.get(k, useful.get(k.split("<")[0]))
+            u = useful.get(k, useful.get(k.split("<")[0]) if k.split("<")[0] not in ("rs_upsweep_kernel", "rs_downsweep_kernel") else None)
             o.write("| `%s` | %.1f | %.1f | %s | %s | %s | %s | %s |\n" % (
                 k[:70], cnt, us, "%.1f" % (hb / 1e6) if hb else "-", "%.0f" % rate if hb else "-",
                 "%.1f" % (100 * rate / PEAK) if hb else "-", "%.1f" % (u / 1e6) if u else "-",
