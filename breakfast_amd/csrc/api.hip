@@ -180,41 +180,41 @@ static const uint64_t* spread_table() {
 // where they differ from the flank they were assigned to, with '|' at the breakpoint (detect.rs:155-162).
 // Returns len + 1, or -1 for a malformed record; writes only when `out` is given and cap suffices.
 int64_t junction_decode(const uint8_t* rec, uint64_t rec_len, uint8_t* out, uint64_t cap, uint64_t* stored) {
-    if (!rec || rec_len < 8) return -1;
-    uint16_t h[4];
-    memcpy(h, rec, 8);
-    const uint32_t L = h[0], bp = h[1], nx = h[2], form = h[3];
-    if (bp > L) return -1;
-    const uint64_t text = (uint64_t)L + 1;
-    if (nx == kJunctionText) {
-        if ((form & ~kJunctionSwapped) != 0 || rec_len < 8 + text) return -1;
+    if (!rec || rec_len < 4) return -1;
+    uint32_t head;
+    memcpy(&head, rec, 4);
+    const uint32_t kind = head & 3u;
+    if (kind == kJrText) {
+        if (rec_len < 8 || (head & 0xff0000f8u)) return -1;
+        uint32_t L;
+        memcpy(&L, rec + 4, 4);
+        const uint32_t bp = (head >> 8) & 0xffffu;
+        if (L > 0xffffu || bp > L) return -1;
+        const uint64_t text = (uint64_t)L + 1;
+        if (rec_len < 8 + text) return -1;
         if (stored) *stored = (8 + text + 3) & ~3ull;
         if (out && cap >= text) memcpy(out, rec + 8, text);
         return (int64_t)text;
     }
-    const uint32_t groups = (L + 31) >> 5;
-    const bool sparse = (form & kJunctionSparse) != 0;
-    const uint32_t n_lower = sparse ? (form & kJunctionCountMask) : 0u, gb = sparse ? 8u : 12u;
-    if (!sparse && (form & kJunctionCountMask) != 0) return -1;
-    if (rec_len < 8 + (uint64_t)gb * groups + 4ull * nx + 2ull * n_lower) return -1;
-    if (stored) *stored = 8 + (uint64_t)gb * groups + 4ull * nx + ((2ull * n_lower + 3) & ~3ull);
-    const uint8_t* g = rec + 8;
-    const uint8_t* xe = g + (uint64_t)gb * groups;           // exception entries
-    const uint8_t* pl = xe + 4ull * nx;                      // lower-case positions (sparse form)
-    for (uint32_t e = 0; e < nx; e++) {                      // validated in the size query too
-        uint16_t k; memcpy(&k, xe + 4 * e, 2);
-        if (k >= L) return -1;
-    }
-    for (uint32_t e = 0; e < n_lower; e++) {
-        uint16_t k; memcpy(&k, pl + 2 * e, 2);
-        if (k >= L) return -1;
-    }
+    if (kind != kJrDense && kind != kJrSparse) return -1;
+    const bool sparse = kind == kJrSparse;
+    const uint32_t L = (head >> 3) & 0x1ffu, bp = (head >> 12) & 0x1ffu, nx = (head >> 21) & 0x3fu, n_lower = head >> 27;
+    if (bp > L || L > 256u || (!sparse && n_lower)) return -1;
+    const uint64_t text = (uint64_t)L + 1;
+    const uint32_t units = (L + 7) >> 3, ub = sparse ? 2u : 3u;
+    const uint64_t body = 4 + (uint64_t)ub * units + 2ull * nx + n_lower;
+    if (rec_len < body) return -1;
+    if (stored) *stored = (body + 3) & ~3ull;
+    const uint8_t* g = rec + 4;
+    const uint8_t* xe = g + (uint64_t)ub * units;            // exception entries {position, printed byte}
+    const uint8_t* pl = xe + 2ull * nx;                      // lower-case positions (sparse form)
+    for (uint32_t e = 0; e < nx; e++) if (xe[2 * e] >= L) return -1;             // validated in the size query too
+    for (uint32_t e = 0; e < n_lower; e++) if (pl[e] >= L) return -1;
     if (!out || cap < text) return (int64_t)text;
     const uint64_t* S = spread_table();
     auto eight = [&](uint32_t k) -> uint64_t {               // the 8 bases from k on, as printed
-        const uint8_t* grp = g + gb * (k >> 5);
-        const uint32_t b = (k >> 3) & 3;
-        const uint8_t lo = grp[b], hi = grp[4 + b], cs = sparse ? 0 : grp[8 + b];
+        const uint8_t* grp = g + ub * (k >> 3);
+        const uint8_t lo = grp[0], hi = grp[1], cs = sparse ? 0 : grp[2];
         // 'A' + 2*lo + 0x13*hi - 0x0f*(lo&hi) = A C T G for codes 0..3; + 0x20 = lower case
         return 0x4141414141414141ull + 2 * S[lo] + 0x13 * S[hi] - 0x0f * S[lo & hi] + 0x20 * S[cs];
     };
@@ -232,12 +232,12 @@ int64_t junction_decode(const uint8_t* rec, uint64_t rec_len, uint8_t* out, uint
         for (uint32_t j = 0; k + j < L; j++) { const uint32_t q = k + j; out[q < bp ? q : q + 1] = (uint8_t)(v >> (8 * j)); }
     }
     for (uint32_t e = 0; e < n_lower; e++) {                 // plain ACGT bases: lower case is + 0x20
-        uint16_t q; memcpy(&q, pl + 2 * e, 2);
+        const uint32_t q = pl[e];
         out[q < bp ? q : q + 1u] |= 0x20;
     }
     for (uint32_t e = 0; e < nx; e++) {                      // exceptions are stored as printed
-        uint16_t q; memcpy(&q, xe + 4 * e, 2);
-        out[q < bp ? q : q + 1u] = xe[4 * e + 2];
+        const uint32_t q = xe[2 * e];
+        out[q < bp ? q : q + 1u] = xe[2 * e + 1];
     }
     out[bp] = '|';
     return (int64_t)text;
@@ -1565,7 +1565,7 @@ int bf_result_attach_finish(bf_ctx* ctx, bf_result* out) {
 }
 
 uint64_t bf_junction_record_bound(const bf_ctx* ctx) {
-    // packed: 8 + 12*ceil(L/32) + 4*(L/8) <= 7L/8 + 20; text: L + 10
+    // packed: 4 + 3*ceil(L/8) + 2*(L/8) + 3 <= 5L/8 + 10; text: L + 12
     return ctx ? (uint64_t)ctx->max_len + 24 : 0;
 }
 

@@ -62,24 +62,28 @@ constexpr uint32_t kEvStrand = 1, kEvMstrand = 2, kEvSwapped = 4, kEvExact = 8, 
 
 // ---- junction records (include/breakfast_hip.h, "Junction records") ------------------------------
 // A surviving read's junction string crosses PCIe (and xGMI on the sharded path) as a self-describing
-// record: 3 bits per base instead of 8 when the read is (almost) plain ACGT.  `max_packed` = 64 * W of the
+// record: 2-3 bits per base instead of 8 when the read is (almost) plain ACGT.  `max_packed` = 64 * W of the
 // ctx's localise kernel; `n_exc` = read bases outside "ACGT" (saturating u16 from the render record).
-constexpr uint32_t kJunctionText = 0xffffu;
+// Header word (little endian u32): bits 0-1 kind (0 text, 1 dense, 2 sparse), bit 2 "the read was reverse-complemented"
+// (detect.rs:112); packed kinds: L in bits 3-11, bp in 12-20, n_exc in 21-26, listed lower-case positions in 27-31;
+// text: bp in bits 8-23 and L in a second word.
+constexpr uint32_t kJrText = 0u, kJrDense = 1u, kJrSparse = 2u;
 __host__ __device__ inline bool junction_packable(uint32_t L, uint32_t n_exc, uint32_t max_packed) {
-    return L <= max_packed && 8u * n_exc <= L;
+    return L <= max_packed && L <= 256u && 8u * n_exc <= L;
 }
 // Packed records come in two forms: with a lower-case (mismatch) bit per base, or -- most reads differ from
-// their flanks in a base or two -- with the lower-case positions listed after the two code planes.
-// header = {u16 len, u16 bp, u16 n_exc | 0xffff, u16 form}; form: bit 15 sparse, bit 14 the read was
-// reverse-complemented (detect.rs:112), low 14 bits = listed lower-case positions (sparse form)
-constexpr uint32_t kJunctionSparse = 0x8000u, kJunctionSwapped = 0x4000u, kJunctionCountMask = 0x3fffu;
+// their flanks in a base or two -- with the lower-case positions listed (a byte each) after the code bits.
 __host__ __device__ inline bool junction_sparse(uint32_t L, uint32_t n_lower) {
-    return n_lower <= kJunctionCountMask && ((2u * n_lower + 3u) & ~3u) < 4u * ((L + 31u) >> 5);
+    return n_lower <= 31u && n_lower < ((L + 7u) >> 3);
 }
+__host__ __device__ inline uint32_t junction_head_packed(bool sparse, bool swapped, uint32_t L, uint32_t bp, uint32_t n_exc, uint32_t n_lower) {
+    return (sparse ? kJrSparse : kJrDense) | (swapped ? 4u : 0u) | (L << 3) | (bp << 12) | (n_exc << 21) | ((sparse ? n_lower : 0u) << 27);
+}
+__host__ __device__ inline uint32_t junction_head_text(bool swapped, uint32_t bp) { return kJrText | (swapped ? 4u : 0u) | ((bp & 0xffffu) << 8); }
 __host__ __device__ inline uint32_t junction_record_bytes(uint32_t L, uint32_t n_exc, uint32_t n_lower, uint32_t max_packed) {
     if (!junction_packable(L, n_exc, max_packed)) return (8u + L + 1u + 3u) & ~3u;
-    const uint32_t g = (L + 31u) >> 5;
-    return junction_sparse(L, n_lower) ? 8u + 8u * g + 4u * n_exc + ((2u * n_lower + 3u) & ~3u) : 8u + 12u * g + 4u * n_exc;
+    const uint32_t u = (L + 7u) >> 3;
+    return ((junction_sparse(L, n_lower) ? 4u + 2u * u + 2u * n_exc + n_lower : 4u + 3u * u + 2u * n_exc) + 3u) & ~3u;
 }
 // What the cluster stage gathers per evidence record by sort permutation, in one 8-byte word instead of four
 // arrays (a random gather costs a whole line whatever it uses): junction record bytes (20 bits), evidence

@@ -910,10 +910,9 @@ render_kernel(uint64_t n, const uint32_t* __restrict__ idx,
     const int64_t bp = (int64_t)(tail & 0xffff), L = (int64_t)((tail >> 32) & 0xffff);
     const bool swapped = ((tail >> 16) & kEvSwapped) != 0;
     if (junction_packable((uint32_t)L, (uint32_t)(tail >> 48), max_packed)) return;      // render_packed_kernel's
-    if (l16 == 0) {                                                      // text record: {len, bp, 0xffff, form} + the string
-        uint16_t* hd = (uint16_t*)(out + joff[i]);                       // records start on 4-byte boundaries
-        hd[0] = (uint16_t)L; hd[1] = (uint16_t)bp; hd[2] = (uint16_t)kJunctionText;
-        hd[3] = (uint16_t)(swapped ? kJunctionSwapped : 0u);
+    if (l16 == 0) {                                                      // text record: {head, len} + the string
+        uint32_t* hd = (uint32_t*)(out + joff[i]);                       // records start on 4-byte boundaries
+        hd[0] = junction_head_text(swapped, (uint32_t)bp); hd[1] = (uint32_t)L;
         for (int64_t q = 8 + L + 1; q & 3; q++) out[joff[i] + q] = 0;    // padding
     }
     const int64_t dst0 = (int64_t)joff[i] + 8, out_len = L + 1;
@@ -988,9 +987,8 @@ __global__ void __launch_bounds__(256) render_text_nibbles_kernel(uint64_t n, co
     if (junction_packable((uint32_t)L, (uint32_t)(tail >> 48), max_packed)) return;      // render_packed_kernel's
     uint8_t* o = out + joff[i];
     if (l16 == 0) {
-        uint16_t* hd = (uint16_t*)o;
-        hd[0] = (uint16_t)L; hd[1] = (uint16_t)bp; hd[2] = (uint16_t)kJunctionText;
-        hd[3] = (uint16_t)(swapped ? kJunctionSwapped : 0u);
+        uint32_t* hd = (uint32_t*)o;
+        hd[0] = junction_head_text(swapped, (uint32_t)bp); hd[1] = (uint32_t)L;
         for (int q = 8 + L + 1; q & 3; q++) o[q] = 0;                                    // padding
     }
     for (int q = l16; q <= L; q += 16) {                                                 // L + 1 output bytes
@@ -1007,12 +1005,10 @@ __global__ void __launch_bounds__(256) render_text_nibbles_kernel(uint64_t n, co
 // Packed junction records: one lane per surviving read whose record is packable (at most 64*W bases, few
 // bases outside ACGT).  The lane re-encodes its read from the ASCII bases exactly as the localise kernel did
 // (same function, so the exception count in the render record is the one found here), re-orients it when the
-// read was reverse-complemented (detect.rs:112), and writes
-//   {u16 len, u16 bp, u16 n_exc, u16 form}, then per 32 bases {u32 lo, u32 hi, u32 lower-case},
-//   then n_exc x {u16 position, u8 printed byte, u8 0}
-// or, when the lower-case bases are few (form = 0x8000 | their number): per 32 bases {u32 lo, u32 hi}, the
-// exception entries, then the lower-case positions as u16 (padded to 4 bytes)
-// -- 52 bytes for a 150-base read with one mismatch against 151 bytes of text: the result copy to the host
+// read was reverse-complemented (detect.rs:112), and writes the record of include/breakfast_hip.h ("Junction
+// records"): a 4-byte header, per 8 bases {lo byte, hi byte} -- or {lo, hi, lower-case} when the lower-case bases are
+// many --, the bases outside ACGT as {position, printed byte}, the lower-case positions as bytes
+// -- 44 bytes for a 150-base read with one mismatch against 151 bytes of text: the result copy to the host
 // is the longest stage of a step, and the .sv formatter expands records at memcpy speed.
 template <int W>
 __global__ void __launch_bounds__(256) render_packed_kernel(uint64_t n, const uint32_t* __restrict__ idx,
@@ -1044,37 +1040,26 @@ __global__ void __launch_bounds__(256) render_packed_kernel(uint64_t n, const ui
 #pragma unroll
     for (int w = 0; w < W; w++) n_lower += (uint32_t)__popcll(cs[w]);
     const bool sparse = junction_sparse((uint32_t)L, n_lower);
-    const int per_group = sparse ? 2 : 3;
+    // the record as a byte stream, written a dword at a time (zero padding at the end comes with the last one)
     uint32_t* __restrict__ o32 = (uint32_t*)(out + joff[i]);
-    o32[0] = (uint32_t)L | ((uint32_t)bp << 16);
-    o32[1] = n_exc | (((sparse ? (kJunctionSparse | n_lower) : 0u) | (swapped ? kJunctionSwapped : 0u)) << 16);
+    uint64_t acc = 0;
+    int have = 0, at = 0;
+    auto put = [&](uint32_t v, int nbytes) {
+        acc |= (uint64_t)v << (8 * have);
+        have += nbytes;
+        if (have >= 4) { o32[at++] = (uint32_t)acc; acc >>= 32; have -= 4; }
+    };
+    put(junction_head_packed(sparse, swapped, (uint32_t)L, (uint32_t)bp, n_exc, n_lower), 4);
 #pragma unroll
-    for (int g = 0; g < 2 * W; g++) {
-        if (32 * g < L) {
-            const int sh = 32 * (g & 1);
-            o32[2 + per_group * g] = (uint32_t)(lo[g >> 1] >> sh);
-            o32[3 + per_group * g] = (uint32_t)(hi[g >> 1] >> sh);
-            if (!sparse) o32[4 + 3 * g] = (uint32_t)(cs[g >> 1] >> sh);
+    for (int u = 0; u < 8 * W; u++) {                                    // 8 bases a step: {lo, hi[, lower case]} bytes
+        if (8 * u < L) {
+            const int sh = 8 * (u & 7);
+            const uint32_t l8 = (uint32_t)(lo[u >> 3] >> sh) & 0xffu, h8 = (uint32_t)(hi[u >> 3] >> sh) & 0xffu;
+            if (sparse) put(l8 | (h8 << 8), 2);
+            else put(l8 | (h8 << 8) | (((uint32_t)(cs[u >> 3] >> sh) & 0xffu) << 16), 3);
         }
-    }
-    uint32_t* __restrict__ xo = o32 + 2 + per_group * ((L + 31) >> 5);
-    if (sparse && n_lower) {                                             // lower-case positions, two per dword
-        uint32_t* __restrict__ po = xo + n_exc;
-        uint32_t pend = 0, cnt = 0;
-#pragma unroll
-        for (int w = 0; w < W; w++) {
-            uint64_t m = cs[w];
-            while (m) {
-                const uint32_t k = 64u * w + (uint32_t)__builtin_ctzll(m);
-                m &= m - 1;
-                if (cnt & 1) po[cnt >> 1] = pend | (k << 16); else pend = k;
-                cnt++;
-            }
-        }
-        if (cnt & 1) po[cnt >> 1] = pend;
     }
     if (n_exc) {                                                         // rare: N and other IUPAC letters, as printed
-        uint32_t e = 0;
 #pragma unroll
         for (int w = 0; w < W; w++) {
             uint64_t m = ex[w];
@@ -1084,10 +1069,21 @@ __global__ void __launch_bounds__(256) render_packed_kernel(uint64_t n, const ui
                 const int k = 64 * w + b;
                 uint32_t c = swapped ? comp_byte(base_at(seq, so, L - 1 - k, packed)) : base_at(seq, so, k, packed);
                 if (((cs[w] >> b) & 1) && c >= 'A' && c <= 'Z') c += 32;  // to_ascii_lowercase, detect.rs:157,161
-                xo[e++] = (uint32_t)k | (c << 16);
+                put((uint32_t)k | (c << 8), 2);
             }
         }
     }
+    if (sparse && n_lower) {                                             // lower-case positions, a byte each
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            uint64_t m = cs[w];
+            while (m) {
+                put(64u * w + (uint32_t)__builtin_ctzll(m), 1);
+                m &= m - 1;
+            }
+        }
+    }
+    if (have) o32[at] = (uint32_t)acc;
 }
 
 // ---------------------------------------------------------------------------------------------

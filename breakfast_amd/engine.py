@@ -340,19 +340,21 @@ def junction_header(records, off: int = 0) -> Tuple[int, int, bool, int]:
     size = lib.bf_junction_record_bytes(rec.ctypes.data + off if rec.size > off else None, max(int(rec.size) - off, 0))
     if size < 0:
         raise BreakfastError(int(size), "malformed junction record")
-    h = np.frombuffer(rec[off:off + 8].tobytes(), "<u2")
-    return int(h[0]), int(h[1]), bool(h[3] & 0x4000), int(size)
+    head = int(np.frombuffer(rec[off:off + 4].tobytes(), "<u4")[0])
+    if head & 3 == 0:                                    # text record: bp in the header word, length in the next one
+        return int(np.frombuffer(rec[off + 4:off + 8].tobytes(), "<u4")[0]), (head >> 8) & 0xffff, bool(head & 4), int(size)
+    return (head >> 3) & 0x1ff, (head >> 12) & 0x1ff, bool(head & 4), int(size)
 
 
 def text_records(text: np.ndarray, off: np.ndarray, swapped: Optional[Sequence[bool]] = None) -> Tuple[np.ndarray, np.ndarray]:
-    """Wraps junction strings as TEXT records {u16 len, u16 bp, u16 0xffff, u16 form} + string, padded to 4
+    """Wraps junction strings as TEXT records {u32 kind 0 | reverse-complemented << 2 | bp << 8, u32 len} + string, padded to 4
     bytes (what an engine without the packed renderer hands to the exchange) -> (records, offsets[n+1])."""
     n = off.shape[0] - 1
     out, ro = [], np.zeros(n + 1, np.uint64)
     tb = np.ascontiguousarray(text, np.uint8).tobytes()
     for i in range(n):
         s = tb[int(off[i]):int(off[i + 1])]
-        rec = np.array([len(s) - 1, s.index(b"|"), 0xffff, 0x4000 if swapped is not None and swapped[i] else 0], "<u2").tobytes() + s
+        rec = np.array([(4 if swapped is not None and swapped[i] else 0) | (s.index(b"|") << 8), len(s) - 1], "<u4").tobytes() + s
         rec += b"\0" * (-len(rec) % 4)
         out.append(rec)
         ro[i + 1] = ro[i] + len(rec)

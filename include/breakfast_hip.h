@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 9
+#define BF_ABI_VERSION 10
 
 enum {
     BF_OK = 0,
@@ -115,25 +115,23 @@ typedef struct {
 
 /* Junction records.  A supporting read's case-marked sequence with '|' at the breakpoint (detect.rs:155-162)
  * leaves the GPU as a self-describing record, because the result copy over PCIe is the longest stage of
- * the path and 3 bits per base say what 8 bits of text say.  Records start on 4-byte boundaries; little endian:
- *     u16 len      read length L
- *     u16 bp       position of '|' in the string (0 <= bp <= L) = breakpoint offset in the re-oriented read
- *     u16 n_exc    number of exception entries, or 0xFFFF = text record
- *     u16 form     bit 15: sparse form; bit 14: the read was reverse-complemented by the reorient step
- *                  (detect.rs:108-113); low 14 bits: n_lower (sparse form only)
- *   text record (reads longer than the packed kernel's 256 bases, or with many bases outside ACGT):
- *     L+1 bytes    the string itself, then zero padding to a multiple of 4 bytes
- *   packed record, dense form:
- *     ceil(L/32) x { u32 lo, u32 hi, u32 lower }   bit j of group g = base k = 32g+j of the printed sequence:
- *                  letter "ACTG"[lo + 2*hi], printed in lower case when `lower` is set
- *     n_exc x { u16 k, u8 byte, u8 0 }             base k prints as `byte` (N and other IUPAC letters)
- *   packed record, sparse form (few mismatches, the usual case):
- *     ceil(L/32) x { u32 lo, u32 hi }
- *     n_exc x { u16 k, u8 byte, u8 0 }
- *     n_lower x u16 k                               base k prints in lower case; zero padding to 4 bytes
- * bf_junction_text() expands one record, bf_result_junction_text() all records of a result, and
+ * the path and 2-3 bits per base say what 8 bits of text say.  Records start on 4-byte boundaries and are zero-padded
+ * to a multiple of 4 bytes; little endian.  First a header word (u32):
+ *     bits 0-1    kind: 0 text, 1 packed dense, 2 packed sparse
+ *     bit  2      the read was reverse-complemented by the reorient step (detect.rs:108-113)
+ *   packed kinds (reads of up to 256 bases with at most one base in eight outside ACGT):
+ *     bits 3-11   L, the read length            bits 12-20  bp, position of '|' in the string (0 <= bp <= L)
+ *     bits 21-26  n_exc, exception entries      bits 27-31  n_lower, listed lower-case positions (sparse; else 0)
+ *   followed by
+ *     ceil(L/8) x { u8 lo, u8 hi }              sparse: bit j of unit u = base k = 8u+j of the printed sequence,
+ *     ceil(L/8) x { u8 lo, u8 hi, u8 lower }    dense:  letter "ACTG"[lo + 2*hi], lower case when `lower` is set
+ *     n_exc x { u8 k, u8 byte }                 base k prints as `byte` (N and other IUPAC letters)
+ *     n_lower x u8 k                            (sparse) base k prints in lower case: the usual case, a mismatch or two
+ *   text kind (longer reads, or many bases outside ACGT): bits 8-23 of the header = bp, then
+ *     u32 L, L+1 bytes: the string itself
  * A record's length follows from its header, so records can be walked one after the other.
- * bf_format_sv() expands them while it prints.  52 bytes instead of 151 for a 150-base read with one mismatch. */
+ * bf_junction_text() expands one record, bf_result_junction_text() all records of a result,
+ * bf_format_sv() expands them while it prints.  44 bytes instead of 151 for a 150-base read with one mismatch. */
 
 /* One supporting read that survived frag-id dedup (detect.rs:247-287), in printed order. */
 typedef struct {

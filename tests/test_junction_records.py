@@ -10,37 +10,43 @@ CODE = {ord("A"): 0, ord("C"): 1, ord("T"): 2, ord("G"): 3}
 
 
 def pack(junction: bytes, form: str = "auto", swapped: bool = False) -> bytes:
-    """Reference packer: the record the GPU writes for this string (form "auto"), or a given packed form."""
+    """Reference packer: the record the GPU writes for this string (form "auto"), or a given packed form.
+    Header word: kind (1 dense, 2 sparse) | reverse-complemented << 2 | L << 3 | bp << 12 | n_exc << 21 | n_lower << 27;
+    then per 8 bases {lo byte, hi byte[, lower-case byte]}, {position, byte} per base outside ACGT, lower-case
+    positions as bytes (sparse), zero padding to 4 bytes.  Packed records hold reads of up to 256 bases."""
     bp = junction.index(b"|")
     seq = junction[:bp] + junction[bp + 1:]
     L = len(seq)
-    groups = (L + 31) // 32
-    lo, hi, cs = [0] * groups, [0] * groups, [0] * groups
+    if L > 256:
+        return text_record(junction, swapped)
+    units = (L + 7) // 8
+    lo, hi, cs = [0] * units, [0] * units, [0] * units
     exc, lower = [], []
     for k, c in enumerate(seq):
         up = c - 32 if 97 <= c <= 122 else c
         if up in CODE:
-            lo[k >> 5] |= (CODE[up] & 1) << (k & 31)
-            hi[k >> 5] |= (CODE[up] >> 1) << (k & 31)
+            lo[k >> 3] |= (CODE[up] & 1) << (k & 7)
+            hi[k >> 3] |= (CODE[up] >> 1) << (k & 7)
             if c != up:
-                cs[k >> 5] |= 1 << (k & 31)
+                cs[k >> 3] |= 1 << (k & 7)
                 lower.append(k)
         else:
             exc.append((k, c))
-    sparse = ((2 * len(lower) + 3) & ~3) < 4 * groups if form == "auto" else form == "sparse"
-    out = np.array([L, bp, len(exc), ((0x8000 | len(lower)) if sparse else 0) | (0x4000 if swapped else 0)], "<u2").tobytes()
-    for g in range(groups):
-        out += np.array([lo[g], hi[g]] + ([] if sparse else [cs[g]]), "<u4").tobytes()
+    fits = len(lower) <= 31 and len(exc) <= 63
+    sparse = (fits and len(lower) < units) if form == "auto" else (form == "sparse" and fits)
+    head = (2 if sparse else 1) | (4 if swapped else 0) | (L << 3) | (bp << 12) | (len(exc) << 21) | ((len(lower) if sparse else 0) << 27)
+    out = np.array([head], "<u4").tobytes()
+    for u in range(units):
+        out += bytes([lo[u], hi[u]] + ([] if sparse else [cs[u]]))
     for k, c in exc:
-        out += np.array([k], "<u2").tobytes() + bytes([c, 0])
+        out += bytes([k, c])
     if sparse:
-        out += np.array(lower, "<u2").tobytes()
-        out += b"\0" * (-len(out) % 4)
-    return out
+        out += bytes(lower)
+    return out + b"\0" * (-len(out) % 4)
 
 
 def text_record(junction: bytes, swapped: bool = False) -> bytes:
-    rec = np.array([len(junction) - 1, junction.index(b"|"), 0xffff, 0x4000 if swapped else 0], "<u2").tobytes() + junction
+    rec = np.array([(4 if swapped else 0) | (junction.index(b"|") << 8), len(junction) - 1], "<u4").tobytes() + junction
     return rec + b"\0" * (-len(rec) % 4)
 
 
@@ -71,20 +77,26 @@ def test_breakpoint_at_either_end_and_known_answer():
     assert engine.junction_text(pack(b"ACGT|")) == b"ACGT|"
     # the survey's known-answer read 1
     j = b"AGTTATCGGTGCCG|AAcTGATGGA"
-    rec = pack(j)                                   # one mismatch: sparse form, 8 + 8 + 4 bytes
-    assert len(rec) == 20 and engine.junction_text(rec) == j
-    assert len(pack(j, "dense")) == 20
+    rec = pack(j)                                   # 24 bases, one mismatch: sparse form, 4 + 3 * 2 + 1 bytes, padded
+    assert len(rec) == 12 and engine.junction_text(rec) == j
+    assert len(pack(j, "dense")) == 16              # 4 + 3 * 3, padded
 
 
 def test_malformed_records_are_rejected():
     good = pack(b"ACGTACGTAC|GTNACGTACGT", "dense")
     sparse = pack(b"ACGTACgTAC|GTNACGTACGT", "sparse")
-    for bad in (b"", good[:5], good[:12], good[:-1], sparse[:-4],
-                sparse[:-4] + np.array([99, 0], "<u2").tobytes(),                  # lower-case position past the end
-                good[:6] + b"\x01\x00" + good[8:],                               # dense form with a count
-                np.array([4, 9, 0, 0], "<u2").tobytes() + b"\0" * 12,            # bp > len
-                np.array([4, 1, 1, 0], "<u2").tobytes() + b"\0" * 12 + np.array([7], "<u2").tobytes() + b"N\0",   # exception past the end
-                np.array([10, 1, 0xffff, 0], "<u2").tobytes() + b"A|CG"):         # text shorter than len+1
+    assert engine.junction_text(good) == b"ACGTACGTAC|GTNACGTACGT" and engine.junction_text(sparse) == b"ACGTACgTAC|GTNACGTACGT"
+    u4 = lambda *w: np.array(w, "<u4").tobytes()
+    head = lambda kind, L, bp, nx=0, nl=0: u4(kind | (L << 3) | (bp << 12) | (nx << 21) | (nl << 27))
+    for bad in (b"", good[:3], good[:8], good[:-4], sparse[:-4],
+                head(2, 21, 10, 0, 1) + sparse[4:4 + 6] + bytes([99, 0]),         # lower-case position past the end
+                head(1, 21, 10, 1, 1) + good[4:],                               # dense form with a count
+                head(1, 4, 9) + b"\0" * 12,                                     # bp > len
+                head(1, 4, 1, 1) + b"\0\0\0" + bytes([7, ord("N")]) + b"\0" * 3,   # exception past the end
+                head(1, 300, 1) + b"\0" * 200,                                  # packed records end at 256 bases
+                u4(3) + b"\0" * 12,                                             # unknown kind
+                u4(0 | (1 << 8), 10) + b"A|CG",                                  # text shorter than len + 1
+                u4(0 | (20 << 8), 10) + b"A|CGACGTACGT"):                        # text: bp > len
         with pytest.raises(engine.BreakfastError):
             engine.junction_text(bad)
 
