@@ -496,6 +496,7 @@ int bf_reset(bf_ctx* ctx) {
     BF_SYNC(ctx, ctx->in_stream);
     BF_SYNC(ctx, ctx->stream);
     ctx->in_pending = false; ctx->n_localised = 0; ctx->consumed = false;
+    ctx->off_pending.clear();
     ctx->rank_hist.assign(ctx->n_contigs, 0);
     ctx->n_reads = 0; ctx->seq_bytes = 0; ctx->frag_bytes = 0;
     ctx->max_len = 0; ctx->min_len = 0xffffffffu; ctx->max_frag = 0;
@@ -583,12 +584,14 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
             uint64_t* fo = so + (cnt + 1);
             bf_hit* hh = (bf_hit*)(fo + (cnt + 1));
             uint16_t* ll = (uint16_t*)(hh + cnt);                // lengths of 4-bit reads
+            uint16_t* fls = ll + cnt;                            // ... and of their fragment ids (the offsets stay here)
             if (wide) {                                          // this job's part of the piece-wide arrays; the caller uploads them
                 const uint64_t pc = sh->p1 - sh->p0;
                 so = (uint64_t*)sh->wide + (job.a - sh->p0);
                 fo = (uint64_t*)sh->wide + (pc + 1) + (job.a - sh->p0);
                 hh = (bf_hit*)((uint64_t*)sh->wide + 2 * (pc + 1)) + (job.a - sh->p0);
                 ll = (uint16_t*)((bf_hit*)((uint64_t*)sh->wide + 2 * (pc + 1)) + pc) + (job.a - sh->p0);
+                fls = (uint16_t*)((bf_hit*)((uint64_t*)sh->wide + 2 * (pc + 1)) + pc) + pc + (job.a - sh->p0);
             }
             const uint64_t s0 = b->seq_off[0], f0 = b->frag_off[0];
             bool ok = true;
@@ -605,6 +608,7 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
                         ok = false; break;
                     }
                     ll[i - job.a] = (uint16_t)L;
+                    fls[i - job.a] = (uint16_t)std::min<uint64_t>(fb - fa, 65535);
                 }
                 if (L > 65535) { sh->error(i, BF_ERR_RANGE, "read %llu has %llu bases; at most 65535 are supported", (unsigned long long)i, (unsigned long long)L); ok = false; break; }
                 if (fl > 65535) { sh->error(i, BF_ERR_RANGE, "fragment id of read %llu has %llu bytes; at most 65535", (unsigned long long)i, (unsigned long long)fl); ok = false; break; }
@@ -624,12 +628,15 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
             if (!ok) return;
             so[cnt] = sh->seq0 + (b->seq_off[job.b] - s0); fo[cnt] = sh->frag0 + (b->frag_off[job.b] - f0);
             if (wide) continue;
-            e = hipMemcpyAsync(ctx->d_seq_off.as<uint64_t>() + sh->n0 + job.a, so, n_off * 8, hipMemcpyHostToDevice, ctx->in_stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_frag_off.as<uint64_t>() + sh->n0 + job.a, fo, n_off * 8, hipMemcpyHostToDevice, ctx->in_stream);
+            if (!b->seq_len) {                                   // ASCII reads: the offsets go up
+                e = hipMemcpyAsync(ctx->d_seq_off.as<uint64_t>() + sh->n0 + job.a, so, n_off * 8, hipMemcpyHostToDevice, ctx->in_stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_frag_off.as<uint64_t>() + sh->n0 + job.a, fo, n_off * 8, hipMemcpyHostToDevice, ctx->in_stream);
+            } else {                                             // 4-bit reads: the lengths do, the device rebuilds the offsets
+                e = hipMemcpyAsync(ctx->d_len.as<uint16_t>() + sh->n0 + job.a, ll, cnt * 2, hipMemcpyHostToDevice, ctx->in_stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_frag_len.as<uint16_t>() + sh->n0 + job.a, fls, cnt * 2, hipMemcpyHostToDevice, ctx->in_stream);
+            }
             if (e == hipSuccess && !sh->hits_direct)
                 e = hipMemcpyAsync(ctx->d_hits.as<bf_hit>() + sh->n0 + job.a, hh, cnt * sizeof(bf_hit), hipMemcpyHostToDevice, ctx->in_stream);
-            if (e == hipSuccess && b->seq_len)
-                e = hipMemcpyAsync(ctx->d_len.as<uint16_t>() + sh->n0 + job.a, ll, cnt * 2, hipMemcpyHostToDevice, ctx->in_stream);
         } else {
             const uint8_t* src = job.kind == 1 ? b->seq_bytes + b->seq_off[0] : b->frag_bytes + b->frag_off[0];
             uint8_t* dst = job.kind == 1 ? ctx->d_seq.as<uint8_t>() + sh->seq0 : ctx->d_frag.as<uint8_t>() + sh->frag0;
@@ -651,6 +658,11 @@ static int reserve_input(bf_ctx* ctx, uint64_t reads, uint64_t seq_bytes, uint64
         BF_SYNC(ctx, ctx->in_stream);
         BF_SYNC(ctx, ctx->stream);
         BF_TRY(ensure(ctx, ctx->d_len, ctx->cap_reads * 2, true));
+    }
+    if (ctx->packed_reads && ctx->d_frag_len.cap < ctx->cap_reads * 2) {
+        BF_SYNC(ctx, ctx->in_stream);
+        BF_SYNC(ctx, ctx->stream);
+        BF_TRY(ensure(ctx, ctx->d_frag_len, ctx->cap_reads * 2, true));
     }
     if (seq_bytes + 64 > ctx->d_seq.cap || frag_bytes + 64 > ctx->d_frag.cap || !ctx->d_seq.p || !ctx->d_frag.p) {
         BF_SYNC(ctx, ctx->in_stream);
@@ -747,6 +759,8 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
     struct TimerGuard {                               // whichever way the call ends, the pair is recorded or dropped
         bf_ctx* c; hipEvent_t a, b; bool ok = false;
         ~TimerGuard() {
+            if (!ok)                                      // a rejected batch: its pieces' offsets are never needed
+                while (!c->off_pending.empty() && c->off_pending.back().r0 >= c->n_reads) c->off_pending.pop_back();
             if (!a) return;
             if (ok && hipEventRecord(b, c->in_stream) == hipSuccess) pending(c).push_back(PendingEvent{"h2d", a, b});
             else { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
@@ -760,7 +774,7 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
     // (the A/B variants of the localise stage keep their one launch over the whole set)
     const bool eager = ctx->genome_ready && !(ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE));
     // reads per offsets job: two offset arrays (+1 entry each) and the hits share one slot
-    const uint64_t per_job = (kStageSlotBytes - 64) / (8 + 8 + sizeof(bf_hit) + 2) - 2;
+    const uint64_t per_job = (kStageSlotBytes - 64) / (8 + 8 + sizeof(bf_hit) + 4) - 2;
     uint32_t mx = ctx->max_len, mn = ctx->min_len, mf = ctx->max_frag;
     const uint64_t piece_reads = ctx->cfg.reserved[2] ? ctx->cfg.reserved[2] : kPieceReads;
     for (uint64_t p0 = 0; p0 < m; p0 += piece_reads) {
@@ -796,7 +810,7 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
         bf_ctx::WideSlot* ws = nullptr;
         if (seq_direct && frag_direct) {
             ws = &ctx->wide[ctx->wide_next++ & 1];
-            const size_t need = (p1 - p0 + 1) * 16 + (p1 - p0) * (sizeof(bf_hit) + 2) + 64;
+            const size_t need = (p1 - p0 + 1) * 16 + (p1 - p0) * (sizeof(bf_hit) + 4) + 64;
             if (ws->used) { BF_HIP(ctx, hipEventSynchronize(ws->ev)); ws->used = false; }
             if (ws->cap < need) {
                 if (ws->p) (void)hipHostFree(ws->p);
@@ -824,10 +838,14 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
             const uint64_t pc = p1 - p0;
             uint64_t* so = (uint64_t*)ws->p; uint64_t* fo = so + (pc + 1);
             bf_hit* hh = (bf_hit*)(fo + (pc + 1)); uint16_t* ll = (uint16_t*)(hh + pc);
-            BF_HIP(ctx, hipMemcpyAsync(ctx->d_seq_off.as<uint64_t>() + sh.n0 + p0, so, (pc + 1) * 8, hipMemcpyHostToDevice, ctx->in_stream));
-            BF_HIP(ctx, hipMemcpyAsync(ctx->d_frag_off.as<uint64_t>() + sh.n0 + p0, fo, (pc + 1) * 8, hipMemcpyHostToDevice, ctx->in_stream));
+            if (!b->seq_len) {
+                BF_HIP(ctx, hipMemcpyAsync(ctx->d_seq_off.as<uint64_t>() + sh.n0 + p0, so, (pc + 1) * 8, hipMemcpyHostToDevice, ctx->in_stream));
+                BF_HIP(ctx, hipMemcpyAsync(ctx->d_frag_off.as<uint64_t>() + sh.n0 + p0, fo, (pc + 1) * 8, hipMemcpyHostToDevice, ctx->in_stream));
+            } else {                                            // both length arrays lie back to back: one copy each
+                BF_HIP(ctx, hipMemcpyAsync(ctx->d_len.as<uint16_t>() + sh.n0 + p0, ll, pc * 2, hipMemcpyHostToDevice, ctx->in_stream));
+                BF_HIP(ctx, hipMemcpyAsync(ctx->d_frag_len.as<uint16_t>() + sh.n0 + p0, ll + pc, pc * 2, hipMemcpyHostToDevice, ctx->in_stream));
+            }
             if (!sh.hits_direct) BF_HIP(ctx, hipMemcpyAsync(ctx->d_hits.as<bf_hit>() + sh.n0 + p0, hh, pc * sizeof(bf_hit), hipMemcpyHostToDevice, ctx->in_stream));
-            if (b->seq_len) BF_HIP(ctx, hipMemcpyAsync(ctx->d_len.as<uint16_t>() + sh.n0 + p0, ll, pc * 2, hipMemcpyHostToDevice, ctx->in_stream));
             BF_HIP(ctx, hipEventRecord(ws->ev, ctx->in_stream));
             ws->used = true;
         }
@@ -835,6 +853,7 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
         if (mn < 2 * ctx->cfg.anchor_len && p0) ctx->n_localised = 0;
         if (mn < 2 * ctx->cfg.anchor_len)
             return fail(ctx, BF_ERR_RANGE, "a read of length %u is shorter than 2 * anchor_len = %u (detect.rs:311 never emits such reads)", mn, 2 * ctx->cfg.anchor_len);
+        if (b->seq_len) ctx->off_pending.push_back(bf_ctx::OffsetPiece{sh.n0 + p0, sh.n0 + p1, sh.seq0 + sa, sh.frag0 + fa});
         if (p1 < m && eager) {
             // a finished piece in the middle of a large batch: localise it behind its upload.  (The batch becomes
             // resident only when its last piece has been checked; a rejected batch drops the evidence again.)

@@ -191,6 +191,10 @@ struct bf_ctx {
     bool in_pending = false;                    // ... and `stream` has not been told to wait for it yet
     struct StageSlot { uint8_t* p = nullptr; hipEvent_t ev = nullptr; bool used = false; };
     std::vector<StageSlot> slots;               // one per host thread, kStageSlotBytes each (allocated on first use)
+    // 4-bit batches: the offsets are not uploaded, the device rebuilds them from the lengths (a read takes ceil(len / 2)
+    // bytes, fragment ids lie back to back): reads [r0, r1) start at these byte offsets; done before anything reads them
+    struct OffsetPiece { uint64_t r0, r1, seq_base, frag_base; };
+    std::vector<OffsetPiece> off_pending;
     struct WideSlot { uint8_t* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
     WideSlot wide[2];                           // piece-wide offset staging for batches in bf_host_alloc memory, used in turn
     uint32_t wide_next = 0;
@@ -328,7 +332,8 @@ struct OnSideStream {
 int genome_pack(bf_ctx* ctx);                       // raw image -> blocks + coarse bitmap
 int run_localise(bf_ctx* ctx, bool defer_counts = false, bool all = true);   // read_meta + packed + exact kernels; all = false:
                                                     // only the reads bf_submit has not localised behind their upload yet
-int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len);   // bf_submit: the packed kernel over reads [n_localised, n)
+int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len);
+int offsets_from_lengths(bf_ctx* ctx, uint64_t n_uploaded);   // 4-bit batches: rebuilds the offset arrays of the uploaded pieces   // bf_submit: the packed kernel over reads [n_localised, n)
 int grow_reads(bf_ctx* ctx, uint64_t cap);          // per-read arrays for `cap` reads, contents kept
 int settle_counts(bf_ctx* ctx);                     // n_exact / n_sigx / n_text_records valid on return
 int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, int n_chunks, uint64_t* chunk_off,

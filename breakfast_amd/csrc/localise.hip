@@ -1134,7 +1134,10 @@ int grow_reads(bf_ctx* ctx, uint64_t cap) {
     BF_TRY(ensure(ctx, ctx->d_seq_off, (cap + 1) * 8, true));
     BF_TRY(ensure(ctx, ctx->d_frag_off, (cap + 1) * 8, true));
     BF_TRY(ensure(ctx, ctx->d_hits, cap * sizeof(bf_hit), true));
-    if (ctx->packed_reads) BF_TRY(ensure(ctx, ctx->d_len, cap * 2, true));      // input in this mode: the lengths came with the reads
+    if (ctx->packed_reads) {                               // inputs in this mode: the lengths came with the reads
+        BF_TRY(ensure(ctx, ctx->d_len, cap * 2, true));
+        BF_TRY(ensure(ctx, ctx->d_frag_len, cap * 2, true));
+    }
     if (ctx->n_localised) {
         const uint64_t stride = (uint64_t)ctx->mask_words + 1;
         BF_TRY(ensure(ctx, ctx->d_len, cap * 2, true)); BF_TRY(ensure(ctx, ctx->d_frag_len, cap * 2, true));
@@ -1146,6 +1149,37 @@ int grow_reads(bf_ctx* ctx, uint64_t cap) {
         BF_TRY(ensure(ctx, ctx->d_sigx, cap * 16, true));
     }
     ctx->cap_reads = cap;
+    return BF_OK;
+}
+
+// 4-bit batches come without their offset arrays (16 of a read's 121 bytes on PCIe): a read takes ceil(len / 2) bytes
+// and fragment ids lie back to back, so an exclusive scan of the lengths of an uploaded piece, started at the piece's
+// first byte (known on the host), IS the offset array.  Per piece and array: widen, scan, add the base.
+__global__ void widen_lengths_kernel(uint32_t* __restrict__ out, const uint16_t* __restrict__ len, uint64_t n, int halve) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = halve ? ((uint32_t)len[i] + 1u) >> 1 : (uint32_t)len[i];
+}
+__global__ void add_base_kernel(uint64_t* __restrict__ off, uint64_t base, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) off[i] += base;
+}
+int offsets_from_lengths(bf_ctx* ctx, uint64_t n_uploaded) {
+    size_t done = 0;
+    for (const bf_ctx::OffsetPiece& pc : ctx->off_pending) {
+        if (pc.r1 > n_uploaded) break;
+        const uint64_t m = pc.r1 - pc.r0;
+        BF_TRY(ensure(ctx, ctx->c_a32, m * 4, false));
+        for (int which = 0; which < 2 && m; which++) {
+            const uint16_t* len = (which ? ctx->d_frag_len.as<uint16_t>() : ctx->d_len.as<uint16_t>()) + pc.r0;
+            uint64_t* off = (which ? ctx->d_frag_off.as<uint64_t>() : ctx->d_seq_off.as<uint64_t>()) + pc.r0;
+            hipLaunchKernelGGL(widen_lengths_kernel, dim3(grid_for(m, 256)), dim3(256), 0, ctx->stream, ctx->c_a32.as<uint32_t>(), len, m, which ? 0 : 1);
+            BF_TRY(scan_u32_to_u64(ctx, ctx->c_a32.as<uint32_t>(), off, m));                   // m + 1 entries, from 0
+            hipLaunchKernelGGL(add_base_kernel, dim3(grid_for(m + 1, 256)), dim3(256), 0, ctx->stream, off, which ? pc.frag_base : pc.seq_base, m + 1);
+        }
+        BF_HIP(ctx, hipGetLastError());
+        done++;
+    }
+    ctx->off_pending.erase(ctx->off_pending.begin(), ctx->off_pending.begin() + (long)done);
     return BF_OK;
 }
 
@@ -1164,7 +1198,7 @@ int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len) {
     const bool keep = r0 > 0;
     const uint64_t cap = std::max<uint64_t>(ctx->cap_reads, n);
     ctx->plane_words = W; ctx->mask_words = Wm;
-    BF_TRY(ensure(ctx, ctx->d_len, cap * 2, keep || ctx->packed_reads)); BF_TRY(ensure(ctx, ctx->d_frag_len, cap * 2, keep));
+    BF_TRY(ensure(ctx, ctx->d_len, cap * 2, keep || ctx->packed_reads)); BF_TRY(ensure(ctx, ctx->d_frag_len, cap * 2, keep || ctx->packed_reads));
     BF_TRY(ensure(ctx, ctx->d_fhash, cap * 8, keep)); BF_TRY(ensure(ctx, ctx->d_key, cap * 8, keep));
     BF_TRY(ensure(ctx, ctx->d_lpos, cap * 4, keep)); BF_TRY(ensure(ctx, ctx->d_rpos, cap * 4, keep));
     BF_TRY(ensure(ctx, ctx->d_bp, cap * 2, keep)); BF_TRY(ensure(ctx, ctx->d_flags, cap * 2, keep));
@@ -1178,6 +1212,7 @@ int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len) {
         BF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));
         ctx->in_pending = false;
     }
+    BF_TRY(offsets_from_lengths(ctx, n));
 
     const bool separate = (ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE)) != 0;
     if (separate && ctx->packed_reads)

@@ -201,7 +201,9 @@ int bf_submit(bf_ctx* ctx, const bf_batch* batch);
  * per byte, high nibble first; every read starts on a byte and takes ceil(len / 2) bytes: seq_off are BYTE offsets,
  * seq_len the bases).  The reads of detect.rs:91 come from a BAM file, whose decoder (detect.rs:321, rust-htslib) emits
  * exactly these sixteen letters, so the packing loses nothing; it halves what crosses PCIe and what every kernel that
- * touches a read has to fetch.  A caller whose reads hold other bytes (lower case, ...) uses bf_submit.  A ctx holds
+ * touches a read has to fetch.  The two offset arrays are read by the host only (validation): what goes to the GPU are
+ * the lengths, 2 + 2 bytes a read instead of 8 + 8, and the device rebuilds the offsets with a scan per uploaded piece.
+ * A caller whose reads hold other bytes (lower case, ...) uses bf_submit.  A ctx holds
  * its reads in one form: mixing the two calls without bf_reset is BF_ERR_STATE. */
 typedef struct {
     uint64_t        n_reads;
