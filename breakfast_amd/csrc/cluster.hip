@@ -102,7 +102,7 @@ __device__ __forceinline__ bool rpos_far(int32_t rs, int32_t rp, int64_t F) {
 // are walked: by one lane when short, by one wave when longer than kBigSegment (duplicate-heavy
 // libraries pile thousands of reads on one junction).
 // csize[p] = cluster size if p is a seed; csize is zero-initialised.
-constexpr uint32_t kBigSegment = 96;
+constexpr uint32_t kBigSegment = 16;            // (96 until round 2: one lane walking a 96-record segment took 64 us, the whole sweep_list launch)
 constexpr uint32_t kCtlWords = 16;       // head of c_big: two list lengths, then 64-bit sums for the host (flag_ge_kernel)
 
 // A SEGMENT is a run of records with equal low 32 key bits (the signature, or its hash): the class keys are

@@ -126,17 +126,21 @@ def test_read_lengths_that_change_the_evidence_layout_between_pieces(order):
         eng.close()
 
 
-def test_finish_then_more_reads_then_finish():
+@pytest.mark.parametrize("packed", [False, True])
+def test_finish_then_more_reads_then_finish(packed):
     """Appending after a bf_finish: only the new reads are localised, the exact kernel only sees its new list
-    entries, and the result is the oracle's for the union (also with every read on the exact path)."""
-    g, b = case(n_frac=0.003)
+    entries, and the result is the oracle's for the union (also with every read on the exact path).  With 4-bit
+    batches the device rebuilds the offsets of every appended piece from its lengths, starting where the resident
+    bytes end."""
+    g, b = case(n_frac=0.003, upper=packed)
     for flags in (0, BF_FLAG_FORCE_EXACT):
         eng = engine.Engine(20, 5000, 2, piece_reads=3000, flags=flags)
         try:
             eng.set_genome(g.names, g.seqs)
             cut = [0, 7000, 7001, 15000, b.n]
             for a, e in zip(cut[:-1], cut[1:]):
-                eng.submit(b.slice(a, e))
+                part = b.slice(a, e)
+                eng.submit(engine.pack_batch(part) if packed else part)
                 assert eng.format_sv(eng.finish()) == oracle_sv(g, b.slice(0, e))
         finally:
             eng.close()
