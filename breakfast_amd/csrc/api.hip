@@ -3,6 +3,7 @@
 // no CPU implementation of the path in this library.
 
 #include "bf_internal.h"
+#include <chrono>
 
 #include <algorithm>
 #include <atomic>
@@ -42,7 +43,16 @@ void trace_line(const bf_ctx* ctx, const char* what, const char* name, const cha
 int traced_sync(bf_ctx* ctx, hipStream_t s, const char* name, const char* file, int line) {
     const bool t = trace_on();
     if (t) trace_line(ctx, "wait", name, file, line);
-    const hipError_t e = hipStreamSynchronize(s);
+    // The waits inside a step are short (tens of microseconds) and the GPU idles until the host is back: poll for a
+    // while before blocking (a blocked thread is woken 15-20 us after the stream drained).
+    hipError_t e = hipErrorNotReady;
+    if (!getenv("BREAKFAST_HIP_NO_SPIN")) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while ((e = hipStreamQuery(s)) == hipErrorNotReady)
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+        if (e != hipSuccess && e != hipErrorNotReady) (void)hipGetLastError();
+    }
+    if (e != hipSuccess) e = hipStreamSynchronize(s);
     if (t) trace_line(ctx, e == hipSuccess ? "done" : "FAILED", name, file, line);
     if (e != hipSuccess) return fail(ctx, BF_ERR_HIP, "hipStreamSynchronize(%s) failed: %s (%s:%d)", name, hipGetErrorString(e), file, line);
     return BF_OK;
