@@ -46,7 +46,8 @@ int traced_sync(bf_ctx* ctx, hipStream_t s, const char* name, const char* file, 
     // The waits inside a step are short (tens of microseconds) and the GPU idles until the host is back: poll for a
     // while before blocking (a blocked thread is woken 15-20 us after the stream drained).
     hipError_t e = hipErrorNotReady;
-    if (!getenv("BREAKFAST_HIP_NO_SPIN")) {
+    static const bool spin = getenv("BREAKFAST_HIP_NO_SPIN") == nullptr;       // (A/B switch)
+    if (spin) {
         const auto t0 = std::chrono::steady_clock::now();
         while ((e = hipStreamQuery(s)) == hipErrorNotReady)
             if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;

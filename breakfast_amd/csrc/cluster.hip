@@ -810,6 +810,7 @@ static int class_order(bf_ctx* ctx, const OwnerView& v, const uint32_t* idx, uin
     const unsigned B = 256;
     int bits = m > (16u << 20) ? 20 : 16;
     if (const char* e = getenv("BREAKFAST_HIP_BUCKET_BITS")) bits = std::min(20, std::max(1, atoi(e)));      // tests: few buckets = chunks that overflow
+    // (read on every call on purpose: the tests change it between engines of one process)
     const uint32_t n_buckets = 1u << bits;
     const uint32_t n_chunks = (uint32_t)((m + kChunkBase - 1) / kChunkBase);
     // chunk table: cstart u32[n_chunks + 1] | osize u32[n_chunks] | obefore u64[n_chunks + 1]
