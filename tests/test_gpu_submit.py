@@ -204,6 +204,36 @@ def test_a_rejected_batch_leaves_the_ctx_as_it_was():
         eng.close()
 
 
+def test_a_rejected_4bit_batch_leaves_the_ctx_as_it_was():
+    """The same for bf_submit_packed: pieces of the rejected batch were uploaded, localised and had their offsets rebuilt
+    on the device before the offending read was seen; nothing of it stays, and the next batch takes its place."""
+    import dataclasses
+    g, b = case(upper=True)
+    good, bad = engine.pack_batch(b.slice(0, 10000)), engine.pack_batch(b.slice(10000, 20000))
+    ref = oracle_sv(g, b.slice(0, 10000))
+    eng = engine.Engine(20, 5000, 2, piece_reads=1500, host_threads=3)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        eng.submit(good)
+        h = bad.hits.copy(); h["contig3"][9000] = 99                       # in the batch's last piece
+        with pytest.raises(engine.BreakfastError) as e:
+            eng.submit(dataclasses.replace(bad, hits=h))
+        assert e.value.code == -1 and "read 9000 " in str(e.value)
+        ln = bad.seq_len.copy(); ln[4000] += 2                             # a length that does not match its bytes
+        with pytest.raises(engine.BreakfastError) as e:
+            eng.submit(dataclasses.replace(bad, seq_len=ln))
+        assert e.value.code == -1 and "read 4000 " in str(e.value)
+        assert eng.stats()[0] == good.n
+        assert eng.format_sv(eng.finish()) == ref
+        eng.submit(bad)                                                    # and the ctx still takes the good version
+        assert eng.format_sv(eng.finish()) == oracle_sv(g, b.slice(0, 20000))
+        pinned = eng.pin_batch(engine.pack_batch(b.slice(20000, b.n)))     # ... and more, from bf_host_alloc memory
+        eng.submit(pinned)
+        assert eng.format_sv(eng.finish()) == oracle_sv(g, b)
+    finally:
+        eng.close()
+
+
 def test_pageable_batches_may_be_freed_on_return_and_pinned_ones_after_the_wait():
     g, b = case()
     ref = oracle_sv(g, b)
