@@ -1019,7 +1019,10 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
     uint64_t ns = 0, total_r = 0;
     BF_TRY(ensure(ctx, ctx->c_flag, std::max(nq, n) * 4, false));
     BF_TRY(ensure(ctx, ctx->c_ord, nq * 4));
-    BF_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[12], 0));
+    {
+        Scope t(ctx, "order_wait");                      // what the main stream idles for the print-order sorts on the side stream
+        BF_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[12], 0));
+    }
     {
         Scope t(ctx, "select");
         const uint32_t* qord = ctx->c_qord.as<uint32_t>();
