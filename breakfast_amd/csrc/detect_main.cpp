@@ -425,6 +425,19 @@ static int detect_sharded(const bf_config& cfg0, const std::vector<int>& devices
     return 0;
 }
 
+// write end of the pipe to the waiting parent (detect only; -1: there is none)
+static int g_done_fd = -1;
+// everything the caller waits for is done: tell the parent, let go of the standard streams (a caller that reads our
+// stdout or stderr through a pipe waits for their last holder), and leave the cleaning up to what follows
+static void work_done(int code) {
+    fflush(stdout); fflush(stderr);
+    if (g_done_fd < 0) return;
+    const unsigned char c = (unsigned char)code;
+    if (write(g_done_fd, &c, 1) != 1) {}
+    close(g_done_fd); g_done_fd = -1;
+    close(0); close(1); close(2);
+}
+
 int main(int argc, char** argv) {
     if (argc >= 2 && strcmp(argv[1], "filter") == 0) return filter_main(argc, argv);        // main.rs:26
     if (argc >= 2 && strcmp(argv[1], "annotate") == 0) return annotate_main(argc, argv);    // main.rs:27
@@ -436,6 +449,29 @@ int main(int argc, char** argv) {
               "  breakfast-hip annotate <sv_path> <bed_path>\n  breakfast-hip anchors [--anchor-len=N] <bam_file>\n"
               "  breakfast-hip hits [--threads=N] [--block-bytes=N] <hits_file> <genome>\n", stderr);
         return -1;
+    }
+    // `detect` does its work in a child process, started before anything touches the GPU.  When the output is written
+    // the child says so and the parent returns; releasing 10 GB of device memory, the pinned buffers and the runtime
+    // (0.18 s for configs[1], most of it inside the driver after exit) then happens behind the caller's back instead of
+    // in front of it.  A child that ends without saying so hands its exit status on.  BREAKFAST_HIP_NO_DETACH=1: one process.
+    if (!anchors_only && !hits_only && !getenv("BREAKFAST_HIP_NO_DETACH")) {
+        int pfd[2];
+        if (pipe(pfd) == 0) {
+            fflush(stdout); fflush(stderr);
+            const pid_t pid = fork();
+            if (pid > 0) {
+                close(pfd[1]);
+                unsigned char code = 0;
+                ssize_t r;
+                while ((r = read(pfd[0], &code, 1)) < 0 && errno == EINTR) {}
+                if (r == 1) _exit(code);
+                int st = 0;
+                while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {}
+                _exit(WIFEXITED(st) ? WEXITSTATUS(st) : 255);
+            }
+            if (pid == 0) { close(pfd[0]); g_done_fd = pfd[1]; }
+            else { close(pfd[0]); close(pfd[1]); }          // fork failed: everything in this process
+        }
     }
     bf_config cfg;
     memset(&cfg, 0, sizeof cfg);
@@ -559,6 +595,7 @@ int main(int argc, char** argv) {
         if (producer.joinable()) producer.join();
         if (child.pid > 0) { int st = 0; waitpid(child.pid, &st, 0); }
         timing.print();
+        work_done(rc);
         return rc;
     }
     if (devices.size() == 1) cfg.device = devices[0];
@@ -744,6 +781,6 @@ int main(int argc, char** argv) {
     if (getenv("BREAKFAST_HIP_TEARDOWN")) { bf_ctx_destroy(ctx); timing.lap("teardown"); }
     timing.print();
     // everything is written: the process ends here and the driver reclaims the GPU memory
-    fflush(stderr);
+    work_done(0);
     _exit(0);
 }

@@ -73,6 +73,9 @@ def main():
     runs = []
     out_path = os.path.join(args.dir, "gpu.sv")
     for r in range(args.runs):
+        # the command returns when its output is complete; the process that did the work frees its GPU context and
+        # pinned memory after that, in the background: let it finish, so that each run is a single invocation
+        time.sleep(1.0)
         with open(out_path, "wb") as fo:
             t = time.time()
             p = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, timeout=900)

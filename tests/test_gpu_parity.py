@@ -451,6 +451,31 @@ def test_cli_driver_error_convention(tmp_path):
     assert p.returncode == 255 and p.stderr.startswith(b"ERROR: ")      # common.rs:8-13: exit(-1)
 
 
+def test_cli_driver_one_process_and_detached_agree(tmp_path):
+    """`detect` hands its status to a waiting parent once the table is written and frees the GPU behind it;
+    BREAKFAST_HIP_NO_DETACH=1 keeps one process.  Same bytes, same status, same stderr either way, and a hit list
+    that fails late (a contig the genome does not have, after the GPU came up) is exit(-1) in both."""
+    import os
+    import subprocess
+    from conftest import GOLDEN, ROOT
+    exe = os.path.join(ROOT, "breakfast_amd", "csrc", "breakfast-hip")
+    fa, lines, (A, F, E), sv = load_golden("kat_survey")
+    prefix = os.path.join(GOLDEN, "kat_survey")
+    bad = tmp_path / "bad.bowtie"
+    bad.write_bytes(lines + b"5p:999999:\t+\tno_such_contig\t27\n3p:999999:fragZ:AGTTATCGGTGCCGAACTGATGGA:\t+\tchr2\t33\n")
+    outs = []
+    for env in ({}, {"BREAKFAST_HIP_NO_DETACH": "1"}):
+        e = dict(os.environ, **env)
+        argv = [exe, "detect", "--anchor-len=%d" % A, "--max-frag-len=%d" % F, "--min-evidence=%d" % E]
+        good = subprocess.run(argv + ["--anchor-hits=%s.bowtie" % prefix, "unused.bam", prefix], capture_output=True,
+                              timeout=120, env=e)
+        assert good.returncode == 0 and good.stdout == sv, good.stderr.decode()
+        late = subprocess.run(argv + ["--anchor-hits=%s" % bad, "unused.bam", prefix], capture_output=True, timeout=120, env=e)
+        assert late.returncode == 255 and late.stderr.count(b"ERROR: ") == 1, late.stderr.decode()
+        outs.append((good.stderr, late.stderr, late.stdout))
+    assert outs[0] == outs[1]
+
+
 def _frag_hash32(b: bytes) -> int:
     """low 32 bits of read_meta_kernel's fragment-id hash (FNV-1a/64 + avalanche)."""
     M = (1 << 64) - 1
