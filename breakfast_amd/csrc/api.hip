@@ -529,6 +529,7 @@ constexpr uint64_t kInlineBytes = 1u << 20;       // pieces below this are stage
 
 static bool is_pinned(const bf_ctx* ctx, const void* p, size_t n) {
     const uint8_t* b = (const uint8_t*)p;
+    std::lock_guard<std::mutex> g(const_cast<bf_ctx*>(ctx)->pinned_mu);
     for (auto& r : ctx->pinned) if (b >= r.first && b + n <= r.first + r.second) return true;
     return false;
 }
@@ -698,7 +699,10 @@ int bf_host_alloc(bf_ctx* ctx, uint64_t bytes, void** out) {
     void* p = nullptr;
     const hipError_t e = hipHostMalloc(&p, std::max<uint64_t>(bytes, 64), hipHostMallocDefault);
     if (e != hipSuccess) return fail(ctx, BF_ERR_NOMEM, "hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
-    ctx->pinned.emplace_back((const uint8_t*)p, (size_t)std::max<uint64_t>(bytes, 64));
+    {
+        std::lock_guard<std::mutex> g(ctx->pinned_mu);
+        ctx->pinned.emplace_back((const uint8_t*)p, (size_t)std::max<uint64_t>(bytes, 64));
+    }
     *out = p;
     return BF_OK;
 }
@@ -706,13 +710,18 @@ int bf_host_alloc(bf_ctx* ctx, uint64_t bytes, void** out) {
 int bf_host_free(bf_ctx* ctx, void* p) {
     if (!ctx) return BF_ERR_INVALID;
     if (!p) return BF_OK;
-    for (size_t i = 0; i < ctx->pinned.size(); i++)
-        if (ctx->pinned[i].first == (const uint8_t*)p) {
-            BF_SYNC(ctx, ctx->in_stream);       // no upload may still be reading it
-            (void)hipHostFree(p);
-            ctx->pinned.erase(ctx->pinned.begin() + (long)i);
-            return BF_OK;
-        }
+    bool known = false;
+    {
+        std::lock_guard<std::mutex> g(ctx->pinned_mu);
+        for (size_t i = 0; i < ctx->pinned.size() && !known; i++)
+            if (ctx->pinned[i].first == (const uint8_t*)p) { ctx->pinned.erase(ctx->pinned.begin() + (long)i); known = true; }
+    }
+    if (known) {
+        BF_HIP(ctx, hipSetDevice(ctx->device));
+        BF_SYNC(ctx, ctx->in_stream);           // no upload may still be reading it
+        (void)hipHostFree(p);
+        return BF_OK;
+    }
     return fail(ctx, BF_ERR_INVALID, "bf_host_free: not a bf_host_alloc pointer of this ctx");
 }
 

@@ -199,6 +199,7 @@ struct bf_ctx {
     WideSlot wide[2];                           // piece-wide offset staging for batches in bf_host_alloc memory, used in turn
     uint32_t wide_next = 0;
     std::vector<std::pair<const uint8_t*, size_t>> pinned;   // bf_host_alloc ranges
+    std::mutex pinned_mu;                       // bf_host_alloc / bf_host_free may come from any thread, beside other calls
     uint32_t host_threads = 0;                  // bf_config.reserved[1], or chosen from the machine
     uint64_t cap_reads = 0;                     // capacity of every per-read array below (inputs and evidence)
     uint64_t n_localised = 0;                   // reads [0, n_localised) have evidence under (plane_words, mask_words)

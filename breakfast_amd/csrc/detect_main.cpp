@@ -70,7 +70,10 @@ int annotate_main(int argc, char** argv);    // text_tools.cpp: src/annotate.rs
     vfprintf(stderr, fmt, ap);
     fputc('\n', stderr);
     va_end(ap);
-    exit(-1);
+    // other threads may be in the middle of GPU calls or writing into pinned memory: no exit handlers (the HIP
+    // runtime's would unmap that memory under them), the process just ends (common.rs:8-13: exit(-1))
+    fflush(stdout); fflush(stderr);
+    _exit(255);
 }
 
 static const char* USAGE =
@@ -253,13 +256,26 @@ static Fasta read_fasta(const std::string& path, int threads) {
 
 // Every piece of every contig to `sink(contig slot, offset inside the contig, bytes, n)`, from `threads` workers.
 static void stream_fasta(const FastaScan& fs, int threads, const std::function<void(uint32_t, uint64_t, const uint8_t*, uint64_t)>& sink) {
+    // a worker joins the lines of its piece in a buffer it keeps (no fresh pages per piece) and hands them on 2 MB at
+    // a time, while they are still in its cache for the sink's copy into pinned memory
+    constexpr size_t kChunk = 2u << 20;
     parallel_for(fs.pieces.size(), threads, [&](size_t i) {
         const long sl = fs.rec_slot[fs.pieces[i].rec];
         if (sl < 0 || fs.pieces[i].len == 0) return;
-        std::unique_ptr<char[]> buf(new char[fs.pieces[i].len]);
-        char* out = buf.get();
-        fs.each_line(fs.pieces[i], [&](const char* s, size_t l) { memcpy(out, s, l); out += l; });
-        sink((uint32_t)sl, fs.pieces[i].out, (const uint8_t*)buf.get(), fs.pieces[i].len);
+        thread_local std::unique_ptr<char[]> buf;
+        thread_local size_t cap = 0;
+        size_t fill = 0;
+        uint64_t at = fs.pieces[i].out;
+        fs.each_line(fs.pieces[i], [&](const char* s, size_t l) {
+            if (fill + l > cap) {
+                if (fill) { sink((uint32_t)sl, at, (const uint8_t*)buf.get(), fill); at += fill; fill = 0; }
+                if (l > cap) { cap = std::max(l, kChunk + (64u << 10)); buf.reset(new char[cap]); }
+            }
+            memcpy(buf.get() + fill, s, l);
+            fill += l;
+            if (fill >= kChunk) { sink((uint32_t)sl, at, (const uint8_t*)buf.get(), fill); at += fill; fill = 0; }
+        });
+        if (fill) sink((uint32_t)sl, at, (const uint8_t*)buf.get(), fill);
     });
 }
 
@@ -310,6 +326,43 @@ static void write_all(int fd, const char* p, size_t n) {
         p += w; n -= (size_t)w;
     }
 }
+
+// bf_host_alloc memory for the parser's batches, handed out in power-of-two blocks from a few large slabs (one call
+// into the driver per slab, not per array).  A released block is handed out again at once: the parser only lets go of
+// arrays it is filling or of batches whose uploads have been waited for.
+struct PinnedHome {
+    static constexpr size_t kHead = 64, kMinBlock = 64u << 10, kSlab = 256u << 20;
+    bf_ctx* ctx = nullptr;
+    std::mutex mu;
+    std::vector<std::vector<void*>> spare;       // by class c: blocks of kMinBlock << c bytes (head included)
+    uint8_t* slab = nullptr;
+    size_t slab_left = 0;
+    void* alloc(size_t bytes) {
+        size_t c = 0;
+        while ((kMinBlock << c) - kHead < bytes) c++;
+        const size_t block = kMinBlock << c;
+        std::lock_guard<std::mutex> g(mu);
+        if (spare.size() <= c) spare.resize(c + 1);
+        uint8_t* p = nullptr;
+        if (!spare[c].empty()) { p = (uint8_t*)spare[c].back(); spare[c].pop_back(); }
+        else {
+            if (slab_left < block) {                  // (what is left of the old slab stays unused)
+                void* q = nullptr;
+                const size_t want = std::max(block, kSlab);
+                if (bf_host_alloc(ctx, want, &q) != BF_OK) return nullptr;
+                slab = (uint8_t*)q; slab_left = want;
+            }
+            p = slab; slab += block; slab_left -= block;
+            *(uint64_t*)p = c;
+        }
+        return p + kHead;
+    }
+    void release(void* q) {
+        uint8_t* p = (uint8_t*)q - kHead;
+        std::lock_guard<std::mutex> g(mu);
+        spare[(size_t)*(uint64_t*)p].push_back(p);
+    }
+};
 
 // One parsed batch (or reads [a, b) of it) to the library, in the form the parser produced it
 static int submit_parsed(bf_ctx* ctx, const hits::Batch& src, uint64_t a, uint64_t b) {
@@ -611,7 +664,9 @@ int main(int argc, char** argv) {
         // The same thread then sends the FASTA's pieces to the GPU from a few workers; bf_submit accepts reads from
         // bf_genome_begin on (their kernels wait for bf_genome_end): the submit thread below waits for that moment.
         std::string ctx_error;
-        std::thread ctx_thread([&] { if (bf_ctx_create(&cfg, &ctx) != BF_OK) ctx_error = bf_last_error(nullptr); });
+        double ctx_at = 0, ready_at = 0, first_submit_at = 0;      // seconds since the process started (--timing)
+        auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - timing.t0).count(); };
+        std::thread ctx_thread([&] { if (bf_ctx_create(&cfg, &ctx) != BF_OK) ctx_error = bf_last_error(nullptr); ctx_at = since_start(); });
         auto fs = scan_fasta(genome_path + ".fa", threads);
         if (announce) fprintf(stderr, "Reading reference genome into memory...\n");
         timing.lap("fasta_scan");
@@ -625,6 +680,13 @@ int main(int argc, char** argv) {
         if (const char* e = getenv("BREAKFAST_HIP_GENOME_THREADS")) g_threads = std::max(1, atoi(e));
         if (const char* e = getenv("BREAKFAST_HIP_PARSER_THREADS")) popt.threads = std::max(1, atoi(e));
         genome_s = 0;
+        // the parser's batches move into the library's pinned memory once the ctx exists: bf_submit then uploads them
+        // from where the parser wrote them instead of copying them into its staging slots first
+        PinnedHome home;
+        const hits::Allocator pinned_mem{[](void* u, size_t bytes) { return ((PinnedHome*)u)->alloc(bytes); },
+                                         [](void* u, void* q) { ((PinnedHome*)u)->release(q); }, &home};
+        std::atomic<const hits::Allocator*> batch_home{nullptr};
+        popt.allocator = &batch_home;
         std::mutex gpu_mu;
         std::condition_variable gpu_cv;
         bool gpu_ready = false;
@@ -657,6 +719,9 @@ int main(int argc, char** argv) {
                     (void)bf_reserve(ctx, n_est, seq_est, (uint64_t)((double)frag * scale) + (1u << 20));   // an estimate: failing is not fatal
                 }
             }
+            ready_at = since_start();
+            home.ctx = ctx;
+            if (!getenv("BREAKFAST_HIP_PAGEABLE_BATCHES")) batch_home.store(&pinned_mem, std::memory_order_release);
             { std::lock_guard<std::mutex> g(gpu_mu); gpu_ready = true; }
             gpu_cv.notify_all();
             const auto t0 = std::chrono::steady_clock::now();
@@ -670,12 +735,15 @@ int main(int argc, char** argv) {
         // parsed batches go to a submit thread through a short queue (in input order: one producer, one consumer), so that
         // the thread that pairs lines across block boundaries is not held up while a batch is staged for the GPU
         submit_s = 0;
-        if (!getenv("BREAKFAST_HIP_PARSER_THREADS")) popt.threads = std::max(1, threads - g_threads);
+        // (two threads fewer than there are left: the submit thread and the reader are busy too, and on a box whose
+        // cores are all taken they were what the parse waited for -- 13 workers of 16 threads: 0.163 s, 11: 0.147 s)
+        if (!getenv("BREAKFAST_HIP_PARSER_THREADS")) popt.threads = std::max(1, threads - g_threads - (threads >= 8 ? 2 : 0));
         {
             std::mutex mu;
             std::condition_variable cv;
             std::deque<hits::Batch> queue;
             std::vector<hits::Batch> spent;           // submitted batches: their buffers go back to the parser
+            std::vector<hits::Batch> in_flight;       // ... those in pinned memory after their uploads have left it
             bool done = false;
             std::thread submitter([&] {
                 { std::unique_lock<std::mutex> lk(gpu_mu); gpu_cv.wait(lk, [&] { return gpu_ready; }); }
@@ -690,10 +758,23 @@ int main(int argc, char** argv) {
                         cv.notify_all();
                     }
                     const auto t0 = std::chrono::steady_clock::now();
+                    if (first_submit_at == 0) first_submit_at = since_start();
                     if (submit_parsed(ctx, b, 0, b.n()) != BF_OK) error("%s", bf_last_error(ctx));
                     submit_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                    std::lock_guard<std::mutex> g(mu);      // pageable arrays are staged when bf_submit returns
-                    spent.push_back(std::move(b));
+                    const hits::Allocator* heap = hits::heap_allocator();
+                    const bool pageable = b.seq.home() == heap && b.frag.home() == heap && b.seq_off.home() == heap &&
+                                          b.frag_off.home() == heap && b.seq_len.home() == heap && b.hits.home() == heap;
+                    if (pageable) {                         // staged when bf_submit returns
+                        std::lock_guard<std::mutex> g(mu);
+                        spent.push_back(std::move(b));
+                        continue;
+                    }
+                    in_flight.push_back(std::move(b));
+                    if (in_flight.size() < 6) continue;
+                    if (bf_submit_wait(ctx) != BF_OK) error("%s", bf_last_error(ctx));
+                    std::lock_guard<std::mutex> g(mu);
+                    for (auto& f : in_flight) spent.push_back(std::move(f));
+                    in_flight.clear();
                 }
             });
             try {
@@ -712,6 +793,8 @@ int main(int argc, char** argv) {
                 { std::lock_guard<std::mutex> g(mu); queue.clear(); done = true; cv.notify_all(); }
                 submitter.join();
                 genome_thread.join();
+                spent.clear(); in_flight.clear();          // they live in the ctx's pinned memory
+                popt.allocator = nullptr;
                 bf_ctx_destroy(ctx);
                 ctx = nullptr;
                 return false;
@@ -722,8 +805,12 @@ int main(int argc, char** argv) {
         if (in_fd > 0) close(in_fd);
         if (producer.joinable()) producer.join();
         if (child.pid > 0) { int st = 0; waitpid(child.pid, &st, 0); }     // the reference never checks it either
+        popt.allocator = nullptr;
         timing.lap("parse_and_submit");
         timing.add("  of_which_bf_submit", submit_s);
+        timing.add("  at_ctx_created", ctx_at);
+        timing.add("  at_gpu_accepts_reads", ready_at);
+        timing.add("  at_first_bf_submit", first_submit_at);
         genome_thread.join();
         if (bf_genome_end(ctx) != BF_OK) error("%s", bf_last_error(ctx));
         fs.reset();                                                 // the genome now lives in HBM

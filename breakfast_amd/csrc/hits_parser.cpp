@@ -31,6 +31,11 @@ static inline uint64_t name_hash(std::string_view s) {
     return h ^ (h >> 29);
 }
 
+const Allocator* heap_allocator() {
+    static const Allocator heap{[](void*, size_t bytes) { return malloc(bytes ? bytes : 1); }, [](void*, void* p) { free(p); }, nullptr};
+    return &heap;
+}
+
 void ContigIndex::build() {
     size_t cap = 16;
     while (cap < names_.size() * 4) cap *= 2;
@@ -200,10 +205,10 @@ struct PairParser {
             out.seq_len.push_back((uint16_t)L);
             out.packed = true;
         } else {
-            out.seq.append(a[3]);
+            out.seq.append(a[3].data(), a[3].size());
         }
         out.seq_off.push_back(out.seq.size());
-        out.frag.append(a[2]); out.frag_off.push_back(out.frag.size());
+        out.frag.append(a[2].data(), a[2].size()); out.frag_off.push_back(out.frag.size());
     }
 };
 
@@ -236,6 +241,9 @@ void parse_block(const Block& b, const PairParser& pair, Parsed& out) {
     out.batch.seq.reserve(pair.pack ? b.n * 3 / 8 : b.n * 3 / 4);
     out.batch.packed = pair.pack;
     out.batch.frag.reserve(b.n / 8);
+    const size_t pairs = b.n / 160 + 16;        // a guess that saves the first doublings; the arrays grow as needed
+    out.batch.hits.reserve(pairs); out.batch.seq_off.reserve(pairs + 1); out.batch.frag_off.reserve(pairs + 1);
+    if (pair.pack) out.batch.seq_len.reserve(pairs);
     try {
         while (s < end) {
             const char* nl = (const char*)memchr(s, '\n', (size_t)(end - s));
@@ -400,7 +408,8 @@ Stats parse_stream(int fd, const ContigIndex& contigs, const std::string& genome
                     std::lock_guard<std::mutex> g(pl.mu);
                     if (!pl.spare.empty()) { out->batch = std::move(pl.spare.back()); pl.spare.pop_back(); }
                 }
-                out->batch.clear();
+                const Allocator* al = opt.allocator ? opt.allocator->load(std::memory_order_acquire) : nullptr;
+                out->batch.clear(al ? al : heap_allocator());
                 const auto t0 = std::chrono::steady_clock::now();
                 parse_block(b, pair, *out);
                 worker_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -456,7 +465,7 @@ Stats parse_stream(int fd, const ContigIndex& contigs, const std::string& genome
             {
                 // whatever the sink left in the batch (its own spent buffers, if it swapped) serves the next block
                 std::lock_guard<std::mutex> g(pl.mu);
-                if (pl.spare.size() < pl.max_in_flight + 8) pl.spare.push_back(std::move(p->batch));
+                if (p->batch.has_room() && pl.spare.size() < pl.max_in_flight + 8) pl.spare.push_back(std::move(p->batch));
             }
             p.reset();
             {

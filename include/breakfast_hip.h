@@ -217,7 +217,9 @@ typedef struct {
 int bf_submit_packed(bf_ctx* ctx, const bf_packed_batch* batch);
 
 /* Pinned host memory for batches (bf_submit uploads from it without staging).  Owned by the ctx: freed by
- * bf_host_free or bf_ctx_destroy.  No counterpart in the reference (its reads never leave host memory). */
+ * bf_host_free or bf_ctx_destroy.  These two calls may come from any thread, also while another thread is inside
+ * another call on the ctx (a parser's workers allocate while a submit thread submits); bf_host_free waits for the
+ * queued uploads.  No counterpart in the reference (its reads never leave host memory). */
 int bf_host_alloc(bf_ctx* ctx, uint64_t bytes, void** out);
 int bf_host_free(bf_ctx* ctx, void* p);
 /* Returns when every upload queued by bf_submit has left host memory (pinned batch buffers may be reused). */
