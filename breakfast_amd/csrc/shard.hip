@@ -210,8 +210,10 @@ struct HostTransport : Transport {
 struct Shard {
     Transport* tr = nullptr;
     std::vector<uint64_t> bases;                // index_base of every rank
-    DevBuf d_send, d_recv, d_req_out, d_req_in, d_place, d_small, d_roff, d_roff_g, d_rbytes;
-    HostBuf h_places, h_roff, h_rbytes;
+    DevBuf d_send, d_recv, d_req_out, d_req_in, d_place, d_src, d_small, d_pick, d_roff, d_roff_g, d_rbytes;
+    HostBuf h_places, h_src, h_roff, h_rbytes;
+    std::vector<uint64_t> block_off, group_read_begin;      // what the last bf_shard_finish's result points at
+    uint64_t last_nr = 0, last_n_in = 0;                    // sizes of the tables left on the device
     ~Shard() { delete tr; }
 };
 
@@ -239,12 +241,20 @@ static int grow_host_keep(bf_ctx* ctx, HostBuf& b, size_t used, size_t need) {
 
 // place[i] = (source rank, slot in that source's record list) of supporting read i: the reads sorted by source rank
 // are position j = order^-1(i); the slot counts from the first request of this owner to that source
-__global__ void place_kernel(bf_place* __restrict__ place, const uint32_t* __restrict__ order, const uint32_t* __restrict__ skey,
-                             const uint64_t* __restrict__ start, const uint64_t* __restrict__ slot_base, uint64_t nr) {
+// src[i] = the source rank alone: all the host needs to walk the records in the order they were asked for
+__global__ void place_kernel(bf_place* __restrict__ place, uint8_t* __restrict__ src, const uint32_t* __restrict__ order,
+                             const uint32_t* __restrict__ skey, const uint64_t* __restrict__ start, const uint64_t* __restrict__ slot_base, uint64_t nr) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nr) return;
     const uint32_t s = skey[j];
     place[order[j]] = bf_place{s, (uint32_t)(slot_base[s] + (j - start[s]))};
+    src[order[j]] = (uint8_t)s;
+}
+
+// out[k] = off[pos[k]]: the record offsets at the boundaries between the owners' request lists
+__global__ void pick_offsets_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ off, const uint64_t* __restrict__ pos, uint32_t n) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = off[pos[k]];
 }
 
 inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
@@ -277,9 +287,9 @@ int shard_attach(bf_ctx* ctx, Transport* tr, uint32_t rank, uint32_t n_ranks, ui
 void shard_destroy(bf_ctx* ctx) {
     Shard* sh = shard_of(ctx);
     if (!sh) return;
-    DevBuf* bufs[] = {&sh->d_send, &sh->d_recv, &sh->d_req_out, &sh->d_req_in, &sh->d_place, &sh->d_small, &sh->d_roff, &sh->d_roff_g, &sh->d_rbytes};
+    DevBuf* bufs[] = {&sh->d_send, &sh->d_recv, &sh->d_req_out, &sh->d_req_in, &sh->d_place, &sh->d_src, &sh->d_small, &sh->d_pick, &sh->d_roff, &sh->d_roff_g, &sh->d_rbytes};
     for (DevBuf* b : bufs) release(ctx, *b);
-    HostBuf* hosts[] = {&sh->h_places, &sh->h_roff, &sh->h_rbytes};
+    HostBuf* hosts[] = {&sh->h_places, &sh->h_src, &sh->h_roff, &sh->h_rbytes};
     for (HostBuf* h : hosts) { if (h->p) (void)hipHostFree(h->p); h->p = nullptr; h->cap = 0; }
     delete sh;
     ctx->shard = nullptr;
@@ -459,9 +469,14 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
     }
     const size_t my_groups = gb.size() - 1;
 
-    std::vector<uint64_t> req_counts(W), start(W + 1), rm((size_t)W * W), ctl(W), recv_before(W, 0);
+    std::vector<uint64_t> req_counts(W), start(W + 1), rm((size_t)W * W), ctl(W), recv_before(W, 0), pick(2 * (size_t)W + 2);
     uint64_t cl_base = 0, rd_base = 0, n_in = 0, rec_total = 0;
+    sh->block_off.assign((size_t)G * W + 1, 0);
+    sh->group_read_begin.assign((size_t)G + 1, 0);
+    sh->last_nr = sh->last_n_in = 0;
     for (uint32_t g = 0; g < G; g++) {
+        sh->group_read_begin[g] = rd_base;
+        for (uint32_t o = 0; o < W; o++) sh->block_off[(size_t)g * W + o] = rec_total;        // (a round nobody asks this rank in)
         // the owner's side: cluster the group
         uint64_t nr_g = 0, ns_g = 0;
         if (g < my_groups && gb[g + 1] > gb[g]) {
@@ -496,10 +511,11 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
         if (n_in + n_in_g > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "sharded path: %llu junction requests for one rank", (unsigned long long)(n_in + n_in_g));
         if (nr_g) {
             BF_TRY(ensure(ctx, sh->d_place, (rd_base + nr_g) * sizeof(bf_place), true));
+            BF_TRY(ensure(ctx, sh->d_src, rd_base + nr_g, true));
             BF_TRY(ensure(ctx, sh->d_small, (size_t)(W + 1) * 8));
             BF_HIP(ctx, hipMemcpyAsync(sh->d_small.p, ctl.data(), (size_t)W * 8, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(place_kernel, dim3(grid_for(nr_g, 256)), dim3(256), 0, st, sh->d_place.as<bf_place>() + rd_base,
-                               ctx->c_d32.as<uint32_t>(), ctx->c_b32.as<uint32_t>(), d_start, sh->d_small.as<uint64_t>(), nr_g);
+                               sh->d_src.as<uint8_t>() + rd_base, ctx->c_d32.as<uint32_t>(), ctx->c_b32.as<uint32_t>(), d_start, sh->d_small.as<uint64_t>(), nr_g);
             BF_HIP(ctx, hipGetLastError());
             BF_SYNC(ctx, st);                                        // (ctl is reused by the next group)
         }
@@ -523,11 +539,23 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
             BF_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, st));
             BF_TRY(render_sizes_checked(ctx, n_in_g, d_idx, d_len, d_bad));
             BF_TRY(render_prepare(ctx, n_in_g, d_idx, sh->d_roff_g, nc, off, d_len));
+            // where owner o's requests of this round begin among the records (the first W + 1 words: positions, the rest: offsets)
+            BF_TRY(ensure(ctx, sh->d_pick, (2 * (size_t)W + 2) * 8));
+            pick[0] = 0;
+            for (uint32_t o = 0; o < W; o++) pick[o + 1] = pick[o] + rm[(size_t)o * W + me];
+            BF_HIP(ctx, hipMemcpyAsync(sh->d_pick.p, pick.data(), (size_t)(W + 1) * 8, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(pick_offsets_kernel, dim3(grid_for(W + 1, 256)), dim3(256), 0, st, sh->d_pick.as<uint64_t>() + (W + 1),
+                               sh->d_roff_g.as<uint64_t>(), sh->d_pick.as<uint64_t>(), W + 1);
+            BF_HIP(ctx, hipGetLastError());
+            BF_HIP(ctx, hipMemcpyAsync(pick.data() + (W + 1), sh->d_pick.as<uint64_t>() + (W + 1), (size_t)(W + 1) * 8, hipMemcpyDeviceToHost, st));
             uint32_t bad = 0;
             BF_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
             BF_SYNC(ctx, st);
             if (bad) return fail(ctx, BF_ERR_HIP, "sharded path: %u requested reads are not resident on rank %u", bad, me);
             const uint64_t total_g = off[nc];
+            if (pick[(size_t)W + 1] != 0 || pick[2 * (size_t)W + 1] != total_g)
+                return fail(ctx, BF_ERR_HIP, "sharded path: the record offsets of round %u do not span its %llu bytes", g, (unsigned long long)total_g);
+            for (uint32_t o = 0; o < W; o++) sh->block_off[(size_t)g * W + o] = rec_total + pick[(size_t)W + 1 + o];
             BF_TRY(ensure(ctx, sh->d_rbytes, std::max<uint64_t>(rec_total + total_g, 1), true));
             BF_TRY(grow_host_keep(ctx, sh->h_rbytes, rec_total, rec_total + total_g));
             BF_TRY(ensure(ctx, sh->d_roff, (n_in + n_in_g + 1) * 8, true));
@@ -549,9 +577,12 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
         cl_base += ns_g; rd_base += nr_g; n_in += n_in_g;
     }
     const uint64_t nr = rd_base, ncl = cl_base;
+    sh->group_read_begin[G] = nr;
+    sh->block_off[(size_t)G * W] = rec_total;
     ctx->out.n_clusters = ncl; ctx->out.n_reads = nr;
     ctx->clustered = true;
-    // rows (when groups appended them: the one-go path has copied them itself), places and record offsets -> host
+    // rows (when groups appended them: the one-go path has copied them itself) and a source rank per read -> host; the
+    // places and record offsets stay on the device (bf_shard_result_places)
     BF_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[0], 0));
     if (G > 1 && ncl) {
@@ -559,25 +590,47 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
         BF_HIP(ctx, hipMemcpyAsync(ctx->out.clusters.p, ctx->c_clusters.p, ncl * sizeof(bf_cluster), hipMemcpyDeviceToHost, ctx->copy_stream));
     }
     if (nr) {
-        BF_TRY(ensure_host(ctx, sh->h_places, nr * sizeof(bf_place)));
-        BF_HIP(ctx, hipMemcpyAsync(sh->h_places.p, sh->d_place.p, nr * sizeof(bf_place), hipMemcpyDeviceToHost, ctx->copy_stream));
-    }
-    if (n_in) {
-        BF_TRY(ensure_host(ctx, sh->h_roff, (n_in + 1) * 8));
-        BF_HIP(ctx, hipMemcpyAsync(sh->h_roff.p, sh->d_roff.p, (n_in + 1) * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
+        BF_TRY(ensure_host(ctx, sh->h_src, nr));
+        BF_HIP(ctx, hipMemcpyAsync(sh->h_src.p, sh->d_src.p, nr, hipMemcpyDeviceToHost, ctx->copy_stream));
     }
     BF_SYNC(ctx, st);
-    BF_SYNC(ctx, ctx->copy_stream);                                  // rows, places and records are in host memory
+    BF_SYNC(ctx, ctx->copy_stream);                                  // rows, source ranks and records are in host memory
     ctx->consumed = true;
+    sh->last_nr = nr; sh->last_n_in = n_in;
 
     out->n_local = n_local; out->n_evidence = ctx->n_evidence;
     out->n_clusters = ncl; out->n_reads = nr;
     out->clusters = ncl ? ctx->out.clusters.as<bf_cluster>() : nullptr;
-    out->places = nr ? sh->h_places.as<bf_place>() : nullptr;
+    out->src_rank = nr ? sh->h_src.as<uint8_t>() : nullptr;
+    out->n_groups = G; out->reserved = 0;
+    out->group_read_begin = sh->group_read_begin.data();
     out->n_records = n_in;
-    out->record_off = n_in ? sh->h_roff.as<uint64_t>() : nullptr;
+    out->block_off = sh->block_off.data();
     out->record_bytes = rec_total ? sh->h_rbytes.as<uint8_t>() : nullptr;
     out->record_size = rec_total;
+    out->places = nullptr; out->record_off = nullptr;
+    return BF_OK;
+}
+
+int bf_shard_result_places(bf_ctx* ctx, bf_shard_result* r) {
+    if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
+    Shard* sh = shard_of(ctx);
+    if (!sh || !r) return fail(ctx, BF_ERR_STATE, "bf_shard_result_places: no sharded result");
+    if (!ctx->clustered || r->n_reads != sh->last_nr || r->n_records != sh->last_n_in || r->block_off != sh->block_off.data())
+        return fail(ctx, BF_ERR_STATE, "bf_shard_result_places: not the result of this ctx's last bf_shard_finish");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    if (sh->last_nr) {
+        BF_TRY(ensure_host(ctx, sh->h_places, sh->last_nr * sizeof(bf_place)));
+        BF_HIP(ctx, hipMemcpyAsync(sh->h_places.p, sh->d_place.p, sh->last_nr * sizeof(bf_place), hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+    if (sh->last_n_in) {
+        BF_TRY(ensure_host(ctx, sh->h_roff, (sh->last_n_in + 1) * 8));
+        BF_HIP(ctx, hipMemcpyAsync(sh->h_roff.p, sh->d_roff.p, (sh->last_n_in + 1) * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+    BF_SYNC(ctx, ctx->copy_stream);
+    r->places = sh->last_nr ? sh->h_places.as<bf_place>() : nullptr;
+    r->record_off = sh->last_n_in ? sh->h_roff.as<uint64_t>() : nullptr;
     return BF_OK;
 }
 
@@ -597,7 +650,8 @@ int64_t bf_shard_format_sv(const bf_ctx* ctx, uint32_t n_ranks, const bf_shard_r
     std::vector<Row> rows;
     for (uint32_t r = 0; r < n_ranks; r++) {
         const bf_shard_result& x = results[r];
-        if ((x.n_clusters && !x.clusters) || (x.n_reads && !x.places) || (x.n_records && (!x.record_off || (x.record_size && !x.record_bytes))))
+        if ((x.n_clusters && !x.clusters) || (x.n_reads && (!x.src_rank || !x.group_read_begin)) || !x.block_off ||
+            (x.record_size && !x.record_bytes) || x.n_groups == 0 || x.n_groups != results[0].n_groups)
             return BF_ERR_INVALID;
         for (uint64_t c = 0; c < x.n_clusters; c++) {
             const bf_cluster& cl = x.clusters[c];
@@ -614,15 +668,46 @@ int64_t bf_shard_format_sv(const bf_ctx* ctx, uint32_t n_ranks, const bf_shard_r
         if ((uint64_t)x.lpos != (uint64_t)y.lpos) return (uint64_t)x.lpos < (uint64_t)y.lpos;
         return x.seed_index < y.seed_index;
     });
-    auto record = [&](const bf_place& p, const uint8_t*& rec, uint64_t& avail) -> bool {
-        if (p.src_rank >= n_ranks) return false;
-        const bf_shard_result& s = results[p.src_rank];
-        if (p.slot >= s.n_records) return false;
-        const uint64_t a = s.record_off[p.slot], b = s.record_off[p.slot + 1];
-        if (a > b || b > s.record_size) return false;
-        rec = s.record_bytes + a; avail = b - a;
-        return true;
-    };
+    // An owner's rows come up in its own order (the merge keeps it), and its supporting reads with them: the records it
+    // asked of source s lie one after the other in s's memory, round by round.  One cursor per (owner, source).
+    const uint32_t G = results[0].n_groups;
+    struct Walk {
+        uint32_t n_ranks, G;
+        const bf_shard_result* results;
+        std::vector<uint64_t> cur, lim;       // [owner * n_ranks + source]
+        std::vector<int64_t> round;           // per owner: the round its cursors stand in
+        std::vector<uint64_t> next_read;      // per owner: reads must come up one after the other
+        void reset() {
+            cur.assign((size_t)n_ranks * n_ranks, 0); lim = cur;
+            round.assign(n_ranks, -1); next_read.assign(n_ranks, 0);
+        }
+        // the record of owner o's supporting read i
+        bool record(uint32_t o, uint64_t i, const uint8_t*& rec, uint64_t& size) {
+            const bf_shard_result& own = results[o];
+            if (i != next_read[o]) return false;
+            next_read[o] = i + 1;
+            while (round[o] + 1 < (int64_t)G && i >= own.group_read_begin[round[o] + 1]) {
+                round[o]++;
+                for (uint32_t s = 0; s < n_ranks; s++) {
+                    cur[(size_t)o * n_ranks + s] = results[s].block_off[(size_t)round[o] * n_ranks + o];
+                    lim[(size_t)o * n_ranks + s] = results[s].block_off[(size_t)round[o] * n_ranks + o + 1];
+                }
+            }
+            if (round[o] < 0 || i >= own.group_read_begin[round[o] + 1]) return false;
+            const uint32_t s = own.src_rank[i];
+            if (s >= n_ranks) return false;
+            uint64_t& c = cur[(size_t)o * n_ranks + s];
+            const uint64_t l = lim[(size_t)o * n_ranks + s];
+            if (c >= l || l > results[s].record_size) return false;
+            rec = results[s].record_bytes + c;
+            const int64_t sz = bf_junction_record_bytes(rec, l - c);
+            if (sz <= 0 || (uint64_t)sz > l - c) return false;
+            size = (uint64_t)sz;
+            c += size;
+            return true;
+        }
+    } walk{n_ranks, G, results, {}, {}, {}, {}};
+    walk.reset();
     uint64_t total = sizeof(header) - 1;
     for (const Row& w : rows) {
         const bf_cluster& cl = key(w);
@@ -631,14 +716,15 @@ int64_t bf_shard_format_sv(const bf_ctx* ctx, uint32_t n_ranks, const bf_shard_r
         const uint64_t k = cl.read_end - cl.read_begin;
         if (k) total += k - 1;
         for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
-            const uint8_t* rec; uint64_t avail;
-            if (!record(results[w.rank_].places[i], rec, avail)) return BF_ERR_INVALID;
-            const int64_t tl = junction_decode(rec, avail, nullptr, 0);
+            const uint8_t* rec; uint64_t size;
+            if (!walk.record(w.rank_, i, rec, size)) return BF_ERR_INVALID;
+            const int64_t tl = junction_decode(rec, size, nullptr, 0);
             if (tl < 0) return BF_ERR_INVALID;
             total += (uint64_t)tl;
         }
     }
     if (!buf || cap < total) return (int64_t)total;
+    walk.reset();
     char* p = buf;
     memcpy(p, header, sizeof(header) - 1); p += sizeof(header) - 1;
     for (const Row& w : rows) {
@@ -653,9 +739,9 @@ int64_t bf_shard_format_sv(const bf_ctx* ctx, uint32_t n_ranks, const bf_shard_r
         p = put_dec64(p, (uint64_t)cl.rpos); *p++ = '\t'; *p++ = '\t';
         for (uint64_t i = cl.read_begin; i < cl.read_end; i++) {
             if (i > cl.read_begin) *p++ = ';';
-            const uint8_t* rec; uint64_t avail;
-            record(results[w.rank_].places[i], rec, avail);
-            p += junction_decode(rec, avail, (uint8_t*)p, ~0ull);
+            const uint8_t* rec; uint64_t size;
+            if (!walk.record(w.rank_, i, rec, size)) return BF_ERR_INVALID;
+            p += junction_decode(rec, size, (uint8_t*)p, ~0ull);
         }
         *p++ = '\t'; *p++ = '\t'; *p++ = '\n';
     }

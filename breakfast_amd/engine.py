@@ -66,8 +66,9 @@ class BfWireLocal(C.Structure):
 
 class BfShardResult(C.Structure):
     _fields_ = [("n_local", C.c_uint64), ("n_evidence", C.c_uint64), ("n_clusters", C.c_uint64), ("n_reads", C.c_uint64),
-                ("clusters", C.c_void_p), ("places", C.c_void_p), ("n_records", C.c_uint64), ("record_off", C.c_void_p),
-                ("record_bytes", C.c_void_p), ("record_size", C.c_uint64)]
+                ("clusters", C.c_void_p), ("src_rank", C.c_void_p), ("n_groups", C.c_uint32), ("reserved", C.c_uint32),
+                ("group_read_begin", C.c_void_p), ("n_records", C.c_uint64), ("block_off", C.c_void_p),
+                ("record_bytes", C.c_void_p), ("record_size", C.c_uint64), ("places", C.c_void_p), ("record_off", C.c_void_p)]
 
 
 PLACE_DTYPE = np.dtype([("src_rank", "<u4"), ("slot", "<u4")])
@@ -79,9 +80,13 @@ class ShardResult:
     n_local: int
     n_evidence: int
     clusters: np.ndarray       # CLUSTER_DTYPE, this owner's rows
-    places: np.ndarray         # PLACE_DTYPE per supporting read
-    record_off: np.ndarray     # uint64[n_records + 1], this SOURCE's junction records
+    src_rank: np.ndarray       # uint8 per supporting read: the rank that holds its record
+    group_read_begin: np.ndarray   # uint64[n_groups + 1]
+    n_records: int
+    block_off: np.ndarray      # uint64[n_groups * n_ranks + 1], this SOURCE's records by (round, owner)
     record_bytes: np.ndarray
+    places: Optional[np.ndarray] = None       # PLACE_DTYPE per supporting read (shard_finish(places=True))
+    record_off: Optional[np.ndarray] = None   # uint64[n_records + 1]
 
 
 class BfEvidenceView(C.Structure):
@@ -105,7 +110,7 @@ ABI_SYMBOLS = [
     "bf_result_attach_finish", "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
     "bf_render_junctions_dev_static", "bf_host_alloc", "bf_host_free", "bf_submit_wait", "bf_reserve",
     "bf_genome_begin", "bf_genome_write", "bf_genome_end", "bf_submit_packed",
-    "bf_shard_unique_id", "bf_shard_init_rccl", "bf_shard_init_host", "bf_shard_finish", "bf_shard_format_sv",
+    "bf_shard_unique_id", "bf_shard_init_rccl", "bf_shard_init_host", "bf_shard_finish", "bf_shard_result_places", "bf_shard_format_sv",
 ]
 
 _lib = None
@@ -157,6 +162,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_shard_init_rccl.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp]
     lib.bf_shard_init_host.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_char_p, C.c_uint64]
     lib.bf_shard_finish.argtypes = [vp, C.POINTER(BfShardResult)]
+    lib.bf_shard_result_places.argtypes = [vp, C.POINTER(BfShardResult)]
     lib.bf_shard_format_sv.argtypes = [vp, C.c_uint32, C.POINTER(BfShardResult), vp, C.c_uint64]
     lib.bf_shard_format_sv.restype = C.c_int64
     lib.bf_localise.argtypes = [vp]
@@ -594,8 +600,10 @@ class Engine:
         self._check(self.lib.bf_shard_finish(self.h, C.byref(r)))
         return r
 
-    def shard_finish(self) -> ShardResult:
+    def shard_finish(self, places: bool = False) -> ShardResult:
         r = self.shard_finish_raw()
+        if places:
+            self._check(self.lib.bf_shard_result_places(self.h, C.byref(r)))
 
         def arr(ptr, n, dt):
             dt = np.dtype(dt)
@@ -603,19 +611,22 @@ class Engine:
                 return np.zeros(0, dt)
             return np.frombuffer((C.c_uint8 * (n * dt.itemsize)).from_address(ptr), dt).copy()
         return ShardResult(int(r.n_local), int(r.n_evidence), arr(r.clusters, r.n_clusters, CLUSTER_DTYPE),
-                           arr(r.places, r.n_reads, PLACE_DTYPE),
-                           arr(r.record_off, r.n_records + 1 if r.n_records else 0, "<u8"), arr(r.record_bytes, r.record_size, "u1"))
+                           arr(r.src_rank, r.n_reads, "u1"), arr(r.group_read_begin, r.n_groups + 1, "<u8"), int(r.n_records),
+                           arr(r.block_off, r.n_groups * self.n_ranks + 1, "<u8"), arr(r.record_bytes, r.record_size, "u1"),
+                           arr(r.places, r.n_reads, PLACE_DTYPE) if places else None,
+                           arr(r.record_off, r.n_records + 1 if r.n_records else 0, "<u8") if places else None)
 
     def shard_format_sv(self, results: Sequence[ShardResult]) -> bytes:
         """detect.rs:201,233-240 for the results of ALL ranks (rank order); needs only this ctx's contig names."""
         n = len(results)
         keep, arr = [], (BfShardResult * n)()
         for i, x in enumerate(results):
-            cl = np.ascontiguousarray(x.clusters, CLUSTER_DTYPE); pl = np.ascontiguousarray(x.places, PLACE_DTYPE)
-            ro = np.ascontiguousarray(x.record_off, np.uint64); rb = np.ascontiguousarray(x.record_bytes, np.uint8)
-            keep += [cl, pl, ro, rb]
-            arr[i] = BfShardResult(x.n_local, x.n_evidence, cl.shape[0], pl.shape[0], _ptr(cl), _ptr(pl),
-                                   max(ro.shape[0] - 1, 0), _ptr(ro), _ptr(rb), rb.size)
+            cl = np.ascontiguousarray(x.clusters, CLUSTER_DTYPE); sr = np.ascontiguousarray(x.src_rank, np.uint8)
+            gb = np.ascontiguousarray(x.group_read_begin, np.uint64); bo = np.ascontiguousarray(x.block_off, np.uint64)
+            rb = np.ascontiguousarray(x.record_bytes, np.uint8)
+            keep += [cl, sr, gb, bo, rb]
+            arr[i] = BfShardResult(x.n_local, x.n_evidence, cl.shape[0], sr.shape[0], _ptr(cl), _ptr(sr), gb.shape[0] - 1, 0,
+                                   _ptr(gb), x.n_records, _ptr(bo), _ptr(rb), rb.size, None, None)
         size = self.lib.bf_shard_format_sv(self.h, n, arr, None, 0)
         self._check(size)
         buf = C.create_string_buffer(int(size) + 1)

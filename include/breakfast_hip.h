@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 10
+#define BF_ABI_VERSION 11
 
 enum {
     BF_OK = 0,
@@ -399,30 +399,44 @@ uint64_t bf_junction_record_bound(const bf_ctx* ctx);
  *                           reference's tie-breaks, detect.rs:193-198); clusters what it owns (detect.rs:190-231,
  *                           247-287).  The case-marked sequences never travel: an owner sends each source rank the
  *                           list of its surviving reads (4 bytes each), the source renders their junction records
- *                           and copies them to ITS host memory, and the owner's `places` say where each supporting
- *                           read's record lives.  Idempotent like bf_finish.
+ *                           and copies them to ITS host memory, and the owner's `src_rank` says on which rank each
+ *                           supporting read's record lives.  Idempotent like bf_finish.
  *   bf_shard_format_sv      detect.rs:201,233-240 for the ranks' results together: owners' rows merged by the seed's
  *                           rank in the reference's sort (contig by name, position as the wrapped usize, input index).
  *                           Pure host code; `results[r]` = rank r's bf_shard_result (all n_ranks of them).
  * No counterpart in the reference, which is one process. */
-typedef struct { uint32_t src_rank; uint32_t slot; } bf_place;    /* record = results[src_rank].records[slot] */
+typedef struct { uint32_t src_rank; uint32_t slot; } bf_place;    /* record = results[src_rank].record_off[slot] */
 typedef struct {
     uint64_t          n_local;         /* reads this rank localised (sum over ranks = the count of detect.rs:190) */
     uint64_t          n_evidence;      /* evidence records this rank owns (clustered here) */
     /* owner side */
     uint64_t          n_clusters, n_reads;
     const bf_cluster* clusters;        /* this owner's rows, in print order among themselves */
-    const bf_place*   places;          /* n_reads: supporting read i of the rows above */
-    /* source side: junction records of this rank's reads that support a row of any owner */
+    const uint8_t*    src_rank;        /* n_reads: the rank whose host memory holds supporting read i's record */
+    uint32_t          n_groups;        /* the cluster stage ran in this many rounds (the same on every rank) */
+    uint32_t          reserved;
+    const uint64_t*   group_read_begin;/* n_groups + 1: supporting reads [b[g], b[g+1]) belong to round g */
+    /* source side: junction records of this rank's reads that support a row of any owner.  They lie in the order they
+     * were asked for: round by round, inside a round owner by owner, inside that in the owner's own result order.
+     * So whoever walks owner o's rows in order finds the records o asked of source s one after the other from
+     * block_off[g * n_ranks + o] on (a record says how long it is, bf_junction_record_bytes): 1 byte per supporting
+     * read crosses PCIe for the book-keeping instead of a 8-byte place and a 8-byte record offset. */
     uint64_t          n_records;
-    const uint64_t*   record_off;      /* n_records + 1 offsets into record_bytes */
+    const uint64_t*   block_off;       /* n_groups * n_ranks + 1 byte offsets into record_bytes */
     const uint8_t*    record_bytes;
     uint64_t          record_size;
+    /* random access, on demand (bf_shard_result_places; NULL before): */
+    const bf_place*   places;          /* n_reads: supporting read i of the rows above */
+    const uint64_t*   record_off;      /* n_records + 1 offsets into record_bytes */
 } bf_shard_result;
 int bf_shard_unique_id(uint8_t id[128]);
 int bf_shard_init_rccl(bf_ctx* ctx, uint32_t rank, uint32_t n_ranks, uint64_t index_base, const uint8_t id[128]);
 int bf_shard_init_host(bf_ctx* ctx, uint32_t rank, uint32_t n_ranks, uint64_t index_base, const char* name, uint64_t slot_bytes);
 int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out);
+/* Fetches the per-read tables that bf_shard_finish leaves on the device (like bf_result_reads for bf_finish): the owner's
+ * `places` and the source's `record_off`, for callers that want a supporting read's record without walking the rows.
+ * `result` must be what this ctx's last bf_shard_finish filled. */
+int bf_shard_result_places(bf_ctx* ctx, bf_shard_result* result);
 int64_t bf_shard_format_sv(const bf_ctx* ctx, uint32_t n_ranks, const bf_shard_result* results, char* buf, uint64_t cap);
 
 /* ---- introspection (tests, bench) ---------------------------------------------------------- */

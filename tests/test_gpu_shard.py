@@ -46,7 +46,7 @@ def run_rank(rank, world, cuts, name, slot_bytes, transport, uid, steps, out_dir
         if hi > lo:
             eng.submit(b.slice(lo, hi))
         for _ in range(steps):                                   # idempotent on the resident reads
-            res = eng.shard_finish()
+            res = eng.shard_finish(places=True)
         assert res.n_local == hi - lo
         pickle.dump(res, open(os.path.join(out_dir, "rank%d.pkl" % rank), "wb"))
     finally:
@@ -57,10 +57,35 @@ def _proc(rank, world, cuts, name, slot_bytes, out_dir, flags=0):
     run_rank(rank, world, cuts, name, slot_bytes, "host", None, 2, out_dir, flags)
 
 
+def check_places(results):
+    """What crosses PCIe by itself (a source rank per read, block offsets per round and owner) against the tables that
+    stay on the device (bf_shard_result_places): the records an owner asked of a source in a round are consecutive slots
+    in result order, and the block offsets are those slots' record offsets."""
+    W = len(results)
+    for o, own in enumerate(results):
+        assert np.array_equal(own.places["src_rank"], own.src_rank)
+        gb = own.group_read_begin
+        assert gb[0] == 0 and gb[-1] == own.src_rank.shape[0] and np.all(np.diff(gb.astype(np.int64)) >= 0)
+        for g in range(gb.shape[0] - 1):
+            for s, src in enumerate(results):
+                lo, hi = int(src.block_off[g * W + o]), int(src.block_off[g * W + o + 1])
+                mine = np.flatnonzero(own.src_rank[int(gb[g]):int(gb[g + 1])] == s) + int(gb[g])
+                slots = own.places["slot"][mine].astype(np.int64)
+                if mine.size == 0:
+                    assert lo == hi
+                    continue
+                assert np.array_equal(slots, slots[0] + np.arange(slots.size))
+                assert int(src.record_off[slots[0]]) == lo and int(src.record_off[slots[-1] + 1]) == hi
+    for src in results:
+        assert int(src.block_off[-1]) == src.record_bytes.size and np.all(np.diff(src.block_off.astype(np.int64)) >= 0)
+        assert src.record_off.shape[0] == (src.n_records + 1 if src.n_records else 0)
+
+
 def merged_sv(out_dir, world):
     g, b, A, F, E = make_case()
     results = [pickle.load(open(os.path.join(out_dir, "rank%d.pkl" % r), "rb")) for r in range(world)]
     assert sum(x.n_local for x in results) == sum(x.n_evidence for x in results) == b.n
+    check_places(results)
     eng = engine.Engine(A, F, E, device=0)
     try:
         eng.set_genome(g.names, g.seqs)
