@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--reads", choices=["packed", "ascii"], default="packed",
                     help="how the reads are handed over and kept resident: BAM 4-bit base codes (bf_submit_packed: what the "
                          "command line's parser produces, the shipped path) or ASCII (bf_submit)")
+    ap.add_argument("--roh-groups", type=int, default=-1, help="contig groups of the reads-on-host leg (-1: like --groups)")
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host loops (resident-input value only)")
     ap.add_argument("--host-threads", type=int, default=0, help="staging threads of bf_submit (0 = library default)")
     args = ap.parse_args()
@@ -267,6 +268,34 @@ def main():
             log(rank, "ascii reads, resident step: %.3f ms, localise %.3f ms" % (dt * 1e3, h2h["ascii_reads"]["resident_step"]["localise_ms"]))
             in_bytes, on_wire = keep_in, keep_wire
 
+    # ---- the same step when the caller keeps its batches (BF_FLAG_READS_ON_HOST): junction records name the read instead
+    #      of carrying its bases back over PCIe.  A second ctx; reported beside `value`, never as `value`. ------------------
+    roh = None
+    if not sharded and not args.no_h2h and args.variant == "fused":
+        e3 = engine.Engine(A, 5000, 2, device=local, groups=args.groups if args.roh_groups < 0 else args.roh_groups, host_threads=args.host_threads,
+                           flags=engine.BF_FLAG_READS_ON_HOST | (engine.BF_FLAG_ONE_STREAM if args.one_stream else 0))
+        e3.set_genome(genome.names, genome.seqs)
+        e3.submit(batch)
+        e3.submit_wait()
+        for _ in range(max(args.warmup, 1)):
+            r_ = e3.finish_raw()
+        e3.kernel_times()
+        e3.sync()
+        t0_ = time.perf_counter()
+        for _ in range(args.steps):
+            r_ = e3.finish_raw()
+        dt = (time.perf_counter() - t0_) / args.steps
+        kt = e3.kernel_times()
+        assert int(r_.n_clusters) == n_clusters and int(r_.n_reads) == n_support, "reads-on-host result differs"
+        roh = {"value": round(n_local / dt, 1), "unit": "reads/s", "ms_per_step": round(dt * 1e3, 3),
+               "record_bytes": int(r_.junction_size), "record_bytes_self_contained": int(last.junction_size),
+               "stage_ms": {k: round(v[0] / args.steps, 4) for k, v in kt.items()},
+               "note": "BF_FLAG_READS_ON_HOST: the caller keeps the submitted batches; records name the read, bf_format_sv "
+                       "reads the bases where the caller left them (same .sv bytes, tests/test_gpu_reads_on_host.py)"}
+        log(rank, "reads stay on the host: %.3f ms per step, %.1f M reads/s, %d record bytes (self-contained: %d)" %
+            (dt * 1e3, n_local / dt / 1e6, roh["record_bytes"], roh["record_bytes_self_contained"]))
+        e3.close()
+
     # ---- roofline of the dominant kernel -----------------------------------------------------------
     loc_ms, loc_n = ktimes.get("localise", (0.0, 0))
     loc_avg_ms = loc_ms / max(loc_n, 1)
@@ -317,7 +346,7 @@ def main():
                        "reads_as": {"packed": "BAM 4-bit base codes (bf_submit_packed)", "ascii": "ASCII (bf_submit)"}[args.reads],
                        "parallelism": "shard%d+alltoall" % world if sharded else "single"},
             "result": {"clusters": n_clusters, "supporting_reads": n_support},
-            "stage_ms": stages, "roofline": roofline, "cpu_baseline": cpu, "host_to_host": h2h,
+            "stage_ms": stages, "roofline": roofline, "cpu_baseline": cpu, "host_to_host": h2h, "reads_on_host": roh,
             "pipeline": pipeline_headline(n_local, L, ms_per_step),
             "published_reference": "~40M BAM reads/min/core whole-file scan (README.md:6), a different stage",
         }

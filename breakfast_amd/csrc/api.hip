@@ -190,11 +190,74 @@ static const uint64_t* spread_table() {
 // Text of one junction record (include/breakfast_hip.h, "Junction records"): the read's bases, lower case
 // where they differ from the flank they were assigned to, with '|' at the breakpoint (detect.rs:155-162).
 // Returns len + 1, or -1 for a malformed record; writes only when `out` is given and cap suffices.
-int64_t junction_decode(const uint8_t* rec, uint64_t rec_len, uint8_t* out, uint64_t cap, uint64_t* stored) {
+static const uint8_t kCompHost[256] = {
+#include "bf_comp_table.inc"
+};
+
+// A reference record (BF_FLAG_READS_ON_HOST): the bases are read where the caller submitted them from.  Returns -2 when
+// the record is well-formed but there is no ctx to find the read with (the stored size is still given).
+static int64_t junction_decode_ref(const uint8_t* rec, uint64_t rec_len, uint32_t head, uint8_t* out, uint64_t cap, uint64_t* stored,
+                                   const bf_ctx* ctx) {
+    if (rec_len < 8) return -1;
+    const bool swapped = (head & 4u) != 0, wide = (head & 8u) != 0;
+    const uint32_t nl = (head >> 4) & 0xfffu, bp = head >> 16;
+    uint32_t r;
+    memcpy(&r, rec + 4, 4);
+    uint64_t body = 8;
+    uint32_t dense_L = 0;
+    if (nl == kJrRefDense) {
+        if (rec_len < 12) return -1;
+        memcpy(&dense_L, rec + 8, 4);
+        if (dense_L > 0xffffu) return -1;
+        body = 12 + ((uint64_t)dense_L + 7) / 8;
+    } else {
+        body = 8 + (uint64_t)nl * (wide ? 2 : 1);
+    }
+    if (rec_len < body) return -1;
+    if (stored) *stored = (body + 3) & ~3ull;
+    if (!ctx) return -2;
+    // the batch that holds resident read r
+    const auto& hr = ctx->host_reads;
+    size_t lo = 0, hi = hr.size();
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (hr[mid].first + hr[mid].n <= r) lo = mid + 1; else hi = mid; }
+    if (lo >= hr.size() || r < hr[lo].first) return -1;
+    const bf_ctx::HostReads& h = hr[lo];
+    const uint64_t k0 = r - h.first;
+    const uint64_t so = h.seq_off[k0];
+    const uint32_t L = h.seq_len ? h.seq_len[k0] : (uint32_t)(h.seq_off[k0 + 1] - so);
+    if (bp > L || wide != (L > 256u) || (nl == kJrRefDense && dense_L != L)) return -1;
+    const uint64_t text = (uint64_t)L + 1;
+    const uint8_t* pl = rec + 8;
+    if (nl != kJrRefDense)
+        for (uint32_t e = 0; e < nl; e++) { uint32_t q = wide ? (uint32_t)pl[2 * e] | ((uint32_t)pl[2 * e + 1] << 8) : pl[e]; if (q >= L) return -1; }
+    if (!out || cap < text) return (int64_t)text;
+    static const char kNib[] = "=ACMGRSVTWYHKDBN";
+    const uint8_t* s = h.seq + so;
+    auto base = [&](uint32_t k) -> uint8_t {                 // base k of the read as submitted
+        if (!h.seq_len) return s[k];
+        const uint8_t b = s[k >> 1];
+        return (uint8_t)kNib[(k & 1) ? (b & 15) : (b >> 4)];
+    };
+    for (uint32_t k = 0; k < L; k++) {                       // re-oriented like detect.rs:112, '|' at bp
+        const uint8_t c = swapped ? kCompHost[base(L - 1 - k)] : base(k);
+        out[k < bp ? k : k + 1] = c;
+    }
+    auto lower = [&](uint32_t q) { uint8_t& c = out[q < bp ? q : q + 1u]; if (c >= 'A' && c <= 'Z') c += 32; };   // to_ascii_lowercase
+    if (nl == kJrRefDense) {
+        for (uint32_t q = 0; q < L; q++) if ((rec[12 + (q >> 3)] >> (q & 7)) & 1) lower(q);
+    } else {
+        for (uint32_t e = 0; e < nl; e++) lower(wide ? (uint32_t)pl[2 * e] | ((uint32_t)pl[2 * e + 1] << 8) : pl[e]);
+    }
+    out[bp] = '|';
+    return (int64_t)text;
+}
+
+int64_t junction_decode(const uint8_t* rec, uint64_t rec_len, uint8_t* out, uint64_t cap, uint64_t* stored, const bf_ctx* ctx) {
     if (!rec || rec_len < 4) return -1;
     uint32_t head;
     memcpy(&head, rec, 4);
     const uint32_t kind = head & 3u;
+    if (kind == kJrRef) return junction_decode_ref(rec, rec_len, head, out, cap, stored, ctx);
     if (kind == kJrText) {
         if (rec_len < 8 || (head & 0xff0000f8u)) return -1;
         uint32_t L;
@@ -508,6 +571,7 @@ int bf_reset(bf_ctx* ctx) {
     BF_SYNC(ctx, ctx->stream);
     ctx->in_pending = false; ctx->n_localised = 0; ctx->consumed = false;
     ctx->off_pending.clear();
+    ctx->host_reads.clear();
     ctx->rank_hist.assign(ctx->n_contigs, 0);
     ctx->n_reads = 0; ctx->seq_bytes = 0; ctx->frag_bytes = 0;
     ctx->max_len = 0; ctx->min_len = 0xffffffffu; ctx->max_frag = 0;
@@ -883,6 +947,8 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
             if (rc != BF_OK) { ctx->n_localised = 0; return rc; }
         }
     }
+    if (ctx->cfg.flags & BF_FLAG_READS_ON_HOST)              // the caller keeps these arrays for the results to point into
+        ctx->host_reads.push_back(bf_ctx::HostReads{ctx->n_reads, m, b->seq_bytes, b->seq_off, b->seq_len});
     ctx->n_reads += m; ctx->seq_bytes += sb; ctx->frag_bytes += fb;
     ctx->max_len = mx; ctx->min_len = mn; ctx->max_frag = mf;
     ctx->localised = false; ctx->imported = false; ctx->consumed = false;
@@ -1002,7 +1068,10 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     const OwnerView v = ctx->imported ? imported_view(ctx) : local_view(ctx);
     ctx->clustered = false; ctx->table_attached = false; ctx->junction_attached = 0; ctx->reads_on_device = false;
     ctx->result_order = false; ctx->sources_on_device = false;
-    if (!ctx->imported && (v.n >= kGroupMinReads || (ctx->cfg.flags & BF_FLAG_GROUPS_ALWAYS)) && !(ctx->cfg.flags & BF_FLAG_ONE_GROUP)) {
+    // (with reference records the copy is a fifth as long and hiding half of it pays for no second group:
+    //  configs[1] 4.02 ms in one go, 4.59 in two groups, 5.08 in three; groups then only when they are asked for)
+    const bool small_records = (ctx->cfg.flags & BF_FLAG_READS_ON_HOST) && !ctx->cfg.reserved[0];
+    if (!ctx->imported && ((v.n >= kGroupMinReads && !small_records) || (ctx->cfg.flags & BF_FLAG_GROUPS_ALWAYS)) && !(ctx->cfg.flags & BF_FLAG_ONE_GROUP)) {
         bool done = false;
         BF_TRY(clusterise_in_groups(ctx, v, &done));
         if (done) return fill_single_rank_result(ctx, out);
@@ -1021,7 +1090,8 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
             // (16 bytes a read, a quarter of the copy) stays on the device until bf_result_reads asks.
             const uint32_t* d_idx = ctx->c_rsrc.as<uint32_t>() + nr;      // out_src_idx
             constexpr int kMaxChunks = 8;
-            const int nc = nr >= (1u << 16) ? kMaxChunks : 1;
+            // (reference records are a few bytes each: a chunk's render would be shorter than its launch)
+            const int nc = nr < (1u << 16) ? 1 : (ctx->cfg.flags & BF_FLAG_READS_ON_HOST) ? 2 : kMaxChunks;
             uint64_t off[kMaxChunks + 1];
             // emit left every supporting read's record size next to the index lists
             BF_TRY(render_prepare(ctx, nr, d_idx, ctx->c_joff, nc, off, ctx->c_rsrc.as<uint32_t>() + 3 * nr));
@@ -1141,7 +1211,7 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t 
                 const uint64_t lim = cjo ? walk_end : r->junction_size;
                 if (at > lim) { bad = true; return; }
                 uint64_t stored = 0;
-                const int64_t tl = junction_decode(r->junction_bytes + at, lim - at, nullptr, 0, &stored);
+                const int64_t tl = junction_decode(r->junction_bytes + at, lim - at, nullptr, 0, &stored, ctx);
                 if (tl < 0) { bad = true; return; }
                 sz += (uint64_t)tl;
                 walk += stored;
@@ -1189,7 +1259,7 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t 
                 if (i > cl.read_begin) *p++ = ';';
                 const uint64_t at = cjo ? walk : r->reads[i].junction_off;
                 uint64_t stored = 0;
-                p += junction_decode(r->junction_bytes + at, r->junction_size - at, (uint8_t*)p, ~0ull, &stored);
+                p += junction_decode(r->junction_bytes + at, r->junction_size - at, (uint8_t*)p, ~0ull, &stored, ctx);
                 walk += stored;
             }
             *p++ = '\t'; *p++ = '\t'; *p++ = '\n';                                      // detect.rs:240
@@ -1215,9 +1285,16 @@ int64_t bf_junction_text(const uint8_t* record, uint64_t avail, char* buf, uint6
     return n < 0 ? (int64_t)BF_ERR_INVALID : n;
 }
 
+int64_t bf_junction_text_of(const bf_ctx* ctx, const uint8_t* record, uint64_t avail, char* buf, uint64_t cap) {
+    if (!ctx) return BF_ERR_INVALID;
+    const int64_t n = junction_decode(record, avail, (uint8_t*)buf, buf ? cap : 0, nullptr, ctx);
+    return n < 0 ? (int64_t)BF_ERR_INVALID : n;
+}
+
 int64_t bf_junction_record_bytes(const uint8_t* record, uint64_t avail) {
     uint64_t stored = 0;
-    if (junction_decode(record, avail, nullptr, 0, &stored) < 0 || stored > ((avail + 3) & ~3ull)) return BF_ERR_INVALID;
+    const int64_t rc = junction_decode(record, avail, nullptr, 0, &stored);
+    if ((rc < 0 && rc != -2) || stored > ((avail + 3) & ~3ull)) return BF_ERR_INVALID;      // (-2: a reference record, sized without its ctx)
     return (int64_t)stored;
 }
 
@@ -1276,6 +1353,8 @@ int64_t bf_result_junction_text(const bf_result* r, uint8_t* text, uint64_t cap,
 int bf_set_rank(bf_ctx* ctx, uint32_t rank, uint32_t n_ranks, uint64_t index_base) {
     if (!ctx) return BF_ERR_INVALID;
     if (n_ranks == 0 || n_ranks > 256 || rank >= n_ranks) return fail(ctx, BF_ERR_INVALID, "bf_set_rank: rank %u of %u", rank, n_ranks);
+    if (n_ranks > 1 && (ctx->cfg.flags & BF_FLAG_READS_ON_HOST))
+        return fail(ctx, BF_ERR_STATE, "BF_FLAG_READS_ON_HOST is for one ctx in one process: records that name a read cannot be expanded on another rank");
     ctx->rank = rank; ctx->n_ranks = n_ranks; ctx->index_base = index_base;
     ctx->src_index_base.clear();
     ctx->imported = false;
@@ -1350,14 +1429,14 @@ int bf_render_junctions(bf_ctx* ctx, uint64_t n, const uint32_t* local_index, co
     // this host-side call hands out TEXT (the device-side call hands out records): expand here
     ctx->render_off_host.assign(n + 1, 0);
     for (uint64_t i = 0; i < n; i++) {
-        const int64_t tl = junction_decode(recs.data() + roff[i], roff[i + 1] - roff[i], nullptr, 0);
+        const int64_t tl = junction_decode(recs.data() + roff[i], roff[i + 1] - roff[i], nullptr, 0, nullptr, ctx);
         if (tl < 0) return fail(ctx, BF_ERR_HIP, "bf_render_junctions: malformed junction record for list entry %llu", (unsigned long long)i);
         ctx->render_off_host[i + 1] = ctx->render_off_host[i] + (uint64_t)tl;
     }
     ctx->render_bytes_host.resize(ctx->render_off_host[n]);
     for (uint64_t i = 0; i < n; i++)
         junction_decode(recs.data() + roff[i], roff[i + 1] - roff[i], ctx->render_bytes_host.data() + ctx->render_off_host[i],
-                        ctx->render_off_host[i + 1] - ctx->render_off_host[i]);
+                        ctx->render_off_host[i + 1] - ctx->render_off_host[i], nullptr, ctx);
     *out_bytes = ctx->render_bytes_host.data(); *out_off = ctx->render_off_host.data();
     return BF_OK;
 }

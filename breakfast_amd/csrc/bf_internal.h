@@ -67,7 +67,7 @@ constexpr uint32_t kEvStrand = 1, kEvMstrand = 2, kEvSwapped = 4, kEvExact = 8, 
 // Header word (little endian u32): bits 0-1 kind (0 text, 1 dense, 2 sparse), bit 2 "the read was reverse-complemented"
 // (detect.rs:112); packed kinds: L in bits 3-11, bp in 12-20, n_exc in 21-26, listed lower-case positions in 27-31;
 // text: bp in bits 8-23 and L in a second word.
-constexpr uint32_t kJrText = 0u, kJrDense = 1u, kJrSparse = 2u;
+constexpr uint32_t kJrText = 0u, kJrDense = 1u, kJrSparse = 2u, kJrRef = 3u;
 __host__ __device__ inline bool junction_packable(uint32_t L, uint32_t n_exc, uint32_t max_packed) {
     return L <= max_packed && L <= 256u && 8u * n_exc <= L;
 }
@@ -84,6 +84,17 @@ __host__ __device__ inline uint32_t junction_record_bytes(uint32_t L, uint32_t n
     if (!junction_packable(L, n_exc, max_packed)) return (8u + L + 1u + 3u) & ~3u;
     const uint32_t u = (L + 7u) >> 3;
     return ((junction_sparse(L, n_lower) ? 4u + 2u * u + 2u * n_exc + n_lower : 4u + 3u * u + 2u * n_exc) + 3u) & ~3u;
+}
+// Reference records (BF_FLAG_READS_ON_HOST): the bases stay in the caller's host arrays, the record names the read.
+// Header: kind 3, bit 2 swapped, bit 3 wide (u16 positions), bits 4-15 n_lower (kJrRefDense: a bit per base), bits
+// 16-31 bp; then the read's number (u32), then the lower-case positions (or u32 L + ceil(L/8) mask bytes).
+constexpr uint32_t kJrRefDense = 4095u;
+__host__ __device__ inline uint32_t junction_ref_bytes(uint32_t L, uint32_t n_lower) {
+    if (n_lower >= kJrRefDense) return (8u + 4u + ((L + 7u) >> 3) + 3u) & ~3u;
+    return (8u + n_lower * (L > 256u ? 2u : 1u) + 3u) & ~3u;
+}
+__host__ __device__ inline uint32_t junction_head_ref(bool swapped, uint32_t L, uint32_t n_lower, uint32_t bp) {
+    return kJrRef | (swapped ? 4u : 0u) | (L > 256u ? 8u : 0u) | ((n_lower >= kJrRefDense ? kJrRefDense : n_lower) << 4) | ((bp & 0xffffu) << 16);
 }
 // What the cluster stage gathers per evidence record by sort permutation, in one 8-byte word instead of four
 // arrays (a random gather costs a whole line whatever it uses): junction record bytes (20 bits), evidence
@@ -199,6 +210,9 @@ struct bf_ctx {
     WideSlot wide[2];                           // piece-wide offset staging for batches in bf_host_alloc memory, used in turn
     uint32_t wide_next = 0;
     std::vector<std::pair<const uint8_t*, size_t>> pinned;   // bf_host_alloc ranges
+    // BF_FLAG_READS_ON_HOST: where the caller keeps the bases of resident reads [first, first + n)
+    struct HostReads { uint64_t first, n; const uint8_t* seq; const uint64_t* seq_off; const uint16_t* seq_len; };
+    std::vector<HostReads> host_reads;
     std::mutex pinned_mu;                       // bf_host_alloc / bf_host_free may come from any thread, beside other calls
     uint32_t host_threads = 0;                  // bf_config.reserved[1], or chosen from the machine
     uint64_t cap_reads = 0;                     // capacity of every per-read array below (inputs and evidence)
@@ -339,7 +353,7 @@ int grow_reads(bf_ctx* ctx, uint64_t cap);          // per-read arrays for `cap`
 int settle_counts(bf_ctx* ctx);                     // n_exact / n_sigx / n_text_records valid on return
 int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, int n_chunks, uint64_t* chunk_off,
                    const uint32_t* d_sizes = nullptr);   // d_sizes: record bytes per list entry when the caller has them
-int64_t junction_decode(const uint8_t* rec, uint64_t avail, uint8_t* out, uint64_t cap, uint64_t* stored = nullptr);   // api.hip, host
+int64_t junction_decode(const uint8_t* rec, uint64_t avail, uint8_t* out, uint64_t cap, uint64_t* stored = nullptr, const bf_ctx* ctx = nullptr);   // api.hip, host
 int render_range(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const DevBuf& d_off, DevBuf& d_bytes);
 int render_range_at(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const uint64_t* d_off, uint8_t* d_bytes);
 int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, DevBuf& d_bytes,

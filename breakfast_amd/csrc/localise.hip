@@ -413,6 +413,7 @@ struct LocaliseArgs {
     const uint8_t* seq;           // fused variant: the reads, ASCII or 4-bit codes
     const uint64_t* seq_off;      // ... and where each starts (bytes)
     uint32_t packed;              // 1: 4-bit codes, lengths in `len`
+    uint32_t by_ref;              // 1: junction records name the read (BF_FLAG_READS_ON_HOST): their size in `info`
     const ContigDev* contigs;
     const GenomeBlock* blocks;
     const uint64_t* coarse;
@@ -679,7 +680,7 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
 #pragma unroll
     for (int w = 0; w < W; w++) n_exc += (uint32_t)__popcll(rex[w]);
     if (!junction_packable((uint32_t)L, n_exc, 64u * W)) atomicAdd(&a.counters[2], 1u);
-    a.info[r] = read_info(junction_record_bytes((uint32_t)L, n_exc, n_lower, 64u * W), fl, (uint32_t)bp, (uint32_t)L);
+    a.info[r] = read_info(a.by_ref ? junction_ref_bytes((uint32_t)L, n_lower) : junction_record_bytes((uint32_t)L, n_exc, n_lower, 64u * W), fl, (uint32_t)bp, (uint32_t)L);
     rec[a.meta_stride - 1] = (uint64_t)(uint16_t)bp | ((uint64_t)fl << 16) | ((uint64_t)(uint16_t)L << 32) | ((uint64_t)n_exc << 48);
     a.flags[r] = fl;
 }
@@ -710,6 +711,7 @@ struct ExactArgs {
     uint64_t* meta;
     int mask_words;          // record stride = mask_words + 1
     uint32_t max_packed;     // longest read a packed junction record can hold
+    uint32_t by_ref;         // junction records name the read (BF_FLAG_READS_ON_HOST)
     uint8_t* sigx;           // 16 bytes per slot
     uint32_t* sigx_slot;     // read -> slot
     uint64_t* info;          // read_info() word
@@ -845,7 +847,7 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
                                    (o.swapped ? kEvSwapped : 0) | kEvExact | (plain ? 0 : kEvSigx));
     a.flags[r] = fl;
     if (!junction_packable((uint32_t)L, n_exc, a.max_packed)) atomicAdd(&a.counters[2], 1u);
-    a.info[r] = read_info(junction_record_bytes((uint32_t)L, n_exc, n_lower, a.max_packed), fl, (uint32_t)bp, (uint32_t)L);
+    a.info[r] = read_info(a.by_ref ? junction_ref_bytes((uint32_t)L, n_lower) : junction_record_bytes((uint32_t)L, n_exc, n_lower, a.max_packed), fl, (uint32_t)bp, (uint32_t)L);
     a.meta[(uint64_t)r * (a.mask_words + 1) + a.mask_words] =
         (uint64_t)(uint16_t)bp | ((uint64_t)fl << 16) | ((uint64_t)(uint16_t)L << 32) | ((uint64_t)n_exc << 48);
     }
@@ -1086,6 +1088,54 @@ __global__ void __launch_bounds__(256) render_packed_kernel(uint64_t n, const ui
     if (have) o32[at] = (uint32_t)acc;
 }
 
+// Reference records (BF_FLAG_READS_ON_HOST): the caller still holds the bases, so a record is the read's number, the
+// breakpoint, the orientation and where the lower-case bases are -- everything from the read's render record, no
+// gather of the read itself.  One lane per surviving read.
+__global__ void __launch_bounds__(256) render_ref_kernel(uint64_t n, const uint32_t* __restrict__ idx,
+                                                         const uint64_t* __restrict__ joff,
+                                                         const uint64_t* __restrict__ meta, int meta_stride,
+                                                         uint8_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = idx[i];
+    const uint64_t* __restrict__ rec = meta + (uint64_t)r * meta_stride;
+    // the record's first words and its tail in one round trip (the usual record has three mask words)
+    uint64_t m4[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) m4[w] = w < meta_stride - 1 ? rec[w] : 0ull;
+    const uint64_t tail = rec[meta_stride - 1];
+    const uint32_t L = (uint32_t)((tail >> 32) & 0xffff), bp = (uint32_t)(tail & 0xffff);
+    const bool swapped = ((tail >> 16) & kEvSwapped) != 0;
+    const int words = min(meta_stride - 1, (int)((L + 63u) >> 6));
+    auto word = [&](int w) -> uint64_t { return w == 0 ? m4[0] : w == 1 ? m4[1] : w == 2 ? m4[2] : w == 3 ? m4[3] : rec[w]; };
+    uint32_t n_lower = 0;
+    for (int w = 0; w < words; w++) n_lower += (uint32_t)__popcll(word(w));
+    uint32_t* __restrict__ o32 = (uint32_t*)(out + joff[i]);
+    uint64_t acc = 0;
+    int have = 0, at = 0;
+    auto put = [&](uint32_t v, int nbytes) {
+        acc |= (uint64_t)v << (8 * have);
+        have += nbytes;
+        if (have >= 4) { o32[at++] = (uint32_t)acc; acc >>= 32; have -= 4; }
+    };
+    put(junction_head_ref(swapped, L, n_lower, bp), 4);
+    put(r, 4);
+    if (n_lower >= kJrRefDense) {
+        put(L, 4);
+        for (uint32_t b = 0; b < ((L + 7u) >> 3); b++) put((uint32_t)(rec[b >> 3] >> (8 * (b & 7))) & 0xffu, 1);
+    } else {
+        const int pb = L > 256u ? 2 : 1;
+        for (int w = 0; w < words; w++) {
+            uint64_t m = word(w);
+            while (m) {
+                put(64u * (uint32_t)w + (uint32_t)__builtin_ctzll(m), pb);
+                m &= m - 1;
+            }
+        }
+    }
+    if (have) o32[at] = (uint32_t)acc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 
@@ -1243,6 +1293,7 @@ int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len) {
     a.planes = ctx->d_planes.as<uint64_t>(); a.len_out = ctx->d_len.as<uint16_t>();
     a.seq = ctx->d_seq.as<uint8_t>(); a.seq_off = ctx->d_seq_off.as<uint64_t>(); a.contigs = ctx->g_contigs.as<ContigDev>();
     a.packed = ctx->packed_reads ? 1u : 0u;
+    a.by_ref = (ctx->cfg.flags & BF_FLAG_READS_ON_HOST) ? 1u : 0u;
     a.blocks = ctx->g_blocks.as<GenomeBlock>(); a.coarse = ctx->g_coarse.as<uint64_t>();
     a.coarse2 = ctx->g_coarse2.as<uint32_t>();
     a.exc = ctx->g_exc.as<uint64_t>(); a.raw = ctx->g_raw.as<uint8_t>();
@@ -1284,7 +1335,7 @@ int run_localise(bf_ctx* ctx, bool defer_counts, bool all) {
         e.contigs = ctx->g_contigs.as<ContigDev>(); e.raw = ctx->g_raw.as<uint8_t>();
         e.key = ctx->d_key.as<uint64_t>(); e.lpos = ctx->d_lpos.as<int32_t>(); e.rpos = ctx->d_rpos.as<int32_t>();
         e.bp = ctx->d_bp.as<uint16_t>(); e.flags = ctx->d_flags.as<uint16_t>(); e.meta = ctx->d_mask.as<uint64_t>();
-        e.mask_words = (int)Wm; e.max_packed = 64u * W; e.info = ctx->d_jrec.as<uint64_t>(); e.sigx = ctx->d_sigx.as<uint8_t>(); e.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
+        e.mask_words = (int)Wm; e.max_packed = 64u * W; e.by_ref = (ctx->cfg.flags & BF_FLAG_READS_ON_HOST) ? 1u : 0u; e.info = ctx->d_jrec.as<uint64_t>(); e.sigx = ctx->d_sigx.as<uint8_t>(); e.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
         Scope t(ctx, "localise_exact");
         const unsigned blocks = (unsigned)std::min<uint64_t>(grid_for(n * 64, 256), 16384);   // oversubscribed: entries differ in length
         hipLaunchKernelGGL(localise_exact_kernel, dim3(blocks), dim3(256), 0, ctx->stream, e);
@@ -1338,6 +1389,11 @@ static int launch_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_idx, const u
     const uint64_t* so = ctx->d_seq_off.as<uint64_t>();
     const uint64_t* meta = ctx->d_mask.as<uint64_t>();
     const bool packed = ctx->packed_reads;
+    if (ctx->cfg.flags & BF_FLAG_READS_ON_HOST) {
+        hipLaunchKernelGGL(render_ref_kernel, g, b, 0, ctx->stream, n, d_idx, d_off, meta, stride, d_bytes);
+        BF_HIP(ctx, hipGetLastError());
+        return BF_OK;
+    }
     if (W == 2) hipLaunchKernelGGL(render_packed_kernel<2>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes, packed);
     else if (W == 3) hipLaunchKernelGGL(render_packed_kernel<3>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes, packed);
     else hipLaunchKernelGGL(render_packed_kernel<4>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes, packed);

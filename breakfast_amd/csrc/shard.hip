@@ -252,7 +252,7 @@ __global__ void place_kernel(bf_place* __restrict__ place, uint8_t* __restrict__
 }
 
 // out[k] = off[pos[k]]: the record offsets at the boundaries between the owners' request lists
-__global__ void pick_offsets_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ off, const uint64_t* __restrict__ pos, uint32_t n) {
+__global__ void pick_block_offsets_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ off, const uint64_t* __restrict__ pos, uint32_t n) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) out[k] = off[pos[k]];
 }
@@ -260,6 +260,10 @@ __global__ void pick_offsets_kernel(uint64_t* __restrict__ out, const uint64_t* 
 inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 int shard_attach(bf_ctx* ctx, Transport* tr, uint32_t rank, uint32_t n_ranks, uint64_t index_base) {
+    if (ctx->cfg.flags & BF_FLAG_READS_ON_HOST) {
+        delete tr;
+        return fail(ctx, BF_ERR_STATE, "BF_FLAG_READS_ON_HOST is for one ctx in one process: records that name a read cannot be expanded on another rank");
+    }
     tr->rank = rank; tr->n = n_ranks;
     Shard* sh = new Shard();
     sh->tr = tr;
@@ -544,7 +548,7 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
             pick[0] = 0;
             for (uint32_t o = 0; o < W; o++) pick[o + 1] = pick[o] + rm[(size_t)o * W + me];
             BF_HIP(ctx, hipMemcpyAsync(sh->d_pick.p, pick.data(), (size_t)(W + 1) * 8, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(pick_offsets_kernel, dim3(grid_for(W + 1, 256)), dim3(256), 0, st, sh->d_pick.as<uint64_t>() + (W + 1),
+            hipLaunchKernelGGL(pick_block_offsets_kernel, dim3(grid_for(W + 1, 256)), dim3(256), 0, st, sh->d_pick.as<uint64_t>() + (W + 1),
                                sh->d_roff_g.as<uint64_t>(), sh->d_pick.as<uint64_t>(), W + 1);
             BF_HIP(ctx, hipGetLastError());
             BF_HIP(ctx, hipMemcpyAsync(pick.data() + (W + 1), sh->d_pick.as<uint64_t>() + (W + 1), (size_t)(W + 1) * 8, hipMemcpyDeviceToHost, st));

@@ -28,6 +28,7 @@ BF_FLAG_ONE_GROUP = 128
 BF_FLAG_GROUPS_ALWAYS = 256
 BF_FLAG_ONE_STREAM = 512
 BF_FLAG_LSD_SORT = 1024
+BF_FLAG_READS_ON_HOST = 2048
 BF_EV_STRAND, BF_EV_MSTRAND, BF_EV_SWAPPED, BF_EV_EXACT, BF_EV_SIGX = 1, 2, 4, 8, 16
 
 HIT_DTYPE = np.dtype([("pos5", "<u4"), ("pos3", "<u4"), ("contig5", "<u2"), ("contig3", "<u2"),
@@ -105,7 +106,7 @@ ABI_SYMBOLS = [
     "bf_localise", "bf_clusterise", "bf_finish", "bf_reset", "bf_sync", "bf_format_sv", "bf_set_rank",
     "bf_exchange_local", "bf_exchange_pack", "bf_exchange_import", "bf_result_sources",
     "bf_render_junctions", "bf_result_sources_dev", "bf_render_junctions_dev", "bf_result_attach_junctions_dev",
-    "bf_evidence_fetch", "bf_kernel_times", "bf_stats", "bf_junction_text", "bf_result_junction_text",
+    "bf_evidence_fetch", "bf_kernel_times", "bf_stats", "bf_junction_text", "bf_junction_text_of", "bf_result_junction_text",
     "bf_result_junction_sizes_dev", "bf_result_layout_dev", "bf_result_attach_records_dev", "bf_result_requests_dev",
     "bf_result_attach_finish", "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
     "bf_render_junctions_dev_static", "bf_host_alloc", "bf_host_free", "bf_submit_wait", "bf_reserve",
@@ -197,6 +198,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_junction_record_bound.restype = C.c_uint64
     lib.bf_junction_text.argtypes = [vp, C.c_uint64, vp, C.c_uint64]
     lib.bf_junction_text.restype = C.c_int64
+    lib.bf_junction_text_of.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
+    lib.bf_junction_text_of.restype = C.c_int64
     lib.bf_result_junction_text.argtypes = [C.POINTER(BfResult), vp, C.c_uint64, vp]
     lib.bf_result_junction_text.restype = C.c_int64
     if path is None:
@@ -429,6 +432,8 @@ class Engine:
         if rc != 0:
             raise BreakfastError(rc, (self.lib.bf_last_error(None) or b"").decode())
         self.h = h
+        self.flags = flags
+        self._kept_reads: list = []
         self.contig_names: List[bytes] = []
 
     def close(self) -> None:
@@ -470,6 +475,8 @@ class Engine:
                 np.ascontiguousarray(b.hits, HIT_DTYPE)]
         cb = BfBatch(b.n, *[a.ctypes.data for a in arrs])
         self._check(self.lib.bf_submit(self.h, C.byref(cb)))
+        if self.flags & BF_FLAG_READS_ON_HOST:
+            self._kept_reads.append(arrs)                 # the library's records point into these until reset()
 
     def submit_packed(self, b: PackedBatch) -> None:
         arrs = [np.ascontiguousarray(b.seq_nibbles, np.uint8), np.ascontiguousarray(b.seq_off, np.uint64),
@@ -477,6 +484,8 @@ class Engine:
                 np.ascontiguousarray(b.frag_off, np.uint64), np.ascontiguousarray(b.hits, HIT_DTYPE)]
         cb = BfPackedBatch(b.n, *[a.ctypes.data for a in arrs])
         self._check(self.lib.bf_submit_packed(self.h, C.byref(cb)))
+        if self.flags & BF_FLAG_READS_ON_HOST:
+            self._kept_reads.append(arrs)
 
     def host_alloc(self, nbytes: int, dtype=np.uint8) -> np.ndarray:
         """A numpy array over bf_host_alloc memory (pinned; owned by the ctx, valid until close())."""
@@ -554,6 +563,18 @@ class Engine:
 
     def reset(self) -> None:
         self._check(self.lib.bf_reset(self.h))
+        self._kept_reads = []
+
+    def junction_text_of(self, records, off: int = 0) -> bytes:
+        """junction_text() for a record of THIS ctx: also expands the reference records of BF_FLAG_READS_ON_HOST."""
+        rec = records if isinstance(records, np.ndarray) else np.frombuffer(records, np.uint8)
+        avail = max(int(rec.size) - off, 0)
+        ptr = rec.ctypes.data + off if avail else None
+        n = self.lib.bf_junction_text_of(self.h, ptr, avail, None, 0)
+        self._check(n)
+        buf = C.create_string_buffer(int(n))
+        self.lib.bf_junction_text_of(self.h, ptr, avail, buf, n)
+        return buf.raw[:n]
 
     def sync(self) -> None:
         self._check(self.lib.bf_sync(self.h))

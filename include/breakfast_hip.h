@@ -74,6 +74,11 @@ typedef struct {
                                        gathers of round 1 instead of the class partition + chunk sort */
 #define BF_FLAG_ONE_STREAM   512u   /* profiling: every kernel and copy of the ctx on ONE stream, nothing overlaps (a kernel trace then
                                       shows each kernel's own duration, not its share of a GPU it has to share with the result copy) */
+#define BF_FLAG_READS_ON_HOST 2048u /* the caller keeps every submitted batch's sequence arrays (seq_bytes / seq_nibbles, seq_off,
+                                       seq_len) valid and unchanged until it is done with the results: junction records then
+                                       name the read instead of carrying its bases (kind 3 below; 12 bytes instead of 44 for a
+                                       150-base read), and bf_format_sv / bf_junction_text_of read the bases where the caller
+                                       left them.  One ctx, one process: not with bf_set_rank / bf_shard_init_*. */
 #define BF_FLAG_DEVICE_ROUTING 16u /* multi-rank: bf_clusterise leaves the read table on the device (result.reads
                                       is NULL, n_reads is set); the bf_result_attach_* calls complete the result */
 
@@ -129,6 +134,12 @@ typedef struct {
  *     n_lower x u8 k                            (sparse) base k prints in lower case: the usual case, a mismatch or two
  *   text kind (longer reads, or many bases outside ACGT): bits 8-23 of the header = bp, then
  *     u32 L, L+1 bytes: the string itself
+ *   reference kind (3; only under BF_FLAG_READS_ON_HOST): the bases stay where the caller submitted them from
+ *     bit 3       wide: lower-case positions are u16 (reads of more than 256 bases), else u8
+ *     bits 4-15   n_lower, listed lower-case positions; 4095: a bit per base instead (u32 L, ceil(L/8) bytes)
+ *     bits 16-31  bp
+ *     u32 read    the read's number among the ctx's resident reads (submit order)
+ *     n_lower x (u8 | u16) k
  * A record's length follows from its header, so records can be walked one after the other.
  * bf_junction_text() expands one record, bf_result_junction_text() all records of a result,
  * bf_format_sv() expands them while it prints.  44 bytes instead of 151 for a 150-base read with one mismatch. */
@@ -262,11 +273,15 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* result, char* buf, uint
  * record.  `avail` = bytes readable from `record` on (at least the record; e.g. junction_size - junction_off).
  * Pure host code, needs no ctx. */
 int64_t bf_junction_text(const uint8_t* record, uint64_t avail, char* buf, uint64_t cap);
+/* bf_junction_text for the records of `ctx`: the only way to expand a reference record (BF_FLAG_READS_ON_HOST), which
+ * names its read and leaves the bases in the caller's arrays. */
+int64_t bf_junction_text_of(const bf_ctx* ctx, const uint8_t* record, uint64_t avail, char* buf, uint64_t cap);
 /* Stored size of the record in bytes (a multiple of 4), or BF_ERR_INVALID. */
 int64_t bf_junction_record_bytes(const uint8_t* record, uint64_t avail);
 
 /* All junction strings of a result, concatenated in read order: text_off receives n_reads+1 offsets,
- * text (capacity cap) the bytes when given and large enough.  Returns the total size or a negative error. */
+ * text (capacity cap) the bytes when given and large enough.  Returns the total size or a negative error
+ * (BF_ERR_INVALID also for results that hold reference records: those need the ctx, bf_junction_text_of). */
 int64_t bf_result_junction_text(const bf_result* result, uint8_t* text, uint64_t cap, uint64_t* text_off);
 
 /* ---- multi-GPU stage calls (one ctx per GPU/process) ------------------ */
