@@ -294,6 +294,23 @@ def main():
                        "reads the bases where the caller left them (same .sv bytes, tests/test_gpu_reads_on_host.py)"}
         log(rank, "reads stay on the host: %.3f ms per step, %.1f M reads/s, %d record bytes (self-contained: %d)" %
             (dt * 1e3, n_local / dt / 1e6, roh["record_bytes"], roh["record_bytes_self_contained"]))
+        # ... and host memory in, host memory out under the same flag (the batch in this ctx's pinned memory)
+        pinned3 = e3.pin_batch(batch)
+
+        def one3():
+            e3.reset()
+            e3.submit(pinned3)
+            return e3.finish_raw()
+        for _ in range(max(args.warmup, 1)):
+            one3()
+        e3.sync()
+        t0_ = time.perf_counter()
+        for _ in range(args.steps):
+            r_ = one3()
+        dt = (time.perf_counter() - t0_) / args.steps
+        assert int(r_.n_clusters) == n_clusters and int(r_.n_reads) == n_support, "reads-on-host result differs"
+        roh["host_to_host"] = {"value": round(n_local / dt, 1), "unit": "reads/s", "ms_per_step": round(dt * 1e3, 3)}
+        log(rank, "reads stay on the host, host to host: %.2f ms per step, %.1f M reads/s" % (dt * 1e3, n_local / dt / 1e6))
         e3.close()
 
     # ---- roofline of the dominant kernel -----------------------------------------------------------
