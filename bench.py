@@ -272,46 +272,50 @@ def main():
     #      of carrying its bases back over PCIe.  A second ctx; reported beside `value`, never as `value`. ------------------
     roh = None
     if not sharded and not args.no_h2h and args.variant == "fused":
-        e3 = engine.Engine(A, 5000, 2, device=local, groups=args.groups if args.roh_groups < 0 else args.roh_groups, host_threads=args.host_threads,
-                           flags=engine.BF_FLAG_READS_ON_HOST | (engine.BF_FLAG_ONE_STREAM if args.one_stream else 0))
-        e3.set_genome(genome.names, genome.seqs)
-        e3.submit(batch)
-        e3.submit_wait()
-        for _ in range(max(args.warmup, 1)):
-            r_ = e3.finish_raw()
-        e3.kernel_times()
-        e3.sync()
-        t0_ = time.perf_counter()
-        for _ in range(args.steps):
-            r_ = e3.finish_raw()
-        dt = (time.perf_counter() - t0_) / args.steps
-        kt = e3.kernel_times()
-        assert int(r_.n_clusters) == n_clusters and int(r_.n_reads) == n_support, "reads-on-host result differs"
-        roh = {"value": round(n_local / dt, 1), "unit": "reads/s", "ms_per_step": round(dt * 1e3, 3),
-               "record_bytes": int(r_.junction_size), "record_bytes_self_contained": int(last.junction_size),
-               "stage_ms": {k: round(v[0] / args.steps, 4) for k, v in kt.items()},
-               "note": "BF_FLAG_READS_ON_HOST: the caller keeps the submitted batches; records name the read, bf_format_sv "
-                       "reads the bases where the caller left them (same .sv bytes, tests/test_gpu_reads_on_host.py)"}
-        log(rank, "reads stay on the host: %.3f ms per step, %.1f M reads/s, %d record bytes (self-contained: %d)" %
-            (dt * 1e3, n_local / dt / 1e6, roh["record_bytes"], roh["record_bytes_self_contained"]))
-        # ... and host memory in, host memory out under the same flag (the batch in this ctx's pinned memory)
-        pinned3 = e3.pin_batch(batch)
+        try:
+            e3 = engine.Engine(A, 5000, 2, device=local, groups=args.groups if args.roh_groups < 0 else args.roh_groups, host_threads=args.host_threads,
+                               flags=engine.BF_FLAG_READS_ON_HOST | (engine.BF_FLAG_ONE_STREAM if args.one_stream else 0))
+            e3.set_genome(genome.names, genome.seqs)
+            e3.submit(batch)
+            e3.submit_wait()
+            for _ in range(max(args.warmup, 1)):
+                r_ = e3.finish_raw()
+            e3.kernel_times()
+            e3.sync()
+            t0_ = time.perf_counter()
+            for _ in range(args.steps):
+                r_ = e3.finish_raw()
+            dt = (time.perf_counter() - t0_) / args.steps
+            kt = e3.kernel_times()
+            assert int(r_.n_clusters) == n_clusters and int(r_.n_reads) == n_support, "reads-on-host result differs"
+            roh = {"value": round(n_local / dt, 1), "unit": "reads/s", "ms_per_step": round(dt * 1e3, 3),
+                   "record_bytes": int(r_.junction_size), "record_bytes_self_contained": int(last.junction_size),
+                   "stage_ms": {k: round(v[0] / args.steps, 4) for k, v in kt.items()},
+                   "note": "BF_FLAG_READS_ON_HOST: the caller keeps the submitted batches; records name the read, bf_format_sv "
+                           "reads the bases where the caller left them (same .sv bytes, tests/test_gpu_reads_on_host.py)"}
+            log(rank, "reads stay on the host: %.3f ms per step, %.1f M reads/s, %d record bytes (self-contained: %d)" %
+                (dt * 1e3, n_local / dt / 1e6, roh["record_bytes"], roh["record_bytes_self_contained"]))
+            # ... and host memory in, host memory out under the same flag (the batch in this ctx's pinned memory)
+            pinned3 = e3.pin_batch(batch)
 
-        def one3():
-            e3.reset()
-            e3.submit(pinned3)
-            return e3.finish_raw()
-        for _ in range(max(args.warmup, 1)):
-            one3()
-        e3.sync()
-        t0_ = time.perf_counter()
-        for _ in range(args.steps):
-            r_ = one3()
-        dt = (time.perf_counter() - t0_) / args.steps
-        assert int(r_.n_clusters) == n_clusters and int(r_.n_reads) == n_support, "reads-on-host result differs"
-        roh["host_to_host"] = {"value": round(n_local / dt, 1), "unit": "reads/s", "ms_per_step": round(dt * 1e3, 3)}
-        log(rank, "reads stay on the host, host to host: %.2f ms per step, %.1f M reads/s" % (dt * 1e3, n_local / dt / 1e6))
-        e3.close()
+            def one3():
+                e3.reset()
+                e3.submit(pinned3)
+                return e3.finish_raw()
+            for _ in range(max(args.warmup, 1)):
+                one3()
+            e3.sync()
+            t0_ = time.perf_counter()
+            for _ in range(args.steps):
+                r_ = one3()
+            dt = (time.perf_counter() - t0_) / args.steps
+            assert int(r_.n_clusters) == n_clusters and int(r_.n_reads) == n_support, "reads-on-host result differs"
+            roh["host_to_host"] = {"value": round(n_local / dt, 1), "unit": "reads/s", "ms_per_step": round(dt * 1e3, 3)}
+            log(rank, "reads stay on the host, host to host: %.2f ms per step, %.1f M reads/s" % (dt * 1e3, n_local / dt / 1e6))
+            e3.close()
+        except Exception as e:                     # an extra leg must not cost the bench line
+            log(rank, "reads-on-host leg failed: %r" % (e,))
+            roh = {"error": repr(e)}
 
     # ---- roofline of the dominant kernel -----------------------------------------------------------
     loc_ms, loc_n = ktimes.get("localise", (0.0, 0))
