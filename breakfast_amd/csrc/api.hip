@@ -423,6 +423,7 @@ int bf_sync(bf_ctx* ctx) {
 // waits for the pieces and packs the images.  bf_genome_set is the three in one call.
 constexpr size_t kStageSlotBytes = 8u << 20;         // pinned staging slots of bf_submit and bf_genome_write
 constexpr uint32_t kGenomeSlots = 16;
+static_assert(kStageSlotBytes == BF_GENOME_FILL_MAX, "bf_genome_fill hands out one staging slot");
 
 int bf_genome_begin(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint64_t* lens) {
     if (!ctx) return BF_ERR_INVALID;
@@ -481,7 +482,7 @@ int bf_genome_begin(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, c
 }
 
 // Thread-safe; reports through its return value only (the message is kept for bf_genome_end).
-int bf_genome_write(bf_ctx* ctx, uint32_t contig, uint64_t offset, const uint8_t* bytes, uint64_t n) {
+static int genome_write_impl(bf_ctx* ctx, uint32_t contig, uint64_t offset, const uint8_t* bytes, uint64_t n, bf_fill_fn fill, void* user) {
     if (!ctx) return BF_ERR_INVALID;
     auto bad = [&](int code, const char* msg) {
         std::lock_guard<std::mutex> g(ctx->genome_mu);
@@ -492,7 +493,8 @@ int bf_genome_write(bf_ctx* ctx, uint32_t contig, uint64_t offset, const uint8_t
     if (contig >= ctx->n_contigs || offset > ctx->contig_host[contig].len || n > ctx->contig_host[contig].len - offset)
         return bad(BF_ERR_RANGE, "bf_genome_write: piece outside its contig");
     if (n == 0) return BF_OK;
-    if (!bytes) return bad(BF_ERR_INVALID, "bf_genome_write: null bytes");
+    if (!bytes && !fill) return bad(BF_ERR_INVALID, "bf_genome_write: null bytes");
+    if (fill && n > kStageSlotBytes) return bad(BF_ERR_RANGE, "bf_genome_fill: a piece of more than BF_GENOME_FILL_MAX bytes");
     if (hipSetDevice(ctx->device) != hipSuccess) return bad(BF_ERR_HIP, "hipSetDevice failed");
     uint8_t* dst = ctx->g_raw.as<uint8_t>() + ctx->contig_host[contig].goff + offset;
     for (uint64_t a = 0; a < n; a += kStageSlotBytes) {
@@ -504,13 +506,23 @@ int bf_genome_write(bf_ctx* ctx, uint32_t contig, uint64_t offset, const uint8_t
             if (hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) return bad(BF_ERR_HIP, "hipEventCreate failed");
         }
         if (sl.used && hipEventSynchronize(sl.ev) != hipSuccess) return bad(BF_ERR_HIP, "hipEventSynchronize failed");
-        memcpy(sl.p, bytes + a, len);
+        if (fill) fill(user, sl.p, len);              // the caller writes the piece straight into the pinned slot
+        else memcpy(sl.p, bytes + a, len);
         if (hipMemcpyAsync(dst + a, sl.p, len, hipMemcpyHostToDevice, ctx->in_stream) != hipSuccess ||
             hipEventRecord(sl.ev, ctx->in_stream) != hipSuccess)
             return bad(BF_ERR_HIP, "genome upload failed");
         sl.used = true;
     }
     return BF_OK;
+}
+
+int bf_genome_write(bf_ctx* ctx, uint32_t contig, uint64_t offset, const uint8_t* bytes, uint64_t n) {
+    return genome_write_impl(ctx, contig, offset, bytes, n, nullptr, nullptr);
+}
+
+int bf_genome_fill(bf_ctx* ctx, uint32_t contig, uint64_t offset, uint64_t n, bf_fill_fn fill, void* user) {
+    if (ctx && !fill) return fail(ctx, BF_ERR_INVALID, "bf_genome_fill: null callback");
+    return genome_write_impl(ctx, contig, offset, nullptr, n, fill, user);
 }
 
 int bf_genome_end(bf_ctx* ctx) {

@@ -254,28 +254,43 @@ static Fasta read_fasta(const std::string& path, int threads) {
     return fa;
 }
 
-// Every piece of every contig to `sink(contig slot, offset inside the contig, bytes, n)`, from `threads` workers.
-static void stream_fasta(const FastaScan& fs, int threads, const std::function<void(uint32_t, uint64_t, const uint8_t*, uint64_t)>& sink) {
-    // a worker joins the lines of its piece in a buffer it keeps (no fresh pages per piece) and hands them on 2 MB at
-    // a time, while they are still in its cache for the sink's copy into pinned memory
+// Every piece of every contig to the library, from `threads` workers.  A piece's lines are joined straight into the
+// pinned memory it is uploaded from (bf_genome_fill); a piece too long for that (a FASTA without line breaks) goes
+// through a buffer the worker keeps, 2 MB at a time (bf_genome_write).
+static void stream_fasta(const FastaScan& fs, int threads, bf_ctx* ctx) {
     constexpr size_t kChunk = 2u << 20;
+    struct Fill { const FastaScan* fs; const FastaScan::Piece* piece; };
     parallel_for(fs.pieces.size(), threads, [&](size_t i) {
         const long sl = fs.rec_slot[fs.pieces[i].rec];
         if (sl < 0 || fs.pieces[i].len == 0) return;
+        static const bool no_fill = getenv("BREAKFAST_HIP_NO_FILL") != nullptr;        // (A/B switch)
+        if (fs.pieces[i].len <= BF_GENOME_FILL_MAX && !no_fill) {
+            Fill f{&fs, &fs.pieces[i]};
+            (void)bf_genome_fill(ctx, (uint32_t)sl, fs.pieces[i].out, fs.pieces[i].len, [](void* u, uint8_t* dst, uint64_t n) {
+                const Fill* f = (const Fill*)u;
+                uint8_t* out = dst;
+                f->fs->each_line(*f->piece, [&](const char* s, size_t l) {
+                    if ((uint64_t)(out - dst) + l <= n) memcpy(out, s, l);
+                    out += l;
+                });
+            }, &f);
+            return;
+        }
         thread_local std::unique_ptr<char[]> buf;
         thread_local size_t cap = 0;
         size_t fill = 0;
         uint64_t at = fs.pieces[i].out;
+        auto flush = [&] { if (fill) (void)bf_genome_write(ctx, (uint32_t)sl, at, (const uint8_t*)buf.get(), fill); at += fill; fill = 0; };
         fs.each_line(fs.pieces[i], [&](const char* s, size_t l) {
             if (fill + l > cap) {
-                if (fill) { sink((uint32_t)sl, at, (const uint8_t*)buf.get(), fill); at += fill; fill = 0; }
+                flush();
                 if (l > cap) { cap = std::max(l, kChunk + (64u << 10)); buf.reset(new char[cap]); }
             }
             memcpy(buf.get() + fill, s, l);
             fill += l;
-            if (fill >= kChunk) { sink((uint32_t)sl, at, (const uint8_t*)buf.get(), fill); at += fill; fill = 0; }
+            if (fill >= kChunk) flush();
         });
-        if (fill) sink((uint32_t)sl, at, (const uint8_t*)buf.get(), fill);
+        flush();
     });
 }
 
@@ -725,7 +740,7 @@ int main(int argc, char** argv) {
             { std::lock_guard<std::mutex> g(gpu_mu); gpu_ready = true; }
             gpu_cv.notify_all();
             const auto t0 = std::chrono::steady_clock::now();
-            stream_fasta(*fs, g_threads, [&](uint32_t c, uint64_t off, const uint8_t* p, uint64_t n) { (void)bf_genome_write(ctx, c, off, p, n); });
+            stream_fasta(*fs, g_threads, ctx);
             genome_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         });
 

@@ -72,6 +72,8 @@ class BfShardResult(C.Structure):
                 ("record_bytes", C.c_void_p), ("record_size", C.c_uint64), ("places", C.c_void_p), ("record_off", C.c_void_p)]
 
 
+FILL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint64)     # bf_fill_fn(user, dst, n)
+
 PLACE_DTYPE = np.dtype([("src_rank", "<u4"), ("slot", "<u4")])
 
 
@@ -110,7 +112,7 @@ ABI_SYMBOLS = [
     "bf_result_junction_sizes_dev", "bf_result_layout_dev", "bf_result_attach_records_dev", "bf_result_requests_dev",
     "bf_result_attach_finish", "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
     "bf_render_junctions_dev_static", "bf_host_alloc", "bf_host_free", "bf_submit_wait", "bf_reserve",
-    "bf_genome_begin", "bf_genome_write", "bf_genome_end", "bf_submit_packed",
+    "bf_genome_begin", "bf_genome_write", "bf_genome_fill", "bf_genome_end", "bf_submit_packed",
     "bf_shard_unique_id", "bf_shard_init_rccl", "bf_shard_init_host", "bf_shard_finish", "bf_shard_result_places", "bf_shard_format_sv",
 ]
 
@@ -153,6 +155,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_genome_begin.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), u64p]
     lib.bf_genome_write.argtypes = [vp, C.c_uint32, C.c_uint64, vp, C.c_uint64]
     lib.bf_genome_end.argtypes = [vp]
+    lib.bf_genome_fill.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, FILL_FN, vp]
     lib.bf_submit.argtypes = [vp, C.POINTER(BfBatch)]
     lib.bf_submit_packed.argtypes = [vp, C.POINTER(BfPackedBatch)]
     lib.bf_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
@@ -461,6 +464,33 @@ class Engine:
         c_seqs = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
         c_lens = (C.c_uint64 * n)(*[a.size for a in arrs])
         self._check(self.lib.bf_genome_set(self.h, n, c_names, c_seqs, c_lens))
+
+    def set_genome_in_pieces(self, names: Sequence[bytes], seqs: Sequence[np.ndarray], piece: int = 1 << 20,
+                             fill: bool = False, order=None) -> None:
+        """bf_genome_begin / bf_genome_write (or, fill=True, bf_genome_fill: the bytes are written by a callback straight
+        into the library's staging memory) / bf_genome_end; `order` permutes the pieces (any order is allowed)."""
+        n = len(names)
+        self.contig_names = [bytes(x) for x in names]
+        arrs = [np.ascontiguousarray(np.frombuffer(s, np.uint8) if isinstance(s, (bytes, bytearray)) else s, dtype=np.uint8) for s in seqs]
+        c_names = (C.c_char_p * n)(*self.contig_names)
+        c_lens = (C.c_uint64 * n)(*[a.size for a in arrs])
+        self._check(self.lib.bf_genome_begin(self.h, n, c_names, c_lens))
+        pieces = [(c, a) for c in range(n) for a in range(0, arrs[c].size, piece)]
+        if order is not None:
+            pieces = [pieces[i] for i in order(len(pieces))]
+        for c, a in pieces:
+            m = min(piece, arrs[c].size - a)
+            if fill:
+                src = arrs[c][a:a + m]
+
+                def cb(user, dst, nbytes, src=src):
+                    C.memmove(dst, src.ctypes.data, nbytes)
+                rc = self.lib.bf_genome_fill(self.h, c, a, m, FILL_FN(cb), None)
+            else:
+                rc = self.lib.bf_genome_write(self.h, c, a, arrs[c][a:a + m].ctypes.data, m)
+            if rc != 0:
+                break                                   # the message is kept for bf_genome_end
+        self._check(self.lib.bf_genome_end(self.h))
 
     @property
     def contig_id(self) -> Dict[bytes, int]:

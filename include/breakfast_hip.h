@@ -191,6 +191,12 @@ int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names,
  * bytes may be freed on return; its errors are returned and repeated by bf_genome_end --, bf_genome_end packs. */
 int bf_genome_begin(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint64_t* lens);
 int bf_genome_write(bf_ctx* ctx, uint32_t contig, uint64_t offset, const uint8_t* bytes, uint64_t n);
+/* bf_genome_write without the copy: the library hands `fill(user, dst, n)` the pinned staging memory the piece is
+ * uploaded from and the caller writes the n bases there (e.g. a FASTA reader joining lines); n <= BF_GENOME_FILL_MAX.
+ * `fill` runs on the calling thread before the call returns.  Thread-safe like bf_genome_write. */
+#define BF_GENOME_FILL_MAX (8u << 20)
+typedef void (*bf_fill_fn)(void* user, uint8_t* dst, uint64_t n);
+int bf_genome_fill(bf_ctx* ctx, uint32_t contig, uint64_t offset, uint64_t n, bf_fill_fn fill, void* user);
 int bf_genome_end(bf_ctx* ctx);
 
 /* ---- the hot path -------------------------------------------------------------------------- */

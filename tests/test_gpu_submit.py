@@ -255,3 +255,33 @@ def test_pageable_batches_may_be_freed_on_return_and_pinned_ones_after_the_wait(
         assert eng.format_sv(eng.finish()) == ref
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("fill", [False, True])
+def test_genome_in_pieces_any_order_and_filled_in_place(fill):
+    """bf_genome_begin / bf_genome_write | bf_genome_fill / bf_genome_end: pieces in any order, written by the caller's
+    callback straight into the staging memory (fill) or copied from its buffer; same table as bf_genome_set."""
+    contigs, gk, spec = synth.config(1, scale=0.002, genome_scale=0.002)
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, spec.anchor_len, 5000, 2)
+    eng = engine.Engine(spec.anchor_len, 5000, 2)
+    try:
+        rng = np.random.default_rng(5)
+        eng.set_genome_in_pieces(g.names, g.seqs, piece=37777, fill=fill, order=lambda n: rng.permutation(n))
+        eng.submit(b)
+        assert eng.format_sv(eng.finish()) == ref.sv
+    finally:
+        eng.close()
+
+
+def test_genome_fill_limits():
+    eng = engine.Engine(20, 5000, 2)
+    try:
+        seq = np.frombuffer(b"ACGT" * (3 << 20), np.uint8)               # 12 MB
+        with pytest.raises(engine.BreakfastError) as e:                   # a piece above BF_GENOME_FILL_MAX
+            eng.set_genome_in_pieces([b"c"], [seq], piece=9 << 20, fill=True)
+        assert "BF_GENOME_FILL_MAX" in str(e.value)
+        eng.set_genome_in_pieces([b"c"], [seq], piece=8 << 20, fill=True)   # exactly the limit is fine
+    finally:
+        eng.close()
