@@ -50,6 +50,8 @@
 #include <fcntl.h>
 #include <spawn.h>
 #include <sys/mman.h>
+#include <signal.h>
+#include <sys/prctl.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -524,8 +526,9 @@ int main(int argc, char** argv) {
     // in front of it.  A child that ends without saying so hands its exit status on.  BREAKFAST_HIP_NO_DETACH=1: one process.
     if (!anchors_only && !hits_only && !getenv("BREAKFAST_HIP_NO_DETACH")) {
         int pfd[2];
-        if (pipe(pfd) == 0) {
+        if (pipe2(pfd, O_CLOEXEC) == 0) {                   // (not for Bowtie to inherit)
             fflush(stdout); fflush(stderr);
+            const pid_t parent = getpid();
             const pid_t pid = fork();
             if (pid > 0) {
                 close(pfd[1]);
@@ -537,7 +540,13 @@ int main(int argc, char** argv) {
                 while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {}
                 _exit(WIFEXITED(st) ? WEXITSTATUS(st) : 255);
             }
-            if (pid == 0) { close(pfd[0]); g_done_fd = pfd[1]; }
+            if (pid == 0) {
+                close(pfd[0]); g_done_fd = pfd[1];
+                // the worker never outlives the process the caller started by more than its own cleaning up: a caller
+                // that kills that process (a time limit, ^C) takes the worker with it
+                prctl(PR_SET_PDEATHSIG, SIGKILL);
+                if (getppid() != parent) _exit(255);
+            }
             else { close(pfd[0]); close(pfd[1]); }          // fork failed: everything in this process
         }
     }
