@@ -553,6 +553,17 @@ def test_full_size_headline_config_is_byte_identical():
         assert hashlib.sha256(eng.format_sv(res2)).hexdigest() == h1
     finally:
         eng.close()
+    # the same input as 4-bit reads whose bases stay with the caller (BF_FLAG_READS_ON_HOST: records name the read)
+    eng = engine.Engine(spec.anchor_len, 5000, 2, flags=engine.BF_FLAG_READS_ON_HOST)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        for a in range(0, b.n, 3000001):
+            eng.submit(engine.pack_batch(b.slice(a, min(b.n, a + 3000001))))
+        res = eng.finish(copy=False)
+        assert res.junction_bytes.size * 4 < len(sv)
+        assert hashlib.sha256(eng.format_sv(res)).hexdigest() == h1
+    finally:
+        eng.close()
     ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, spec.anchor_len, 5000, 2)
     assert n_clusters == ref.n_clusters > 100000
     assert len(sv) == len(ref.sv) and sv == ref.sv
