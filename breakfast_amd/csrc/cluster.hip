@@ -284,10 +284,12 @@ struct MemberView {
 };
 
 __device__ __forceinline__ bool same_frag_bytes(const MemberView& m, uint32_t ra, uint32_t rb) {
-    const uint32_t la = m.frag_len[ra];
-    if (la != m.frag_len[rb]) return false;
-    const uint8_t* a = m.frag + m.frag_off[ra];
-    const uint8_t* b = m.frag + m.frag_off[rb];
+    // lengths and offsets in one round trip (not the offsets only after the lengths have come back)
+    const uint32_t la = m.frag_len[ra], lb = m.frag_len[rb];
+    const uint64_t oa = m.frag_off[ra], ob = m.frag_off[rb];
+    if (la != lb) return false;
+    const uint8_t* a = m.frag + oa;
+    const uint8_t* b = m.frag + ob;
     uint32_t diff = 0;                       // no early exit: the hashes already agree, the ids almost surely too
     for (uint32_t k = 0; k < la; k++) diff |= (uint32_t)(a[k] ^ b[k]);
     return diff == 0;
@@ -315,31 +317,38 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
     const int32_t lp = v.slpos[p], rp = v.srpos[p];
     const bool in_wave = m.qsize[q] <= m.wave_max;
     const uint64_t cbase = in_wave ? 0 : m.qboff[q];
-    auto put = [&](uint64_t slot, uint64_t spos) {
-        const uint32_t rec = v.perm[spos];
+    auto put = [&](uint64_t slot, uint64_t spos, uint32_t rec) {
         m.members[slot] = (uint32_t)spos;
         const uint64_t info = m.info[rec];
+        const uint64_t fh = m.fhash[rec];
         const uint32_t l = info_bp(info), r = info_len(info) - l;
         const uint32_t score = min(l, r) * 10000u + max(l, r);       // detect.rs:273-279
         if (in_wave) {
             const uint32_t i = (uint32_t)(slot - base);
-            if (i < kWaveDedupMax) { s_fh[wv][i] = m.fhash[rec]; s_sc[wv][i] = score; s_rc[wv][i] = rec; }
+            if (i < kWaveDedupMax) { s_fh[wv][i] = fh; s_sc[wv][i] = score; s_rc[wv][i] = rec; }
         } else {
             const uint64_t ci = cbase + (slot - base);
-            m.mkey[ci] = (q << kMemberHashBits) | (m.fhash[rec] & ((1ull << kMemberHashBits) - 1));
+            m.mkey[ci] = (q << kMemberHashBits) | (fh & ((1ull << kMemberHashBits) - 1));
             m.bslot[ci] = (uint32_t)slot;
             m.mscore[slot] = score;
         }
     };
-    if (lane == 0) put(base, p);
-    uint64_t cnt = 1;
-    for (uint64_t s0 = p + 1;; s0 += 64) {
+    // The seed is its own first member: the scan starts AT it.  The wave's life is a chain of round trips to HBM (it is
+    // latency-bound: some 100k waves of ~18 us each), so everything a step needs is requested at once -- key, both
+    // positions and the record id of all 64 candidates, unconditionally -- instead of one array after the other as the
+    // short-circuit tests would have it.
+    uint64_t cnt = 0;
+    for (uint64_t s0 = p;; s0 += 64) {
         const uint64_t s = s0 + lane;
-        bool live = s < v.n && seg_of(v.skey[s]) == seg_of(key) && !beyond(v.slpos[s], lp, v.F);
+        const bool in = s < v.n;
+        const uint64_t ks = in ? v.skey[s] : 0;
+        const int32_t ls = in ? v.slpos[s] : 0, rs = in ? v.srpos[s] : 0;
+        const uint32_t rec = in ? v.perm[s] : 0;
+        const bool live = in && seg_of(ks) == seg_of(key) && !beyond(ls, lp, v.F);
         const uint64_t live_mask = __ballot(live);
-        bool take = live && v.skey[s] == key && !rpos_far(v.srpos[s], rp, v.F) && same_sigx(v, key, p, s);
+        const bool take = live && ks == key && !rpos_far(rs, rp, v.F) && same_sigx(v, key, p, s);
         const uint64_t take_mask = __ballot(take);
-        if (take) put(base + cnt + __popcll(take_mask & ((1ull << lane) - 1)), s);
+        if (take) put(base + cnt + __popcll(take_mask & ((1ull << lane) - 1)), s, rec);
         cnt += __popcll(take_mask);
         if (live_mask != ~0ull) break;        // the break tests are monotone in sorted order
     }
