@@ -122,7 +122,7 @@ typedef struct {
  * leaves the GPU as a self-describing record, because the result copy over PCIe is the longest stage of
  * the path and 2-3 bits per base say what 8 bits of text say.  Records start on 4-byte boundaries and are zero-padded
  * to a multiple of 4 bytes; little endian.  First a header word (u32):
- *     bits 0-1    kind: 0 text, 1 packed dense, 2 packed sparse
+ *     bits 0-1    kind: 0 text, 1 packed dense, 2 packed sparse, 3 reference (BF_FLAG_READS_ON_HOST only)
  *     bit  2      the read was reverse-complemented by the reorient step (detect.rs:108-113)
  *   packed kinds (reads of up to 256 bases with at most one base in eight outside ACGT):
  *     bits 3-11   L, the read length            bits 12-20  bp, position of '|' in the string (0 <= bp <= L)
