@@ -615,11 +615,37 @@ int main(int argc, char** argv) {
         const int fd = pos[0] == "-" ? 0 : open(pos[0].c_str(), O_RDONLY);
         if (fd < 0) error("Cannot open file %s for reading.", pos[0].c_str());
         popt.pack = reads_form == 1;
+        // tests: BREAKFAST_HIP_TEST_ALLOCATOR=k moves the parser's batches to another allocator after k batches, the way
+        // `detect` moves them into pinned memory once the GPU context exists (counts come out on stderr)
+        struct Counting { std::atomic<uint64_t> allocs{0}, releases{0}, live_bytes{0}; } counting;
+        const hits::Allocator test_mem{
+            [](void* u, size_t bytes) -> void* {
+                Counting* c = (Counting*)u;
+                uint64_t* q = (uint64_t*)malloc(bytes + 16);
+                if (!q) return nullptr;
+                q[0] = bytes; q[1] = 0x5eedf00d;
+                c->allocs++; c->live_bytes += bytes;
+                memset(q + 2, 0xa5, bytes);                         // nothing may rely on fresh memory being zero
+                return q + 2;
+            },
+            [](void* u, void* ptr) {
+                Counting* c = (Counting*)u;
+                uint64_t* q = (uint64_t*)ptr - 2;
+                if (q[1] != 0x5eedf00d) { fprintf(stderr, "test allocator: released a pointer it never handed out\n"); abort(); }
+                q[1] = 0;
+                c->releases++; c->live_bytes -= q[0];
+                free(q);
+            }, &counting};
+        std::atomic<const hits::Allocator*> batch_home{nullptr};
+        const char* switch_after = getenv("BREAKFAST_HIP_TEST_ALLOCATOR");
+        uint64_t batches = 0;
+        if (switch_after) popt.allocator = &batch_home;
         try {
             uint64_t counted = 0;
             const bool count_only = getenv("BREAKFAST_HIP_COUNT_ONLY") != nullptr;     // parser timing: no text
             hits::parse_stream(fd, contigs, pos[1], popt, [&](hits::Batch& b) {
                 counted += b.n();
+                if (switch_after && batches++ == (uint64_t)atoll(switch_after)) batch_home.store(&test_mem, std::memory_order_release);
                 for (size_t i = 0; i < (count_only ? 0 : b.n()); i++) {
                     const bf_hit& h = b.hits[i];
                     fwrite(b.frag.data() + b.frag_off[i], 1, b.frag_off[i + 1] - b.frag_off[i], stdout);
@@ -634,6 +660,9 @@ int main(int argc, char** argv) {
             });
             if (count_only) fprintf(stderr, "%llu pairs\n", (unsigned long long)counted);
         } catch (const std::exception& e) { error("%s", e.what()); }
+        if (switch_after)
+            fprintf(stderr, "test allocator: %llu allocations, %llu releases, %llu bytes live\n", (unsigned long long)counting.allocs.load(),
+                    (unsigned long long)counting.releases.load(), (unsigned long long)counting.live_bytes.load());
         fflush(stdout);
         return 0;
     }

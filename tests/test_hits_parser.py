@@ -169,3 +169,26 @@ def test_a_read_outside_the_alphabet_cannot_be_packed(tmp_path, seq):
     assert p.returncode == 255 and b"outside BAM's base alphabet" in p.stderr
     p = run_hits(tmp_path, fa, text)
     assert p.returncode == 0 and seq in p.stdout
+
+
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("switch_after,block", [(0, 3000), (3, 3000), (40, 700), (10 ** 9, 3000)])
+def test_batches_move_to_another_allocator_while_the_parse_runs(tmp_path, packed, switch_after, block):
+    """hits::Options::allocator: `detect` points the parser's batches at pinned memory once the GPU context exists.
+    Here a counting allocator takes over after `switch_after` batches (recycled heap batches move, new ones start
+    there, arrays that outgrow their block are re-homed): same output, every block released once."""
+    import re
+    g, text = lossy_text(11)
+    (tmp_path / "g.fa").write_bytes(g.fasta())
+    (tmp_path / "hits.txt").write_bytes(text)
+    cmd = [EXE, "hits", "--threads=3", "--block-bytes=%d" % block] + (["--packed-reads"] if packed else [])
+    cmd += [str(tmp_path / "hits.txt"), str(tmp_path / "g")]
+    plain = subprocess.run(cmd, capture_output=True, timeout=120)
+    moved = subprocess.run(cmd, capture_output=True, timeout=120, env=dict(os.environ, BREAKFAST_HIP_TEST_ALLOCATOR=str(switch_after)))
+    assert plain.returncode == 0 and moved.returncode == 0, moved.stderr.decode()
+    assert moved.stdout == plain.stdout and len(plain.stdout) > 1000
+    m = re.search(rb"test allocator: (\d+) allocations, (\d+) releases, (\d+) bytes live", moved.stderr)
+    assert m, moved.stderr
+    allocs, releases, live = (int(x) for x in m.groups())
+    assert allocs == releases and live == 0
+    assert (allocs > 0) == (switch_after < 10 ** 9)
