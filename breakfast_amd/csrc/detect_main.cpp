@@ -705,7 +705,7 @@ int main(int argc, char** argv) {
         return rc;
     }
     if (devices.size() == 1) cfg.device = devices[0];
-    cfg.reserved[1] = (uint32_t)std::max(2, threads / 5);              // staging threads of bf_submit: the copies are light
+    cfg.reserved[1] = (uint32_t)std::max(2, threads / 4);              // staging threads of bf_submit (they check the batches)
     if (const char* e = getenv("BREAKFAST_HIP_STAGE_THREADS")) cfg.reserved[1] = (uint32_t)std::max(1, atoi(e));
     bf_ctx* ctx = nullptr;
     double genome_s = 0, submit_s = 0;
@@ -728,8 +728,9 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < fs->names.size(); i++) { names.push_back(fs->names[i].c_str()); contigs.add(fs->names[i], (uint32_t)i); }
         if (names.empty()) error("Genome FASTA file %s.fa holds no sequences.", genome_path.c_str());
         contigs.build();
-        // the parser is what the wall clock waits for: it gets four fifths of the threads, the genome stream the rest
-        int g_threads = std::max(1, threads / 5);
+        // half of the threads parse, a quarter joins and uploads the FASTA, the rest is for bf_submit's checks, the submit
+        // thread and the reader (measured with 16 threads: 8 + 4 + 4 gives 0.285-0.294 s, 11 + 3 + 3 gives 0.298-0.306 s)
+        int g_threads = std::max(1, threads / 4);
         if (const char* e = getenv("BREAKFAST_HIP_GENOME_THREADS")) g_threads = std::max(1, atoi(e));
         if (const char* e = getenv("BREAKFAST_HIP_PARSER_THREADS")) popt.threads = std::max(1, atoi(e));
         genome_s = 0;
@@ -788,9 +789,7 @@ int main(int argc, char** argv) {
         // parsed batches go to a submit thread through a short queue (in input order: one producer, one consumer), so that
         // the thread that pairs lines across block boundaries is not held up while a batch is staged for the GPU
         submit_s = 0;
-        // (two threads fewer than there are left: the submit thread and the reader are busy too, and on a box whose
-        // cores are all taken they were what the parse waited for -- 13 workers of 16 threads: 0.163 s, 11: 0.147 s)
-        if (!getenv("BREAKFAST_HIP_PARSER_THREADS")) popt.threads = std::max(1, threads - g_threads - (threads >= 8 ? 2 : 0));
+        if (!getenv("BREAKFAST_HIP_PARSER_THREADS")) popt.threads = std::max(1, threads >= 8 ? threads / 2 : threads - g_threads);
         {
             std::mutex mu;
             std::condition_variable cv;

@@ -160,6 +160,24 @@ int split_fields(std::string_view s, char d, int want, std::string_view* out) {
     throw ParseError(std::string(what) + ": " + std::string(line.substr(0, 200)));
 }
 
+// The read number of a line that starts "5p:<digits>:" or "3p:<digits>:" (what Bowtie writes): returns where the text
+// after that second colon begins, 0 for any other line (read_number below then does what the reference's split does).
+inline size_t canonical_number(std::string_view line, uint64_t& num) {
+    const char* p = line.data();
+    const size_t n = line.size();
+    if (n < 5 || p[1] != 'p' || p[2] != ':' || (p[0] != '5' && p[0] != '3')) return 0;
+    size_t i = 3;
+    uint64_t v = 0;
+    for (; i < n && i < 3 + 19; i++) {
+        const unsigned d = (unsigned)(p[i] - '0');
+        if (d > 9) break;
+        v = v * 10 + d;
+    }
+    if (i == 3 || i >= n || p[i] != ':') return 0;
+    num = v;
+    return i + 1;
+}
+
 // `line.split(':').nth(1).unwrap().parse().unwrap()`, detect.rs:79
 uint64_t read_number(std::string_view line) {
     std::string_view f[2];
@@ -178,6 +196,76 @@ struct PairParser {
             throw ParseError("Anchor aligned to a contig that " + genome_path +
                              ".fa does not contain (the reference panics here, detect.rs:115).");
         return id;
+    }
+
+    // "\t<strand>\t<contig>\t<pos>" from `p` on, the way Bowtie writes it: one-character strand, a contig name, digits up to
+    // the end of the line (or a further tab).  False for anything else: the caller then takes the general path.
+    static bool tail_fields(const char* p, const char* end, bool& plus, std::string_view& name, uint64_t& pos) {
+        if (end - p < 6 || p[0] != '\t' || p[2] != '\t') return false;
+        plus = p[1] == '+';
+        const char* c = p + 3;
+        const char* q = c;
+        while (q < end && *q != '\t') q++;
+        if (q == end || q == c) return false;
+        name = std::string_view(c, (size_t)(q - c));
+        const char* d = q + 1;
+        if (d == end || end - d > 19) return false;
+        uint64_t v = 0;
+        for (; d < end && *d != '\t'; d++) {
+            const unsigned k = (unsigned)(*d - '0');
+            if (k > 9) return false;
+            v = v * 10 + k;
+        }
+        if (d == q + 1) return false;
+        pos = v;
+        return true;
+    }
+
+    // The same pair when both lines look the way Bowtie writes them -- "5p:<n>:" / "3p:<n>:<fragment>:<bases>:" followed by
+    // the three tab-separated fields -- in one pass over each line instead of a dozen searches (a search costs more in
+    // call overhead than in bytes on lines this short).  `p5` / `p3`: where the lines' text continues after "<n>:".
+    // Returns false, having changed nothing, when a line is anything else; operator() below then does what the
+    // reference's split() calls do, errors included.
+    bool fast(std::string_view prev, size_t p5, std::string_view line, size_t p3, Batch& out) const {
+        if (p5 == 0 || p3 == 0) return false;
+        const char* l = line.data();
+        const char* lend = l + line.size();
+        const char* f = l + p3;                                        // fragment id: up to the next ':'
+        const char* fe = f;
+        while (fe < lend && *fe != ':' && *fe != '\t') fe++;
+        if (fe == lend || *fe != ':') return false;
+        const char* sq = fe + 1;                                        // bases: up to the next ':', which a tab follows
+        const char* se = (const char*)memchr(sq, ':', (size_t)(lend - sq));
+        if (!se || se + 1 >= lend || se[1] != '\t') return false;
+        if (memchr(sq, '\t', (size_t)(se - sq))) return false;
+        bool plus5, plus3;
+        std::string_view n5, n3;
+        uint64_t pos5, pos3;
+        if (!tail_fields(se + 1, lend, plus3, n3, pos3)) return false;
+        if (!tail_fields(prev.data() + p5, prev.data() + prev.size(), plus5, n5, pos5)) return false;
+        if (pos5 >= 0x80000000ull || pos3 >= 0x80000000ull) return false;
+        const int c5 = contigs.find(n5), c3 = contigs.find(n3);
+        if (c5 < 0 || c3 < 0) return false;
+        const size_t L = (size_t)(se - sq);
+        if (pack) {
+            if (L > 65535) return false;
+            const size_t at = out.seq.size();
+            out.seq.resize(at + (L + 1) / 2);
+            if (!pack_bases(sq, L, (uint8_t*)out.seq.data() + at)) { out.seq.resize(at); return false; }
+            out.seq_len.push_back((uint16_t)L);
+            out.packed = true;
+        } else {
+            out.seq.append(sq, L);
+        }
+        bf_hit h;
+        memset(&h, 0, sizeof h);
+        h.pos5 = (uint32_t)pos5; h.pos3 = (uint32_t)pos3;
+        h.contig5 = (uint16_t)c5; h.contig3 = (uint16_t)c3;
+        h.strands = (uint8_t)((plus5 ? 1 : 0) | (plus3 ? 2 : 0));
+        out.hits.push_back(h);
+        out.seq_off.push_back(out.seq.size());
+        out.frag.append(f, (size_t)(fe - f)); out.frag_off.push_back(out.frag.size());
+        return true;
     }
 
     // detect.rs:89-103 for one (5p line, 3p line) pair
@@ -237,6 +325,7 @@ void parse_block(const Block& b, const PairParser& pair, Parsed& out) {
     const char* end = b.p + b.n;
     std::string_view prev;
     uint64_t prev_num = 0;
+    size_t prev_at = 0;                          // canonical_number() of `prev`
     out.bytes = b.n;
     out.batch.seq.reserve(pair.pack ? b.n * 3 / 8 : b.n * 3 / 4);
     out.batch.packed = pair.pack;
@@ -253,12 +342,14 @@ void parse_block(const Block& b, const PairParser& pair, Parsed& out) {
             const std::string_view line(s, len);
             s = nl ? nl + 1 : end;
             out.lines++;
-            const uint64_t num = read_number(line);
+            uint64_t num = 0;
+            const size_t at = canonical_number(line, num);
+            if (!at) num = read_number(line);
             const bool is5 = line.substr(0, 3) == "5p:", is3 = line.substr(0, 3) == "3p:";
-            if (is5) { prev = line; prev_num = num; out.has5 = true; continue; }      // detect.rs:81-84
+            if (is5) { prev = line; prev_num = num; prev_at = at; out.has5 = true; continue; }      // detect.rs:81-84
             if (!out.has5) { out.lead.push_back(Lead{std::string(line), num, is3}); continue; }
             if (is3 && num != prev_num) continue;                                      // detect.rs:85-87
-            pair(prev, line, out.batch);
+            if (!(is3 && pair.fast(prev, prev_at, line, at, out.batch))) pair(prev, line, out.batch);
         }
     } catch (const Unpackable& ex) {
         out.error = ex.what(); out.unpackable = true;
