@@ -460,10 +460,11 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
     if (ctx->cfg.flags & BF_FLAG_ONE_GROUP) G = 1;
     else if (ctx->cfg.reserved[0]) G = std::min<uint32_t>(ctx->cfg.reserved[0], 64u);
     else if (ctx->cfg.flags & BF_FLAG_GROUPS_ALWAYS) G = 2;
-    // (by itself the stage runs in one go: measured on one MI355X through RCCL, configs[1], two groups 9.19 ms per step
-    //  against 9.24, three 9.57, four 9.96 -- a group costs some sixty launches and five host round trips, and the step is
-    //  bound by the host's launch rate before the first byte leaves and by PCIe afterwards, so the overlap buys nothing)
-    (void)max_owned;
+    // Two groups once an owner holds 4M records and more: the first group's records cross PCIe while the second is
+    // clustered.  Measured on one MI355X through RCCL, configs[1]: 7.57 ms per step against 7.93 in one go, three groups
+    // 7.97 -- a group costs some sixty launches, two collectives and five host round trips.  (While a place and an offset
+    // per read still travelled the copy was the longer part either way and groups bought nothing: 9.19 against 9.24.)
+    else if (max_owned >= (1ull << 22)) G = 2;
     std::vector<uint64_t> gb{0, v.n};
     if (G > 1 && v.n) {
         std::vector<uint64_t> hist;
