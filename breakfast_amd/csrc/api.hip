@@ -391,6 +391,7 @@ void bf_ctx_destroy(bf_ctx* ctx) {
     if (ctx->in_stream) (void)hipStreamSynchronize(ctx->in_stream);
     drop_pending(ctx);
     shard_destroy(ctx);
+    delete ctx->pool; ctx->pool = nullptr;
     for (auto& sl : ctx->slots) { if (sl.p) (void)hipHostFree(sl.p); if (sl.ev) (void)hipEventDestroy(sl.ev); }
     ctx->slots.clear();
     for (auto& w : ctx->wide) { if (w.p) (void)hipHostFree(w.p); if (w.ev) (void)hipEventDestroy(w.ev); w = bf_ctx::WideSlot{}; }
@@ -655,6 +656,7 @@ static bool slot_ready(bf_ctx* ctx, bf_ctx::StageSlot& sl) {
 static void submit_worker(SubmitShared* sh, int slot_id) {
     bf_ctx* ctx = sh->ctx;
     const BatchView* b = sh->bat;
+    // (a pool thread keeps the device it set on its first job; setting it again is cheap)
     if (hipSetDevice(ctx->device) != hipSuccess) { sh->error(0, BF_ERR_HIP, "hipSetDevice failed in a staging thread"); return; }
     bf_ctx::StageSlot& sl = ctx->slots[slot_id];
     uint32_t mx = 0, mn = 0xffffffffu, mf = 0;
@@ -920,9 +922,8 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
         const size_t nt = staged < kInlineBytes ? 1 : std::min<size_t>(ctx->host_threads, sh.jobs.size());
         if (nt <= 1) submit_worker(&sh, 0);
         else {
-            std::vector<std::thread> pool;
-            for (size_t t = 0; t < nt; t++) pool.emplace_back(submit_worker, &sh, (int)t);
-            for (auto& th : pool) th.join();
+            if (!ctx->pool) ctx->pool = new HostPool();
+            ctx->pool->run((int)nt, [&sh](int t) { submit_worker(&sh, t); });
         }
         if (sh.err_code != BF_OK) {
             // nothing of this batch becomes resident: its uploads only touched memory beyond n_reads, and whatever

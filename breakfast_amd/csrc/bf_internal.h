@@ -5,6 +5,9 @@
 #include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <thread>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -119,6 +122,55 @@ struct WireHeader {     // 40 B, followed by frag bytes (fixed stride) and optio
 };
 static_assert(sizeof(WireHeader) == 40, "wire header layout");
 
+// ---- a few host threads that stay (bf_submit's checks and staging copies) ----------------------
+// run(n, f): f(0) on the caller, f(1) .. f(n-1) on pool threads; returns when all are done.  One run at a time.
+class HostPool {
+public:
+    ~HostPool() {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void run(int n, const std::function<void(int)>& f) {
+        if (n <= 1) { f(0); return; }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            while ((int)th_.size() < n - 1) { const int k = (int)th_.size() + 1; th_.emplace_back([this, k] { work(k); }); }
+            fn_ = &f; n_ = n; pending_ = n - 1; gen_++;
+        }
+        cv_.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void work(int k) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)>* f = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                if (k < n_) f = fn_;
+            }
+            if (!f) continue;
+            (*f)(k);
+            std::lock_guard<std::mutex> g(mu_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int n_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
 // ---- device buffer ---------------------------------------------------------------------------
 struct DevBuf {
     void* p = nullptr;
@@ -215,6 +267,8 @@ struct bf_ctx {
     std::vector<HostReads> host_reads;
     std::mutex pinned_mu;                       // bf_host_alloc / bf_host_free may come from any thread, beside other calls
     uint32_t host_threads = 0;                  // bf_config.reserved[1], or chosen from the machine
+    bf::HostPool* pool = nullptr;               // bf_submit's helpers: threads that stay (a submit of 70k reads is 0.2 ms of work,
+                                                // starting and joining three threads for it took as long again)
     uint64_t cap_reads = 0;                     // capacity of every per-read array below (inputs and evidence)
     uint64_t n_localised = 0;                   // reads [0, n_localised) have evidence under (plane_words, mask_words)
     std::vector<uint64_t> rank_hist;            // resident reads per left contig rank after the reorient step (detect.rs:108-113:
