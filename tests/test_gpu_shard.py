@@ -191,3 +191,60 @@ def test_command_line_sharded_over_one_gpu(tmp_path, devices):
     assert p.returncode == 0, p.stderr.decode()
     assert p.stdout == po.detect(g.fasta(), text.split(b"\n")[:-1], A, F, E)
     assert b"Found 12000 rearrangement supporting reads." in p.stderr
+
+
+def test_two_ranks_with_owners_large_enough_for_two_groups(tmp_path):
+    """From 4M records per owner on the owners cluster in two contig groups by themselves (the sources render and copy a
+    group's records while the next one is clustered).  9M reads over two ranks (threads, host transport), the merged .sv
+    against the single-GPU path's on the same reads -- which tests/test_gpu_parity.py holds against the oracle at this size."""
+    import hashlib
+    contigs, gk, spec = synth.config(1, scale=0.9, genome_scale=0.02)
+    spec.margin = 10000 + 2 * spec.read_len + 128
+    g = synth.make_genome(contigs, **gk)
+    b = engine.pack_batch(synth.make_reads(g, spec))
+    A = spec.anchor_len
+    single = engine.Engine(A, 5000, 2)
+    try:
+        single.set_genome(g.names, g.seqs)
+        single.submit(b)
+        want = hashlib.sha256(single.format_sv(single.finish(copy=False))).hexdigest()
+    finally:
+        single.close()
+    world, cuts = 2, [0, b.n * 2 // 5, b.n]
+    name = "/bf_test_%s" % uuid.uuid4().hex[:12]
+    results, errors = [None] * world, []
+
+    def part(lo, hi):
+        so, fo = b.seq_off, b.frag_off
+        return engine.PackedBatch(b.seq_nibbles[int(so[lo]):int(so[hi])], so[lo:hi + 1] - so[lo], b.seq_len[lo:hi],
+                                  b.frag_bytes[int(fo[lo]):int(fo[hi])], fo[lo:hi + 1] - fo[lo], b.hits[lo:hi])
+
+    def work(rank):
+        try:
+            eng = engine.Engine(A, 5000, 2, device=0)
+            try:
+                eng.set_genome(g.names, g.seqs)
+                eng.shard_init_host(rank, world, cuts[rank], name, 64 << 20)
+                eng.submit(part(cuts[rank], cuts[rank + 1]))
+                res = eng.shard_finish()
+                assert len(res.group_read_begin) == 3, "expected two groups, got %d" % (len(res.group_read_begin) - 1)
+                results[rank] = res
+            finally:
+                eng.close()
+        except Exception as e:                                   # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=280)
+    assert not errors, errors
+    assert sum(x.n_evidence for x in results) == b.n and min(x.n_evidence for x in results) >= 1 << 22
+    eng = engine.Engine(A, 5000, 2, device=0)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        got = hashlib.sha256(eng.shard_format_sv(results)).hexdigest()
+    finally:
+        eng.close()
+    assert got == want
