@@ -109,3 +109,41 @@ def test_not_with_more_than_one_rank():
         eng.set_rank(0, 1, 0)
     finally:
         eng.close()
+
+
+def test_mutated_reference_records_are_refused_or_stay_in_bounds():
+    """bf_junction_text_of on reference records with flipped bytes: an error or a string of some resident read's length,
+    never a write past the buffer (a guard band behind it survives), never a read past the caller's arrays."""
+    contigs, gk, spec = synth.config(1, scale=0.002, genome_scale=0.002)
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    eng = engine.Engine(spec.anchor_len, 5000, 2, flags=BF_FLAG_READS_ON_HOST)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        eng.submit(b)
+        res = eng.finish()
+        lib = eng.lib
+        rng = np.random.default_rng(3)
+        offs = res.reads["junction_off"].astype(np.int64)
+        ends = np.append(offs[1:], res.junction_bytes.size)
+        n_ok = n_bad = 0
+        for trial in range(3000):
+            k = int(rng.integers(0, offs.size))
+            rec = res.junction_bytes[offs[k]:ends[k]].copy()
+            for _ in range(int(rng.integers(1, 3))):
+                rec[int(rng.integers(0, rec.size))] = int(rng.integers(0, 256))
+            if trial % 5 == 0:
+                rec = rec[:int(rng.integers(0, rec.size))].copy()
+            ptr = rec.ctypes.data if rec.size else None
+            n = lib.bf_junction_text_of(eng.h, ptr, rec.size, None, 0)
+            if n < 0:
+                n_bad += 1
+                continue
+            n_ok += 1
+            assert 1 <= n <= 65536
+            buf = np.full(n + 64, 0xEE, np.uint8)
+            assert lib.bf_junction_text_of(eng.h, ptr, rec.size, buf.ctypes.data, n) == n
+            assert np.all(buf[n:] == 0xEE)
+        assert n_ok > 100 and n_bad > 100
+    finally:
+        eng.close()

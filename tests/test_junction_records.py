@@ -157,3 +157,51 @@ def test_records_found_through_cluster_offsets():
         n = lib.bf_result_junction_text(engine.C.byref(r), None, 0, off.ctypes.data)
         if n < 0:
             raise engine.BreakfastError(int(n), "no way to the records")
+
+
+def test_mutated_records_never_read_past_their_bytes():
+    """Random byte flips, truncations and random bytes: the decoder answers with a length or BF_ERR_INVALID, and what it
+    writes stays inside the buffer it was given (a guard band behind it must survive); a reference record (kind 3) is
+    sized without its ctx and refused by the ctx-less expander."""
+    import ctypes as C
+    lib = engine.load_library()
+    lib.bf_junction_record_bytes.restype = C.c_int64
+    lib.bf_junction_record_bytes.argtypes = [C.c_void_p, C.c_uint64]
+    rng = np.random.default_rng(77)
+    guard = 64
+    n_ok = n_bad = 0
+    for trial in range(4000):
+        L = int(rng.integers(1, 300))
+        rec = bytearray(pack(random_junction(rng, L, n_exc=int(rng.integers(0, 4)))))
+        how = trial % 4
+        if how == 0:                                              # flip a few bytes
+            for _ in range(int(rng.integers(1, 4))):
+                rec[int(rng.integers(0, len(rec)))] = int(rng.integers(0, 256))
+        elif how == 1:                                            # cut it short
+            rec = rec[:int(rng.integers(0, len(rec)))]
+        elif how == 2:                                            # noise
+            rec = bytearray(rng.integers(0, 256, size=int(rng.integers(0, 80)), dtype=np.uint8).tobytes())
+        # how == 3: left intact
+        src = np.frombuffer(bytes(rec), np.uint8).copy() if rec else np.zeros(0, np.uint8)
+        ptr = src.ctypes.data if src.size else None
+        n = lib.bf_junction_text(ptr, src.size, None, 0)
+        sz = lib.bf_junction_record_bytes(ptr, src.size)
+        if n < 0:
+            n_bad += 1
+            assert n == -1 and (sz == -1 or (src.size >= 4 and src[0] & 3 == 3))   # BF_ERR_INVALID (kind 3: sized, not expanded)
+            continue
+        n_ok += 1
+        assert 1 <= n <= 65536 and 0 < sz <= ((src.size + 3) & ~3)
+        buf = np.full(n + guard, 0xEE, np.uint8)
+        assert lib.bf_junction_text(ptr, src.size, buf.ctypes.data, n) == n
+        assert np.all(buf[n:] == 0xEE) and bytes(buf[:n]).count(b"|") >= 1
+        if how == 3:
+            assert sz == len(rec)
+    assert n_ok > 1000 and n_bad > 500
+
+    # a reference record: header kind 3, two lower-case positions
+    ref = np.array([3 | (2 << 4) | (5 << 16), 7], "<u4").tobytes() + bytes([1, 9, 0, 0])
+    src = np.frombuffer(ref, np.uint8).copy()
+    assert lib.bf_junction_record_bytes(src.ctypes.data, src.size) == 12
+    assert lib.bf_junction_text(src.ctypes.data, src.size, None, 0) == -1
+    assert lib.bf_junction_record_bytes(src.ctypes.data, 9) == -1
