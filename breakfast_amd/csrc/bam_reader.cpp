@@ -231,14 +231,23 @@ Reader::~Reader() {
 }
 
 bool Reader::next_view(RecordView& v) {
-    uint8_t b4[4];
-    if (!read_exact(b4, 4, true)) return false;
-    const uint32_t block_size = le32(b4);
+    uint32_t block_size;
+    if (p_->cur.size() - p_->cur_pos >= 4) {                     // the usual case: the length lies in the current block
+        block_size = le32(p_->cur.data() + p_->cur_pos);
+        p_->cur_pos += 4;
+    } else {
+        uint8_t b4[4];
+        if (!read_exact(b4, 4, true)) return false;
+        block_size = le32(b4);
+    }
     if (block_size < 32) throw std::runtime_error("corrupt BAM record");
     const uint8_t* p;
     if (p_->cur.size() - p_->cur_pos >= block_size) {            // whole record inside the current block
         p = p_->cur.data() + p_->cur_pos;
         p_->cur_pos += block_size;
+        // the walk touches a record's first line or two and hops on: ask for the next record's while this one is
+        // looked at (the block was inflated by another thread, none of it is in this core's cache)
+        if (p_->cur.size() - p_->cur_pos >= 64) __builtin_prefetch(p + block_size + 4, 0, 1);
     } else {
         spill_.resize(block_size);
         read_exact(spill_.data(), block_size, false);
