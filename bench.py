@@ -23,6 +23,14 @@ roofline the dominant kernel, `localise`: algorithmic bytes/read (SURVEY.md sect
          duration measured with HIP events on the library's stream, against 8 TB/s HBM3E.
 cpu_baseline  the C++ restatement of the reference (oracle/, single thread like detect.rs:76-241)
          timed on a bounded sample of the same batch on this host's cores.
+--gpus N  one process per GPU.  Under torchrun (WORLD_SIZE set) this process is one rank; without it the command
+         starts its N ranks itself, as fresh processes of a parent that never touches the GPU, and exits non-zero when
+         a rank fails -- it never measures fewer GPUs than it was asked for.  Every rank runs the library's sharded
+         path (bf_shard_finish over RCCL).  configs[1] is weak scaling (10M reads per rank); --config 2 is BASELINE's
+         strong-scaling case: the 100M reads are 16 blocks over one junction table (synth.BLOCKS) and rank r of N holds
+         the contiguous blocks [16r/N, 16(r+1)/N), whatever N is ("scaling": "strong").
+--check  the GPU's table against the oracle's on a sample (one GPU), and on the sharded path the merged table of all
+         ranks (bf_shard_format_sv) against the one-GPU table of the same reads (SHA-256).
 """
 import argparse
 import json
@@ -40,8 +48,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from breakfast_amd import engine, synth  # noqa: E402
-from breakfast_amd.distributed import bind_to_gpu_numa_node, init_from_env  # noqa: E402
+from breakfast_amd import engine, launch, synth  # noqa: E402
+from breakfast_amd.launch import bind_to_gpu_numa_node, init_from_env  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -66,7 +74,6 @@ def claim_stdout():
 
 
 def main():
-    json_out = claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -96,12 +103,23 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="staging threads of bf_submit (0 = library default)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher above us: start the ranks here.  Nothing in this process has touched the GPU (no HIP call, no
+        # torch.cuda.is_available()), and it never will: the ranks are children, this process only waits for them.
+        raise SystemExit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    json_out = claim_stdout()
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %s ranks (WORLD_SIZE); refusing to measure another "
+                         "number of GPUs than asked for" % (args.gpus, os.environ.get("WORLD_SIZE")))
     rank, world, local = init_from_env()
     forced = args.exchange and world == 1
     if world != args.gpus:
-        log(rank, "note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE); refusing to measure another "
+                         "number of GPUs than asked for" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants GPU %d but this machine has %d" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     node = bind_to_gpu_numa_node(local) if world > 1 else None
@@ -127,20 +145,37 @@ def main():
             sq[np.cumsum(mask[:-1]) > 0] |= 0x20
     log(rank, "genome: %d contigs, %.3f Gb in %.1fs" % (len(contigs), sum(l for _, l in contigs) / 1e9, time.time() - t0))
     t1 = time.time()
-    spec.read_seed = spec.seed * 1000 + rank          # same junctions on every rank, different reads
-    spec.frag_base = rank * spec.n_reads
-    batch = synth.make_reads(genome, spec)
-    if args.soft_mask > 0:
-        batch.seq_bytes &= np.uint8(0xDF)              # sequencer reads are upper case whatever the reference's case
-    n_local = batch.n
-    ascii_batch = batch
-    log(rank, "reads: %d x %d bp per rank in %.1fs" % (n_local, L, time.time() - t1))
-    if args.reads == "packed" and args.variant in ("fused", "exact"):
-        t1 = time.time()
-        batch = engine.pack_batch(ascii_batch)
-        log(rank, "reads packed to 4-bit codes in %.1fs (the parser's job on the command line)" % (time.time() - t1))
-    else:
+    strong = args.config == 2
+    want_packed = args.reads == "packed" and args.variant in ("fused", "exact")
+    if not want_packed:
         args.reads = "ascii"
+    if strong:
+        # configs[2]: the SAME 100M reads for every N, as 16 blocks; this rank holds a contiguous run of them
+        my_blocks = list(synth.rank_blocks(rank, world))
+        index_base = synth.block_first_read(spec, my_blocks[0])
+        total_reads = spec.n_reads
+        specs = [synth.block_spec(spec, k) for k in my_blocks]
+    else:
+        # weak scaling: same junctions on every rank, different reads
+        spec.read_seed = spec.seed * 1000 + rank
+        spec.frag_base = rank * spec.n_reads
+        index_base = rank * spec.n_reads
+        total_reads = spec.n_reads * world
+        specs = [spec]
+    ascii_batch, batches = None, []
+    for sp in specs:
+        blk = synth.make_reads(genome, sp)
+        if args.soft_mask > 0:
+            blk.seq_bytes &= np.uint8(0xDF)            # sequencer reads are upper case whatever the reference's case
+        if ascii_batch is None:
+            ascii_batch = blk                          # CPU baseline sample, --check sample, the ASCII legs
+        batches.append(engine.pack_batch(blk) if want_packed else blk)
+    n_local = sum(b.n for b in batches)
+    batch = batches[0]
+    log(rank, "reads: %d x %d bp on this rank (%d block(s)%s) in %.1fs" %
+        (n_local, L, len(batches), ", as 4-bit codes: the parser's job on the command line" if want_packed else "", time.time() - t1))
+    if n_local > 20_000_000 or len(batches) > 1:
+        args.no_h2h = True                             # the host-to-host legs pin a second copy of the batch: configs[1]-sized runs only
 
     # ---- resident inputs -------------------------------------------------------------------------
     eng = engine.Engine(A, 5000, 2, device=local, groups=args.groups, host_threads=args.host_threads, flags=(engine.BF_FLAG_ONE_STREAM if args.one_stream else 0) | {"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER,
@@ -155,20 +190,21 @@ def main():
         box = [engine.Engine.shard_unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(box, src=0)
-        eng.shard_init_rccl(rank, world, rank * n_local, box[0])
-    eng.submit(batch)
+        eng.shard_init_rccl(rank, world, index_base, box[0])
+    for b_ in batches:
+        eng.submit(b_)
     eng.submit_wait()
 
     def nbytes(b):
         return sum(getattr(b, f).nbytes for f in b.__dataclass_fields__)
-    in_bytes = nbytes(batch)
+    in_bytes = sum(nbytes(b_) for b_ in batches)
 
     def wire_bytes(b):
         """what crosses PCIe: for 4-bit batches the library uploads lengths (2 + 2 bytes a read) instead of the two offset arrays"""
         if isinstance(b, engine.PackedBatch):
             return nbytes(b) - b.seq_off.nbytes - b.frag_off.nbytes + 2 * b.n
         return nbytes(b)
-    on_wire = wire_bytes(batch)
+    on_wire = sum(wire_bytes(b_) for b_ in batches)
     log(rank, "reads resident in HBM in %.2fs (first hand-over, buffers still growing: %.2f GB/s)" %
         (time.time() - t3, in_bytes / 1e9 / max(time.time() - t3, 1e-9)))
 
@@ -205,7 +241,10 @@ def main():
         dist.all_reduce(t)
         n_clusters, n_support = (int(v) for v in t.tolist())
 
-    total_reads = n_local * world
+    if world > 1:                                      # what the ranks really hold (strong scaling: the sum is the config)
+        t = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        assert int(t.item()) == total_reads, "ranks hold %d reads, the workload has %d" % (int(t.item()), total_reads)
     ms_per_step = elapsed / args.steps * 1e3
     value = total_reads * args.steps / elapsed
 
@@ -333,7 +372,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         import oracle_lib as ol
-        ns = min(args.cpu_sample, n_local)
+        ns = min(args.cpu_sample, ascii_batch.n)
         sample = ascii_batch.slice(0, ns)
         og = ol.OracleGenome(genome.names, genome.seqs)
         tc = time.perf_counter()
@@ -344,7 +383,7 @@ def main():
                          "cluster table, no .sv text), C++ restatement of detect.rs:105-287, single thread, %.1fs"
                          % (ns, dt),
                "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
-        if args.check:
+        if args.check and not sharded:
             ref = ol.detect_batch(og, genome.names, sample, A, 5000, 2)
             e2 = engine.Engine(A, 5000, 2, device=local)
             e2.set_genome(genome.names, genome.seqs)
@@ -355,19 +394,25 @@ def main():
             if not same:
                 raise SystemExit("bench --check: GPU .sv differs from the oracle's on the sample")
 
+    shard_check = sharded_check(args, eng, rank, world, dev, genome, spec, strong, A) if (args.check and sharded) else None
+
     if rank == 0:
         out = {
             "metric": "candidate reads/sec breakpoint-localised+deduped", "value": round(value, 1), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64 bit-planes",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8/u64 bit-planes",
             "data": "synthetic (seed %d): random hg38-sized genome, simulated junction reads + the Bowtie1 hits of their anchors" % spec.seed,
-            "config": {"workload": "configs[%d]: %d unaligned 2x%d bp reads per GPU with anchor hits on a %.2f Gb genome, anchor length %d"
+            "config": {"workload": ("configs[2]: %d unaligned 2x%d bp reads in %d blocks sharded over %d GPU(s) in contiguous input ranges, "
+                                    "anchor hits on a %.2f Gb genome, anchor length %d" % (total_reads, L, synth.BLOCKS, world, sum(l for _, l in contigs) / 1e9, A))
+                       if strong else
+                       "configs[%d]: %d unaligned 2x%d bp reads per GPU with anchor hits on a %.2f Gb genome, anchor length %d"
                        % (args.config, n_local, L, sum(l for _, l in contigs) / 1e9, A),
-                       "reads_per_gpu": n_local, "read_len": L, "anchor_len": A, "max_frag_len": 5000, "min_evidence": 2,
+                       "reads_per_gpu": n_local, "reads_total": total_reads, "read_len": L, "anchor_len": A, "max_frag_len": 5000, "min_evidence": 2,
                        "reads_as": {"packed": "BAM 4-bit base codes (bf_submit_packed)", "ascii": "ASCII (bf_submit)"}[args.reads],
                        "parallelism": "shard%d+alltoall" % world if sharded else "single"},
             "result": {"clusters": n_clusters, "supporting_reads": n_support},
             "stage_ms": stages, "roofline": roofline, "cpu_baseline": cpu, "host_to_host": h2h, "reads_on_host": roh,
+            "sharded_check": shard_check,
             "pipeline": pipeline_headline(n_local, L, ms_per_step),
             "published_reference": "~40M BAM reads/min/core whole-file scan (README.md:6), a different stage",
         }
@@ -376,6 +421,51 @@ def main():
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def sharded_check(args, eng, rank, world, dev, genome, spec, strong, A):
+    """--check on the sharded path: the merged table of all ranks (bf_shard_format_sv over the ranks' results) against the
+    table ONE GPU makes of the same reads through bf_finish (which the parity tests hold against the oracle): SHA-256.
+    Rank 0 regenerates the other ranks' reads for the one-GPU run, so this is for --scale'd runs or a roomy host."""
+    import hashlib
+    mine = eng.shard_finish()
+    if world > 1:
+        box = [None] * world if rank == 0 else None
+        dist.gather_object(mine, box, dst=0)
+    else:
+        box = [mine]
+    if rank != 0:
+        return None
+    merged = hashlib.sha256(memoryview(eng.shard_format_sv(box, as_array=True))).hexdigest()
+    e2 = engine.Engine(A, 5000, 2, device=dev.index)
+    try:
+        e2.set_genome(genome.names, genome.seqs)
+        if strong:
+            all_specs = [synth.block_spec(spec, k) for k in range(synth.BLOCKS)]
+        else:
+            import copy
+            all_specs = []
+            for r in range(world):
+                sp = copy.copy(spec)
+                sp.read_seed = spec.seed * 1000 + r
+                sp.frag_base = r * spec.n_reads
+                all_specs.append(sp)
+        n_all = 0
+        for sp in all_specs:
+            blk = synth.make_reads(genome, sp)
+            if args.soft_mask > 0:
+                blk.seq_bytes &= np.uint8(0xDF)
+            n_all += blk.n
+            e2.submit(engine.pack_batch(blk) if args.reads == "packed" else blk)
+        single = hashlib.sha256(memoryview(e2.format_sv(e2.finish(copy=False, reads=False), as_array=True))).hexdigest()
+    finally:
+        e2.close()
+    same = merged == single
+    log(rank, "sharded --check: merged table of %d rank(s) %s the one-GPU table of the same %d reads (sha256 %s)" %
+        (world, "==" if same else "DIFFERS FROM", n_all, merged[:16]))
+    if not same:
+        raise SystemExit("bench --check: the sharded path's merged .sv differs from the one-GPU .sv")
+    return {"ranks": world, "reads": n_all, "sha256": merged, "identical_to_one_gpu": True}
 
 
 def pipeline_headline(n_local, L, ms_per_step):

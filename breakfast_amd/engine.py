@@ -254,7 +254,7 @@ class PackedBatch:
         return int(self.hits.shape[0])
 
 
-def pack_batch(b: Batch, chunk: int = 1 << 20) -> PackedBatch:
+def pack_batch(b: Batch, chunk: int = 1 << 20, threads: int = 0) -> PackedBatch:
     """ASCII reads -> 4-bit codes (what a parser that packs while it copies would produce).  Raises ValueError when a
     read holds a byte outside "=ACMGRSVTWYHKDBN" (such batches go through bf_submit as ASCII)."""
     lut = np.full(256, 255, np.uint8)
@@ -268,7 +268,17 @@ def pack_batch(b: Batch, chunk: int = 1 << 20) -> PackedBatch:
     np.cumsum(nbytes, out=boff[1:])
     out = np.zeros(int(boff[-1]), np.uint8)
     seq = np.ascontiguousarray(b.seq_bytes, np.uint8)
-    for a in range(0, b.n, chunk):
+    if lens.size and int(lens.min()) == int(lens.max()) and int(so[0]) == 0:
+        from . import synth                                  # reads of one length: the C helper, when it is built
+        fast = synth.fast_lib()
+        if fast is not None:
+            bad = fast.bf_synth_pack_fixed(out.ctypes.data, seq.ctypes.data, b.n, int(lens[0]))
+            if bad:
+                raise ValueError("a read holds a byte outside BAM's base alphabet %r" % NIBBLE_CODES)
+            return PackedBatch(out, boff.astype(np.uint64), lens.astype(np.uint16), np.ascontiguousarray(b.frag_bytes, np.uint8),
+                               np.ascontiguousarray(b.frag_off, np.uint64), np.ascontiguousarray(b.hits, HIT_DTYPE))
+
+    def one(a: int) -> None:
         e = min(b.n, a + chunk)
         codes = lut[seq[int(so[a]):int(so[e])]]
         if codes.size and int(codes.max()) == 255:
@@ -287,6 +297,20 @@ def pack_batch(b: Batch, chunk: int = 1 << 20) -> PackedBatch:
             hi = (k & 1) == 0
             out[byte[hi]] = codes[hi] << 4
             out[byte[~hi]] |= codes[~hi]
+
+    starts = list(range(0, b.n, chunk))
+    if threads <= 0:
+        try:
+            threads = min(16, len(os.sched_getaffinity(0)))
+        except Exception:
+            threads = min(16, os.cpu_count() or 1)
+    if len(starts) > 1 and threads > 1:              # chunks write disjoint byte ranges (every read starts on a byte)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(min(threads, len(starts))) as ex:
+            list(ex.map(one, starts))
+    else:
+        for a in starts:
+            one(a)
     return PackedBatch(out, boff.astype(np.uint64), lens.astype(np.uint16), np.ascontiguousarray(b.frag_bytes, np.uint8),
                        np.ascontiguousarray(b.frag_off, np.uint64), np.ascontiguousarray(b.hits, HIT_DTYPE))
 
@@ -609,8 +633,9 @@ class Engine:
     def sync(self) -> None:
         self._check(self.lib.bf_sync(self.h))
 
-    def format_sv(self, res: Result) -> bytes:
-        """stdout bytes of `breakfast detect` for this result (detect.rs:201,233-240)."""
+    def format_sv(self, res: Result, as_array: bool = False):
+        """stdout bytes of `breakfast detect` for this result (detect.rs:201,233-240); as_array: a uint8 array instead
+        of bytes (no extra copies: the table of 100M reads is 6 GB)."""
         cl = np.ascontiguousarray(res.clusters, CLUSTER_DTYPE)
         rd = np.ascontiguousarray(res.reads, READ_DTYPE)
         jb = np.ascontiguousarray(res.junction_bytes, np.uint8)
@@ -622,10 +647,10 @@ class Engine:
         r = BfResult(res.n_evidence, cl.shape[0], n_reads, _ptr(cl), _ptr(rd), _ptr(jb), jb.size, _ptr(cjo))
         n = self.lib.bf_format_sv(self.h, C.byref(r), None, 0)
         self._check(n)
-        buf = C.create_string_buffer(int(n) + 1)
-        n2 = self.lib.bf_format_sv(self.h, C.byref(r), buf, n)
+        buf = np.empty(int(n) + 1, np.uint8)
+        n2 = self.lib.bf_format_sv(self.h, C.byref(r), buf.ctypes.data, n)
         self._check(n2)
-        return buf.raw[:n]
+        return buf[:n] if as_array else buf[:n].tobytes()
 
     # -- the sharded path in one call (bf_shard_*) --
     @staticmethod
@@ -667,7 +692,7 @@ class Engine:
                            arr(r.places, r.n_reads, PLACE_DTYPE) if places else None,
                            arr(r.record_off, r.n_records + 1 if r.n_records else 0, "<u8") if places else None)
 
-    def shard_format_sv(self, results: Sequence[ShardResult]) -> bytes:
+    def shard_format_sv(self, results: Sequence[ShardResult], as_array: bool = False):
         """detect.rs:201,233-240 for the results of ALL ranks (rank order); needs only this ctx's contig names."""
         n = len(results)
         keep, arr = [], (BfShardResult * n)()
@@ -680,9 +705,9 @@ class Engine:
                                    _ptr(gb), x.n_records, _ptr(bo), _ptr(rb), rb.size, None, None)
         size = self.lib.bf_shard_format_sv(self.h, n, arr, None, 0)
         self._check(size)
-        buf = C.create_string_buffer(int(size) + 1)
-        self._check(self.lib.bf_shard_format_sv(self.h, n, arr, buf, size))
-        return buf.raw[:size]
+        buf = np.empty(int(size) + 1, np.uint8)
+        self._check(self.lib.bf_shard_format_sv(self.h, n, arr, buf.ctypes.data, size))
+        return buf[:size] if as_array else buf[:size].tobytes()
 
     # -- multi-GPU stage calls --
     def set_rank(self, rank: int, n_ranks: int, index_base: int) -> None:

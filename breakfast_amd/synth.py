@@ -36,6 +36,42 @@ HG38 = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 
         ("chrM", 16569)]
 
 
+_fast = None
+
+
+def fast_lib():
+    """csrc/libbf_synth.so (synth_fill.c: the generator's two inner loops in C + OpenMP), or None: the numpy code
+    below then does the same work, byte for byte, a dozen times slower.  BREAKFAST_SYNTH_NUMPY=1 forces numpy."""
+    global _fast
+    if _fast is None:
+        _fast = False
+        so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libbf_synth.so")
+        if os.path.exists(so) and os.environ.get("BREAKFAST_SYNTH_NUMPY") != "1":
+            try:
+                import ctypes as C
+                lib = C.CDLL(so)
+                lib.bf_synth_fill.restype = None
+                lib.bf_synth_fill.argtypes = [C.c_void_p] * 10 + [C.c_int64, C.c_int64, C.c_void_p]
+                lib.bf_synth_pack_fixed.restype = C.c_int64
+                lib.bf_synth_pack_fixed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+                _fast = lib
+            except OSError:
+                _fast = False
+    return _fast or None
+
+
+def host_threads() -> int:
+    """Worker threads for the generators: the GPU boxes give a job 16 CPUs whatever os.cpu_count() says."""
+    env = os.environ.get("BREAKFAST_SYNTH_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        have = len(os.sched_getaffinity(0))
+    except Exception:
+        have = os.cpu_count() or 1
+    return max(1, min(16, have))
+
+
 @dataclass
 class Genome:
     names: List[bytes]
@@ -74,7 +110,7 @@ def make_genome(contigs: Sequence[Tuple[str, int]], seed: int = SEED, end_n: int
         return s
 
     names = [name.encode() for name, _ in contigs]
-    workers = max(1, min(8, os.cpu_count() or 1, len(contigs)))
+    workers = max(1, min(host_threads(), len(contigs)))
     if workers == 1:
         seqs = [one(ci) for ci in range(len(contigs))]
     else:
@@ -200,20 +236,30 @@ def make_reads(genome: Genome, spec: ReadSpec) -> Batch:
     hits["contig5"] = np.where(flip, c2, c1)
     hits["contig3"] = np.where(flip, c1, c2)
     hits["strands"] = (np.where(flip, ~s2, s1).astype(np.uint8) | (np.where(flip, ~s1, s2).astype(np.uint8) << 1))
+    fast = fast_lib()
+    if fast is not None:                                    # the whole gather in C (same bytes); errors are added per chunk below
+        cc = [np.ascontiguousarray(a, np.int64) for a in (base1, base2, dir1, dir2, b)]
+        bb = [np.ascontiguousarray(a, np.uint8) for a in (flip, s1, s2)]
+        fast.bf_synth_fill(seq.ctypes.data, cat.ctypes.data, *[a.ctypes.data for a in cc], *[a.ctypes.data for a in bb],
+                           n, L, _COMP.ctypes.data)
+
     def build_chunk(ci: int) -> None:
         lo = ci * spec.chunk
         hi = min(n, lo + spec.chunk)
         sl = slice(lo, hi)
         crng = np.random.Generator(np.random.PCG64([rseed, 7, ci]))   # per-chunk stream: thread-count independent
-        f = flip[sl, None]
-        ko = np.where(f, L - 1 - k, k)                      # position inside the unflipped read
-        left = ko < b[sl, None]
-        gpos = np.where(left, base1[sl, None] + dir1[sl, None] * ko, base2[sl, None] + dir2[sl, None] * ko)
-        r = cat[gpos]
-        del gpos
-        need_comp = np.where(left, ~s1[sl, None], ~s2[sl, None]) ^ f
-        r = np.where(need_comp, _COMP[r], r)
-        del need_comp, left, ko
+        if fast is not None:
+            r = seq[sl]
+        else:
+            f = flip[sl, None]
+            ko = np.where(f, L - 1 - k, k)                      # position inside the unflipped read
+            left = ko < b[sl, None]
+            gpos = np.where(left, base1[sl, None] + dir1[sl, None] * ko, base2[sl, None] + dir2[sl, None] * ko)
+            r = cat[gpos]
+            del gpos
+            need_comp = np.where(left, ~s1[sl, None], ~s2[sl, None]) ^ f
+            r = np.where(need_comp, _COMP[r], r)
+            del need_comp, left, ko
         # sequencing errors outside the anchors (an error inside an anchor = no bowtie hit)
         m = hi - lo
         for rate, kind in ((spec.subst_rate, 0), (spec.n_rate, 1)):
@@ -229,10 +275,11 @@ def make_reads(genome: Genome, spec: ReadSpec) -> Batch:
                 r[rows, colz] = np.where(np.isin(cur, _ACGT), alt, cur)
             else:
                 r[rows, colz] = ord("N")
-        seq[sl] = r
+        if fast is None:
+            seq[sl] = r
 
     n_chunks = (n + spec.chunk - 1) // spec.chunk
-    workers = max(1, min(8, (os.cpu_count() or 1), n_chunks))
+    workers = max(1, min(host_threads(), n_chunks))
     if workers == 1:
         for ci in range(n_chunks):
             build_chunk(ci)
@@ -245,6 +292,35 @@ def make_reads(genome: Genome, spec: ReadSpec) -> Batch:
     frag[:, 1:] = _digits(fid, width)
     return Batch(seq.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(L),
                  frag.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(width + 1), hits)
+
+
+# ---- a config as independent blocks --------------------------------------------------------------------------------
+# configs[2] (100M reads sharded over 2/4/8 GPUs) is DEFINED as kBlocks blocks over one junction table: block b holds
+# n_reads / kBlocks reads drawn with its own read seed, fragment ids numbered from b * block size.  Rank r of N holds
+# the contiguous blocks [kBlocks * r / N, kBlocks * (r + 1) / N) -- "contiguous line ranges" of SURVEY.md section 8d --
+# so the workload is the same bytes for every N (strong scaling), a rank generates only its own slice, and a one-GPU
+# run of the whole config builds it block by block.
+BLOCKS = 16
+
+
+def block_spec(spec: ReadSpec, block: int, n_blocks: int = BLOCKS) -> ReadSpec:
+    """ReadSpec of block `block` of `n_blocks`: its share of the reads, its own read seed and fragment id range."""
+    import copy
+    lo = spec.n_reads * block // n_blocks
+    hi = spec.n_reads * (block + 1) // n_blocks
+    s = copy.copy(spec)
+    s.n_reads = hi - lo
+    s.read_seed = spec.seed * 1000 + 500 + block
+    s.frag_base = spec.frag_base + lo
+    return s
+
+
+def block_first_read(spec: ReadSpec, block: int, n_blocks: int = BLOCKS) -> int:
+    return spec.n_reads * block // n_blocks
+
+
+def rank_blocks(rank: int, world: int, n_blocks: int = BLOCKS) -> range:
+    return range(n_blocks * rank // world, n_blocks * (rank + 1) // world)
 
 
 def bowtie_lines_slow(batch: Batch, contig_names: Sequence[bytes], first_read_num: int = 1) -> bytes:
