@@ -610,26 +610,32 @@ __global__ void group_id_kernel(uint32_t* __restrict__ gid, const uint64_t* __re
 // (bf_submit's staging threads count them from the hits: the rank after the reorient step is the smaller of the two
 // anchors' ranks), so the cut costs the GPU one radix pass on the rank bits of the class keys and a sum.
 // Records per left contig rank of an IMPORTED view (the sharded path: what arrived is not what bf_submit counted):
-// block histograms in LDS, one atomic per non-empty bin and block.  Up to 4096 contigs.
+// block histograms in LDS, one atomic per non-empty bin and block.  A launch counts the ranks of one window of
+// kRankHistMax bins; genomes with more contigs (up to the 16384 the key has room for) take a launch per window.
 constexpr uint32_t kRankHistMax = 4096;
 __global__ void __launch_bounds__(256) rank_hist_kernel(unsigned long long* __restrict__ hist, const uint64_t* __restrict__ key, int shift,
-                                                        uint32_t mask, uint32_t bins, uint64_t n) {
+                                                        uint32_t mask, uint32_t bin0, uint32_t bins, uint64_t n) {
     __shared__ uint32_t h[kRankHistMax];
     for (uint32_t b = threadIdx.x; b < bins; b += 256) h[b] = 0;
     __syncthreads();
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
-        atomicAdd(&h[min((uint32_t)(key[i] >> shift) & mask, bins - 1)], 1u);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t r = ((uint32_t)(key[i] >> shift) & mask) - bin0;      // (wraps for ranks below the window)
+        if (r < bins) atomicAdd(&h[r], 1u);
+    }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < bins; b += 256) if (h[b]) atomicAdd(&hist[b], (unsigned long long)h[b]);
+    for (uint32_t b = threadIdx.x; b < bins; b += 256) if (h[b]) atomicAdd(&hist[bin0 + b], (unsigned long long)h[b]);
 }
 int rank_histogram(bf_ctx* ctx, const OwnerView& v, std::vector<uint64_t>& hist) {
     hist.assign(ctx->n_contigs, 0);
-    if (v.n == 0 || ctx->n_contigs > kRankHistMax) return BF_OK;
+    if (v.n == 0) return BF_OK;
     const hipStream_t st = ctx->stream;
     BF_TRY(ensure(ctx, ctx->c_bstart, std::max<size_t>((size_t)ctx->n_contigs * 8, 64), false));
     BF_HIP(ctx, hipMemsetAsync(ctx->c_bstart.p, 0, (size_t)ctx->n_contigs * 8, st));
-    hipLaunchKernelGGL(rank_hist_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(v.n, 256), 512)), dim3(256), 0, st,
-                       (unsigned long long*)ctx->c_bstart.p, v.key, key_rank_shift(ctx->contig_bits), (1u << ctx->contig_bits) - 1, ctx->n_contigs, v.n);
+    for (uint32_t bin0 = 0; bin0 < ctx->n_contigs; bin0 += kRankHistMax)
+        hipLaunchKernelGGL(rank_hist_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(v.n, 256), 512)), dim3(256), 0, st,
+                           (unsigned long long*)ctx->c_bstart.p, v.key, key_rank_shift(ctx->contig_bits), (1u << ctx->contig_bits) - 1, bin0,
+                           std::min(kRankHistMax, ctx->n_contigs - bin0), v.n);
+    BF_HIP(ctx, hipGetLastError());
     BF_HIP(ctx, hipMemcpyAsync(hist.data(), ctx->c_bstart.p, (size_t)ctx->n_contigs * 8, hipMemcpyDeviceToHost, st));
     BF_SYNC(ctx, st);
     return BF_OK;

@@ -458,22 +458,44 @@ static int detect_sharded(const bf_config& cfg0, const std::vector<int>& devices
     std::vector<bf_ctx*> ctxs(W, nullptr);
     std::vector<bf_shard_result> results(W);
     std::vector<std::string> errors(W);
+    // The ranks are threads of this process.  A rank that fails on its own (no such device, no memory for the genome, a
+    // rejected batch) must not leave the others waiting inside a collective: RCCL has no time-out.  So every rank first
+    // does everything that can fail locally, the ranks then agree -- on the host -- that all of them got there, and only
+    // then does anyone enter bf_shard_init_* / bf_shard_finish; the same again between the two.
+    struct Agree {
+        std::mutex mu; std::condition_variable cv;
+        uint32_t n, arrived = 0; uint64_t gen = 0; bool ok = true, last = true;
+        bool all_ok(bool mine) {
+            std::unique_lock<std::mutex> lk(mu);
+            ok = ok && mine;
+            if (++arrived == n) { last = ok; ok = true; arrived = 0; gen++; cv.notify_all(); return last; }
+            const uint64_t g = gen;
+            cv.wait(lk, [&] { return gen != g; });
+            return last;
+        }
+    } agree;
+    agree.n = W;
     std::vector<std::thread> pool;
     for (uint32_t r = 0; r < W; r++) {
         pool.emplace_back([&, r] {
             bf_config cfg = cfg0;
             cfg.device = devices[r];
-            if (bf_ctx_create(&cfg, &ctxs[r]) != BF_OK) { errors[r] = bf_last_error(nullptr); return; }
-            bf_ctx* ctx = ctxs[r];
+            bf_ctx* ctx = nullptr;
             auto check = [&](int rc) { if (rc != BF_OK && errors[r].empty()) errors[r] = bf_last_error(ctx); return rc == BF_OK; };
-            if (!check(bf_genome_set(ctx, (uint32_t)names.size(), names.data(), seqs.data(), fa.lens.data()))) return;
             const uint64_t lo = n_total * r / W, hi = n_total * (r + 1) / W;
-            if (!check(shared_gpu ? bf_shard_init_host(ctx, r, W, lo, shm_name, 64u << 20) : bf_shard_init_rccl(ctx, r, W, lo, uid))) return;
-            for (size_t k = 0; k < all.size(); k++) {                // the parts of the parsed batches inside [lo, hi)
+            // 1. everything local: ctx, genome, this rank's reads (bf_last_error(NULL) is per thread)
+            bool ok = check(bf_ctx_create(&cfg, &ctxs[r]));
+            ctx = ctxs[r];
+            ok = ok && check(bf_genome_set(ctx, (uint32_t)names.size(), names.data(), seqs.data(), fa.lens.data()));
+            for (size_t k = 0; ok && k < all.size(); k++) {          // the parts of the parsed batches inside [lo, hi)
                 const uint64_t a = std::max(lo, first[k]), b = std::min(hi, first[k + 1]);
-                if (a >= b) continue;
-                if (!check(submit_parsed(ctx, all[k], a - first[k], b - first[k]))) return;
+                if (a < b) ok = check(submit_parsed(ctx, all[k], a - first[k], b - first[k]));
             }
+            if (!agree.all_ok(ok)) return;
+            // 2. join the other ranks
+            ok = check(shared_gpu ? bf_shard_init_host(ctx, r, W, lo, shm_name, 64u << 20) : bf_shard_init_rccl(ctx, r, W, lo, uid));
+            if (!agree.all_ok(ok)) return;
+            // 3. the sharded path
             check(bf_shard_finish(ctx, &results[r]));
         });
     }

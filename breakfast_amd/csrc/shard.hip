@@ -113,13 +113,19 @@ struct RcclTransport : Transport {
         if (self) BF_HIP(ctx, hipMemcpyAsync(d_recv + roff[rank], d_send + soff[rank], self, hipMemcpyDeviceToDevice, ctx->stream));
         if (n > 1) {
             BF_NCCL(ctx, rccl().GroupStart());
-            for (uint32_t r = 0; r < n; r++) {
+            // an error inside the group is remembered, the group is closed whatever happened (an open group would swallow
+            // every later RCCL call of this thread), and only then reported
+            ncclResult_t bad = ncclSuccess;
+            const char* what = "";
+            for (uint32_t r = 0; r < n && bad == ncclSuccess; r++) {
                 if (r == rank) continue;
                 const uint64_t sb = bytes[(size_t)rank * n + r], rb = bytes[(size_t)r * n + rank];
-                if (sb) BF_NCCL(ctx, rccl().Send(d_send + soff[r], sb, ncclUint8, (int)r, comm, ctx->stream));
-                if (rb) BF_NCCL(ctx, rccl().Recv(d_recv + roff[r], rb, ncclUint8, (int)r, comm, ctx->stream));
+                if (sb && (bad = rccl().Send(d_send + soff[r], sb, ncclUint8, (int)r, comm, ctx->stream)) != ncclSuccess) { what = "ncclSend"; break; }
+                if (rb && (bad = rccl().Recv(d_recv + roff[r], rb, ncclUint8, (int)r, comm, ctx->stream)) != ncclSuccess) { what = "ncclRecv"; break; }
             }
-            BF_NCCL(ctx, rccl().GroupEnd());
+            const ncclResult_t end = rccl().GroupEnd();
+            if (bad != ncclSuccess) return fail(ctx, BF_ERR_HIP, "%s failed inside the all-to-all group: %s", what, rccl().GetErrorString(bad));
+            if (end != ncclSuccess) return fail(ctx, BF_ERR_HIP, "ncclGroupEnd failed: %s", rccl().GetErrorString(end));
         }
         return BF_OK;
     }
@@ -130,10 +136,22 @@ struct ShmHeader {
     std::atomic<uint32_t> ready;          // kShmMagic once rank 0 has initialised the header
     std::atomic<uint32_t> arrived, sense; // sense-reversing barrier
     uint32_t n_ranks; uint64_t slot_bytes, ctl_words;
+    // A rank that opens the name may find the segment a crashed run left behind (same name, `ready` set) before rank 0
+    // of THIS run has replaced it.  So it says hello with a token of its own and waits for a LIVE rank 0 to repeat the
+    // token; no answer within kShmHelloMs means nobody is home: it lets go and opens the name again.
+    std::atomic<uint64_t> hello[64], ack[64];
 };
+static_assert(sizeof(ShmHeader) <= 4096, "the header has one page");
 constexpr uint32_t kShmMagic = 0xbf5a4d31u;
 constexpr uint64_t kShmCtlWords = 4096;   // u64 per rank for all_gather (n_ranks * k must fit: 64 ranks x 64 words)
 constexpr int kShmTimeoutSec = 180;
+constexpr int kShmHelloMs = 250;
+static uint64_t shm_token(uint32_t rank) {
+    timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
+    uint64_t x = ((uint64_t)ts.tv_sec << 32) ^ (uint64_t)ts.tv_nsec ^ ((uint64_t)getpid() << 20) ^ ((uint64_t)rank << 56) ^ 0x9e3779b97f4a7c15ull;
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+    return x | 1;                          // never 0 (a fresh segment's words)
+}
 
 struct HostTransport : Transport {
     std::string name;
@@ -340,39 +358,65 @@ int bf_shard_init_host(bf_ctx* ctx, uint32_t rank, uint32_t n_ranks, uint64_t in
     HostTransport* tr = new HostTransport();
     tr->name = name; tr->slot_bytes = slot_bytes; tr->n = n_ranks; tr->rank = rank;
     tr->size = 4096 + (size_t)n_ranks * kShmCtlWords * 8 + (size_t)n_ranks * slot_bytes;
-    int fd = -1;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto timed_out = [&] { return std::chrono::steady_clock::now() - t_begin > std::chrono::seconds(kShmTimeoutSec); };
     if (rank == 0) {
         shm_unlink(name);                                        // a stale segment of a crashed run
-        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd >= 0 && ftruncate(fd, (off_t)tr->size) != 0) { close(fd); fd = -1; shm_unlink(name); }
         tr->owner = fd >= 0;
-    } else {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {                                               // until rank 0 has created and sized it
-            fd = shm_open(name, O_RDWR, 0600);
-            struct stat st;
-            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= tr->size) break;
-            if (fd >= 0) { close(fd); fd = -1; }
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kShmTimeoutSec)) break;
-            std::this_thread::sleep_for(std::chrono::milliseconds(2));
-        }
-    }
-    if (fd < 0) { delete tr; return fail(ctx, BF_ERR_STATE, "bf_shard_init_host: shared memory segment %s is not available", name); }
-    void* m = mmap(nullptr, tr->size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) { delete tr; return fail(ctx, BF_ERR_NOMEM, "bf_shard_init_host: mmap of %zu bytes failed", tr->size); }
-    tr->base = (uint8_t*)m; tr->hdr = (ShmHeader*)m;
-    if (rank == 0) {
+        if (fd < 0) { delete tr; return fail(ctx, BF_ERR_STATE, "bf_shard_init_host: shared memory segment %s is not available", name); }
+        void* m = mmap(nullptr, tr->size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { delete tr; return fail(ctx, BF_ERR_NOMEM, "bf_shard_init_host: mmap of %zu bytes failed", tr->size); }
+        tr->base = (uint8_t*)m; tr->hdr = (ShmHeader*)m;
         tr->hdr->arrived.store(0); tr->hdr->sense.store(0);
+        for (auto& w : tr->hdr->hello) w.store(0);
+        for (auto& w : tr->hdr->ack) w.store(0);
         tr->hdr->n_ranks = n_ranks; tr->hdr->slot_bytes = slot_bytes; tr->hdr->ctl_words = kShmCtlWords;
         tr->hdr->ready.store(kShmMagic, std::memory_order_release);
-    } else {
-        const auto t0 = std::chrono::steady_clock::now();
-        while (tr->hdr->ready.load(std::memory_order_acquire) != kShmMagic) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kShmTimeoutSec)) { delete tr; return fail(ctx, BF_ERR_STATE, "bf_shard_init_host: rank 0 never initialised %s", name); }
-            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        // answer every rank's hello (a rank may say hello more than once: it re-opens the name until somebody answers)
+        for (uint32_t seen = 1; seen < n_ranks;) {
+            seen = 1;
+            for (uint32_t r = 1; r < n_ranks; r++) {
+                const uint64_t h = tr->hdr->hello[r].load(std::memory_order_acquire);
+                if (h) { tr->hdr->ack[r].store(h, std::memory_order_release); seen++; }
+            }
+            if (seen < n_ranks) {
+                if (timed_out()) { delete tr; return fail(ctx, BF_ERR_STATE, "bf_shard_init_host: only %u of %u ranks joined %s within %d s", seen, n_ranks, name, kShmTimeoutSec); }
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
         }
-        if (tr->hdr->n_ranks != n_ranks || tr->hdr->slot_bytes != slot_bytes) { delete tr; return fail(ctx, BF_ERR_INVALID, "bf_shard_init_host: ranks disagree about the segment's shape"); }
+    } else {
+        const uint64_t token = shm_token(rank);                  // one token per call: an answer stays valid when the name is opened again
+        for (;;) {                                               // until a live rank 0 answers in the segment the name leads to
+            if (timed_out()) { delete tr; return fail(ctx, BF_ERR_STATE, "bf_shard_init_host: rank 0 never answered in %s (%d s)", name, kShmTimeoutSec); }
+            int fd = shm_open(name, O_RDWR, 0600);
+            struct stat st;
+            if (fd < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size < tr->size) {
+                if (fd >= 0) close(fd);
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                continue;
+            }
+            void* m = mmap(nullptr, tr->size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (m == MAP_FAILED) { delete tr; return fail(ctx, BF_ERR_NOMEM, "bf_shard_init_host: mmap of %zu bytes failed", tr->size); }
+            ShmHeader* h = (ShmHeader*)m;
+            bool home = false;
+            const auto t0 = std::chrono::steady_clock::now();
+            bool said = false;
+            while (std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(kShmHelloMs)) {
+                if (h->ready.load(std::memory_order_acquire) == kShmMagic) {
+                    if (!said) { h->hello[rank].store(token, std::memory_order_release); said = true; }
+                    if (h->ack[rank].load(std::memory_order_acquire) == token) { home = true; break; }
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+            if (!home) { munmap(m, tr->size); continue; }        // a segment nobody answers in (stale, or rank 0 is still on its way)
+            tr->base = (uint8_t*)m; tr->hdr = h;
+            if (h->n_ranks != n_ranks || h->slot_bytes != slot_bytes) { delete tr; return fail(ctx, BF_ERR_INVALID, "bf_shard_init_host: ranks disagree about the segment's shape"); }
+            break;
+        }
     }
     // pinning the staging slots lets the device copies run at PCIe rate (best effort)
     tr->registered = hipHostRegister(tr->base, tr->size, hipHostRegisterDefault) == hipSuccess;

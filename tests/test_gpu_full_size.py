@@ -99,6 +99,8 @@ def make_blocks(cfg):
             blocks = list(ex.map(lambda k: synth.make_reads(g, synth.block_spec(spec, k)), range(synth.BLOCKS)))
     else:
         blocks = [synth.make_reads(g, spec)]
+    if cfg == 0:                                                   # the generator copies the genome's case (a soft-masked run); a
+        blocks[0].seq_bytes &= np.uint8(0xDF)                      # sequencer's reads are upper case (the ASCII form: see the test)
     log("%d reads x %d bp in %d block(s), %.0fs" % (sum(b.n for b in blocks), spec.read_len, len(blocks), time.time() - t))
     return g, spec, blocks
 
