@@ -81,9 +81,8 @@ def main():
     ap.add_argument("--config", type=int, default=1, help="index into BASELINE.json configs (default 1)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink reads AND genome (smoke runs only)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads in the CPU baseline sample (0 = skip)")
-    ap.add_argument("--variant", choices=["fused", "separate", "coop", "exact"], default="fused",
-                    help="A/B of the localise stage: fused encode+localise (shipped), separate encode kernel, "
-                         "separate encode + cooperative LDS-staged gather, every read through the byte-exact kernel")
+    ap.add_argument("--variant", choices=["fused", "exact"], default="fused",
+                    help="the localise stage: the packed kernel (shipped), or every read through the byte-exact kernel (diagnostic)")
     ap.add_argument("--exchange", action="store_true",
                     help="with one GPU: run the sharded code path anyway (bf_shard_finish over RCCL with one rank: pack -> "
                          "all-to-all with itself -> import -> cluster -> request lists -> source-side records), to time "
@@ -178,8 +177,7 @@ def main():
         args.no_h2h = True                             # the host-to-host legs pin a second copy of the batch: configs[1]-sized runs only
 
     # ---- resident inputs -------------------------------------------------------------------------
-    eng = engine.Engine(A, 5000, 2, device=local, groups=args.groups, host_threads=args.host_threads, flags=(engine.BF_FLAG_ONE_STREAM if args.one_stream else 0) | {"fused": 0, "separate": engine.BF_FLAG_SEPARATE_ENCODE, "coop": engine.BF_FLAG_COOP_GATHER,
-                                                                               "exact": engine.BF_FLAG_FORCE_EXACT}[args.variant])
+    eng = engine.Engine(A, 5000, 2, device=local, groups=args.groups, host_threads=args.host_threads, flags=(engine.BF_FLAG_ONE_STREAM if args.one_stream else 0) | {"fused": 0, "exact": engine.BF_FLAG_FORCE_EXACT}[args.variant])
     t2 = time.time()
     eng.set_genome(genome.names, genome.seqs)
     log(rank, "genome packed into HBM in %.1fs" % (time.time() - t2))

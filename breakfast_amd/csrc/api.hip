@@ -141,22 +141,9 @@ static OwnerView local_view(bf_ctx* ctx) {
     v.info = ctx->d_jrec.as<uint64_t>();
     return v;
 }
-static OwnerView imported_view(bf_ctx* ctx) {
-    OwnerView v;
-    v.n = ctx->n_imported;
-    v.key = ctx->i_key.as<uint64_t>(); v.lpos = ctx->i_lpos.as<int32_t>(); v.rpos = ctx->i_rpos.as<int32_t>();
-    v.fhash = ctx->i_fhash.as<uint64_t>(); v.bp = ctx->i_bp.as<uint16_t>(); v.len = ctx->i_len.as<uint16_t>();
-    v.flags = ctx->i_flags.as<uint16_t>();
-    v.frag = ctx->i_frag.as<uint8_t>(); v.frag_off = ctx->i_frag_off.as<uint64_t>(); v.frag_len = ctx->i_frag_len.as<uint16_t>();
-    v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
-    v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>();
-    v.info = ctx->i_jrec.as<uint64_t>();
-    return v;
-}
-
 static void free_all(bf_ctx* ctx) {
     DevBuf* all[] = {&ctx->g_blocks, &ctx->g_exc, &ctx->g_raw, &ctx->g_coarse, &ctx->g_coarse2, &ctx->g_contigs, &ctx->d_seq, &ctx->d_seq_off,
-        &ctx->d_frag, &ctx->d_frag_off, &ctx->d_hits, &ctx->d_planes, &ctx->d_len, &ctx->d_frag_len, &ctx->d_fhash,
+        &ctx->d_frag, &ctx->d_frag_off, &ctx->d_hits, &ctx->d_len, &ctx->d_frag_len, &ctx->d_fhash,
         &ctx->d_key, &ctx->d_lpos, &ctx->d_rpos, &ctx->d_bp, &ctx->d_flags, &ctx->d_mask, &ctx->d_jrec, &ctx->d_exact_list,
         &ctx->d_counters, &ctx->d_sigx, &ctx->d_sigx_slot, &ctx->d_send, &ctx->d_part_key, &ctx->d_part_idx,
         &ctx->d_part_tmp, &ctx->i_key, &ctx->i_lpos, &ctx->i_rpos, &ctx->i_fhash, &ctx->i_bp, &ctx->i_len, &ctx->i_flags,
@@ -165,7 +152,7 @@ static void free_all(bf_ctx* ctx) {
         &ctx->c_slpos, &ctx->c_srpos, &ctx->c_reported, &ctx->c_csize, &ctx->c_flag, &ctx->c_scan, &ctx->c_qseed,
         &ctx->c_qsize, &ctx->c_qoff, &ctx->c_members, &ctx->c_leader, &ctx->c_rep, &ctx->c_qnrep, &ctx->c_ctl, &ctx->c_sel,
         &ctx->c_ord, &ctx->c_clusters, &ctx->c_reads, &ctx->c_misc, &ctx->c_joff, &ctx->c_jbytes, &ctx->c_rsrc,
-        &ctx->c_tables, &ctx->c_mkey_s, &ctx->c_slot, &ctx->c_big, &ctx->c_cjo, &ctx->c_aoff, &ctx->c_err, &ctx->c_tmp2, &ctx->c_qord, &ctx->c_gidx, &ctx->c_hist, &ctx->c_comp, &ctx->c_bstart, &ctx->c_chunk, &ctx->c_pos2, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
+        &ctx->c_tables, &ctx->c_mkey_s, &ctx->c_slot, &ctx->c_big, &ctx->c_cjo, &ctx->c_aoff, &ctx->c_err, &ctx->c_tmp2, &ctx->c_qord, &ctx->c_gidx, &ctx->c_hist, &ctx->c_comp, &ctx->c_bstart, &ctx->c_chunk, &ctx->c_pos2, &ctx->c_desc, &ctx->c_desc2, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
     for (DevBuf* b : all) release(ctx, *b);
     HostBuf* hosts[] = {&ctx->out.clusters, &ctx->out.reads, &ctx->out.src, &ctx->out.junction, &ctx->out.cjo};
     for (HostBuf* h : hosts) { if (h->p) (void)hipHostFree(h->p); h->p = nullptr; h->cap = 0; }
@@ -543,7 +530,7 @@ int bf_genome_end(bf_ctx* ctx) {
     BF_SYNC(ctx, ctx->stream);
     ctx->genome_ready = true;
     // reads that arrived while the genome was still on its way
-    if (ctx->n_reads > ctx->n_localised && !(ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE))) {
+    if (ctx->n_reads > ctx->n_localised) {
         BF_HIP(ctx, hipEventRecord(ctx->ev_in, ctx->in_stream));
         ctx->in_pending = true;
         BF_TRY(localise_uploaded(ctx, ctx->n_reads, ctx->max_len));
@@ -825,8 +812,6 @@ int bf_submit_packed(bf_ctx* ctx, const bf_packed_batch* b) {
     if (!b) return fail(ctx, BF_ERR_INVALID, "bf_submit_packed: null batch");
     if (b->n_reads && !b->seq_len) return fail(ctx, BF_ERR_INVALID, "bf_submit_packed: null seq_len");
     if (ctx->n_reads && !ctx->packed_reads && b->n_reads) return fail(ctx, BF_ERR_STATE, "bf_submit_packed after bf_submit: a ctx holds its reads in one form; call bf_reset first");
-    if (ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE))
-        return fail(ctx, BF_ERR_STATE, "the A/B variants with a separate encode kernel read ASCII reads only (bf_submit)");
     const BatchView v{b->n_reads, b->seq_nibbles, b->seq_off, b->seq_len, b->frag_bytes, b->frag_off, b->hits};
     return submit_impl(ctx, &v);
 }
@@ -869,8 +854,7 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
     sh.hits_direct = is_pinned(ctx, b->hits, m * sizeof(bf_hit));
     sh.hist.assign(ctx->n_contigs, 0);
     if (ctx->slots.size() < ctx->host_threads) ctx->slots.resize(ctx->host_threads);
-    // (the A/B variants of the localise stage keep their one launch over the whole set)
-    const bool eager = ctx->genome_ready && !(ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE));
+    const bool eager = ctx->genome_ready;
     // reads per offsets job: two offset arrays (+1 entry each) and the hits share one slot
     const uint64_t per_job = (kStageSlotBytes - 64) / (8 + 8 + sizeof(bf_hit) + 4) - 2;
     uint32_t mx = ctx->max_len, mn = ctx->min_len, mf = ctx->max_frag;
@@ -1076,15 +1060,15 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     if (!out) return fail(ctx, BF_ERR_INVALID, "bf_clusterise: null result");
     memset(out, 0, sizeof *out);
     if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_clusterise before bf_localise");
-    if (ctx->n_ranks > 1 && !ctx->imported) return fail(ctx, BF_ERR_STATE, "bf_clusterise on a multi-rank ctx before bf_exchange_import");
+    if (ctx->shard) return fail(ctx, BF_ERR_STATE, "bf_clusterise on a ctx of the sharded path; use bf_shard_finish");
     BF_HIP(ctx, hipSetDevice(ctx->device));
-    const OwnerView v = ctx->imported ? imported_view(ctx) : local_view(ctx);
-    ctx->clustered = false; ctx->table_attached = false; ctx->junction_attached = 0; ctx->reads_on_device = false;
-    ctx->result_order = false; ctx->sources_on_device = false;
+    ctx->imported = false;
+    const OwnerView v = local_view(ctx);
+    ctx->clustered = false; ctx->reads_on_device = false;
     // (with reference records the copy is a fifth as long and hiding half of it pays for no second group:
     //  configs[1] 4.02 ms in one go, 4.59 in two groups, 5.08 in three; groups then only when they are asked for)
     const bool small_records = (ctx->cfg.flags & BF_FLAG_READS_ON_HOST) && !ctx->cfg.reserved[0];
-    if (!ctx->imported && ((v.n >= kGroupMinReads && !small_records) || (ctx->cfg.flags & BF_FLAG_GROUPS_ALWAYS)) && !(ctx->cfg.flags & BF_FLAG_ONE_GROUP)) {
+    if (((v.n >= kGroupMinReads && !small_records) || (ctx->cfg.flags & BF_FLAG_GROUPS_ALWAYS)) && !(ctx->cfg.flags & BF_FLAG_ONE_GROUP)) {
         bool done = false;
         BF_TRY(clusterise_in_groups(ctx, v, &done));
         if (done) return fill_single_rank_result(ctx, out);
@@ -1094,9 +1078,8 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     const uint64_t nr = ctx->out.n_reads;
     const uint64_t ncl = ctx->out.n_clusters;
     if (nr) {
-        if (ctx->imported) { BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read))); }
-        if (!ctx->imported) {
-            // single rank: the surviving reads are local.  Their junction records are rendered chunk by
+        {
+            // the surviving reads are local.  Their junction records are rendered chunk by
             // chunk, in printed order; every finished chunk goes to pinned host memory on the copy
             // stream while the next chunk renders.  A cluster's records are contiguous and each says
             // how long it is, so the host gets one offset per CLUSTER; the read table {index, offset}
@@ -1132,8 +1115,6 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
             ctx->reads_on_device = true;
             BF_HIP(ctx, hipEventRecord(ctx->ev[10], ctx->copy_stream));
             BF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[10], 0));
-        } else if (!(ctx->cfg.flags & BF_FLAG_DEVICE_ROUTING)) {
-            BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
         }
     }
     BF_SYNC(ctx, ctx->stream);
@@ -1142,10 +1123,10 @@ int bf_clusterise(bf_ctx* ctx, bf_result* out) {
     out->n_clusters = ctx->out.n_clusters;
     out->n_reads = nr;
     out->clusters = ctx->out.clusters.as<bf_cluster>();
-    out->reads = (!ctx->imported || (ctx->cfg.flags & BF_FLAG_DEVICE_ROUTING)) ? nullptr : ctx->out.reads.as<bf_read>();
+    out->reads = nullptr;                                          // bf_result_reads
     out->junction_bytes = ctx->out.junction.as<uint8_t>();
     out->junction_size = ctx->out.junction_size;
-    out->cluster_junction_off = (!ctx->imported && nr) ? ctx->out.cjo.as<uint64_t>() : nullptr;
+    out->cluster_junction_off = nr ? ctx->out.cjo.as<uint64_t>() : nullptr;
     return BF_OK;
 }
 
@@ -1157,8 +1138,7 @@ int bf_result_reads(bf_ctx* ctx, bf_result* result) {
     if (result->n_reads != ctx->out.n_reads || result->clusters != ctx->out.clusters.as<bf_cluster>())
         return fail(ctx, BF_ERR_STATE, "bf_result_reads: not the result of this ctx's last bf_clusterise");
     const uint64_t nr = ctx->out.n_reads;
-    if (ctx->imported && (ctx->cfg.flags & BF_FLAG_DEVICE_ROUTING) && !ctx->table_attached)
-        return fail(ctx, BF_ERR_STATE, "bf_result_reads before bf_result_layout_dev / bf_result_attach_junctions_dev");
+    if (ctx->shard) return fail(ctx, BF_ERR_STATE, "bf_result_reads on a ctx of the sharded path; use bf_shard_result_places");
     if (ctx->reads_on_device && nr) {
         BF_HIP(ctx, hipSetDevice(ctx->device));
         BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
@@ -1173,7 +1153,7 @@ int bf_result_reads(bf_ctx* ctx, bf_result* result) {
 int bf_finish(bf_ctx* ctx, bf_result* out) {
     if (!ctx) return BF_ERR_INVALID;
     BF_TRACE_CALL(ctx);
-    if (ctx->n_ranks > 1) return fail(ctx, BF_ERR_STATE, "bf_finish on a multi-rank ctx; use the stage calls");
+    if (ctx->shard) return fail(ctx, BF_ERR_STATE, "bf_finish on a ctx of the sharded path; use bf_shard_finish");
     BF_TRY(localise_deferred(ctx));
     BF_TRY(bf_clusterise(ctx, out));
     ctx->consumed = true;
@@ -1361,66 +1341,7 @@ int64_t bf_result_junction_text(const bf_result* r, uint8_t* text, uint64_t cap,
     return (int64_t)total;
 }
 
-// ---- multi-GPU stage calls -------------------------------------------------------------------
-
-int bf_set_rank(bf_ctx* ctx, uint32_t rank, uint32_t n_ranks, uint64_t index_base) {
-    if (!ctx) return BF_ERR_INVALID;
-    if (n_ranks == 0 || n_ranks > 256 || rank >= n_ranks) return fail(ctx, BF_ERR_INVALID, "bf_set_rank: rank %u of %u", rank, n_ranks);
-    if (n_ranks > 1 && (ctx->cfg.flags & BF_FLAG_READS_ON_HOST))
-        return fail(ctx, BF_ERR_STATE, "BF_FLAG_READS_ON_HOST is for one ctx in one process: records that name a read cannot be expanded on another rank");
-    ctx->rank = rank; ctx->n_ranks = n_ranks; ctx->index_base = index_base;
-    ctx->src_index_base.clear();
-    ctx->imported = false;
-    return BF_OK;
-}
-
-int bf_exchange_local(bf_ctx* ctx, bf_wire_local* out) {
-    if (!ctx || !out) return BF_ERR_INVALID;
-    BF_TRACE_CALL(ctx);
-    if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_exchange_local before bf_localise");
-    out->max_frag_len_bytes = ctx->max_frag;
-    BF_TRY(settle_counts(ctx));
-    out->has_exact_sig = ctx->n_sigx ? 1 : 0;
-    return BF_OK;
-}
-
-int bf_exchange_pack(bf_ctx* ctx, const bf_wire_local* agreed, void* dev_send, uint64_t dev_send_bytes, uint64_t* counts,
-                     void** dev_out, uint32_t* record_bytes) {
-    if (!ctx) return BF_ERR_INVALID;
-    BF_TRACE_CALL(ctx);
-    if (!agreed || !counts || !dev_out || !record_bytes) return fail(ctx, BF_ERR_INVALID, "bf_exchange_pack: null argument");
-    if (!ctx->localised) return fail(ctx, BF_ERR_STATE, "bf_exchange_pack before bf_localise");
-    BF_HIP(ctx, hipSetDevice(ctx->device));
-    return run_partition(ctx, *agreed, dev_send, dev_send_bytes, counts, dev_out, record_bytes);
-}
-
-int bf_exchange_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts, const uint64_t* src_index_base) {
-    if (!ctx) return BF_ERR_INVALID;
-    BF_TRACE_CALL(ctx);
-    if (!src_counts || !src_index_base) return fail(ctx, BF_ERR_INVALID, "bf_exchange_import: null argument");
-    BF_HIP(ctx, hipSetDevice(ctx->device));
-    ctx->src_index_base.assign(src_index_base, src_index_base + ctx->n_ranks);
-    uint64_t n = 0; for (uint32_t r = 0; r < ctx->n_ranks; r++) n += src_counts[r];
-    if (n && !dev_recv) return fail(ctx, BF_ERR_INVALID, "bf_exchange_import: null receive buffer");
-    return run_import(ctx, dev_recv, src_counts);
-}
-
-int bf_result_sources(bf_ctx* ctx, const uint32_t** src_rank, const uint32_t** src_index) {
-    if (!ctx || !src_rank || !src_index) return BF_ERR_INVALID;
-    BF_TRACE_CALL(ctx);
-    if (!ctx->imported || !ctx->clustered)
-        return fail(ctx, BF_ERR_STATE, "bf_result_sources is only meaningful after bf_exchange_import + bf_clusterise");
-    if (ctx->sources_on_device) {
-        const uint64_t nr = ctx->out.n_reads;
-        BF_HIP(ctx, hipSetDevice(ctx->device));
-        BF_TRY(ensure_host(ctx, ctx->out.src, nr * 8));
-        BF_HIP(ctx, hipMemcpyAsync(ctx->out.src.p, ctx->c_rsrc.p, nr * 8, hipMemcpyDeviceToHost, ctx->stream));
-        BF_SYNC(ctx, ctx->stream);
-        ctx->sources_on_device = false;
-    }
-    *src_rank = ctx->out.src.as<uint32_t>(); *src_index = ctx->out.src.as<uint32_t>() + ctx->out.n_reads;
-    return BF_OK;
-}
+// ---- junction strings on request ---------------------------------------------------------------
 
 int bf_render_junctions(bf_ctx* ctx, uint64_t n, const uint32_t* local_index, const uint8_t** out_bytes, const uint64_t** out_off) {
     if (!ctx || !out_bytes || !out_off) return BF_ERR_INVALID;
@@ -1454,24 +1375,6 @@ int bf_render_junctions(bf_ctx* ctx, uint64_t n, const uint32_t* local_index, co
     return BF_OK;
 }
 
-// ---- device-resident junction routing (multi-GPU; every pointer below is device memory) ------
-
-int bf_result_sources_dev(bf_ctx* ctx, uint32_t* dev_src_rank, uint32_t* dev_src_index) {
-    if (!ctx) return BF_ERR_INVALID;
-    BF_TRACE_CALL(ctx);
-    if (!ctx->imported || !ctx->clustered)
-        return fail(ctx, BF_ERR_STATE, "bf_result_sources_dev is only meaningful after bf_exchange_import + bf_clusterise");
-    const uint64_t nr = ctx->out.n_reads;
-    if (nr == 0) return BF_OK;
-    if (!dev_src_rank || !dev_src_index) return fail(ctx, BF_ERR_INVALID, "bf_result_sources_dev: null output");
-    BF_HIP(ctx, hipSetDevice(ctx->device));
-    const uint32_t* src = ctx->c_rsrc.as<uint32_t>();                  // out_src_rank[nr], out_src_idx[nr]
-    BF_HIP(ctx, hipMemcpyAsync(dev_src_rank, src, nr * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    BF_HIP(ctx, hipMemcpyAsync(dev_src_index, src + nr, nr * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    BF_SYNC(ctx, ctx->stream);
-    return BF_OK;
-}
-
 int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_index, uint64_t* dev_off,
                             uint8_t* dev_bytes, uint64_t dev_bytes_cap, uint64_t* total) {
     if (!ctx || !total) return BF_ERR_INVALID;
@@ -1482,217 +1385,6 @@ int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_i
         return fail(ctx, BF_ERR_INVALID, "bf_render_junctions_dev: dev_bytes/dev_local_index must be 4-byte and dev_off 8-byte aligned");
     BF_HIP(ctx, hipSetDevice(ctx->device));
     return render_dev(ctx, n, dev_local_index, dev_off, dev_bytes, dev_bytes_cap, total);
-}
-
-int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const uint8_t* dev_bytes, uint64_t size,
-                                   bf_result* out) {
-    if (!ctx) return BF_ERR_INVALID;
-    BF_TRACE_CALL(ctx);
-    if (!out) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junctions_dev: null result");
-    if (!ctx->imported || !ctx->clustered)
-        return fail(ctx, BF_ERR_STATE, "bf_result_attach_junctions_dev is only meaningful after bf_exchange_import + bf_clusterise");
-    const uint64_t nr = ctx->out.n_reads;
-    if (nr && !dev_joff) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junctions_dev: null offsets");
-    if (size && !dev_bytes) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_junctions_dev: null junction bytes");
-    BF_HIP(ctx, hipSetDevice(ctx->device));
-    if (nr) {
-        BF_TRY(patch_reads_off(ctx, dev_joff, nr));
-        BF_TRY(ensure_host(ctx, ctx->out.reads, nr * sizeof(bf_read)));
-        BF_HIP(ctx, hipMemcpyAsync(ctx->out.reads.p, ctx->c_reads.p, nr * sizeof(bf_read), hipMemcpyDeviceToHost, ctx->stream));
-    }
-    ctx->out.junction_size = size;
-    if (size) {
-        BF_TRY(ensure_host(ctx, ctx->out.junction, size));
-        BF_HIP(ctx, hipMemcpyAsync(ctx->out.junction.p, dev_bytes, size, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    BF_SYNC(ctx, ctx->stream);
-    ctx->table_attached = true;
-    memset(out, 0, sizeof *out);
-    out->n_evidence = ctx->n_evidence;
-    out->n_clusters = ctx->out.n_clusters;
-    out->n_reads = nr;
-    out->clusters = ctx->out.clusters.as<bf_cluster>();
-    out->reads = ctx->out.reads.as<bf_read>();
-    out->junction_bytes = ctx->out.junction.as<uint8_t>();
-    out->junction_size = size;
-    return BF_OK;
-}
-
-// Pipelined form of bf_result_attach_junctions_dev.  The owner knows every supporting read's record size
-// from the exchange (bf_result_junction_sizes_dev), so it can lay out its junction buffer, send the read
-// table to the host while the records are still being requested, and then hand over the records piece by
-// piece as they arrive; the copies run on the ctx's copy stream behind the caller's next collective.
-int bf_result_junction_sizes_dev(bf_ctx* ctx, uint32_t* dev_len) {
-    if (!ctx) return BF_ERR_INVALID;
-    BF_TRACE_CALL(ctx);
-    if (!ctx->imported || !ctx->clustered)
-        return fail(ctx, BF_ERR_STATE, "bf_result_junction_sizes_dev is only meaningful after bf_exchange_import + bf_clusterise");
-    const uint64_t nr = ctx->out.n_reads;
-    if (nr == 0) return BF_OK;
-    if (!dev_len) return fail(ctx, BF_ERR_INVALID, "bf_result_junction_sizes_dev: null output");
-    BF_HIP(ctx, hipSetDevice(ctx->device));
-    BF_TRY(read_sizes(ctx, dev_len, nr));
-    BF_SYNC(ctx, ctx->stream);
-    return BF_OK;
-}
-
-// bf_result_layout_dev in two halves, so that bf_result_requests_dev can put its own work before the one
-// synchronisation: everything queued / everything the host does with the numbers that came back.
-static int layout_enqueue(bf_ctx* ctx, uint32_t n_pieces, bool fetch_piece_bytes) {
-    const uint64_t nr = ctx->out.n_reads, ncl = ctx->out.n_clusters;
-    ctx->piece_read.assign(n_pieces + 1, 0); ctx->piece_byte.assign(n_pieces + 1, 0);
-    ctx->piece_done.assign(n_pieces, 0);
-    for (uint32_t c = 0; c <= n_pieces; c++) ctx->piece_read[c] = nr * c / n_pieces;
-    ctx->junction_attached = 0; ctx->requests_ordered = false;
-    if (!nr) return BF_OK;
-    // record offsets in result order from the sizes the exchange brought along; the read table is finished
-    // on the device (bf_result_reads fetches it), the host gets one offset per cluster
-    BF_TRY(ensure(ctx, ctx->c_joff, (nr + 1) * 8));
-    BF_TRY(scan_u32_to_u64(ctx, ctx->c_rsrc.as<uint32_t>() + 3 * nr, ctx->c_joff.as<uint64_t>(), nr));
-    BF_TRY(patch_reads_off(ctx, ctx->c_joff.as<uint64_t>(), nr));
-    BF_TRY(ensure(ctx, ctx->c_cjo, (ncl + 1) * 8));
-    BF_TRY(ensure_host(ctx, ctx->out.cjo, (ncl + 1) * 8));
-    BF_TRY(cluster_record_offsets(ctx, ctx->c_joff.as<uint64_t>(), ctx->c_cjo.as<uint64_t>(), ncl));
-    BF_TRY(ensure(ctx, ctx->c_err, 16));
-    BF_HIP(ctx, hipMemsetAsync(ctx->c_err.p, 0, 16, ctx->stream));
-    for (uint32_t c = 0; c <= n_pieces && fetch_piece_bytes; c++)      // (small copies cost 30 us each)
-        BF_HIP(ctx, hipMemcpyAsync(&ctx->piece_byte[c], ctx->c_joff.as<uint64_t>() + ctx->piece_read[c], 8,
-                                   hipMemcpyDeviceToHost, ctx->stream));
-    BF_HIP(ctx, hipMemcpyAsync(ctx->out.cjo.p, ctx->c_cjo.p, (ncl + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    return BF_OK;
-}
-static int layout_complete(bf_ctx* ctx, uint32_t n_pieces, uint64_t* piece_read_begin, uint64_t* piece_byte_off) {
-    if (ctx->out.n_reads) {
-        const uint64_t total = ctx->piece_byte[n_pieces];
-        BF_TRY(ensure(ctx, ctx->c_jbytes, total ? total : 1));
-        BF_TRY(ensure_host(ctx, ctx->out.junction, total));
-        ctx->out.junction_size = total;
-        ctx->reads_on_device = true;
-    } else {
-        ctx->out.junction_size = 0;
-    }
-    ctx->result_order = true; ctx->table_attached = true;
-    for (uint32_t c = 0; c <= n_pieces; c++) { piece_read_begin[c] = ctx->piece_read[c]; piece_byte_off[c] = ctx->piece_byte[c]; }
-    return BF_OK;
-}
-
-int bf_result_layout_dev(bf_ctx* ctx, uint32_t n_pieces, uint64_t* piece_read_begin, uint64_t* piece_byte_off) {
-    if (!ctx) return BF_ERR_INVALID;
-    BF_TRACE_CALL(ctx);
-    if (!ctx->imported || !ctx->clustered)
-        return fail(ctx, BF_ERR_STATE, "bf_result_layout_dev is only meaningful after bf_exchange_import + bf_clusterise");
-    if (n_pieces == 0 || n_pieces > 64 || !piece_read_begin || !piece_byte_off)
-        return fail(ctx, BF_ERR_INVALID, "bf_result_layout_dev: 1..64 pieces and two output arrays");
-    BF_HIP(ctx, hipSetDevice(ctx->device));
-    BF_TRY(layout_enqueue(ctx, n_pieces, true));
-    BF_SYNC(ctx, ctx->stream);
-    return layout_complete(ctx, n_pieces, piece_read_begin, piece_byte_off);
-}
-
-int bf_result_requests_dev(bf_ctx* ctx, uint32_t n_pieces, uint32_t* dev_req, uint64_t* counts, uint64_t* bytes,
-                           uint64_t* piece_read_begin, uint64_t* piece_byte_off) {
-    if (!ctx) return BF_ERR_INVALID;
-    BF_TRACE_CALL(ctx);
-    if (!ctx->imported || !ctx->clustered)
-        return fail(ctx, BF_ERR_STATE, "bf_result_requests_dev is only meaningful after bf_exchange_import + bf_clusterise");
-    if (n_pieces == 0 || n_pieces > 64 || !counts || !bytes || !piece_read_begin || !piece_byte_off)
-        return fail(ctx, BF_ERR_INVALID, "bf_result_requests_dev: 1..64 pieces and four output arrays");
-    const uint64_t nr = ctx->out.n_reads;
-    if (nr && !dev_req) return fail(ctx, BF_ERR_INVALID, "bf_result_requests_dev: null request list");
-    if ((uintptr_t)dev_req & 3) return fail(ctx, BF_ERR_INVALID, "bf_result_requests_dev: dev_req must be 4-byte aligned");
-    BF_HIP(ctx, hipSetDevice(ctx->device));
-    const uint32_t groups = n_pieces * ctx->n_ranks;
-    BF_TRY(layout_enqueue(ctx, n_pieces, false));
-    std::vector<uint64_t> start(groups + 1, 0), bound(groups + 1, 0);
-    if (nr) {
-        uint64_t *d_start = nullptr, *d_bytes = nullptr;
-        BF_TRY(order_requests(ctx, n_pieces, dev_req, &d_start, &d_bytes));
-        BF_HIP(ctx, hipMemcpyAsync(start.data(), d_start, (groups + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        BF_HIP(ctx, hipMemcpyAsync(bound.data(), d_bytes, (groups + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    uint64_t total_check = 0;
-    if (nr) BF_HIP(ctx, hipMemcpyAsync(&total_check, ctx->c_joff.as<uint64_t>() + nr, 8, hipMemcpyDeviceToHost, ctx->stream));
-    BF_SYNC(ctx, ctx->stream);
-    // a piece's groups are exactly its reads, so the byte bounds of its first group are the piece's own
-    for (uint32_t c = 0; c <= n_pieces && nr; c++) {
-        if (start[c * ctx->n_ranks] != ctx->piece_read[c])
-            return fail(ctx, BF_ERR_HIP, "bf_result_requests_dev: piece %u: request order and layout disagree", c);
-        ctx->piece_byte[c] = bound[c * ctx->n_ranks];
-    }
-    if (nr && ctx->piece_byte[n_pieces] != total_check)
-        return fail(ctx, BF_ERR_HIP, "bf_result_requests_dev: record bytes in request order and in result order disagree");
-    BF_TRY(layout_complete(ctx, n_pieces, piece_read_begin, piece_byte_off));
-    for (uint32_t k = 0; k < groups; k++) { counts[k] = start[k + 1] - start[k]; bytes[k] = bound[k + 1] - bound[k]; }
-    ctx->requests_ordered = nr > 0;
-    return BF_OK;
-}
-
-int bf_result_attach_records_dev(bf_ctx* ctx, uint32_t piece, const uint8_t* dev_records, uint64_t size, const int64_t* dev_read_pos) {
-    if (!ctx) return BF_ERR_INVALID;
-    BF_TRACE_CALL(ctx);
-    if (!ctx->imported || !ctx->clustered || !ctx->result_order)
-        return fail(ctx, BF_ERR_STATE, "bf_result_attach_records_dev before bf_result_layout_dev");
-    if (piece >= ctx->piece_done.size()) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: piece %u of %zu", piece, ctx->piece_done.size());
-    if (ctx->piece_done[piece]) return fail(ctx, BF_ERR_STATE, "bf_result_attach_records_dev: piece %u attached twice", piece);
-    const uint64_t r0 = ctx->piece_read[piece], r1 = ctx->piece_read[piece + 1];
-    const uint64_t b0 = ctx->piece_byte[piece], b1 = ctx->piece_byte[piece + 1];
-    if (size != b1 - b0)
-        return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: piece %u holds %llu record bytes, %llu given", piece,
-                    (unsigned long long)(b1 - b0), (unsigned long long)size);
-    if (r1 > r0 && !dev_records) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: null records");
-    if (r1 > r0 && !dev_read_pos && !ctx->requests_ordered)
-        return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: null read positions without bf_result_requests_dev");
-    if (((uintptr_t)dev_records & 3) || ((uintptr_t)dev_read_pos & 7))
-        return fail(ctx, BF_ERR_INVALID, "bf_result_attach_records_dev: dev_records must be 4-byte, dev_read_pos 8-byte aligned");
-    BF_HIP(ctx, hipSetDevice(ctx->device));
-    if (r1 > r0) {
-        if (dev_read_pos) {
-            if (ctx->requests_ordered) return fail(ctx, BF_ERR_STATE, "bf_result_attach_records_dev: after bf_result_requests_dev the "
-                                                   "records come in its order (dev_read_pos == NULL)");
-            BF_TRY(scatter_records(ctx, r0, r1, dev_records, size, dev_read_pos));
-        } else {
-            BF_TRY(scatter_ordered(ctx, r0, r1, dev_records, size));
-        }
-        if (size) {
-            hipEvent_t ev = ctx->ev[1 + piece % 8];
-            BF_HIP(ctx, hipEventRecord(ev, ctx->stream));
-            BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ev, 0));
-            BF_HIP(ctx, hipMemcpyAsync(ctx->out.junction.as<uint8_t>() + b0, ctx->c_jbytes.as<uint8_t>() + b0, size,
-                                       hipMemcpyDeviceToHost, ctx->copy_stream));
-        }
-    }
-    ctx->piece_done[piece] = 1;
-    ctx->junction_attached += size;
-    return BF_OK;
-}
-
-int bf_result_attach_finish(bf_ctx* ctx, bf_result* out) {
-    if (!ctx) return BF_ERR_INVALID;
-    BF_TRACE_CALL(ctx);
-    if (!out) return fail(ctx, BF_ERR_INVALID, "bf_result_attach_finish: null result");
-    if (!ctx->imported || !ctx->clustered || !ctx->result_order)
-        return fail(ctx, BF_ERR_STATE, "bf_result_attach_finish before bf_result_layout_dev");
-    BF_HIP(ctx, hipSetDevice(ctx->device));
-    uint32_t err = 0;
-    if (ctx->out.n_reads) BF_HIP(ctx, hipMemcpyAsync(&err, ctx->c_err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    BF_SYNC(ctx, ctx->stream);
-    BF_SYNC(ctx, ctx->copy_stream);
-    if (ctx->out.n_reads == 0) ctx->out.junction_size = 0;
-    if (ctx->junction_attached != ctx->out.junction_size)
-        return fail(ctx, BF_ERR_STATE, "bf_result_attach_finish: %llu of %llu junction bytes were attached",
-                    (unsigned long long)ctx->junction_attached, (unsigned long long)ctx->out.junction_size);
-    if (err)
-        return fail(ctx, BF_ERR_INVALID, "bf_result_attach_finish: a piece's read positions or record bytes did not match the "
-                    "sizes the exchange announced (code %u)", err);
-    memset(out, 0, sizeof *out);
-    out->n_evidence = ctx->n_evidence;
-    out->n_clusters = ctx->out.n_clusters;
-    out->n_reads = ctx->out.n_reads;
-    out->clusters = ctx->out.clusters.as<bf_cluster>();
-    out->junction_bytes = ctx->out.junction.as<uint8_t>();
-    out->junction_size = ctx->out.junction_size;
-    out->cluster_junction_off = ctx->out.n_reads ? ctx->out.cjo.as<uint64_t>() : nullptr;   // reads: bf_result_reads
-    return BF_OK;
 }
 
 uint64_t bf_junction_record_bound(const bf_ctx* ctx) {

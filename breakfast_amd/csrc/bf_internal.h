@@ -17,6 +17,12 @@
 
 #include "../../include/breakfast_hip.h"
 
+// Wire format parameters of the evidence exchange that all ranks must agree on (the maximum over the ranks of each field)
+struct bf_wire_local {
+    uint32_t max_frag_len_bytes;  // longest fragment id on this rank
+    uint32_t has_exact_sig;       // 1 if any evidence carries a non-ACGT signature
+};
+
 namespace bf {
 
 // ---- genome image ---------------------------------------------------------------------------
@@ -302,7 +308,7 @@ struct bf_ctx {
     void* scratch = nullptr;                    // this device's copy of the static scratch array (localise.hip, scratch_setup)
     void* shard = nullptr;                      // bf::Shard (shard.hip): transport and buffers of the in-library sharded path
     bool counts_pending = false;                // ... not yet read back: settle_counts() after the next synchronisation
-    bf::DevBuf d_planes, d_len, d_frag_len, d_fhash;
+    bf::DevBuf d_len, d_frag_len, d_fhash;
     bf::DevBuf d_key, d_lpos, d_rpos, d_bp, d_flags, d_mask, d_jrec;   // d_jrec: read_info() words
     bf::DevBuf d_exact_list, d_counters, d_sigx, d_sigx_slot;
 
@@ -317,20 +323,15 @@ struct bf_ctx {
     bf::DevBuf d_send, d_part_key, d_part_idx, d_part_tmp;
     bf::DevBuf i_key, i_lpos, i_rpos, i_fhash, i_bp, i_len, i_flags, i_frag, i_frag_off, i_frag_len, i_sigx,
         i_sigx_slot, i_src_rank, i_src_idx, i_jrec;
-    bool table_attached = false;                // the read table of the last bf_clusterise is (being) copied to the host
-    uint64_t junction_attached = 0;             // junction bytes queued for the host so far
     bool reads_on_device = false;               // the finished read table waits in c_reads for bf_result_reads
-    bool sources_on_device = false;             // multi-rank: out.src not copied yet (bf_result_sources does it)
     uint64_t rsrc_stride = 0;                   // c_rsrc = 4 arrays of this many entries (source rank, source index, record, bytes)
-    bool requests_ordered = false;              // bf_result_requests_dev left its order in c_d32 / c_aoff
-    bool result_order = false;                  // multi-rank: bf_result_layout_dev laid the records out in result order
-    std::vector<uint64_t> piece_read, piece_byte;   // its pieces: read ranges and their byte ranges (n_pieces + 1 each)
-    std::vector<uint8_t> piece_done;
 
     // cluster stage scratch + results
     bf::DevBuf c_tmp, c_a32, c_b32, c_c32, c_d32, c_k64a, c_k64b, c_slpos, c_srpos, c_reported,
         c_csize, c_flag, c_scan, c_qseed, c_qsize, c_qoff, c_members, c_leader, c_rep, c_qnrep,
         c_ctl, c_sel, c_ord, c_clusters, c_reads, c_misc, c_pos2, c_joff, c_jbytes, c_rsrc, c_tables, c_mkey_s, c_slot, c_big, c_cjo, c_aoff, c_err, c_tmp2, c_qord, c_gidx, c_hist, c_comp, c_bstart, c_chunk;
+    bf::DevBuf c_desc, c_desc2;                 // tile descriptors of the one-launch scans (primitives.hip): main / side stream
+    uint32_t scan_epoch = 0, scan_epoch2 = 0;   // ... and the epoch of the last scan on each
     bf::ClusterOut out;
     std::vector<uint64_t> render_off_host;
     std::vector<uint8_t> render_bytes_host;
@@ -393,8 +394,12 @@ struct Scope {
 // sort / scan workspace c_tmp) goes to the side stream with a workspace of its own instead.
 struct OnSideStream {
     bf_ctx* ctx;
-    explicit OnSideStream(bf_ctx* c) : ctx(c) { std::swap(ctx->stream, ctx->side_stream); std::swap(ctx->c_tmp, ctx->c_tmp2); }
-    ~OnSideStream() { std::swap(ctx->stream, ctx->side_stream); std::swap(ctx->c_tmp, ctx->c_tmp2); }
+    explicit OnSideStream(bf_ctx* c) : ctx(c) { flip(); }
+    ~OnSideStream() { flip(); }
+    void flip() {
+        std::swap(ctx->stream, ctx->side_stream); std::swap(ctx->c_tmp, ctx->c_tmp2);
+        std::swap(ctx->c_desc, ctx->c_desc2); std::swap(ctx->scan_epoch, ctx->scan_epoch2);
+    }
 };
 
 // localise.hip ----------------------------------------------------------------------------------
@@ -452,10 +457,6 @@ int scan_max_u32_inplace(bf_ctx* ctx, uint32_t* data, uint64_t n);              
 int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n);
 int patch_reads_off(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n, uint64_t rd_base = 0, uint64_t byte_base = 0);
 int cluster_record_offsets(bf_ctx* ctx, const uint64_t* d_joff, uint64_t* d_out, uint64_t n_clusters, uint64_t byte_base = 0);
-int order_requests(bf_ctx* ctx, uint32_t K, uint32_t* d_req, uint64_t** d_start, uint64_t** d_bytes);
 int order_requests_range(bf_ctx* ctx, uint64_t rd_base, uint64_t nr, uint32_t* d_req, uint64_t** d_start);
-int scatter_ordered(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_records, uint64_t size);
-int scatter_records(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_records, uint64_t size, const int64_t* d_pos);
-int read_sizes(bf_ctx* ctx, uint32_t* d_out, uint64_t n);
 
 }  // namespace bf

@@ -47,19 +47,6 @@ __global__ void gather_key_kernel(uint64_t* out, const uint64_t* __restrict__ in
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[idx[i]];
 }
-// identity permutation + the two positions of a record side by side, so that the gather by sort
-// permutation below costs one random 8-byte access per record instead of two 4-byte ones
-__global__ void iota_zip_kernel(uint32_t* idx, int2* pos2, const int32_t* __restrict__ lpos,
-                                const int32_t* __restrict__ rpos, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { idx[i] = (uint32_t)i; pos2[i] = make_int2(lpos[i], rpos[i]); }
-}
-__global__ void gather_pos_kernel(int32_t* slpos, int32_t* srpos, const int2* __restrict__ pos2,
-                                  const uint32_t* __restrict__ perm, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const int2 p = pos2[perm[i]]; slpos[i] = p.x; srpos[i] = p.y; }
-}
-
 struct SweepView {
     uint64_t n;
     const uint64_t* skey;     // sorted class keys
@@ -662,7 +649,6 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
         if (run >= n * bounds.size() / max_groups && run > bounds.back() && run < n && bounds.size() < 255) bounds.push_back(run);
     }
     bounds.push_back(n);
-    const bool lsd = (ctx->cfg.flags & BF_FLAG_LSD_SORT) != 0;
     BF_TRY(ensure(ctx, ctx->c_gidx, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_hist, 64 + ctx->n_contigs, false));
     BF_TRY(ensure(ctx, ctx->c_c32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_k64a, n * 8, false));
     BF_HIP(ctx, hipMemsetAsync(ctx->c_hist.p, 0, 8, st));
@@ -672,11 +658,7 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
     if (bounds.size() > 2) {
         hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, ctx->c_c32.as<uint32_t>(), n);
         const unsigned shift = (unsigned)key_rank_shift(ctx->contig_bits);
-        if (lsd) {
-            // round 1's cut: record ids ordered by contig rank, input order inside
-            BF_TRY(sort_pairs<uint64_t>(ctx, v.key, ctx->c_k64a.as<uint64_t>(), ctx->c_c32.as<uint32_t>(), ctx->c_gidx.as<uint32_t>(), n,
-                                        shift, shift + (unsigned)ctx->contig_bits));
-        } else {
+        {
             // record ids ordered by GROUP, input order inside: a group's ids ascend, so what reads the records through them
             // walks memory once (ordered by rank, a group was a dozen interleaved walks: 835 MB fetched for 60 MB used)
             BF_TRY(ensure(ctx, ctx->c_a32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_b32, n * 4, false));
@@ -694,17 +676,6 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
     BF_TRY(settle_counts(ctx));                           // the localise counters came along with this synchronisation
     return BF_OK;
 }
-// sort keys and record ids of a group
-__global__ void group_keys_kernel(uint32_t* __restrict__ key, uint32_t* __restrict__ val, const uint32_t* __restrict__ idx,
-                                  const int32_t* __restrict__ lpos, uint64_t m) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < m) { const uint32_t i = idx[j]; val[j] = i; key[j] = (uint32_t)lpos[i]; }
-}
-__global__ void zip_pos_kernel(int2* __restrict__ pos2, const int32_t* __restrict__ lpos, const int32_t* __restrict__ rpos, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) pos2[i] = make_int2(lpos[i], rpos[i]);
-}
-
 // ---- sorted space without a full sort: class partition + chunk sort ----------------------------------
 // What the sweep needs (detect.rs:193-227 restricted to one class, see the header comment of this file) is: the records
 // of one signature side by side, inside a signature in (lpos as u32, input index) order.  The ORDER OF THE SIGNATURES
@@ -876,40 +847,17 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
     // --min-evidence=0 prints what 1 prints.  (Unclamped, `csize >= 0` would also flag the non-seeds, whose csize is 0.)
     const uint32_t min_evidence = std::max(ctx->cfg.min_evidence, 1u);
 
-    // 1. stable sort by (key, lpos): LSD, lpos first
+    // 1. sorted space: every signature's records side by side in (lpos, input index) order (class_order)
     BF_TRY(ensure(ctx, ctx->c_a32, n * 4)); BF_TRY(ensure(ctx, ctx->c_b32, n * 4));
     BF_TRY(ensure(ctx, ctx->c_c32, n * 4));
     BF_TRY(ensure(ctx, ctx->c_k64a, n * 8)); BF_TRY(ensure(ctx, ctx->c_k64b, n * 8));
     BF_TRY(ensure(ctx, ctx->c_slpos, n * 4)); BF_TRY(ensure(ctx, ctx->c_srpos, n * 4));
     BF_TRY(ensure(ctx, ctx->c_pos2, v.n * 8));
     uint32_t* perm = ctx->c_a32.as<uint32_t>();
-    if (!(ctx->cfg.flags & BF_FLAG_LSD_SORT)) {
+    {
         Scope t(ctx, "sort");
         const SortedOut so{ctx->c_k64b.as<uint64_t>(), ctx->c_slpos.as<int32_t>(), ctx->c_srpos.as<int32_t>(), perm};
         BF_TRY(class_order(ctx, v, grp ? grp->idx : nullptr, n, so));
-    } else {
-        Scope t(ctx, "sort");
-        const uint32_t* keys1 = (const uint32_t*)v.lpos;
-        if (!grp) {
-            hipLaunchKernelGGL(iota_zip_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_a32.as<uint32_t>(), ctx->c_pos2.as<int2>(),
-                               v.lpos, v.rpos, n);
-        } else {
-            if (grp->cl_base + grp->rd_base == 0 && grp->idx == ctx->c_gidx.as<uint32_t>())   // first group: positions of all records
-                hipLaunchKernelGGL(zip_pos_kernel, dim3(grid_for(v.n, B)), dim3(B), 0, st, ctx->c_pos2.as<int2>(), v.lpos, v.rpos, v.n);
-            BF_TRY(ensure(ctx, ctx->c_d32, n * 4, false));
-            hipLaunchKernelGGL(group_keys_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_d32.as<uint32_t>(),
-                               ctx->c_a32.as<uint32_t>(), grp->idx, v.lpos, n);
-            keys1 = ctx->c_d32.as<uint32_t>();
-        }
-        BF_TRY(sort_pairs<uint32_t>(ctx, keys1, ctx->c_b32.as<uint32_t>(), ctx->c_a32.as<uint32_t>(),
-                                    ctx->c_c32.as<uint32_t>(), n, 0, 32));
-        hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_k64a.as<uint64_t>(), v.key,
-                           ctx->c_c32.as<uint32_t>(), n);
-        // on the 32 signature bits only (see seg_of): contig ranks and strands are compared, not sorted
-        BF_TRY(sort_pairs<uint64_t>(ctx, ctx->c_k64a.as<uint64_t>(), ctx->c_k64b.as<uint64_t>(), ctx->c_c32.as<uint32_t>(),
-                                    perm, n, 0, kKeySigBits));
-        hipLaunchKernelGGL(gather_pos_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_slpos.as<int32_t>(),
-                           ctx->c_srpos.as<int32_t>(), ctx->c_pos2.as<int2>(), perm, n);
     }
     BF_HIP(ctx, hipGetLastError());
 
@@ -1090,7 +1038,6 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
     if (grp) {                                            // the caller copies the rows when the last group is through
         grp->ns = ns; grp->nr = total_r;
         ctx->out.n_clusters = cl_base + ns; ctx->out.n_reads = rd_base + total_r;
-        ctx->sources_on_device = false;
         return BF_OK;
     }
     ctx->out.n_clusters = ns; ctx->out.n_reads = total_r;
@@ -1099,10 +1046,6 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
     BF_HIP(ctx, hipEventRecord(ctx->ev[11], st));
     BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[11], 0));
     BF_HIP(ctx, hipMemcpyAsync(ctx->out.clusters.p, ctx->c_clusters.p, ns * sizeof(bf_cluster), hipMemcpyDeviceToHost, ctx->copy_stream));
-    // multi-rank: (source rank, source index) of every supporting read wait in c_rsrc; bf_result_sources copies
-    // them for a host that routes the junction requests itself, bf_result_sources_dev hands them to one that
-    // routes on the device
-    ctx->sources_on_device = total_r && v.src_rank;
     return BF_OK;
 }
 
@@ -1371,50 +1314,6 @@ int cluster_record_offsets(bf_ctx* ctx, const uint64_t* d_joff, uint64_t* d_out,
     BF_HIP(ctx, hipGetLastError());
     return BF_OK;
 }
-// Multi-rank, result-order layout: the records of reads [r0, r1) arrived back to back in the order `pos` names
-// (grouped by source rank); each goes to where the scan of the record sizes put its read (c_joff).
-// err[0] becomes non-zero when the list or the bytes are not what the sizes say.
-__global__ void arrival_sizes_kernel(uint32_t* __restrict__ len, const int64_t* __restrict__ pos,
-                                     const uint32_t* __restrict__ jrec, uint64_t count, uint64_t r0, uint64_t r1,
-                                     uint32_t* err) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= count) return;
-    const int64_t p = pos[j];
-    const bool ok = p >= (int64_t)r0 && p < (int64_t)r1;
-    len[j] = ok ? jrec[p] : 0u;
-    if (!ok) err[0] = 1u;
-}
-__global__ void __launch_bounds__(256) scatter_records_kernel(uint32_t* __restrict__ dst, const uint64_t* __restrict__ joff,
-                                                              const uint32_t* __restrict__ src, const uint64_t* __restrict__ aoff,
-                                                              const int64_t* __restrict__ pos, uint64_t count, uint64_t size,
-                                                              uint64_t r0, uint64_t r1, uint32_t* err) {
-    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t j = g >> 4;                                     // 16 lanes per record
-    const uint32_t l = (uint32_t)g & 15u;
-    if (j >= count) return;
-    if (j == count - 1 && l == 0 && aoff[count] != size) err[0] = 2u;
-    const int64_t p = pos[j];
-    if (p < (int64_t)r0 || p >= (int64_t)r1) return;
-    const uint64_t a = aoff[j], words = (aoff[j + 1] - a) >> 2;
-    if (a + (words << 2) > size) { err[0] = 3u; return; }
-    const uint64_t d = joff[p] >> 2;
-    for (uint64_t w = l; w < words; w += 16) dst[d + w] = src[(a >> 2) + w];
-}
-int scatter_records(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_records, uint64_t size, const int64_t* d_pos) {
-    const uint64_t count = r1 - r0, nr = ctx->out.n_reads;
-    if (!count) return BF_OK;
-    BF_TRY(ensure(ctx, ctx->c_aoff, count * 4 + (count + 1) * 8 + 16));
-    uint64_t* aoff = ctx->c_aoff.as<uint64_t>();
-    uint32_t* len = (uint32_t*)(aoff + count + 1);
-    hipLaunchKernelGGL(arrival_sizes_kernel, dim3(grid_for(count, 256)), dim3(256), 0, ctx->stream, len, d_pos,
-                       ctx->c_rsrc.as<uint32_t>() + 3 * nr, count, r0, r1, ctx->c_err.as<uint32_t>());
-    BF_TRY(scan_u32_to_u64(ctx, len, aoff, count));
-    hipLaunchKernelGGL(scatter_records_kernel, dim3(grid_for(count * 16, 256)), dim3(256), 0, ctx->stream,
-                       ctx->c_jbytes.as<uint32_t>(), ctx->c_joff.as<uint64_t>(), (const uint32_t*)d_records, aoff, d_pos,
-                       count, size, r0, r1, ctx->c_err.as<uint32_t>());
-    BF_HIP(ctx, hipGetLastError());
-    return BF_OK;
-}
 // Owner side of the junction routing in one go: the supporting reads ordered by (piece, source rank), result
 // order inside; what each (piece, rank) group asks for and how many record bytes it will bring back.
 __global__ void request_keys_kernel(uint32_t* __restrict__ key, uint32_t* __restrict__ val, const uint32_t* __restrict__ src_rank,
@@ -1446,45 +1345,6 @@ __global__ void request_bounds_kernel(uint64_t* __restrict__ start, uint64_t* __
     }
     start[k] = lo; bytes[k] = aoff[lo];
 }
-__global__ void __launch_bounds__(256) scatter_ordered_kernel(uint32_t* __restrict__ dst, const uint64_t* __restrict__ joff,
-                                                              const uint32_t* __restrict__ src, const uint64_t* __restrict__ aoff,
-                                                              const uint32_t* __restrict__ order, uint64_t r0, uint64_t r1,
-                                                              uint64_t size, uint32_t* err) {
-    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t j = r0 + (g >> 4);                              // 16 lanes per record
-    const uint32_t l = (uint32_t)g & 15u;
-    if (j >= r1) return;
-    const uint64_t a = aoff[j] - aoff[r0], words = (aoff[j + 1] - aoff[j]) >> 2;
-    if (a + (words << 2) > size) { err[0] = 3u; return; }
-    const uint64_t d = joff[order[j]] >> 2;
-    for (uint64_t w = l; w < words; w += 16) dst[d + w] = src[(a >> 2) + w];
-}
-// c_aoff: u64 aoff[nr + 1], u64 start[groups + 1], u64 bytes[groups + 1], u32 len[nr]; c_d32 = order; the caller's dev_req
-int order_requests(bf_ctx* ctx, uint32_t K, uint32_t* d_req, uint64_t** d_start, uint64_t** d_bytes) {
-    const uint64_t nr = ctx->out.n_reads;
-    const uint32_t W = ctx->n_ranks, groups = K * W;
-    const hipStream_t st = ctx->stream;
-    BF_TRY(ensure(ctx, ctx->c_a32, nr * 4, false)); BF_TRY(ensure(ctx, ctx->c_b32, nr * 4, false));
-    BF_TRY(ensure(ctx, ctx->c_c32, nr * 4, false)); BF_TRY(ensure(ctx, ctx->c_d32, nr * 4, false));
-    BF_TRY(ensure(ctx, ctx->c_aoff, (nr + 1) * 8 + (size_t)(groups + 1) * 16 + nr * 4 + 16));
-    uint64_t* aoff = ctx->c_aoff.as<uint64_t>();
-    uint64_t* start = aoff + nr + 1; uint64_t* bytes = start + groups + 1;
-    uint32_t* len = (uint32_t*)(bytes + groups + 1);
-    const uint32_t* src = ctx->c_rsrc.as<uint32_t>();               // out_src_rank, out_src_idx, out_rec, out_jrec
-    hipLaunchKernelGGL(request_keys_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, st, ctx->c_a32.as<uint32_t>(),
-                       ctx->c_c32.as<uint32_t>(), src, nr, K, W);
-    unsigned bits = 1; while ((1u << bits) < groups) bits++;
-    BF_TRY(sort_pairs<uint32_t>(ctx, ctx->c_a32.as<uint32_t>(), ctx->c_b32.as<uint32_t>(), ctx->c_c32.as<uint32_t>(),
-                                ctx->c_d32.as<uint32_t>(), nr, 0, bits));
-    hipLaunchKernelGGL(request_gather_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, st, d_req, len, ctx->c_d32.as<uint32_t>(),
-                       src + nr, src + 3 * nr, nr);
-    BF_TRY(scan_u32_to_u64(ctx, len, aoff, nr));
-    hipLaunchKernelGGL(request_bounds_kernel, dim3(grid_for(groups + 1, 256)), dim3(256), 0, st, start, bytes,
-                       ctx->c_b32.as<uint32_t>(), aoff, nr, groups);
-    BF_HIP(ctx, hipGetLastError());
-    *d_start = start; *d_bytes = bytes;
-    return BF_OK;
-}
 // The same for supporting reads [rd_base, rd_base + nr) of a result that is appended group by group (one piece):
 // d_req[j] = source index of the j-th request in (source rank, result order); start[s] = first request to rank s.
 // Leaves the order in c_d32 and the sorted source ranks in c_b32 (place_kernel reads them).
@@ -1511,19 +1371,6 @@ int order_requests_range(bf_ctx* ctx, uint64_t rd_base, uint64_t nr, uint32_t* d
                        ctx->c_b32.as<uint32_t>(), aoff, nr, W);
     BF_HIP(ctx, hipGetLastError());
     *d_start = start;
-    return BF_OK;
-}
-int scatter_ordered(bf_ctx* ctx, uint64_t r0, uint64_t r1, const uint8_t* d_records, uint64_t size) {
-    if (r1 <= r0) return BF_OK;
-    hipLaunchKernelGGL(scatter_ordered_kernel, dim3(grid_for((r1 - r0) * 16, 256)), dim3(256), 0, ctx->stream,
-                       ctx->c_jbytes.as<uint32_t>(), ctx->c_joff.as<uint64_t>(), (const uint32_t*)d_records,
-                       ctx->c_aoff.as<uint64_t>(), ctx->c_d32.as<uint32_t>(), r0, r1, size, ctx->c_err.as<uint32_t>());
-    BF_HIP(ctx, hipGetLastError());
-    return BF_OK;
-}
-// record bytes of the result's supporting reads (left by emit next to the index lists)
-int read_sizes(bf_ctx* ctx, uint32_t* d_out, uint64_t n) {
-    if (n) BF_HIP(ctx, hipMemcpyAsync(d_out, ctx->c_rsrc.as<uint32_t>() + 3 * n, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
     return BF_OK;
 }
 int patch_reads(bf_ctx* ctx, const uint64_t* d_joff, uint64_t n) { return patch_reads_off(ctx, d_joff, n); }

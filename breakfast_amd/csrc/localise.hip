@@ -1,16 +1,17 @@
 // Per-read kernels of the `breakfast detect` hot path for gfx950 (MI355X):
 //   genome_pack    raw FASTA bytes -> 2-bit block image + coarse exception bitmap   (detect.rs:48-56)
-//   encode_reads   ASCII reads -> bit planes (lo, hi, exception), transposed         (detect.rs:91)
-//   hash_frags     fragment ids -> 64-bit hashes                                     (detect.rs:90)
-//   localise_fast  reorient + two flank gathers + split scan + signature + coords    (detect.rs:105-187)
+//   read_meta      fragment ids -> 64-bit hashes, lengths                            (detect.rs:90)
+//   localise_fast  read -> bit planes in registers (detect.rs:91), reorient + two flank gathers + split scan +
+//                  signature + coords                                                (detect.rs:105-187)
 //   localise_exact the same on raw bytes for reads/windows the packed path cannot represent
 //   render         case-marked junction strings of surviving reads                   (detect.rs:155-162)
 //
 // Mapping (wave64): one lane per read.  All per-read state (3 read planes, 2x2 window planes,
 // 2 mismatch masks) lives in registers as W 64-bit words, bit k <-> read base k, so the split scan
-// is popcount + a branch-free running sum and never touches LDS.  Read planes and every output are
-// stored transposed ([word][read]) so that a wave's loads/stores are contiguous; the only
-// uncoalesced traffic is the inherent one, the two 16*(W+1)-byte window gathers per read.
+// is popcount + a branch-free running sum and never touches LDS.  The only uncoalesced traffic is the
+// inherent one, the two 16*(W+1)-byte window gathers per read.  (Round 1's A/B variants -- a separate
+// wave-ballot encode kernel, a cooperative LDS-staged gather -- lost on measurement and were removed in
+// round 3: profiles/r01*)
 
 #include "bf_internal.h"
 
@@ -75,58 +76,6 @@ __global__ void __launch_bounds__(256) genome_pack_kernel(const uint8_t* __restr
         coarse[t >> 6] = flags;
         // second level: one bit per coarse word (4096 bases); zero-initialised, set bits are rare
         if (flags) atomicOr(&coarse2[t >> 11], 1u << ((t >> 6) & 31));
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// encode_reads: one wave encodes 64 consecutive reads.  For read i and word w the 64 lanes load the
-// 64 bases [64w, 64w+64) (one coalesced 64-byte access), classify them, and three wave ballots ARE
-// the three plane words (bit k <-> base 64w+k); lane i keeps them, so after the loop lane i holds
-// read base+i and the plane stores are contiguous.  planes[(p*W + w)*n + r], p = 0 lo, 1 hi,
-// 2 exception.  Reads longer than 64*W get zero planes and are left to the exact kernel.
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
-    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, lane);
-    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-template <int W>
-__global__ void __launch_bounds__(256) encode_reads_kernel(uint64_t n, const uint8_t* __restrict__ seq,
-                                                           const uint64_t* __restrict__ seq_off,
-                                                           uint64_t* __restrict__ planes) {
-    const int lane = threadIdx.x & 63;
-    const uint64_t base = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64;
-    if (base >= n) return;                                   // wave-uniform
-    const uint64_t r = base + lane;
-    uint64_t o = 0;
-    uint32_t L = 0;
-    if (r < n) { o = seq_off[r]; L = (uint32_t)(seq_off[r + 1] - o); }
-    uint64_t lo[W], hi[W], ex[W];
-#pragma unroll
-    for (int w = 0; w < W; w++) lo[w] = hi[w] = ex[w] = 0;
-    if (L > 64u * W) L = 0;                                  // too long for the packed path: zero planes
-#pragma unroll 4
-    for (int i = 0; i < 64; i++) {                           // lanes past n carry L = 0
-        const uint64_t oi = readlane64(o, i);
-        const uint32_t Li = (uint32_t)__builtin_amdgcn_readlane((int)L, i);
-#pragma unroll
-        for (int w = 0; w < W; w++) {
-            const uint32_t pos = 64u * w + lane;
-            const bool in = pos < Li;
-            const uint32_t c = in ? seq[oi + pos] : (uint32_t)'A';
-            const uint32_t code = (c >> 1) & 3;              // A0 C1 T2 G3
-            const bool exc = c != ((0x47544341u >> (8 * code)) & 0xffu);   // not one of "ACGT"
-            const uint64_t blo = __ballot(in && (code & 1)), bhi = __ballot(in && (code >> 1)), bex = __ballot(exc);
-            if (lane == i) { lo[w] = blo; hi[w] = bhi; ex[w] = bex; }
-        }
-    }
-    if (r < n) {
-#pragma unroll
-        for (int w = 0; w < W; w++) {
-            planes[((uint64_t)(0 * W + w)) * n + r] = lo[w];
-            planes[((uint64_t)(1 * W + w)) * n + r] = hi[w];
-            planes[((uint64_t)(2 * W + w)) * n + r] = ex[w];
-        }
     }
 }
 
@@ -206,48 +155,6 @@ __device__ __forceinline__ uint32_t sigx_hash(const uint8_t (&sb)[16]) {
 #pragma unroll
     for (int k = 0; k < 16; k++) { h ^= sb[k]; h *= 0x01000193u; }
     return h;
-}
-
-// Cooperative form of the same gather: the wave's 64 windows are fetched as 64*(W+1) 16-byte
-// pieces, piece p = block p%(W+1) of the window of lane p/(W+1), so the W+1 adjacent lanes that
-// fetch one window's consecutive blocks sit in ONE load instruction and coalesce into one or two
-// 64-byte requests (issued per lane, one block per instruction, the same line is requested W+1
-// times while its first miss is still in flight: rocprofv3 showed 5.0 128-byte requests per read
-// against the 3.4 the addresses need).  Pieces go through LDS rows of RS16*16 bytes
-// (48 B for W=2, 80 B otherwise: conflict-free for the ds_read_b128 lane groups).
-template <int W> struct CoopGeom {
-    static constexpr int NB = W + 1;
-    static constexpr int RS16 = (NB == 3) ? 3 : 5;
-    static constexpr int WAVE_U4 = 64 * RS16;              // uint4 per wave per window
-};
-
-template <int W>
-__device__ __forceinline__ void coop_fetch(const GenomeBlock* __restrict__ blocks, uint32_t first_block,
-                                           uint4* __restrict__ wlds, int lane) {
-    constexpr int NB = CoopGeom<W>::NB, RS16 = CoopGeom<W>::RS16;
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-        const int p = 64 * k + lane;
-        const int ri = p / NB, bi = p - ri * NB;
-        const uint32_t src = (uint32_t)__shfl((int)first_block, ri);
-        wlds[ri * RS16 + bi] = ((const uint4*)blocks)[(uint64_t)src + bi];
-    }
-}
-
-template <int W>
-__device__ __forceinline__ void coop_take(const uint4* __restrict__ wlds, int lane, int sh,
-                                          uint64_t (&lo)[W], uint64_t (&hi)[W]) {
-    constexpr int RS16 = CoopGeom<W>::RS16;
-    uint4 x[W + 1];
-#pragma unroll
-    for (int i = 0; i <= W; i++) x[i] = wlds[lane * RS16 + i];
-#pragma unroll
-    for (int w = 0; w < W; w++) {
-        const uint64_t l0 = ((uint64_t)x[w].y << 32) | x[w].x, h0 = ((uint64_t)x[w].w << 32) | x[w].z;
-        const uint64_t l1 = ((uint64_t)x[w + 1].y << 32) | x[w + 1].x, h1 = ((uint64_t)x[w + 1].w << 32) | x[w + 1].z;
-        lo[w] = (l0 >> sh) | ((l1 << 1) << (63 - sh));
-        hi[w] = (h0 >> sh) | ((h1 << 1) << (63 - sh));
-    }
 }
 
 template <int W>
@@ -407,10 +314,9 @@ struct LocaliseArgs {
     int cb;                  // bits per contig rank in the class key
     uint32_t force_exact;
     const bf_hit* hits;
-    const uint16_t* len;          // separate-encode variant: read lengths (input)
-    uint16_t* len_out;            // fused variant: read lengths (output)
-    const uint64_t* planes;       // separate-encode variant
-    const uint8_t* seq;           // fused variant: the reads, ASCII or 4-bit codes
+    const uint16_t* len;          // 4-bit reads: their lengths (input)
+    uint16_t* len_out;            // ASCII reads: their lengths (output)
+    const uint8_t* seq;           // the reads, ASCII or 4-bit codes
     const uint64_t* seq_off;      // ... and where each starts (bytes)
     uint32_t packed;              // 1: 4-bit codes, lengths in `len`
     uint32_t by_ref;              // 1: junction records name the read (BF_FLAG_READS_ON_HOST): their size in `info`
@@ -467,22 +373,14 @@ __device__ __forceinline__ uint64_t make_key(const Oriented& o, bool sigx, uint3
 
 // (No occupancy attribute here: at W=3 the kernel takes 102 VGPRs = 4 waves/SIMD; forcing 5, 6 or 8 waves
 // spills and measured 1.12, 1.45 and 2.30 ms against 1.07 ms.)
-template <int W, bool COOP, bool FUSED, bool PACKED = false>
+template <int W, bool PACKED>
 __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a) {
-    __shared__ uint4 lds[COOP ? 4 * 2 * CoopGeom<W>::WAVE_U4 : 1];
-    const uint64_t r_raw = a.r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = r_raw < a.n;
-    if (!COOP && !live) return;
-    const uint64_t r = live ? r_raw : a.n - 1;           // COOP: every lane of the wave takes part in the gather
-    uint64_t so = 0;
+    const uint64_t r = a.r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n) return;
+    const uint64_t so = a.seq_off[r];
     int L;
-    if (FUSED) {
-        so = a.seq_off[r];
-        if (PACKED) L = a.len[r];
-        else { L = (int)(a.seq_off[r + 1] - so); a.len_out[r] = (uint16_t)L; }
-    } else {
-        L = a.len[r];
-    }
+    if (PACKED) L = a.len[r];
+    else { L = (int)(a.seq_off[r + 1] - so); a.len_out[r] = (uint16_t)L; }
     const int A = a.A;
     const bf_hit h = a.hits[r];
     const Oriented o = orient(h, a.contigs);
@@ -495,42 +393,18 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
     const uint64_t lg = o.c.goff + (uint64_t)(ok ? ls : 0);
     const uint64_t rg = o.mc.goff + (uint64_t)(ok ? rs : 0);
 
+    // read bases are requested first and the flank windows right after, so the encode arithmetic
+    // runs while the window gathers are still in flight (vmcnt retires in issue order)
     uint64_t rlo[W], rhi[W], rex[W];
-    if (FUSED) {
-        // read bases are requested first and the flank windows right after, so the encode arithmetic
-        // runs while the window gathers are still in flight (vmcnt retires in issue order)
-        if (L <= 64 * W) {
-            if (PACKED) encode_nibbles<W>(a.seq, so, L, rlo, rhi, rex); else encode_ascii<W>(a.seq, so, L, rlo, rhi, rex);
-        } else {
-#pragma unroll
-            for (int w = 0; w < W; w++) rlo[w] = rhi[w] = rex[w] = 0;
-        }
+    if (L <= 64 * W) {
+        if (PACKED) encode_nibbles<W>(a.seq, so, L, rlo, rhi, rex); else encode_ascii<W>(a.seq, so, L, rlo, rhi, rex);
     } else {
 #pragma unroll
-        for (int w = 0; w < W; w++) {
-            rlo[w] = a.planes[((uint64_t)(0 * W + w)) * a.n + r];
-            rhi[w] = a.planes[((uint64_t)(1 * W + w)) * a.n + r];
-            rex[w] = a.planes[((uint64_t)(2 * W + w)) * a.n + r];
-        }
+        for (int w = 0; w < W; w++) rlo[w] = rhi[w] = rex[w] = 0;
     }
     uint64_t llo[W], lhi[W], qlo[W], qhi[W];
-    if (COOP) {
-        const int lane = threadIdx.x & 63;
-        uint4* wl = lds + (threadIdx.x >> 6) * 2 * CoopGeom<W>::WAVE_U4;
-        uint4* wr = wl + CoopGeom<W>::WAVE_U4;
-        coop_fetch<W>(a.blocks, (uint32_t)block_slot(lg >> 6), wl, lane);
-        coop_fetch<W>(a.blocks, (uint32_t)block_slot(rg >> 6), wr, lane);
-        // LDS operations of one wave execute in order; only the compiler must not reorder them
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        coop_take<W>(wl, lane, (int)(lg & 63), llo, lhi);
-        coop_take<W>(wr, lane, (int)(rg & 63), qlo, qhi);
-    } else {
-        load_window<W>(a.blocks, lg, llo, lhi);
-        load_window<W>(a.blocks, rg, qlo, qhi);
-    }
-    if (COOP && !live) return;
+    load_window<W>(a.blocks, lg, llo, lhi);
+    load_window<W>(a.blocks, rg, qlo, qhi);
     bool flagged = false;        // a window touches a 64-base block that holds a byte outside ACGT
     {
         // exception test, two levels.  Level 2 (one bit per 4096 bases, ~100 KB for hg38, L2-resident)
@@ -1154,14 +1028,8 @@ int genome_pack(bf_ctx* ctx) {
 template <int W>
 static void launch_fast(bf_ctx* ctx, const LocaliseArgs& a) {
     const dim3 g(grid_for(a.n - a.r0, 256)), b(256);
-    if (ctx->cfg.flags & BF_FLAG_COOP_GATHER)
-        hipLaunchKernelGGL((localise_fast_kernel<W, true, false>), g, b, 0, ctx->stream, a);
-    else if (ctx->cfg.flags & BF_FLAG_SEPARATE_ENCODE)
-        hipLaunchKernelGGL((localise_fast_kernel<W, false, false>), g, b, 0, ctx->stream, a);
-    else if (a.packed)
-        hipLaunchKernelGGL((localise_fast_kernel<W, false, true, true>), g, b, 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((localise_fast_kernel<W, false, true>), g, b, 0, ctx->stream, a);
+    if (a.packed) hipLaunchKernelGGL((localise_fast_kernel<W, true>), g, b, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((localise_fast_kernel<W, false>), g, b, 0, ctx->stream, a);
 }
 
 int settle_counts(bf_ctx* ctx) {
@@ -1264,20 +1132,6 @@ int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len) {
     }
     BF_TRY(offsets_from_lengths(ctx, n));
 
-    const bool separate = (ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE)) != 0;
-    if (separate && ctx->packed_reads)
-        return fail(ctx, BF_ERR_STATE, "the A/B variants with a separate encode kernel read ASCII reads only (bf_submit, not bf_submit_packed)");
-    if (separate) {                                        // A/B variants: always the whole set (run_localise sees to it)
-        BF_TRY(ensure(ctx, ctx->d_planes, (size_t)3 * W * n * 8));
-        Scope t(ctx, "encode_reads");
-        const dim3 eg(grid_for(((n + 63) / 64) * 64, 256));
-        if (W == 2) hipLaunchKernelGGL(encode_reads_kernel<2>, eg, dim3(256), 0, ctx->stream, n, ctx->d_seq.as<uint8_t>(),
-                                       ctx->d_seq_off.as<uint64_t>(), ctx->d_planes.as<uint64_t>());
-        else if (W == 3) hipLaunchKernelGGL(encode_reads_kernel<3>, eg, dim3(256), 0, ctx->stream, n, ctx->d_seq.as<uint8_t>(),
-                                            ctx->d_seq_off.as<uint64_t>(), ctx->d_planes.as<uint64_t>());
-        else hipLaunchKernelGGL(encode_reads_kernel<4>, eg, dim3(256), 0, ctx->stream, n, ctx->d_seq.as<uint8_t>(),
-                                ctx->d_seq_off.as<uint64_t>(), ctx->d_planes.as<uint64_t>());
-    }
     {
         Scope t(ctx, "read_meta");
         hipLaunchKernelGGL(read_meta_kernel, dim3(grid_for(n - r0, 256)), dim3(256), 0, ctx->stream, r0, n,
@@ -1290,7 +1144,7 @@ int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len) {
     LocaliseArgs a{};
     a.r0 = r0; a.n = n; a.A = (int)A; a.cb = ctx->contig_bits; a.force_exact = (ctx->cfg.flags & BF_FLAG_FORCE_EXACT) ? 1u : 0u;
     a.hits = ctx->d_hits.as<bf_hit>(); a.len = ctx->d_len.as<uint16_t>();
-    a.planes = ctx->d_planes.as<uint64_t>(); a.len_out = ctx->d_len.as<uint16_t>();
+    a.len_out = ctx->d_len.as<uint16_t>();
     a.seq = ctx->d_seq.as<uint8_t>(); a.seq_off = ctx->d_seq_off.as<uint64_t>(); a.contigs = ctx->g_contigs.as<ContigDev>();
     a.packed = ctx->packed_reads ? 1u : 0u;
     a.by_ref = (ctx->cfg.flags & BF_FLAG_READS_ON_HOST) ? 1u : 0u;
@@ -1323,7 +1177,7 @@ int run_localise(bf_ctx* ctx, bool defer_counts, bool all) {
         return fail(ctx, BF_ERR_RANGE, "a read of length %u is shorter than 2 * anchor_len = %u "
                     "(the reference only emits reads with len >= 2*anchor_len, detect.rs:311)",
                     ctx->min_len, 2 * A);
-    if (all || (ctx->cfg.flags & (BF_FLAG_COOP_GATHER | BF_FLAG_SEPARATE_ENCODE))) ctx->n_localised = 0;
+    if (all) ctx->n_localised = 0;
     BF_TRY(localise_uploaded(ctx, n, ctx->max_len));
     const uint32_t Wm = ctx->mask_words, W = ctx->plane_words;
     {

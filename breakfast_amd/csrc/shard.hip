@@ -490,8 +490,7 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
     v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
     v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>();
     v.info = ctx->i_jrec.as<uint64_t>();
-    ctx->clustered = false; ctx->table_attached = false; ctx->junction_attached = 0; ctx->reads_on_device = false;
-    ctx->result_order = false; ctx->sources_on_device = false;
+    ctx->clustered = false; ctx->reads_on_device = false;
     ctx->out.n_clusters = ctx->out.n_reads = 0; ctx->n_evidence = v.n;
 
     uint64_t max_owned = 0;
@@ -691,8 +690,36 @@ static inline char* put_dec64(char* p, uint64_t v) {
     return p;
 }
 
+struct SvNames {                       // what the merge needs of a genome: names by contig id and their byte-wise order
+    uint32_t n_contigs = 0;
+    std::vector<std::string> contig_names;
+    std::vector<uint32_t> contig_rank;
+};
+static int64_t shard_format_sv_impl(const SvNames* ctx, uint32_t n_ranks, const bf_shard_result* results, char* buf, uint64_t cap);
+
 int64_t bf_shard_format_sv(const bf_ctx* ctx, uint32_t n_ranks, const bf_shard_result* results, char* buf, uint64_t cap) {
     if (!ctx || !results || n_ranks == 0) return BF_ERR_INVALID;
+    SvNames nm;
+    nm.n_contigs = ctx->n_contigs; nm.contig_names = ctx->contig_names; nm.contig_rank = ctx->contig_rank;
+    return shard_format_sv_impl(&nm, n_ranks, results, buf, cap);
+}
+
+int64_t bf_shard_format_sv_names(uint32_t n_contigs, const char* const* names, uint32_t n_ranks, const bf_shard_result* results,
+                                 char* buf, uint64_t cap) {
+    if (!names || !results || n_ranks == 0 || n_contigs == 0) return BF_ERR_INVALID;
+    SvNames nm;
+    nm.n_contigs = n_contigs;
+    for (uint32_t i = 0; i < n_contigs; i++) { if (!names[i]) return BF_ERR_INVALID; nm.contig_names.emplace_back(names[i]); }
+    // rank = position in byte-wise name order (Rust String Ord, detect.rs:194), as bf_genome_begin derives it
+    std::vector<uint32_t> order(n_contigs);
+    for (uint32_t i = 0; i < n_contigs; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return nm.contig_names[a] < nm.contig_names[b]; });
+    nm.contig_rank.assign(n_contigs, 0);
+    for (uint32_t r = 0; r < n_contigs; r++) nm.contig_rank[order[r]] = r;
+    return shard_format_sv_impl(&nm, n_ranks, results, buf, cap);
+}
+
+static int64_t shard_format_sv_impl(const SvNames* ctx, uint32_t n_ranks, const bf_shard_result* results, char* buf, uint64_t cap) {
     static const char header[] = "CHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tCHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\t"
                                  "SUPPORTING READS\tSIGNATURE\tNOTES\n";                 // detect.rs:201
     struct Row { uint32_t rank_; uint64_t idx; };

@@ -19,15 +19,11 @@ LIB_PATH = os.environ.get("BREAKFAST_HIP_LIB") or os.path.join(_HERE, "csrc", "l
 
 BF_FLAG_KEEP_EVIDENCE = 1
 BF_FLAG_FORCE_EXACT = 2
-BF_FLAG_COOP_GATHER = 4
-BF_FLAG_SEPARATE_ENCODE = 8
-BF_FLAG_DEVICE_ROUTING = 16
 BF_FLAG_SORTED_DEDUP = 32
 BF_FLAG_WEAK_DEDUP_HASH = 64
 BF_FLAG_ONE_GROUP = 128
 BF_FLAG_GROUPS_ALWAYS = 256
 BF_FLAG_ONE_STREAM = 512
-BF_FLAG_LSD_SORT = 1024
 BF_FLAG_READS_ON_HOST = 2048
 BF_EV_STRAND, BF_EV_MSTRAND, BF_EV_SWAPPED, BF_EV_EXACT, BF_EV_SIGX = 1, 2, 4, 8, 16
 
@@ -59,10 +55,6 @@ class BfResult(C.Structure):
     _fields_ = [("n_evidence", C.c_uint64), ("n_clusters", C.c_uint64), ("n_reads", C.c_uint64),
                 ("clusters", C.c_void_p), ("reads", C.c_void_p), ("junction_bytes", C.c_void_p),
                 ("junction_size", C.c_uint64), ("cluster_junction_off", C.c_void_p)]
-
-
-class BfWireLocal(C.Structure):
-    _fields_ = [("max_frag_len_bytes", C.c_uint32), ("has_exact_sig", C.c_uint32)]
 
 
 class BfShardResult(C.Structure):
@@ -105,15 +97,14 @@ class BfKernelTime(C.Structure):
 # every symbol include/breakfast_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "bf_abi_version", "bf_ctx_create", "bf_ctx_destroy", "bf_last_error", "bf_genome_set", "bf_submit",
-    "bf_localise", "bf_clusterise", "bf_finish", "bf_reset", "bf_sync", "bf_format_sv", "bf_set_rank",
-    "bf_exchange_local", "bf_exchange_pack", "bf_exchange_import", "bf_result_sources",
-    "bf_render_junctions", "bf_result_sources_dev", "bf_render_junctions_dev", "bf_result_attach_junctions_dev",
+    "bf_localise", "bf_clusterise", "bf_finish", "bf_reset", "bf_sync", "bf_format_sv",
+    "bf_render_junctions", "bf_render_junctions_dev", "bf_render_junctions_dev_static",
     "bf_evidence_fetch", "bf_kernel_times", "bf_stats", "bf_junction_text", "bf_junction_text_of", "bf_result_junction_text",
-    "bf_result_junction_sizes_dev", "bf_result_layout_dev", "bf_result_attach_records_dev", "bf_result_requests_dev",
-    "bf_result_attach_finish", "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
-    "bf_render_junctions_dev_static", "bf_host_alloc", "bf_host_free", "bf_submit_wait", "bf_reserve",
+    "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
+    "bf_host_alloc", "bf_host_free", "bf_submit_wait", "bf_reserve",
     "bf_genome_begin", "bf_genome_write", "bf_genome_fill", "bf_genome_end", "bf_submit_packed",
     "bf_shard_unique_id", "bf_shard_init_rccl", "bf_shard_init_host", "bf_shard_finish", "bf_shard_result_places", "bf_shard_format_sv",
+    "bf_shard_format_sv_names",
 ]
 
 _lib = None
@@ -169,6 +160,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_shard_result_places.argtypes = [vp, C.POINTER(BfShardResult)]
     lib.bf_shard_format_sv.argtypes = [vp, C.c_uint32, C.POINTER(BfShardResult), vp, C.c_uint64]
     lib.bf_shard_format_sv.restype = C.c_int64
+    lib.bf_shard_format_sv_names.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(BfShardResult), vp, C.c_uint64]
+    lib.bf_shard_format_sv_names.restype = C.c_int64
     lib.bf_localise.argtypes = [vp]
     lib.bf_clusterise.argtypes = [vp, C.POINTER(BfResult)]
     lib.bf_finish.argtypes = [vp, C.POINTER(BfResult)]
@@ -177,26 +170,14 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_sync.argtypes = [vp]
     lib.bf_format_sv.argtypes = [vp, C.POINTER(BfResult), vp, C.c_uint64]
     lib.bf_format_sv.restype = C.c_int64
-    lib.bf_set_rank.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64]
-    lib.bf_exchange_local.argtypes = [vp, C.POINTER(BfWireLocal)]
-    lib.bf_exchange_pack.argtypes = [vp, C.POINTER(BfWireLocal), vp, C.c_uint64, u64p, C.POINTER(vp), C.POINTER(C.c_uint32)]
-    lib.bf_exchange_import.argtypes = [vp, vp, u64p, u64p]
-    lib.bf_result_sources.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.bf_render_junctions.argtypes = [vp, C.c_uint64, vp, C.POINTER(vp), C.POINTER(vp)]
-    lib.bf_result_sources_dev.argtypes = [vp, vp, vp]
     lib.bf_render_junctions_dev.argtypes = [vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]
     lib.bf_render_junctions_dev_static.argtypes = [vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]
-    lib.bf_result_attach_junctions_dev.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(BfResult)]
     lib.bf_junction_record_bytes.argtypes = [vp, C.c_uint64]
     lib.bf_junction_record_bytes.restype = C.c_int64
     lib.bf_evidence_fetch.argtypes = [vp, C.POINTER(BfEvidenceView)]
     lib.bf_kernel_times.argtypes = [vp, C.POINTER(C.POINTER(BfKernelTime)), C.POINTER(C.c_uint32)]
     lib.bf_stats.argtypes = [vp, u64p, u64p]
-    lib.bf_result_junction_sizes_dev.argtypes = [vp, vp]
-    lib.bf_result_layout_dev.argtypes = [vp, C.c_uint32, u64p, u64p]
-    lib.bf_result_requests_dev.argtypes = [vp, C.c_uint32, vp, u64p, u64p, u64p, u64p]
-    lib.bf_result_attach_records_dev.argtypes = [vp, C.c_uint32, vp, C.c_uint64, vp]
-    lib.bf_result_attach_finish.argtypes = [vp, C.POINTER(BfResult)]
     lib.bf_junction_record_bound.argtypes = [vp]
     lib.bf_junction_record_bound.restype = C.c_uint64
     lib.bf_junction_text.argtypes = [vp, C.c_uint64, vp, C.c_uint64]
@@ -322,10 +303,7 @@ class Result:
     clusters: np.ndarray      # CLUSTER_DTYPE
     reads: np.ndarray         # READ_DTYPE
     junction_bytes: np.ndarray
-    src_rank: Optional[np.ndarray] = None
-    src_index: Optional[np.ndarray] = None
     n_reads: int = -1         # supporting reads (== reads.shape[0] unless the table is still on the device)
-    junction_sizes: Optional[np.ndarray] = None   # record bytes per read (stand-in engines of the sharded path)
     cluster_junction_off: Optional[np.ndarray] = None   # uint64[n_clusters + 1], one-GPU results (include/breakfast_hip.h)
 
     def junction(self, k: int) -> bytes:
@@ -380,21 +358,6 @@ def junction_header(records, off: int = 0) -> Tuple[int, int, bool, int]:
     if head & 3 == 0:                                    # text record: bp in the header word, length in the next one
         return int(np.frombuffer(rec[off + 4:off + 8].tobytes(), "<u4")[0]), (head >> 8) & 0xffff, bool(head & 4), int(size)
     return (head >> 3) & 0x1ff, (head >> 12) & 0x1ff, bool(head & 4), int(size)
-
-
-def text_records(text: np.ndarray, off: np.ndarray, swapped: Optional[Sequence[bool]] = None) -> Tuple[np.ndarray, np.ndarray]:
-    """Wraps junction strings as TEXT records {u32 kind 0 | reverse-complemented << 2 | bp << 8, u32 len} + string, padded to 4
-    bytes (what an engine without the packed renderer hands to the exchange) -> (records, offsets[n+1])."""
-    n = off.shape[0] - 1
-    out, ro = [], np.zeros(n + 1, np.uint64)
-    tb = np.ascontiguousarray(text, np.uint8).tobytes()
-    for i in range(n):
-        s = tb[int(off[i]):int(off[i + 1])]
-        rec = np.array([(4 if swapped is not None and swapped[i] else 0) | (s.index(b"|") << 8), len(s) - 1], "<u4").tobytes() + s
-        rec += b"\0" * (-len(rec) % 4)
-        out.append(rec)
-        ro[i + 1] = ro[i] + len(rec)
-    return np.frombuffer(b"".join(out), np.uint8).copy(), ro
 
 
 def _ptr(a: Optional[np.ndarray]) -> Optional[int]:
@@ -590,13 +553,7 @@ class Engine:
         if not r.reads and r.cluster_junction_off:          # a one-GPU result: the table is still on the device
             self._check(self.lib.bf_result_reads(self.h, C.byref(r)))
         self._last = r
-        res = self._wrap(r, copy)
-        if copy and r.n_reads and getattr(self, "n_ranks", 1) > 1:
-            sr, si = C.c_void_p(), C.c_void_p()
-            self._check(self.lib.bf_result_sources(self.h, C.byref(sr), C.byref(si)))
-            res.src_rank = np.frombuffer((C.c_uint32 * r.n_reads).from_address(sr.value), np.uint32).copy()
-            res.src_index = np.frombuffer((C.c_uint32 * r.n_reads).from_address(si.value), np.uint32).copy()
-        return res
+        return self._wrap(r, copy)
 
     def finish(self, copy: bool = True, reads: bool = True) -> Result:
         """bf_finish; reads=False leaves the read table on the device (Result.reads is empty, the records are
@@ -694,51 +651,15 @@ class Engine:
 
     def shard_format_sv(self, results: Sequence[ShardResult], as_array: bool = False):
         """detect.rs:201,233-240 for the results of ALL ranks (rank order); needs only this ctx's contig names."""
-        n = len(results)
-        keep, arr = [], (BfShardResult * n)()
-        for i, x in enumerate(results):
-            cl = np.ascontiguousarray(x.clusters, CLUSTER_DTYPE); sr = np.ascontiguousarray(x.src_rank, np.uint8)
-            gb = np.ascontiguousarray(x.group_read_begin, np.uint64); bo = np.ascontiguousarray(x.block_off, np.uint64)
-            rb = np.ascontiguousarray(x.record_bytes, np.uint8)
-            keep += [cl, sr, gb, bo, rb]
-            arr[i] = BfShardResult(x.n_local, x.n_evidence, cl.shape[0], sr.shape[0], _ptr(cl), _ptr(sr), gb.shape[0] - 1, 0,
-                                   _ptr(gb), x.n_records, _ptr(bo), _ptr(rb), rb.size, None, None)
-        size = self.lib.bf_shard_format_sv(self.h, n, arr, None, 0)
+        arr, keep = _shard_result_array(results)
+        size = self.lib.bf_shard_format_sv(self.h, len(results), arr, None, 0)
         self._check(size)
         buf = np.empty(int(size) + 1, np.uint8)
-        self._check(self.lib.bf_shard_format_sv(self.h, n, arr, buf.ctypes.data, size))
+        self._check(self.lib.bf_shard_format_sv(self.h, len(results), arr, buf.ctypes.data, size))
+        del keep
         return buf[:size] if as_array else buf[:size].tobytes()
 
-    # -- multi-GPU stage calls --
-    def set_rank(self, rank: int, n_ranks: int, index_base: int) -> None:
-        self._check(self.lib.bf_set_rank(self.h, rank, n_ranks, index_base))
-        self.n_ranks = n_ranks
-
-    def exchange_local(self) -> Tuple[int, int]:
-        w = BfWireLocal()
-        self._check(self.lib.bf_exchange_local(self.h, C.byref(w)))
-        return int(w.max_frag_len_bytes), int(w.has_exact_sig)
-
-    @staticmethod
-    def wire_record_bytes(max_frag_len_bytes: int, has_exact_sig: int) -> int:
-        return 40 + ((max_frag_len_bytes + 7) & ~7) + (16 if has_exact_sig else 0)
-
-    def exchange_pack(self, max_frag_len_bytes: int, has_exact_sig: int, n_ranks: int, dev_send: int = 0,
-                      dev_send_bytes: int = 0) -> Tuple[np.ndarray, int, int]:
-        """-> (counts per owner rank, device pointer of the packed records, record bytes)"""
-        w = BfWireLocal(max_frag_len_bytes, has_exact_sig)
-        counts = np.zeros(n_ranks, np.uint64)
-        ptr, rec = C.c_void_p(), C.c_uint32()
-        self._check(self.lib.bf_exchange_pack(self.h, C.byref(w), C.c_void_p(dev_send or None), dev_send_bytes,
-                                              counts.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(ptr), C.byref(rec)))
-        return counts, int(ptr.value or 0), int(rec.value)
-
-    def exchange_import(self, dev_ptr: int, src_counts: np.ndarray, src_index_base: np.ndarray) -> None:
-        sc = np.ascontiguousarray(src_counts, np.uint64)
-        sb = np.ascontiguousarray(src_index_base, np.uint64)
-        self._check(self.lib.bf_exchange_import(self.h, C.c_void_p(dev_ptr), sc.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                                sb.ctypes.data_as(C.POINTER(C.c_uint64))))
-
+    # -- junction strings on request --
     def render_junctions(self, local_index: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         idx = np.ascontiguousarray(local_index, np.uint32)
         pb, po = C.c_void_p(), C.c_void_p()
@@ -749,10 +670,7 @@ class Engine:
               else np.zeros(0, np.uint8))
         return by, off
 
-    # device-resident routing: arguments are raw device pointers (e.g. torch tensors' data_ptr())
-    def result_sources_dev(self, dev_src_rank: int, dev_src_index: int) -> None:
-        self._check(self.lib.bf_result_sources_dev(self.h, C.c_void_p(dev_src_rank or None), C.c_void_p(dev_src_index or None)))
-
+    # device index lists: arguments are raw device pointers (e.g. torch tensors' data_ptr())
     def render_junctions_dev(self, n: int, dev_index: int, dev_off: int, dev_bytes: int = 0, cap: int = 0) -> int:
         """-> total bytes; with dev_bytes == 0 only the n+1 offsets are written (size query)."""
         total = C.c_uint64()
@@ -766,45 +684,6 @@ class Engine:
         self._check(self.lib.bf_render_junctions_dev_static(self.h, n, C.c_void_p(dev_index or None), C.c_void_p(dev_off),
                                                             C.c_void_p(dev_bytes or None), cap, C.byref(total)))
         return int(total.value)
-
-    def attach_junctions_dev(self, dev_joff: int, dev_bytes: int, size: int, copy: bool = False) -> Result:
-        r = BfResult()
-        self._check(self.lib.bf_result_attach_junctions_dev(self.h, C.c_void_p(dev_joff or None),
-                                                            C.c_void_p(dev_bytes or None), size, C.byref(r)))
-        self._last = r
-        return self._wrap(r, copy)
-
-    def result_junction_sizes_dev(self, dev_len: int) -> None:
-        self._check(self.lib.bf_result_junction_sizes_dev(self.h, C.c_void_p(dev_len or None)))
-
-    def result_layout_dev(self, n_pieces: int) -> Tuple[np.ndarray, np.ndarray]:
-        """-> (piece_read_begin, piece_byte_off), n_pieces + 1 entries each (bf_result_layout_dev)."""
-        rb = (C.c_uint64 * (n_pieces + 1))()
-        bo = (C.c_uint64 * (n_pieces + 1))()
-        self._check(self.lib.bf_result_layout_dev(self.h, n_pieces, rb, bo))
-        return np.array(rb[:], np.int64), np.array(bo[:], np.int64)
-
-    def result_requests_dev(self, n_pieces: int, n_ranks: int, dev_req: int):
-        """-> (counts[piece, rank], bytes[piece, rank], piece_read_begin, piece_byte_off) (bf_result_requests_dev)."""
-        g = n_pieces * n_ranks
-        cnt, by = (C.c_uint64 * g)(), (C.c_uint64 * g)()
-        rb, bo = (C.c_uint64 * (n_pieces + 1))(), (C.c_uint64 * (n_pieces + 1))()
-        self._check(self.lib.bf_result_requests_dev(self.h, n_pieces, C.c_void_p(dev_req or None), cnt, by, rb, bo))
-        return (np.array(cnt[:], np.int64).reshape(n_pieces, n_ranks), np.array(by[:], np.int64).reshape(n_pieces, n_ranks),
-                np.array(rb[:], np.int64), np.array(bo[:], np.int64))
-
-    def attach_records_dev(self, piece: int, dev_records: int, size: int, dev_read_pos: int) -> None:
-        self._check(self.lib.bf_result_attach_records_dev(self.h, piece, C.c_void_p(dev_records or None), size,
-                                                          C.c_void_p(dev_read_pos or None)))
-
-    def attach_finish(self, copy: bool = False, reads: bool = True) -> Result:
-        """bf_result_attach_finish; reads=True also fetches the read table (bf_result_reads)."""
-        r = BfResult()
-        self._check(self.lib.bf_result_attach_finish(self.h, C.byref(r)))
-        if reads:
-            self._check(self.lib.bf_result_reads(self.h, C.byref(r)))
-        self._last = r
-        return self._wrap(r, copy)
 
     def junction_record_bound(self) -> int:
         return int(self.lib.bf_junction_record_bound(self.h))
@@ -834,6 +713,35 @@ class Engine:
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self.lib.bf_stats(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+
+def _shard_result_array(results: Sequence[ShardResult]):
+    n = len(results)
+    keep, arr = [], (BfShardResult * n)()
+    for i, x in enumerate(results):
+        cl = np.ascontiguousarray(x.clusters, CLUSTER_DTYPE); sr = np.ascontiguousarray(x.src_rank, np.uint8)
+        gb = np.ascontiguousarray(x.group_read_begin, np.uint64); bo = np.ascontiguousarray(x.block_off, np.uint64)
+        rb = np.ascontiguousarray(x.record_bytes, np.uint8)
+        keep += [cl, sr, gb, bo, rb]
+        arr[i] = BfShardResult(x.n_local, x.n_evidence, cl.shape[0], sr.shape[0], _ptr(cl), _ptr(sr), gb.shape[0] - 1, 0,
+                               _ptr(gb), x.n_records, _ptr(bo), _ptr(rb), rb.size, None, None)
+    return arr, keep
+
+
+def shard_format_sv(contig_names: Sequence[bytes], results: Sequence[ShardResult]) -> bytes:
+    """bf_shard_format_sv_names: the merge of all ranks' results into the reference's stdout (detect.rs:201,233-240) by a
+    process that holds no GPU and no ctx -- pure host code of the library."""
+    lib = load_library()
+    arr, keep = _shard_result_array(results)
+    names = (C.c_char_p * len(contig_names))(*[bytes(n) for n in contig_names])
+    size = lib.bf_shard_format_sv_names(len(contig_names), names, len(results), arr, None, 0)
+    if size < 0:
+        raise BreakfastError(int(size), "bf_shard_format_sv_names: malformed shard results")
+    buf = np.empty(int(size) + 1, np.uint8)
+    if lib.bf_shard_format_sv_names(len(contig_names), names, len(results), arr, buf.ctypes.data, size) != size:
+        raise BreakfastError(-1, "bf_shard_format_sv_names: size changed between calls")
+    del keep
+    return buf[:size].tobytes()
 
 
 def detect(fasta: Dict[bytes, bytes], bowtie_lines: Iterable[bytes], anchor_len: int = 30,

@@ -10,8 +10,8 @@
  * convention `ERROR: <msg>` on stderr + exit(-1), src/common.rs:8-13).
  *
  * Threading: like the reference's consume loop (one thread, detect.rs:76) a bf_ctx is
- * single-caller.  One ctx drives one GPU; multi-GPU runs use one ctx (one process) per GPU and the
- * bf_exchange_* stage calls below.
+ * single-caller.  One ctx drives one GPU; multi-GPU runs use one ctx (one process or thread) per GPU and the
+ * bf_shard_* calls below.
  *
  * The library has NO CPU fallback: without a usable gfx950 device every compute entry point fails
  * with BF_ERR_NO_DEVICE.
@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 11
+#define BF_ABI_VERSION 12
 
 enum {
     BF_OK = 0,
@@ -61,8 +61,7 @@ typedef struct {
 
 #define BF_FLAG_KEEP_EVIDENCE 1u   /* keep per-read evidence readable via bf_evidence_fetch (tests) */
 #define BF_FLAG_FORCE_EXACT   2u   /* route every read through the byte-exact kernel (tests)        */
-#define BF_FLAG_COOP_GATHER     4u /* A/B: separate encode kernel + cooperative (LDS-staged) flank gather */
-#define BF_FLAG_SEPARATE_ENCODE 8u /* A/B: separate encode kernel + per-lane flank gather               */
+/* (4, 8, 16 and 1024 were round-1 A/B variants and the stage-call routing flag; removed with ABI version 12) */
 #define BF_FLAG_SORTED_DEDUP   32u /* A/B + tests: fragment-id dedup by the sorted-run kernels even when every cluster
                                       fits the in-wave form (they are the path of clusters above 256 members) */
 #define BF_FLAG_WEAK_DEDUP_HASH 64u /* tests: the in-wave dedup groups on 3 hash bits, so that its byte verification fails
@@ -70,17 +69,13 @@ typedef struct {
 #define BF_FLAG_ONE_GROUP    128u   /* A/B + tests: cluster all contigs in one go instead of a few contig ranks at a time with
                                       each group's records copied to the host behind the next group's kernels */
 #define BF_FLAG_GROUPS_ALWAYS 256u  /* tests: the groups even for inputs below the size where they pay (4M reads) */
-#define BF_FLAG_LSD_SORT    1024u   /* A/B + tests: the cluster stage orders its records with the eight-pass LSD radix sort and three
-                                       gathers of round 1 instead of the class partition + chunk sort */
 #define BF_FLAG_ONE_STREAM   512u   /* profiling: every kernel and copy of the ctx on ONE stream, nothing overlaps (a kernel trace then
                                       shows each kernel's own duration, not its share of a GPU it has to share with the result copy) */
 #define BF_FLAG_READS_ON_HOST 2048u /* the caller keeps every submitted batch's sequence arrays (seq_bytes / seq_nibbles, seq_off,
                                        seq_len) valid and unchanged until it is done with the results: junction records then
                                        name the read instead of carrying its bases (kind 3 below; 12 bytes instead of 44 for a
                                        150-base read), and bf_format_sv / bf_junction_text_of read the bases where the caller
-                                       left them.  One ctx, one process: not with bf_set_rank / bf_shard_init_*. */
-#define BF_FLAG_DEVICE_ROUTING 16u /* multi-rank: bf_clusterise leaves the read table on the device (result.reads
-                                      is NULL, n_reads is set); the bf_result_attach_* calls complete the result */
+                                       left them.  One ctx, one process: not with bf_shard_init_*. */
 
 /* One pair of anchor alignments = the fields the consume loop parses out of a `5p:`/`3p:` line
  * pair (detect.rs:94-103): bowtie's strand, contig and 1-based leftmost offset (-B1) of each anchor.
@@ -155,15 +150,13 @@ typedef struct {
  * bf_finish / bf_clusterise bring to the host: rows, junction records in printed order (a cluster's records are
  * contiguous, each says how long it is) and one offset per cluster.  The read table -- which input read each
  * string came from, and each record's own offset -- is a quarter of the bytes; it is complete on the device and
- * comes over when bf_result_reads() asks for it.  Multi-rank results are laid out the same way
- * (bf_result_layout_dev ... bf_result_attach_finish); only the one-shot bf_result_attach_junctions_dev, whose
- * caller chooses the record order, returns the table and no cluster_junction_off. */
+ * comes over when bf_result_reads() asks for it. */
 typedef struct {
     uint64_t          n_evidence;     /* the count the reference logs at detect.rs:190 */
     uint64_t          n_clusters;
     uint64_t          n_reads;
     const bf_cluster* clusters;       /* output order = the reference's print order */
-    const bf_read*    reads;          /* NULL until bf_result_reads() (one-GPU results) */
+    const bf_read*    reads;          /* NULL until bf_result_reads() */
     const uint8_t*    junction_bytes;
     uint64_t          junction_size;
     const uint64_t*   cluster_junction_off;  /* n_clusters + 1: the records of cluster c's reads, in read order, are
@@ -290,62 +283,20 @@ int64_t bf_junction_record_bytes(const uint8_t* record, uint64_t avail);
  * (BF_ERR_INVALID also for results that hold reference records: those need the ctx, bf_junction_text_of). */
 int64_t bf_result_junction_text(const bf_result* result, uint8_t* text, uint64_t cap, uint64_t* text_off);
 
-/* ---- multi-GPU stage calls (one ctx per GPU/process) ------------------ */
-/* The path shards by contiguous input ranges; rank r's reads have global indices
- * [index_base, index_base + n).  Evidence of one breakpoint class must meet on one rank, so after
- * bf_localise every rank packs its evidence into per-owner buckets (owner = hash(class) % n_ranks),
- * the HOST performs one all-to-all of the packed device buffers (RCCL via torch.distributed, or any
- * transport), and the received records are imported before bf_clusterise.  Supporting reads are then
- * rendered on their source rank with bf_render_junctions. */
+/* ---- junction strings on request ---------------------------------------------------------------- */
 
-int bf_set_rank(bf_ctx* ctx, uint32_t rank, uint32_t n_ranks, uint64_t index_base);
-
-/* Wire format parameters all ranks must agree on (caller all-reduces MAX of each field). */
-typedef struct {
-    uint32_t max_frag_len_bytes;  /* longest fragment id on this rank */
-    uint32_t has_exact_sig;       /* 1 if any evidence carries a non-ACGT signature */
-} bf_wire_local;
-int bf_exchange_local(bf_ctx* ctx, bf_wire_local* out);
-
-/* Packs evidence into a device send buffer grouped by owner rank (source order kept inside each
- * group).  counts[r] = records for rank r; every record has *record_bytes bytes (a function of
- * `agreed` only: 40 + round_up(max_frag_len_bytes, 8) + 16 * has_exact_sig).  If dev_send is not
- * NULL the records are written there (caller-owned device memory, e.g. a torch tensor, of
- * dev_send_bytes >= n_resident_reads * record_bytes); otherwise into ctx-owned device memory.
- * *dev_out receives the buffer actually used. */
-int bf_exchange_pack(bf_ctx* ctx, const bf_wire_local* agreed, void* dev_send, uint64_t dev_send_bytes,
-                     uint64_t* counts /* n_ranks */, void** dev_out, uint32_t* record_bytes);
-
-/* Imports the received records (device pointer, ordered by source rank then source order);
- * src_counts[r] = how many came from rank r, src_index_base[r] = rank r's index_base. */
-int bf_exchange_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts /* n_ranks */,
-                       const uint64_t* src_index_base /* n_ranks */);
-
-/* After bf_clusterise on an owner rank: for every supporting read, (source rank, source-local index).
- * Arrays of result.n_reads entries, owned by the ctx. */
-int bf_result_sources(bf_ctx* ctx, const uint32_t** src_rank, const uint32_t** src_index);
-
-/* On a source rank: renders the junction strings of the given local read indices (device work) and
- * expands them to TEXT on the host.  out_bytes/out_off (n+1 offsets) are owned by the ctx until the
- * next call. */
+/* Renders the junction strings (detect.rs:155-162) of the given resident reads (device work) and expands them to
+ * TEXT on the host.  out_bytes/out_off (n+1 offsets) are owned by the ctx until the next call.  Needs bf_localise
+ * (or bf_finish) first.  The reference builds this string for every read (detect.rs:155-162); here only the reads
+ * that survive are rendered by bf_finish, and this call serves a caller that wants others (tests compare ALL reads). */
 int bf_render_junctions(bf_ctx* ctx, uint64_t n, const uint32_t* local_index,
                         const uint8_t** out_bytes, const uint64_t** out_off);
 
-/* Device-resident form of the two calls above, for callers whose transport moves device memory
- * (RCCL): nothing but a few counters crosses PCIe until the final result lands in host memory.
- * Every pointer named dev_* is device memory owned by the caller; each call returns after its GPU
- * work has completed (the ctx runs on its own stream).  No counterpart in the reference: detect.rs
- * is one process.
- *
- * bf_result_sources_dev: copies (source rank, source-local index) of the result.n_reads supporting
- * reads of the last bf_clusterise into two caller arrays of n_reads uint32 each. */
-int bf_result_sources_dev(bf_ctx* ctx, uint32_t* dev_src_rank, uint32_t* dev_src_index);
-
-/* On a source rank: junction RECORDS (detect.rs:155-162; format above) of n local reads given as a device
- * index list.  dev_off receives n+1 byte offsets, *total their sum.  With dev_bytes == NULL only offsets
- * and *total are produced (size query); otherwise dev_bytes (capacity dev_bytes_cap >= *total)
- * receives the text.  An index outside the resident reads is an error, never dereferenced.
- * dev_bytes and dev_local_index must be 4-byte aligned, dev_off 8-byte aligned. */
+/* The same for a DEVICE index list into caller-owned device memory, as junction RECORDS (format above): dev_off
+ * receives n+1 byte offsets, *total their sum.  With dev_bytes == NULL only offsets and *total are produced (size
+ * query); otherwise dev_bytes (capacity dev_bytes_cap >= *total) receives the records.  An index outside the resident
+ * reads is an error, never dereferenced.  dev_bytes and dev_local_index must be 4-byte aligned, dev_off 8-byte
+ * aligned.  Returns after its GPU work has completed.  No counterpart in the reference. */
 int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_index, uint64_t* dev_off,
                             uint8_t* dev_bytes, uint64_t dev_bytes_cap, uint64_t* total);
 
@@ -360,52 +311,15 @@ int bf_render_junctions_dev(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_i
 #define BF_STATIC_RENDER_MAX_READS (1u << 20)
 int bf_render_junctions_dev_static(bf_ctx* ctx, uint64_t n, const uint32_t* dev_local_index, uint64_t* dev_off,
                                    uint8_t* dev_bytes, uint64_t dev_bytes_cap, uint64_t* total);
-
-/* On an owner rank, after the junction records of its supporting reads have arrived in device memory:
- * dev_joff[i] locates read i's record inside dev_bytes (size bytes).  Patches the read table, copies
- * table and records to the ctx's pinned host memory and fills *out with the complete result, laid out
- * as bf_finish returns it on one GPU. */
-int bf_result_attach_junctions_dev(bf_ctx* ctx, const uint64_t* dev_joff, const uint8_t* dev_bytes, uint64_t size,
-                                   bf_result* out);
-
-/* Pipelined form, which lays the result out exactly as bf_finish does on one GPU (records in printed order, one
- * offset per cluster, the read table left on the device for bf_result_reads).  The exchange carries every
- * read's junction record size, so an owner rank knows where each record belongs before any has arrived:
- *   bf_result_junction_sizes_dev   record bytes of the result.n_reads supporting reads -> dev_len[n_reads]
- *   bf_result_layout_dev           cuts the supporting reads into n_pieces (<= 64) ranges of result order:
- *                                  piece c = reads [piece_read_begin[c], piece_read_begin[c+1]), whose records
- *                                  are bytes [piece_byte_off[c], piece_byte_off[c+1]) of the junction buffer
- *                                  (both arrays: n_pieces + 1 entries, host memory)
- *   bf_result_attach_records_dev   the records of one piece as they arrived: back to back in dev_records, in the
- *                                  order of dev_read_pos (result positions of the piece's reads, each once;
- *                                  any order, e.g. grouped by source rank).  Moves each record to its place and
- *                                  queues the piece's bytes for the host on the ctx's copy stream; returns at
- *                                  once (the caller keeps both buffers alive until bf_result_attach_finish)
- *   bf_result_requests_dev         bf_result_layout_dev plus the request lists, in one call and one
- *                                  synchronisation: orders the supporting reads by (piece, source rank), result
- *                                  order inside; dev_req[n_reads] receives their source-local indices in that
- *                                  order (a piece's part, split by counts, is what its index all-to-all sends);
- *                                  counts[p * n_ranks + s] = requests of piece p to rank s, bytes[...] = the
- *                                  record bytes they bring back.  bf_result_attach_records_dev then takes a
- *                                  piece's records in exactly that order, with dev_read_pos == NULL
- *   bf_result_attach_finish        waits for the copies, checks that every piece came and that sizes agreed,
- *                                  fills *out
- * so that each piece's host copy runs behind the caller's render + all-to-all of the next one.  No counterpart
- * in the reference (one process). */
-int bf_result_junction_sizes_dev(bf_ctx* ctx, uint32_t* dev_len);
-int bf_result_layout_dev(bf_ctx* ctx, uint32_t n_pieces, uint64_t* piece_read_begin, uint64_t* piece_byte_off);
-int bf_result_requests_dev(bf_ctx* ctx, uint32_t n_pieces, uint32_t* dev_req, uint64_t* counts /* n_pieces * n_ranks */,
-                           uint64_t* bytes /* n_pieces * n_ranks */, uint64_t* piece_read_begin, uint64_t* piece_byte_off);
-int bf_result_attach_records_dev(bf_ctx* ctx, uint32_t piece, const uint8_t* dev_records, uint64_t size,
-                                 const int64_t* dev_read_pos);
-int bf_result_attach_finish(bf_ctx* ctx, bf_result* out);
 /* Upper bound of a resident read's junction record in bytes (sizing of bf_render_junctions_dev buffers). */
 uint64_t bf_junction_record_bound(const bf_ctx* ctx);
 
 /* ---- the sharded path in one call (north_star item 4) ------------------ */
-/* The stage calls above leave the all-to-all to the caller.  The calls below run the whole sharded path inside
+/* The path shards by contiguous input ranges; rank r's reads have global indices [index_base, index_base + n).
+ * Evidence of one breakpoint class must meet on one rank.  The calls below run the whole sharded path inside
  * the library, from C, with no orchestration language in between: one ctx per GPU, each driven by its own thread
- * or process; the ranks call the same functions in the same order.
+ * or process; the ranks call the same functions in the same order.  (Until ABI version 11 a set of stage calls --
+ * bf_set_rank, bf_exchange_*, bf_result_attach_* -- left the all-to-all to the caller; nothing used them any more.)
  *
  *   bf_shard_unique_id      rank 0 makes the 128-byte RCCL id (ncclGetUniqueId); the launcher hands it to every rank
  *   bf_shard_init_rccl      joins the communicator (ncclCommInitRank): evidence crosses xGMI, device to device.
@@ -459,6 +373,9 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out);
  * `result` must be what this ctx's last bf_shard_finish filled. */
 int bf_shard_result_places(bf_ctx* ctx, bf_shard_result* result);
 int64_t bf_shard_format_sv(const bf_ctx* ctx, uint32_t n_ranks, const bf_shard_result* results, char* buf, uint64_t cap);
+/* The same without a ctx (a merging process that holds no GPU): contig names as given to bf_genome_set. */
+int64_t bf_shard_format_sv_names(uint32_t n_contigs, const char* const* names, uint32_t n_ranks, const bf_shard_result* results,
+                                 char* buf, uint64_t cap);
 
 /* ---- introspection (tests, bench) ---------------------------------------------------------- */
 

@@ -10,8 +10,8 @@ import oracle_lib as ol
 from conftest import golden_names, load_golden
 
 from breakfast_amd import engine, synth
-from breakfast_amd.engine import (BF_FLAG_COOP_GATHER, BF_FLAG_FORCE_EXACT, BF_FLAG_KEEP_EVIDENCE, BF_FLAG_SEPARATE_ENCODE,
-                                  BF_FLAG_SORTED_DEDUP, BF_FLAG_WEAK_DEDUP_HASH, BF_FLAG_GROUPS_ALWAYS, BF_FLAG_ONE_GROUP)
+from breakfast_amd.engine import (BF_FLAG_FORCE_EXACT, BF_FLAG_KEEP_EVIDENCE, BF_FLAG_SORTED_DEDUP, BF_FLAG_WEAK_DEDUP_HASH,
+                                  BF_FLAG_GROUPS_ALWAYS, BF_FLAG_ONE_GROUP)
 
 pytestmark = pytest.mark.gpu
 
@@ -179,17 +179,6 @@ def test_one_form_of_reads_per_ctx_and_packed_validation():
         engine.pack_batch(engine.make_batch([b"ACGTacgt" * 6], [b"f"], [(1, 100, 0, 0, 3)]))
 
 
-@pytest.mark.parametrize("flag", [BF_FLAG_COOP_GATHER, BF_FLAG_SEPARATE_ENCODE])
-@pytest.mark.parametrize("cfg,scale,gscale", [(0, 0.05, 0.02), (1, 0.004, 0.002), (4, 0.002, 0.002)])
-def test_scaled_baseline_config_ab_variants(cfg, scale, gscale, flag):
-    # the A/B variants of the localise stage (separate encode kernel; cooperative gather) must give
-    # the same answers as the shipped fused kernel
-    contigs, gk, spec = synth.config(cfg, scale=scale, genome_scale=gscale)
-    g = synth.make_genome(contigs, **gk)
-    b = synth.make_reads(g, spec)
-    check_against_oracle(g, b, spec.anchor_len, flags=flag)
-
-
 @pytest.mark.parametrize("cfg,scale,gscale", [(0, 0.05, 0.02), (1, 0.004, 0.002), (3, 0.001, 0.002)])
 def test_scaled_baseline_config_sorted_dedup(cfg, scale, gscale):
     # fragment-id dedup by the sorted-run kernels (the path of clusters above 256 members) instead of the in-wave form
@@ -231,16 +220,6 @@ def test_dedup_over_cluster_sizes(n_reads, n_events):
     check_against_oracle(g, b, 20, flags=BF_FLAG_SORTED_DEDUP)
     # three hash bits: different fragment ids meet in one hash group, the byte check fails, the wave redoes its cluster
     check_against_oracle(g, b, 20, flags=BF_FLAG_WEAK_DEDUP_HASH)
-
-
-@pytest.mark.parametrize("cfg,scale,gscale", [(0, 0.05, 0.02), (1, 0.004, 0.002), (3, 0.001, 0.002), (4, 0.002, 0.002)])
-def test_scaled_baseline_config_lsd_sort(cfg, scale, gscale):
-    """The round-1 ordering of the cluster stage (eight LSD radix passes + gathers), kept for A/B."""
-    contigs, gk, spec = synth.config(cfg, scale=scale, genome_scale=gscale)
-    g = synth.make_genome(contigs, **gk)
-    b = synth.make_reads(g, spec)
-    check_against_oracle(g, b, spec.anchor_len, flags=engine.BF_FLAG_LSD_SORT)
-    check_against_oracle(g, b, spec.anchor_len, flags=engine.BF_FLAG_LSD_SORT | BF_FLAG_GROUPS_ALWAYS)
 
 
 @pytest.mark.parametrize("bits", [None, "20", "9", "1"])
@@ -303,9 +282,9 @@ def test_soft_masked_and_n_reference():
     check_against_oracle(g, upper, 30, expect_exact=lambda x, n: 0 < x < n // 2)
 
 
-def test_heavily_soft_masked_genome_every_variant():
+def test_heavily_soft_masked_genome():
     # half of the genome in lowercase runs of 50..3000 bases, windows straddling run boundaries, every
-    # strand combination; shipped kernel and both A/B variants
+    # strand combination; the packed kernel and the byte-exact kernel
     rng = np.random.Generator(np.random.PCG64(17))
     contigs = [("chr1", 250000), ("chr2", 150000), ("chrM", 40000)]
     g = synth.make_genome(contigs, seed=15, end_n=500)
@@ -322,8 +301,7 @@ def test_heavily_soft_masked_genome_every_variant():
         # (reads drawn from the IUPAC stretch carry those codes themselves and go to the exact kernel)
         res, ref = check_against_oracle(g, b, A, expect_exact=lambda x, n: x < n // 50)
         assert ref.n_clusters > 20
-        for flag in (BF_FLAG_COOP_GATHER, BF_FLAG_SEPARATE_ENCODE):
-            check_against_oracle(g, b, A, flags=flag)
+        check_against_oracle(g, b, A, flags=BF_FLAG_FORCE_EXACT)
 
 
 def test_mixed_read_lengths_and_batches():

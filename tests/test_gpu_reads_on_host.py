@@ -103,10 +103,9 @@ def test_not_with_more_than_one_rank():
     try:
         eng.set_genome([b"c"], [np.frombuffer(b"ACGT" * 100, np.uint8)])
         with pytest.raises(engine.BreakfastError):
-            eng.set_rank(0, 2, 0)
-        with pytest.raises(engine.BreakfastError):
             eng.shard_init_rccl(0, 1, 0, engine.Engine.shard_unique_id())
-        eng.set_rank(0, 1, 0)
+        with pytest.raises(engine.BreakfastError):
+            eng.shard_init_host(0, 1, 0, "/bf_test_roh", 1 << 16)
     finally:
         eng.close()
 

@@ -193,6 +193,158 @@ def test_command_line_sharded_over_one_gpu(tmp_path, devices):
     assert b"Found 12000 rearrangement supporting reads." in p.stderr
 
 
+def run_as_threads(g, parts, bases, A, F=5000, E=2, flags=0, slot_bytes=8 << 20, name=None, delay=None, timeout=280):
+    """One thread and one ctx per rank on the test box's one GPU (the host transport), rank r holding parts[r] (a Batch, a
+    PackedBatch or None) whose first read is global read bases[r] -> the ranks' ShardResults."""
+    world = len(parts)
+    name = name or "/bf_test_%s" % uuid.uuid4().hex[:12]
+    results, errors = [None] * world, []
+
+    def work(rank):
+        try:
+            if delay:
+                import time
+                time.sleep(delay[rank])
+            eng = engine.Engine(A, F, E, device=0, flags=flags)
+            try:
+                eng.set_genome(g.names, g.seqs)
+                eng.shard_init_host(rank, world, int(bases[rank]), name, slot_bytes)
+                if parts[rank] is not None and parts[rank].n:
+                    eng.submit(parts[rank])
+                results[rank] = eng.shard_finish()
+            finally:
+                eng.close()
+        except Exception as e:                                   # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=timeout)
+    assert not errors, errors
+    assert all(x is not None for x in results), "a rank did not finish"
+    return results
+
+
+def merged(g, results, A, F=5000, E=2):
+    """the ranks' results as the reference's stdout: with a ctx, and by the ctx-free merge (what a process without a GPU
+    runs) -- the same bytes"""
+    eng = engine.Engine(A, F, E, device=0)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        sv = eng.shard_format_sv(results)
+    finally:
+        eng.close()
+    assert engine.shard_format_sv(g.names, results) == sv
+    return sv
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_config2_scaled_over_ranks(world):
+    """BASELINE configs[2] (100M reads as 16 blocks, sharded over 2/4/8 GPUs in contiguous input ranges), scaled to 400k reads
+    on 1.5 % of the genome: rank r holds the blocks bench.py gives it, through bf_shard_finish; merged table == oracle."""
+    contigs, gk, spec = synth.config(2, scale=0.004, genome_scale=0.015)
+    spec.margin = 10000 + 2 * spec.read_len + 128
+    g = synth.make_genome(contigs, **gk)
+    blocks = [synth.make_reads(g, synth.block_spec(spec, k)) for k in range(synth.BLOCKS)]
+    import test_gpu_submit as tgs
+    whole = tgs.concat(blocks)
+    ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, whole, spec.anchor_len, 5000, 2)
+    assert ref.n_clusters > 2000
+    parts = [tgs.concat([blocks[k] for k in synth.rank_blocks(r, world)]) for r in range(world)]
+    bases = [synth.block_first_read(spec, synth.rank_blocks(r, world)[0]) for r in range(world)]
+    results = run_as_threads(g, parts, bases, spec.anchor_len)
+    assert sum(x.n_local for x in results) == sum(x.n_evidence for x in results) == whole.n
+    assert merged(g, results, spec.anchor_len) == ref.sv
+
+
+def test_eight_ranks_uneven_empty_shards_and_a_hot_class():
+    """World size 8 (what configs[2] shards over): owner = mix64(class) % 8, arrival order = input order, merged print
+    order; uneven shards, two of them empty, one holding a single read; a third of the reads on two hot junctions, so
+    two classes own most of the evidence and ownership is skewed."""
+    contigs = [("chr1", 90000), ("chr10", 70000), ("chr2", 80000), ("chrX", 60000)]
+    g = synth.make_genome(contigs, seed=51)
+    spec = synth.ReadSpec(n_reads=1600, read_len=80, anchor_len=20, n_events=40, singleton_frac=0.2, mate_frac=0.6,
+                          hot_frac=0.35, hot_events=2, seed=53, margin=300)
+    b = synth.make_reads(g, spec)
+    n = b.n
+    ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, 20, 5000, 2)
+    assert ref.n_clusters > 10
+    cuts = [0, n // 3, n // 3 + 1, n // 3 + 1, n // 2, (3 * n) // 4, (3 * n) // 4, (7 * n) // 8, n]
+    parts = [b.slice(cuts[r], cuts[r + 1]) if cuts[r + 1] > cuts[r] else None for r in range(8)]
+    for flags in (0, engine.BF_FLAG_GROUPS_ALWAYS):
+        results = run_as_threads(g, parts, cuts[:8], 20, flags=flags, slot_bytes=1 << 16)
+        owned = [x.n_evidence for x in results]
+        assert sum(owned) == n and max(owned) > 3 * (n // 16), owned    # the hot classes make ownership uneven
+        assert [x.n_local for x in results] == [cuts[r + 1] - cuts[r] for r in range(8)]
+        assert merged(g, results, 20) == ref.sv
+
+
+def test_two_ranks_at_half_a_million_reads():
+    contigs, gk, spec = synth.config(1, scale=0.05, genome_scale=0.05)      # 500k reads, 154 Mb genome, 25 contigs
+    spec.margin = 10000 + 2 * spec.read_len + 128
+    g = synth.make_genome(contigs, **gk)
+    b = synth.make_reads(g, spec)
+    ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, spec.anchor_len, 5000, 2)
+    assert ref.n_clusters > 3000
+    cuts = [0, (2 * b.n) // 5, b.n]
+    results = run_as_threads(g, [b.slice(cuts[0], cuts[1]), b.slice(cuts[1], cuts[2])], cuts[:2], spec.anchor_len)
+    assert merged(g, results, spec.anchor_len) == ref.sv
+
+
+def test_scaffold_rich_genome_in_groups():
+    """More contigs than one launch of the owners' rank histogram counts (4096 bins of LDS; the key has room for 16384
+    contigs): the contig groups of the sharded path must still cut the imported records by left contig rank."""
+    n_contigs = 5000
+    contigs = [("scaf%05d" % i, 2500) for i in range(n_contigs)]
+    g = synth.make_genome(contigs, seed=91)
+    spec = synth.ReadSpec(n_reads=20000, read_len=100, anchor_len=20, n_events=600, singleton_frac=0.3, mate_frac=0.3,
+                          deletion_frac=0.2, seed=93, margin=120)
+    b = synth.make_reads(g, spec)
+    ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, 20, 5000, 2)
+    assert ref.n_clusters > 300
+    left = np.minimum(b.hits["contig5"], b.hits["contig3"])                  # (names sort like their numbers here)
+    assert int(left.max()) > 4096                                            # reads whose rank lies in the second window
+    cuts = [0, b.n // 2, b.n]
+    results = run_as_threads(g, [b.slice(0, cuts[1]), b.slice(cuts[1], b.n)], cuts[:2], 20, flags=engine.BF_FLAG_GROUPS_ALWAYS)
+    assert all(len(x.group_read_begin) == 3 for x in results)               # two groups each
+    assert merged(g, results, 20) == ref.sv
+    # and the one-GPU path on the same genome (its histogram comes from bf_submit's staging threads)
+    eng = engine.Engine(20, 5000, 2, flags=engine.BF_FLAG_GROUPS_ALWAYS)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        eng.submit(b)
+        assert eng.format_sv(eng.finish()) == ref.sv
+    finally:
+        eng.close()
+
+
+def test_a_stale_segment_of_a_crashed_run_is_not_joined():
+    """A segment of the same name and shape with `ready` set, left by a run that died: a rank that opens the name before
+    rank 0 has replaced it must not settle there (it says hello and nobody answers), but find the new segment."""
+    import struct
+    g, b, A, F, E = make_case(n_reads=3000)
+    ref = oracle_sv(g, b, A, F, E)
+    name = "/bf_test_%s" % uuid.uuid4().hex[:12]
+    slot = 1 << 16
+    size = 4096 + 2 * 4096 * 8 + 2 * slot
+    with open("/dev/shm" + name, "wb") as f:
+        f.truncate(size)
+        f.seek(0)
+        f.write(struct.pack("<IIIIQQ", 0xbf5a4d31, 0, 0, 2, slot, 4096))     # ShmHeader: ready, arrived, sense, n_ranks, slot_bytes, ctl_words
+    try:
+        cuts = [0, b.n // 2, b.n]
+        # rank 1 arrives first and finds the stale segment; rank 0 replaces it half a second later
+        results = run_as_threads(g, [b.slice(0, cuts[1]), b.slice(cuts[1], b.n)], cuts[:2], A, slot_bytes=slot, name=name, delay=[0.6, 0.0])
+        assert merged(g, results, A) == ref
+    finally:
+        try:
+            os.unlink("/dev/shm" + name)
+        except FileNotFoundError:
+            pass
+
+
 def test_two_ranks_with_owners_large_enough_for_two_groups(tmp_path):
     """From 4M records per owner on the owners cluster in two contig groups by themselves (the sources render and copy a
     group's records while the next one is clustered).  9M reads over two ranks (threads, host transport), the merged .sv

@@ -81,6 +81,37 @@ def test_static_scratch_entry_point_matches_the_allocating_one():
         other.close()
 
 
+def test_static_scratch_entry_point_allocates_nothing():
+    """What the entry point is for: after a warm-up call, calls of any size up to the limit leave the ctx's device memory
+    (bf_stats: every hipMalloc of the library goes through one book-keeping function) and the GPU's free memory as they were."""
+    g, b = make_case()
+    dev = torch.device("cuda", 0)
+    eng = engine.Engine(20, 5000, 2, device=0)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        eng.submit(b)
+        eng.localise()
+        rng = np.random.default_rng(12)
+        sizes = (100, 40000, 7, 25000)
+        # every torch tensor up front: torch's allocator must not move the GPU's free memory during the measured calls
+        idx = {n: torch.from_numpy(rng.integers(0, b.n, size=n).astype(np.int32)).to(dev) for n in sizes}
+        off = torch.zeros(max(sizes) + 1, dtype=torch.int64, device=dev)
+        cap = max(sizes) * eng.junction_record_bound() + 64
+        out = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        eng.render_junctions_dev_static(sizes[0], idx[sizes[0]].data_ptr(), off.data_ptr(), out.data_ptr(), cap)      # warm-up
+        torch.cuda.synchronize()
+        held = eng.stats()[1]
+        free0 = torch.cuda.mem_get_info(dev)[0]
+        for n in sizes[1:]:
+            assert eng.render_junctions_dev_static(n, idx[n].data_ptr(), off.data_ptr(), out.data_ptr(), cap) > 0
+            assert eng.stats()[1] == held, "the static entry point grew the ctx's device memory"
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(dev)[0] == free0, "the GPU's free memory changed across the static calls"
+        # (the allocating entry point, for contrast, is allowed to: its buffers grow with the list)
+    finally:
+        eng.close()
+
+
 def test_static_scratch_entry_point_limits_and_errors():
     g, b = make_case()
     dev = torch.device("cuda", 0)
