@@ -152,7 +152,7 @@ static void free_all(bf_ctx* ctx) {
         &ctx->c_slpos, &ctx->c_srpos, &ctx->c_reported, &ctx->c_csize, &ctx->c_flag, &ctx->c_scan, &ctx->c_qseed,
         &ctx->c_qsize, &ctx->c_qoff, &ctx->c_members, &ctx->c_leader, &ctx->c_rep, &ctx->c_qnrep, &ctx->c_ctl, &ctx->c_sel,
         &ctx->c_ord, &ctx->c_clusters, &ctx->c_reads, &ctx->c_misc, &ctx->c_joff, &ctx->c_jbytes, &ctx->c_rsrc,
-        &ctx->c_tables, &ctx->c_mkey_s, &ctx->c_slot, &ctx->c_big, &ctx->c_cjo, &ctx->c_aoff, &ctx->c_err, &ctx->c_tmp2, &ctx->c_qord, &ctx->c_gidx, &ctx->c_hist, &ctx->c_comp, &ctx->c_bstart, &ctx->c_chunk, &ctx->c_pos2, &ctx->c_desc, &ctx->c_desc2, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
+        &ctx->c_tables, &ctx->c_mkey_s, &ctx->c_slot, &ctx->c_big, &ctx->c_cjo, &ctx->c_aoff, &ctx->c_err, &ctx->c_tmp2, &ctx->c_qord, &ctx->c_gidx, &ctx->c_hist, &ctx->c_comp, &ctx->c_bstart, &ctx->c_chunk, &ctx->c_pos2, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
     for (DevBuf* b : all) release(ctx, *b);
     HostBuf* hosts[] = {&ctx->out.clusters, &ctx->out.reads, &ctx->out.src, &ctx->out.junction, &ctx->out.cjo};
     for (HostBuf* h : hosts) { if (h->p) (void)hipHostFree(h->p); h->p = nullptr; h->cap = 0; }
@@ -358,7 +358,8 @@ int bf_ctx_create(const bf_config* cfg, bf_ctx** out) {
         ctx->host_threads = cfg->reserved[1] ? std::min<uint32_t>(cfg->reserved[1], 64u) : std::max(1u, std::min(hw ? hw : 1u, 16u));
     }
     for (auto& e2 : ctx->ev) ok = ok && hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&ctx->h_counts, 64, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&ctx->h_counts, 64 + kMailWords * 8, hipHostMallocDefault) == hipSuccess;
+    if (ok) { memset(ctx->h_counts, 0, 64 + kMailWords * 8); ctx->h_mail = (uint64_t*)(ctx->h_counts + 16); }
     if (!ok) { bf_ctx_destroy(ctx); return fail(nullptr, BF_ERR_HIP, "could not create the copy stream / events"); }
     if (scratch_setup(ctx) != BF_OK) {               // the device is current (hipSetDevice above)
         const std::string why = ctx->err;
@@ -1012,6 +1013,7 @@ static int clusterise_in_groups(bf_ctx* ctx, const OwnerView& v, bool* done) {
     uint64_t cl_base = 0, rd_base = 0, byte_base = 0;
     for (size_t g = 0; g + 1 < gb.size(); g++) {
         ClusterGroup grp{ctx->c_gidx.as<uint32_t>() + gb[g], gb[g + 1] - gb[g], cl_base, rd_base, v.n};
+        grp.g = (int)g;
         BF_TRY(run_cluster(ctx, v, &grp));
         if (!grp.nr) continue;
         const uint64_t stride = ctx->rsrc_stride;

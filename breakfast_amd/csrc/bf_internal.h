@@ -303,7 +303,15 @@ struct bf_ctx {
     uint64_t n_exact = 0;
     uint64_t n_sigx = 0;                        // evidence whose signature holds a non-ACGT byte
     uint64_t n_text_records = 0;                // resident reads whose junction record cannot be packed
-    uint32_t* h_counts = nullptr;               // pinned, 64 B (bf_ctx_create): words 0-2 the localise kernels' counters on their way
+    uint64_t* h_mail = nullptr;                 // pinned (behind h_counts): kMailWords 64-bit words the cluster stage's counts come
+                                                // back in -- several device words queued with mail_fetch(), ONE wait for all of them
+                                                // (a copy into pageable memory is a round trip of its own, ~25 us of idle GPU each)
+    std::vector<uint64_t> tables_key;           // what c_tables holds (index bases + contig count): uploaded when it changes
+    std::vector<std::pair<uint32_t, uint32_t>> group_ranks;   // cluster_groups: first and last left contig rank of every group
+    bool order_full = false;                    // the short print-order sort met something it does not handle (long tie runs, a
+                                                // position outside its mapped range): the ctx uses the full two-sort order from then on
+    bool saw_overflow = false;                  // a chunk too large for the LDS sort has come up: class_order waits for the count again
+    uint32_t* h_counts = nullptr;               // pinned (bf_ctx_create): words 0-2 the localise kernels' counters on their way
                                                 // to the three fields above, words 8-11 the read-backs of bf_render_junctions_dev_static
     void* scratch = nullptr;                    // this device's copy of the static scratch array (localise.hip, scratch_setup)
     void* shard = nullptr;                      // bf::Shard (shard.hip): transport and buffers of the in-library sharded path
@@ -330,8 +338,6 @@ struct bf_ctx {
     bf::DevBuf c_tmp, c_a32, c_b32, c_c32, c_d32, c_k64a, c_k64b, c_slpos, c_srpos, c_reported,
         c_csize, c_flag, c_scan, c_qseed, c_qsize, c_qoff, c_members, c_leader, c_rep, c_qnrep,
         c_ctl, c_sel, c_ord, c_clusters, c_reads, c_misc, c_pos2, c_joff, c_jbytes, c_rsrc, c_tables, c_mkey_s, c_slot, c_big, c_cjo, c_aoff, c_err, c_tmp2, c_qord, c_gidx, c_hist, c_comp, c_bstart, c_chunk;
-    bf::DevBuf c_desc, c_desc2;                 // tile descriptors of the one-launch scans (primitives.hip): main / side stream
-    uint32_t scan_epoch = 0, scan_epoch2 = 0;   // ... and the epoch of the last scan on each
     bf::ClusterOut out;
     std::vector<uint64_t> render_off_host;
     std::vector<uint8_t> render_bytes_host;
@@ -379,6 +385,12 @@ struct TraceCall {
 };
 #define BF_TRACE_CALL(ctx) bf::TraceCall trace_call_(ctx, __func__)
 
+constexpr int kMailWords = 32;
+// queues the copy of n 64-bit device words into mailbox slots [slot, slot + n); valid after the next wait for ctx->stream
+inline int mail_fetch(bf_ctx* ctx, int slot, const void* d_src, int n = 1) {
+    BF_HIP(ctx, hipMemcpyAsync(ctx->h_mail + slot, d_src, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return BF_OK;
+}
 int ensure(bf_ctx* ctx, DevBuf& b, size_t bytes, bool keep = false);
 int ensure_host(bf_ctx* ctx, HostBuf& b, size_t bytes);
 void release(bf_ctx* ctx, DevBuf& b);
@@ -394,12 +406,8 @@ struct Scope {
 // sort / scan workspace c_tmp) goes to the side stream with a workspace of its own instead.
 struct OnSideStream {
     bf_ctx* ctx;
-    explicit OnSideStream(bf_ctx* c) : ctx(c) { flip(); }
-    ~OnSideStream() { flip(); }
-    void flip() {
-        std::swap(ctx->stream, ctx->side_stream); std::swap(ctx->c_tmp, ctx->c_tmp2);
-        std::swap(ctx->c_desc, ctx->c_desc2); std::swap(ctx->scan_epoch, ctx->scan_epoch2);
-    }
+    explicit OnSideStream(bf_ctx* c) : ctx(c) { std::swap(ctx->stream, ctx->side_stream); std::swap(ctx->c_tmp, ctx->c_tmp2); }
+    ~OnSideStream() { std::swap(ctx->stream, ctx->side_stream); std::swap(ctx->c_tmp, ctx->c_tmp2); }
 };
 
 // localise.hip ----------------------------------------------------------------------------------
@@ -433,6 +441,7 @@ struct ClusterGroup {
     const uint32_t* idx; uint64_t m;
     uint64_t cl_base, rd_base, cap;
     uint64_t ns = 0, nr = 0;           // out: clusters and supporting reads this group added
+    int g = -1;                        // the group's number in the cut cluster_groups made (ctx->group_ranks[g]: its contig ranks)
 };
 int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::vector<uint64_t>& bounds, uint64_t* record_bytes,
                    const std::vector<uint64_t>* view_hist = nullptr);   // view_hist: records per left contig rank of an imported view

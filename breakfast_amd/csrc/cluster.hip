@@ -39,10 +39,6 @@ static int fetch_u64(bf_ctx* ctx, const uint64_t* d, uint64_t* h) {
 }
 
 // ---- small kernels ----------------------------------------------------------------------------
-__global__ void iota_kernel(uint32_t* out, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (uint32_t)i;
-}
 __global__ void gather_key_kernel(uint64_t* out, const uint64_t* __restrict__ in, const uint32_t* __restrict__ idx, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[idx[i]];
@@ -99,9 +95,15 @@ constexpr uint32_t kCtlWords = 16;       // head of c_big: two list lengths, the
 // compares the whole key, like detect.rs:218-223 compares every field, and the break test on lpos stays monotone.
 __device__ __forceinline__ uint32_t seg_of(uint64_t key) { return (uint32_t)key; }
 
-__global__ void __launch_bounds__(256) head_mark_kernel(const uint64_t* __restrict__ skey, uint32_t* __restrict__ head, uint64_t n) {
+// (also clears what the sweep starts from -- reported[], csize[], the control words -- instead of three memset launches)
+__global__ void __launch_bounds__(256) head_mark_kernel(const uint64_t* __restrict__ skey, uint32_t* __restrict__ head, uint64_t n,
+                                                        uint8_t* __restrict__ reported, uint32_t* __restrict__ csize, uint32_t* __restrict__ ctl) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) head[i] = (i == 0 || seg_of(skey[i - 1]) != seg_of(skey[i])) ? (uint32_t)i : 0u;
+    if (i < kCtlWords) ctl[i] = 0;
+    if (i < n) {
+        head[i] = (i == 0 || seg_of(skey[i - 1]) != seg_of(skey[i])) ? (uint32_t)i : 0u;
+        reported[i] = 0; csize[i] = 0;
+    }
 }
 
 __global__ void __launch_bounds__(256) covered_kernel(const SweepView v, const uint32_t* __restrict__ head,
@@ -131,12 +133,12 @@ __global__ void __launch_bounds__(256) tails_kernel(const SweepView v, const uin
 }
 
 // one lane per listed short segment: the reference's two loops as they are
-__global__ void __launch_bounds__(64) sweep_list_kernel(const SweepView v, uint8_t* __restrict__ reported,
-                                                        uint32_t* __restrict__ csize, const uint32_t* __restrict__ small_list,
-                                                        const uint32_t* __restrict__ counts) {
+__device__ __forceinline__ void sweep_list_part(const SweepView& v, uint8_t* __restrict__ reported,
+                                                uint32_t* __restrict__ csize, const uint32_t* __restrict__ small_list,
+                                                const uint32_t* __restrict__ counts, uint32_t block, uint32_t n_blocks) {
     // fixed grid; the list's length stays on the device (no host round trip between tails_kernel and this one)
     const uint32_t n_small = counts[0];
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_small; k += gridDim.x * blockDim.x) {
+    for (uint32_t k = block * blockDim.x + threadIdx.x; k < n_small; k += n_blocks * blockDim.x) {
     const uint64_t i = small_list[k];
     const uint32_t seg = seg_of(v.skey[i]);
     uint64_t e = i + 1;
@@ -161,11 +163,12 @@ __global__ void __launch_bounds__(64) sweep_list_kernel(const SweepView v, uint8
 
 // One wave per long segment: seeds are still taken in order (the sweep is sequential in the seeds),
 // but finding the next unreported read and testing a seed's window run 64 reads at a time.
-__global__ void __launch_bounds__(256) sweep_big_kernel(const SweepView v, uint8_t* reported, uint32_t* __restrict__ csize,
-                                                        const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ counts) {
+__device__ __forceinline__ void sweep_big_part(const SweepView& v, uint8_t* reported, uint32_t* __restrict__ csize,
+                                               const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ counts,
+                                               uint32_t block, uint32_t n_blocks) {
     const int lane = threadIdx.x & 63;
-    const uint32_t n_big = counts[1], n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < n_big; b += n_waves) {      // wave-uniform
+    const uint32_t n_big = counts[1], n_waves = (n_blocks * blockDim.x) >> 6;
+    for (uint32_t b = (block * blockDim.x + threadIdx.x) >> 6; b < n_big; b += n_waves) {      // wave-uniform
     const uint64_t i = big_list[b];
     const uint32_t seg = seg_of(v.skey[i]);
     uint64_t e = i;                                          // segment end
@@ -201,6 +204,16 @@ __global__ void __launch_bounds__(256) sweep_big_kernel(const SweepView v, uint8
         cursor = p + 1;
     }
     }
+}
+
+// Both walks in one launch (the lists are usually short, a launch of its own cost each 6 us of nothing): the first
+// `list_blocks` workgroups take the short segments a lane each, the others the long ones a wave each.  Different
+// segments, so the two halves never touch the same records.
+__global__ void __launch_bounds__(256) sweep_walk_kernel(const SweepView v, uint8_t* reported, uint32_t* __restrict__ csize,
+                                                         const uint32_t* __restrict__ small_list, const uint32_t* __restrict__ big_list,
+                                                         const uint32_t* __restrict__ counts, uint32_t list_blocks) {
+    if (blockIdx.x < list_blocks) sweep_list_part(v, reported, csize, small_list, counts, blockIdx.x, list_blocks);
+    else sweep_big_part(v, reported, csize, big_list, counts, blockIdx.x - list_blocks, gridDim.x - list_blocks);
 }
 
 // flag[i] = val[i] >= thr, and the sums the host needs to size what follows, so that they come along with the
@@ -243,10 +256,16 @@ __global__ void compact_seeds_kernel(const uint32_t* __restrict__ flag, const ui
         qseed[q] = (uint32_t)i; qsize[q] = c; qbig[q] = c > wave_max ? c : 0u;
     }
 }
+// out[k] = value[i] (or i) of the k-th flagged i; with `look`: out2[k] = look[out[k]] as well (one launch instead of two)
 __global__ void compact_index_kernel(const uint32_t* __restrict__ flag, const uint64_t* __restrict__ scan,
-                                     uint32_t* out, uint64_t n, const uint32_t* __restrict__ value = nullptr) {
+                                     uint32_t* out, uint64_t n, const uint32_t* __restrict__ value = nullptr,
+                                     const uint32_t* __restrict__ look = nullptr, uint32_t* __restrict__ out2 = nullptr) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && flag[i]) out[scan[i]] = value ? value[i] : (uint32_t)i;
+    if (i < n && flag[i]) {
+        const uint32_t x = value ? value[i] : (uint32_t)i;
+        out[scan[i]] = x;
+        if (look) out2[scan[i]] = look[x];
+    }
 }
 
 // Hash bits in the member sort key: enough to keep runs of equal keys short (a cluster rarely holds
@@ -495,21 +514,63 @@ struct OrderView {
     const uint32_t* qseed; const uint64_t* skey; const int32_t* slpos; const uint32_t* perm;
     const uint32_t* src_rank; const uint32_t* src_idx; int cb;
 };
+// The short print-order sort.  The order is (contig rank, lpos as the wrapped usize, input index of the seed): 5 + 32 + 24
+// and more significant bits, eight 8-bit passes in two sorts of ~50k keys each, sixteen launches at the latency floor --
+// longer than the dedup kernels they run beside.  Here: ONE sort on the bits that can differ -- the rank relative to the
+// group's first rank, and the position mapped into [0, 2^pos_bits): non-negative positions as they are, the few negative
+// ones (the reference's wrapped usize: they sort AFTER every real position, among themselves by value) at the top of the
+// range -- 32 bits for hg38 in two groups, four passes; the input index then only orders the rare seeds that share
+// contig and position, which a fix-up pass does run by run.  What the short form does not handle (a position outside the
+// mapped range, a tie run longer than kTieMax) raises a flag, and the ctx falls back to the two full sorts for good.
+constexpr uint32_t kTieMax = 64;
+constexpr int32_t kNegRoom = 1 << 18;                      // lpos >= -(65535 + 32767): room for the negative positions
+struct ShortOrder { uint32_t rank_lo; int pos_bits; uint32_t* flag; };
+__global__ void cluster_keys_short_kernel(const OrderView o, uint64_t* kpos, uint64_t* kidx, uint32_t* __restrict__ iota, uint64_t nq, ShortOrder so) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nq) return;
+    iota[k] = (uint32_t)k;
+    const uint32_t p = o.qseed[k];
+    const uint32_t rec = o.perm[p];
+    const int32_t lp = o.slpos[p];
+    const int64_t top = (int64_t)1 << so.pos_bits;
+    int64_t m = lp >= 0 ? (int64_t)lp : top + lp;
+    if ((lp >= 0 && m >= top - kNegRoom) || (lp < 0 && lp < -kNegRoom)) { atomicOr(so.flag, 1u); m = 0; }
+    const uint64_t rank = (o.skey[p] >> key_rank_shift(o.cb)) - so.rank_lo;
+    kpos[k] = (rank << so.pos_bits) | (uint64_t)m;
+    const uint64_t sr = o.src_rank ? o.src_rank[rec] : 0, si = o.src_idx ? o.src_idx[rec] : rec;
+    kidx[k] = (sr << 32) | si;
+}
+// qord[] is in (rank, position) order, stable on the sorted-space order of the seeds; a run of equal keys is put into
+// input-index order by the thread at its head
+__global__ void order_ties_kernel(const uint64_t* __restrict__ skeys, uint32_t* __restrict__ qord, const uint64_t* __restrict__ kidx,
+                                  uint64_t nq, uint32_t* flag) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nq) return;
+    const uint64_t key = skeys[k];
+    if ((k > 0 && skeys[k - 1] == key) || k + 1 >= nq || skeys[k + 1] != key) return;      // not the head of a run of two or more
+    uint64_t e = k + 2;
+    while (e < nq && e - k <= kTieMax && skeys[e] == key) e++;
+    if (e - k > kTieMax) { atomicOr(flag, 2u); return; }
+    for (uint64_t a = k + 1; a < e; a++) {                   // insertion sort on the seeds' input indices
+        const uint32_t q = qord[a];
+        const uint64_t x = kidx[q];
+        uint64_t b = a;
+        while (b > k && kidx[qord[b - 1]] > x) { qord[b] = qord[b - 1]; b--; }
+        qord[b] = q;
+    }
+}
+
 // sort keys of surviving clusters: (contig rank, lpos as sorted, input order of the seed)
-__global__ void cluster_keys_kernel(const OrderView o, const uint32_t* __restrict__ sel, uint64_t* kpos, uint64_t* kidx, uint64_t ns) {
+__global__ void cluster_keys_kernel(const OrderView o, const uint32_t* __restrict__ sel, uint64_t* kpos, uint64_t* kidx, uint32_t* __restrict__ iota, uint64_t ns) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ns) return;
+    iota[k] = (uint32_t)k;                                  // the sort's values
     const uint32_t p = o.qseed[sel ? sel[k] : k];
     const uint32_t rec = o.perm[p];
     kpos[k] = ((o.skey[p] >> key_rank_shift(o.cb)) << 32) | (uint32_t)o.slpos[p];
     const uint64_t sr = o.src_rank ? o.src_rank[rec] : 0, si = o.src_idx ? o.src_idx[rec] : rec;
     kidx[k] = (sr << 32) | si;
 }
-__global__ void gather_u32_kernel(uint32_t* out, const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[idx[i]];
-}
-
 struct EmitView {
     const uint32_t* ord;        // output order -> q
     const uint64_t* roff;       // output order -> first supporting read
@@ -587,10 +648,10 @@ __global__ void __launch_bounds__(256) record_bytes_kernel(const uint64_t* __res
     __syncthreads();
     if (threadIdx.x == 0 && w[0] + w[1] + w[2] + w[3]) atomicAdd(sum, w[0] + w[1] + w[2] + w[3]);
 }
-__global__ void group_id_kernel(uint32_t* __restrict__ gid, const uint64_t* __restrict__ key, const uint8_t* __restrict__ group_of_rank,
-                                int shift, uint32_t mask, uint64_t n) {
+__global__ void group_id_kernel(uint32_t* __restrict__ gid, uint32_t* __restrict__ iota, const uint64_t* __restrict__ key,
+                                const uint8_t* __restrict__ group_of_rank, int shift, uint32_t mask, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) gid[i] = group_of_rank[(uint32_t)(key[i] >> shift) & mask];
+    if (i < n) { gid[i] = group_of_rank[(uint32_t)(key[i] >> shift) & mask]; iota[i] = (uint32_t)i; }
 }
 // -> bounds: positions in c_gidx (record ids ordered by contig rank, input order inside) where the groups start;
 // one group (bounds = {0, n}) when there is nothing to gain.  The reads per left contig rank are known on the host
@@ -643,8 +704,11 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
     bounds.assign(1, 0);
     uint64_t run = 0;
     std::vector<uint8_t> group_of(ctx->n_contigs, 0);
+    ctx->group_ranks.clear();
     for (uint32_t r = 0; r < ctx->n_contigs; r++) {
         group_of[r] = (uint8_t)(bounds.size() - 1);
+        if (ctx->group_ranks.size() < bounds.size()) ctx->group_ranks.emplace_back(r, r);
+        ctx->group_ranks.back().second = r;
         run += rank_hist[r];
         if (run >= n * bounds.size() / max_groups && run > bounds.back() && run < n && bounds.size() < 255) bounds.push_back(run);
     }
@@ -654,9 +718,8 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
     BF_HIP(ctx, hipMemsetAsync(ctx->c_hist.p, 0, 8, st));
     hipLaunchKernelGGL(record_bytes_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, 256), 1024)), dim3(256), 0, st, v.info, n,
                        (unsigned long long*)ctx->c_hist.p);
-    BF_HIP(ctx, hipMemcpyAsync(record_bytes, ctx->c_hist.p, 8, hipMemcpyDeviceToHost, st));
+    BF_TRY(mail_fetch(ctx, 0, ctx->c_hist.p));            // read after the wait at the end: no round trip of its own
     if (bounds.size() > 2) {
-        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, ctx->c_c32.as<uint32_t>(), n);
         const unsigned shift = (unsigned)key_rank_shift(ctx->contig_bits);
         {
             // record ids ordered by GROUP, input order inside: a group's ids ascend, so what reads the records through them
@@ -664,8 +727,8 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
             BF_TRY(ensure(ctx, ctx->c_a32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_b32, n * 4, false));
             uint8_t* d_tab = ctx->c_hist.as<uint8_t>() + 64;
             BF_HIP(ctx, hipMemcpyAsync(d_tab, group_of.data(), ctx->n_contigs, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(group_id_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, ctx->c_b32.as<uint32_t>(), v.key, d_tab, (int)shift,
-                               (1u << ctx->contig_bits) - 1, n);
+            hipLaunchKernelGGL(group_id_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, ctx->c_b32.as<uint32_t>(), ctx->c_c32.as<uint32_t>(), v.key,
+                               d_tab, (int)shift, (1u << ctx->contig_bits) - 1, n);
             unsigned gbits = 1;
             while ((1u << gbits) < bounds.size() - 1) gbits++;
             BF_TRY(sort_pairs<uint32_t>(ctx, ctx->c_b32.as<uint32_t>(), ctx->c_a32.as<uint32_t>(), ctx->c_c32.as<uint32_t>(),
@@ -673,6 +736,7 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
         }
     }
     BF_SYNC(ctx, st);                                     // (group_of is read by the copy above until here)
+    *record_bytes = ctx->h_mail[0];
     BF_TRY(settle_counts(ctx));                           // the localise counters came along with this synchronisation
     return BF_OK;
 }
@@ -751,7 +815,14 @@ __global__ void __launch_bounds__(256) chunk_sort_kernel(const uint32_t* __restr
     if (size == 0) return;
     const uint64_t ob = obefore[c];
     if (size > kChunkCap) {                                      // set aside, in order (stable)
-        for (uint32_t r = t; r < size; r += 256) { side_comp[ob + r] = comp[s + r]; side_val[ob + r] = val[s + r]; }
+        // ... and copied, unsorted, to where the side sort will put them: the stage runs on without waiting for the count
+        // of such records (usually none); should there be some, what follows reads valid records and is redone
+        const uint64_t tail = (uint64_t)cstart[gridDim.x] - obefore[gridDim.x];
+        for (uint32_t r = t; r < size; r += 256) {
+            const uint64_t cc = comp[s + r]; const RsV3 vv = val[s + r];
+            side_comp[ob + r] = cc; side_val[ob + r] = vv;
+            put_sorted(out, tail + ob + r, cc, vv);
+        }
         return;
     }
     uint32_t P = 64;
@@ -791,7 +862,9 @@ __global__ void side_write_kernel(const uint64_t* __restrict__ comp, const RsV3*
 }
 
 // records [0, m) of the group (idx: their ids, or null = all of the view) -> sorted space
-static int class_order(bf_ctx* ctx, const OwnerView& v, const uint32_t* idx, uint64_t m, const SortedOut& out) {
+// wait_over: wait for the number of set-aside records and sort them (one host round trip); otherwise the count is left
+// in mailbox slot 3 for the caller's next wait, and the caller redoes the stage with wait_over should it not be zero.
+static int class_order(bf_ctx* ctx, const OwnerView& v, const uint32_t* idx, uint64_t m, const SortedOut& out, bool wait_over) {
     const hipStream_t st = ctx->stream;
     const unsigned B = 256;
     int bits = m > (16u << 20) ? 20 : 16;
@@ -821,6 +894,10 @@ static int class_order(bf_ctx* ctx, const OwnerView& v, const uint32_t* idx, uin
     hipLaunchKernelGGL(chunk_sort_kernel, dim3(n_chunks), dim3(256), 0, st, cstart, obefore, comp_s, val_s, out, comp_in, val_in);
     BF_HIP(ctx, hipGetLastError());
     uint64_t n_over = 0;
+    if (!wait_over) {                                   // the caller reads mailbox slot 3 at its next wait (usually zero)
+        BF_TRY(mail_fetch(ctx, 3, obefore + n_chunks));
+        return BF_OK;
+    }
     BF_TRY(fetch_u64(ctx, obefore + n_chunks, &n_over));
     if (n_over) {
         if (n_over > m) return fail(ctx, BF_ERR_HIP, "class order: %llu records set aside out of %llu", (unsigned long long)n_over, (unsigned long long)m);
@@ -832,7 +909,22 @@ static int class_order(bf_ctx* ctx, const OwnerView& v, const uint32_t* idx, uin
 }
 
 // ---- the cluster stage -----------------------------------------------------------------------
+static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, bool wait_over, bool* redo);
+
+// The stage does not wait for the count of records the LDS chunk sort had to set aside (a signature with more than 1024
+// records: duplicate-heavy libraries); the count comes back with the sweep's own wait.  Should it not be zero, the stage is
+// done again for this group with the wait, and the ctx waits from then on (such inputs have them in every group).
 int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
+    for (int attempt = 0; attempt < 3; attempt++) {       // (each reason for a second go turns itself off)
+        bool redo = false;
+        BF_TRY(run_cluster_once(ctx, v, grp, ctx->saw_overflow, &redo));
+        if (!redo) return BF_OK;
+    }
+    return fail(ctx, BF_ERR_STATE, "the cluster stage asked for another go three times");
+}
+
+static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, bool wait_over, bool* redo) {
+    *redo = false;
     const uint64_t n = grp ? grp->m : v.n;                 // records in sorted space; record ids stay v's
     hipStream_t st = ctx->stream;
     if (!grp || grp->cl_base + grp->rd_base == 0) {
@@ -857,7 +949,7 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
     {
         Scope t(ctx, "sort");
         const SortedOut so{ctx->c_k64b.as<uint64_t>(), ctx->c_slpos.as<int32_t>(), ctx->c_srpos.as<int32_t>(), perm};
-        BF_TRY(class_order(ctx, v, grp ? grp->idx : nullptr, n, so));
+        BF_TRY(class_order(ctx, v, grp ? grp->idx : nullptr, n, so, wait_over));
     }
     BF_HIP(ctx, hipGetLastError());
 
@@ -878,30 +970,34 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
         // lists of segments that need a walk: counts[0] short ones, counts[1] long ones
         // c_big: counts[2], then four 64-bit sums (flag_ge_kernel), then the lists
         BF_TRY(ensure(ctx, ctx->c_big, (n + n / kBigSegment + 8 + kCtlWords) * 4));
-        BF_HIP(ctx, hipMemsetAsync(ctx->c_reported.p, 0, n, st));
-        BF_HIP(ctx, hipMemsetAsync(ctx->c_csize.p, 0, n * 4, st));
-        BF_HIP(ctx, hipMemsetAsync(ctx->c_big.p, 0, kCtlWords * 4, st));
         uint32_t* counts = ctx->c_big.as<uint32_t>();
         sums = (unsigned long long*)(counts + 2);
         uint32_t* big_list = counts + kCtlWords; uint32_t* small_list = big_list + n / kBigSegment + 2;
         uint32_t* head = ctx->c_flag.as<uint32_t>();          // reused for the min_evidence flags below
         uint32_t* covered = ctx->c_b32.as<uint32_t>();        // free since the sort
-        hipLaunchKernelGGL(head_mark_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, sv.skey, head, n);
+        hipLaunchKernelGGL(head_mark_kernel, dim3(grid_for(std::max<uint64_t>(n, kCtlWords), B)), dim3(B), 0, st, sv.skey, head, n,
+                           ctx->c_reported.as<uint8_t>(), ctx->c_csize.as<uint32_t>(), counts);
         BF_TRY(scan_max_u32_inplace(ctx, head, n));
         hipLaunchKernelGGL(covered_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, sv, head, covered);
         BF_TRY(scan_u32_to_u64(ctx, covered, ctx->c_scan.as<uint64_t>(), n));
         hipLaunchKernelGGL(tails_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, sv, head, ctx->c_scan.as<uint64_t>(),
                            ctx->c_csize.as<uint32_t>(), small_list, big_list, counts);
-        hipLaunchKernelGGL(sweep_list_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, 64), 4096)), dim3(64), 0, st, sv,
-                           ctx->c_reported.as<uint8_t>(), ctx->c_csize.as<uint32_t>(), small_list, counts);
-        hipLaunchKernelGGL(sweep_big_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, kBigSegment) / 4 + 1, 1024)), dim3(B), 0, st, sv,
-                           ctx->c_reported.as<uint8_t>(), ctx->c_csize.as<uint32_t>(), big_list, counts);
+        {
+            const unsigned list_blocks = (unsigned)std::min<uint64_t>(grid_for(n, 256), 1024);
+            const unsigned big_blocks = (unsigned)std::min<uint64_t>(grid_for(n, kBigSegment) / 4 + 1, 1024);
+            hipLaunchKernelGGL(sweep_walk_kernel, dim3(list_blocks + big_blocks), dim3(B), 0, st, sv, ctx->c_reported.as<uint8_t>(),
+                               ctx->c_csize.as<uint32_t>(), small_list, big_list, counts, list_blocks);
+        }
         hipLaunchKernelGGL(flag_ge_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, B), kFlagGrid)), dim3(B), 0, st,
                            ctx->c_flag.as<uint32_t>(), ctx->c_csize.as<uint32_t>(), min_evidence, n, wave_max, sums);
         BF_TRY(scan_u32_to_u64(ctx, ctx->c_flag.as<uint32_t>(), ctx->c_scan.as<uint64_t>(), n));
-        // members of the qualifying clusters, and of those too large for the in-wave dedup: same synchronisation
-        BF_HIP(ctx, hipMemcpyAsync(totals, sums, 16, hipMemcpyDeviceToHost, st));
-        BF_TRY(fetch_u64(ctx, ctx->c_scan.as<uint64_t>() + n, &nq));
+        // members of the qualifying clusters, and of those too large for the in-wave dedup; the number of qualifying
+        // clusters; the records class_order set aside: one wait for all of them (mailbox)
+        BF_TRY(mail_fetch(ctx, 0, sums, 2));
+        BF_TRY(mail_fetch(ctx, 2, ctx->c_scan.as<uint64_t>() + n));
+        BF_SYNC(ctx, st);
+        totals[0] = ctx->h_mail[0]; totals[1] = ctx->h_mail[1]; nq = ctx->h_mail[2];
+        if (!wait_over && ctx->h_mail[3] != 0) { ctx->saw_overflow = true; *redo = true; return BF_OK; }
         BF_TRY(settle_counts(ctx));                       // the localise counters came along with this synchronisation
     }
     if (nq == 0) return BF_OK;
@@ -916,33 +1012,9 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
     hipLaunchKernelGGL(compact_seeds_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
                        ctx->c_scan.as<uint64_t>(), ctx->c_csize.as<uint32_t>(), ctx->c_qseed.as<uint32_t>(),
                        ctx->c_qsize.as<uint32_t>(), n, wave_max, qbig);
-    // The reference's print order of the QUALIFYING clusters (their seeds are known now; which of them survive
-    // the dedup only selects from this order): two small, latency-bound radix sorts, queued on the side stream
-    // so that they run beside the member / dedup kernels instead of after them.
     BF_TRY(ensure(ctx, ctx->c_qord, nq * 4));
     BF_TRY(ensure(ctx, ctx->c_misc, nq * 8 * 4));
-    BF_HIP(ctx, hipEventRecord(ctx->ev[9], st));
-    BF_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev[9], 0));
-    {
-        OnSideStream aux(ctx);
-        Scope t(ctx, "order");
-        const hipStream_t as = ctx->stream;
-        uint64_t* kpos = ctx->c_misc.as<uint64_t>();
-        uint64_t* kidx = kpos + nq; uint64_t* kpos2 = kidx + nq; uint64_t* kidx2 = kpos2 + nq;
-        OrderView ov{ctx->c_qseed.as<uint32_t>(), sv.skey, sv.slpos, perm, v.src_rank, v.src_idx, ctx->contig_bits};
-        hipLaunchKernelGGL(cluster_keys_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, ov, (const uint32_t*)nullptr, kpos, kidx, nq);
-        // LSD: input order first, then (contig rank, lpos).  values = q; c_b32 / c_c32 are free since the sweep
-        uint32_t* va = ctx->c_b32.as<uint32_t>(); uint32_t* vb = ctx->c_c32.as<uint32_t>();
-        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, va, nq);
-        // significant bits of (source rank << 32 | source index): on one rank the index alone, below n
-        unsigned idx_bits = 64;
-        if (!v.src_rank) { idx_bits = 1; while (idx_bits < 32 && (1ull << idx_bits) < v.n) idx_bits++; }
-        else { unsigned rb = 1; while ((1u << rb) < ctx->n_ranks) rb++; idx_bits = 32 + rb; }
-        BF_TRY(sort_pairs<uint64_t>(ctx, kidx, kidx2, va, vb, nq, 0, idx_bits));
-        hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, kpos2, kpos, vb, nq);
-        BF_TRY(sort_pairs<uint64_t>(ctx, kpos2, kidx2, vb, ctx->c_qord.as<uint32_t>(), nq, 0, 32 + ctx->contig_bits));
-        BF_HIP(ctx, hipEventRecord(ctx->ev[12], as));
-    }
+    BF_HIP(ctx, hipEventRecord(ctx->ev[9], st));          // the seeds are known: the side stream may order them (queued below)
     BF_TRY(scan_u32_to_u64(ctx, ctx->c_qsize.as<uint32_t>(), ctx->c_qoff.as<uint64_t>(), nq));
     BF_TRY(scan_u32_to_u64(ctx, qbig, qboff, nq));
     if (total_m > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "cluster membership list too long (%llu)", (unsigned long long)total_m);
@@ -976,6 +1048,48 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
                                ctx->c_rep.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>(), mv.qsize, wave_max);
         }
     }
+    // The reference's print order of the QUALIFYING clusters (their seeds are known now; which of them survive
+    // the dedup only selects from this order): two small, latency-bound radix sorts, queued on the side stream
+    // so that they run beside the member / dedup kernels instead of after them.
+    // (Queued AFTER the dedup kernels on purpose: the host needs ~0.2 ms to issue these sixteen launches, and while it
+    // did so before the dedup kernels were queued the main stream sat idle for that long.)
+    BF_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev[9], 0));
+    uint32_t* order_flag = nullptr;
+    {
+        OnSideStream aux(ctx);
+        Scope t(ctx, "order");
+        const hipStream_t as = ctx->stream;
+        uint64_t* kpos = ctx->c_misc.as<uint64_t>();
+        uint64_t* kidx = kpos + nq; uint64_t* kpos2 = kidx + nq; uint64_t* kidx2 = kpos2 + nq;
+        OrderView ov{ctx->c_qseed.as<uint32_t>(), sv.skey, sv.slpos, perm, v.src_rank, v.src_idx, ctx->contig_bits};
+        // values = q; c_b32 / c_c32 are free since the sweep
+        uint32_t* va = ctx->c_b32.as<uint32_t>(); uint32_t* vb = ctx->c_c32.as<uint32_t>();
+        if (!ctx->order_full) {
+            // the short form: one sort on (rank in the group, mapped position), ties put right afterwards
+            uint32_t rank_lo = 0, rank_hi = ctx->n_contigs - 1;
+            if (grp && grp->g >= 0 && (size_t)grp->g < ctx->group_ranks.size()) { rank_lo = ctx->group_ranks[grp->g].first; rank_hi = ctx->group_ranks[grp->g].second; }
+            uint64_t longest = 1;
+            for (uint32_t r = rank_lo; r <= rank_hi; r++) longest = std::max<uint64_t>(longest, ctx->contig_host[ctx->contig_by_rank[r]].len);
+            int pos_bits = 1; while (((uint64_t)1 << pos_bits) < longest + (1u << 17) + (uint64_t)kNegRoom) pos_bits++;
+            int rank_bits = 0; while (((uint32_t)1 << rank_bits) < rank_hi - rank_lo + 1) rank_bits++;
+            order_flag = ctx->c_big.as<uint32_t>() + 12;   // a control word the sweep is done with (cleared by head_mark_kernel)
+            hipLaunchKernelGGL(cluster_keys_short_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, ov, kpos, kidx, va, nq,
+                               ShortOrder{rank_lo, pos_bits, order_flag});
+            BF_TRY(sort_pairs<uint64_t>(ctx, kpos, kpos2, va, ctx->c_qord.as<uint32_t>(), nq, 0, (unsigned)(pos_bits + rank_bits)));
+            hipLaunchKernelGGL(order_ties_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, kpos2, ctx->c_qord.as<uint32_t>(), kidx, nq, order_flag);
+        } else {
+            // LSD: input order first, then (contig rank, lpos)
+            hipLaunchKernelGGL(cluster_keys_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, ov, (const uint32_t*)nullptr, kpos, kidx, va, nq);
+            // significant bits of (source rank << 32 | source index): on one rank the index alone, below n
+            unsigned idx_bits = 64;
+            if (!v.src_rank) { idx_bits = 1; while (idx_bits < 32 && (1ull << idx_bits) < v.n) idx_bits++; }
+            else { unsigned rb = 1; while ((1u << rb) < ctx->n_ranks) rb++; idx_bits = 32 + rb; }
+            BF_TRY(sort_pairs<uint64_t>(ctx, kidx, kidx2, va, vb, nq, 0, idx_bits));
+            hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, kpos2, kpos, vb, nq);
+            BF_TRY(sort_pairs<uint64_t>(ctx, kpos2, kidx2, vb, ctx->c_qord.as<uint32_t>(), nq, 0, 32 + ctx->contig_bits));
+        }
+        BF_HIP(ctx, hipEventRecord(ctx->ev[12], as));
+    }
     BF_HIP(ctx, hipGetLastError());
 
     // 4. surviving clusters in the reference's print order: the survivors of the order computed beside the dedup
@@ -992,15 +1106,17 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
         hipLaunchKernelGGL(flag_ge_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(nq, B), kFlagGrid)), dim3(B), 0, st,
                            ctx->c_flag.as<uint32_t>(), ctx->c_qnrep.as<uint32_t>(), min_evidence, nq, 0u, sums + 2, qord);
         BF_TRY(scan_u32_to_u64(ctx, ctx->c_flag.as<uint32_t>(), ctx->c_scan.as<uint64_t>(), nq));
-        BF_HIP(ctx, hipMemcpyAsync(&total_r, sums + 2, 8, hipMemcpyDeviceToHost, st));   // the reads that will be printed
-        BF_TRY(fetch_u64(ctx, ctx->c_scan.as<uint64_t>() + nq, &ns));
+        BF_TRY(mail_fetch(ctx, 0, sums + 2));              // the reads that will be printed
+        BF_TRY(mail_fetch(ctx, 1, ctx->c_scan.as<uint64_t>() + nq));
+        if (order_flag) BF_TRY(mail_fetch(ctx, 2, ctx->c_big.as<uint32_t>() + 12));      // (8 bytes: the flag and its neighbour)
+        BF_SYNC(ctx, st);
+        total_r = ctx->h_mail[0]; ns = ctx->h_mail[1];
+        if (order_flag && (uint32_t)ctx->h_mail[2] != 0) { ctx->order_full = true; *redo = true; return BF_OK; }
         if (ns == 0) return BF_OK;
         // ord[k'] = the k'-th surviving cluster in print order; nrep in that order -> read offsets
-        hipLaunchKernelGGL(compact_index_kernel, dim3(grid_for(nq, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
-                           ctx->c_scan.as<uint64_t>(), ctx->c_ord.as<uint32_t>(), nq, qord);
         uint32_t* vb = ctx->c_c32.as<uint32_t>();
-        hipLaunchKernelGGL(gather_u32_kernel, dim3(grid_for(ns, B)), dim3(B), 0, st, vb, ctx->c_qnrep.as<uint32_t>(),
-                           ctx->c_ord.as<uint32_t>(), ns);
+        hipLaunchKernelGGL(compact_index_kernel, dim3(grid_for(nq, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
+                           ctx->c_scan.as<uint64_t>(), ctx->c_ord.as<uint32_t>(), nq, qord, ctx->c_qnrep.as<uint32_t>(), vb);
         BF_TRY(scan_u32_to_u64(ctx, vb, ctx->c_scan.as<uint64_t>(), ns));
     }
 
@@ -1014,10 +1130,24 @@ int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp) {
     ctx->rsrc_stride = stride;
     std::vector<uint64_t> bases = ctx->src_index_base;
     if (bases.empty()) bases.assign(1, ctx->index_base);
-    BF_TRY(ensure(ctx, ctx->c_tables, bases.size() * 8 + (size_t)ctx->n_contigs * 4 + 16));
-    BF_HIP(ctx, hipMemcpyAsync(ctx->c_tables.p, bases.data(), bases.size() * 8, hipMemcpyHostToDevice, st));
-    uint32_t* d_rank2id = (uint32_t*)((uint8_t*)ctx->c_tables.p + bases.size() * 8);
-    BF_HIP(ctx, hipMemcpyAsync(d_rank2id, ctx->contig_by_rank.data(), (size_t)ctx->n_contigs * 4, hipMemcpyHostToDevice, st));
+    uint32_t* d_rank2id = nullptr;
+    {
+        // the two small tables emit reads (index base per source rank, contig id per rank): uploaded when they change, not
+        // per call (two copies from pageable memory in front of every emit were two round trips)
+        std::vector<uint64_t> key = bases;
+        key.push_back(ctx->n_contigs);
+        for (uint32_t r = 0; r < ctx->n_contigs; r++) key.push_back(ctx->contig_by_rank[r]);
+        const size_t need = bases.size() * 8 + (size_t)ctx->n_contigs * 4 + 16;
+        const bool fresh = ctx->c_tables.cap < need || key != ctx->tables_key;
+        BF_TRY(ensure(ctx, ctx->c_tables, need));
+        d_rank2id = (uint32_t*)((uint8_t*)ctx->c_tables.p + bases.size() * 8);
+        if (fresh) {
+            BF_HIP(ctx, hipMemcpyAsync(ctx->c_tables.p, bases.data(), bases.size() * 8, hipMemcpyHostToDevice, st));
+            BF_HIP(ctx, hipMemcpyAsync(d_rank2id, ctx->contig_by_rank.data(), (size_t)ctx->n_contigs * 4, hipMemcpyHostToDevice, st));
+            BF_SYNC(ctx, st);                             // (the sources are host vectors)
+            ctx->tables_key = key;
+        }
+    }
     EmitView ev{};
     ev.ord = ctx->c_ord.as<uint32_t>(); ev.roff = ctx->c_scan.as<uint64_t>();
     ev.qseed = ctx->c_qseed.as<uint32_t>(); ev.qsize = ctx->c_qsize.as<uint32_t>(); ev.qoff = ctx->c_qoff.as<uint64_t>();
@@ -1056,9 +1186,9 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 }
 // owner = hash(class key) % n_ranks: the key holds the whole class and no positions, so every
 // member of a cluster (same class, windows of positions) lands on one rank.
-__global__ void owner_kernel(uint32_t* owner, const uint64_t* __restrict__ key, uint32_t n_ranks, uint64_t n) {
+__global__ void owner_kernel(uint32_t* owner, uint32_t* __restrict__ iota, const uint64_t* __restrict__ key, uint32_t n_ranks, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) owner[i] = (uint32_t)(mix64(key[i]) % n_ranks);
+    if (i < n) { owner[i] = (uint32_t)(mix64(key[i]) % n_ranks); iota[i] = (uint32_t)i; }
 }
 __global__ void bucket_start_kernel(uint64_t* start, const uint32_t* __restrict__ owner_sorted, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1219,8 +1349,7 @@ int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint
     uint32_t* own = ctx->d_part_key.as<uint32_t>(); uint32_t* own_s = own + n;
     uint32_t* idx = ctx->d_part_idx.as<uint32_t>(); uint32_t* order = idx + n;
     const unsigned B = 256;
-    hipLaunchKernelGGL(owner_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, own, ctx->d_key.as<uint64_t>(), R, n);
-    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, idx, n);
+    hipLaunchKernelGGL(owner_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, own, idx, ctx->d_key.as<uint64_t>(), R, n);
     unsigned bits = 1; while ((1u << bits) < R) bits++;
     BF_TRY(sort_pairs<uint32_t>(ctx, own, own_s, idx, order, n, 0, bits));   // stable: source order kept per owner
     std::vector<uint64_t> start(R + 1, n);

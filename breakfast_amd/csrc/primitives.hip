@@ -249,8 +249,8 @@ int radix_sort_kv3(bf_ctx* ctx, const uint64_t* kin, uint64_t* kout, const RsV3*
 }
 
 // ---- scans -------------------------------------------------------------------------------------------
-// Two forms.  Reduce-then-scan in three launches, without waiting between workgroups: tile totals, an exclusive scan
-// of the (few thousand) totals by one block, and the scan proper; and (below) the same in one launch.  A tile is 256 x 16 consecutive elements;
+// Reduce-then-scan without waiting between workgroups: tile totals, then the scan proper, in which every tile adds
+// up the totals of the tiles before it (very long inputs: an exclusive scan of the totals by one block in between).  A tile is 256 x 16 consecutive elements;
 // thread t holds elements [16t, 16t+16) of its tile.
 constexpr int kScanItems = 16;
 constexpr int kScanTile = 256 * kScanItems;
@@ -360,79 +360,36 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, Out
         if (first + i < n) out[first + i] = (Out)Op::apply(before, v[i]);
 }
 
-// ---- the same scan in ONE launch ----------------------------------------------------------------------------
-// Decoupled look-back (Merrill & Garland): a tile publishes its aggregate, then adds up its predecessors' published
-// values until it meets one that already knows its inclusive prefix, and publishes its own.  A cluster stage runs some
-// sixteen scans per contig group, most of them over arrays of a few MB: at three launches each they were launch- and
-// latency-bound (0.33 ms of kernels per step at 1-18 % of anything, and a third of the stage's launches).
-//   - a tile's number is a TICKET drawn when its workgroup starts, so every predecessor a workgroup waits for is already
-//     running (or done): no assumption about the order in which the hardware starts workgroups;
-//   - status, value and the scan's EPOCH share one 64-bit word (2 + 10 + 52 bits), read and written with agent-scope
-//     atomics: nothing to order, and the descriptors of the previous scan need no clearing -- their epoch is old.  The
-//     host counts epochs per descriptor buffer and clears the buffer when the ten bits wrap;
-//   - the ticket counter is put back to zero by the workgroup that drew the last ticket.
-// Sums must stay below 2^52 (they are record bytes, member counts and flags of at most 2^32 elements).
-constexpr uint64_t kDescAgg = 1, kDescIncl = 2;
-constexpr uint32_t kDescEpochs = 1024;
-__device__ __forceinline__ uint64_t desc_pack(uint64_t value, uint32_t epoch, uint64_t status) { return (value << 12) | ((uint64_t)epoch << 2) | status; }
-
+// The tile's place among the tiles, computed by the tile itself: everything before tile b = the combination of
+// tile_total[0 .. b).  A few thousand totals (L2-resident), ten loads a thread: cheaper than a launch of its own
+// for a one-block scan of the totals, which is what a cluster stage's sixteen scans per contig group paid for.
 template <class Op>
-__device__ __forceinline__ uint64_t wave_reduce(uint64_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, o);
-        v = Op::apply(v, other);
-    }
-    return v;
+__device__ __forceinline__ uint64_t tiles_before(const uint64_t* __restrict__ tile_total, uint32_t b, uint64_t* s_wave) {
+    uint64_t x = Op::id();
+    for (uint32_t i = threadIdx.x; i < b; i += 256) x = Op::apply(x, tile_total[i]);
+    uint64_t total;
+    block_scan_incl<Op>(x, s_wave, total);
+    __syncthreads();                                                  // s_wave is reused by the caller
+    return total;
 }
 
+// Inclusive scan of in[0..n) into out[0..n) from the RAW tile totals (no carry launch); otherwise scan_apply_kernel.
 template <class Op, class Out>
-__global__ void __launch_bounds__(256) scan_onepass_kernel(const uint32_t* in, Out* out, uint64_t n, uint64_t* ctl /* [0]: tickets; [1 ..]: descriptors */,
-                                                           uint32_t epoch, uint32_t tiles, Out* zero_at) {
+__global__ void __launch_bounds__(256) scan_apply2_kernel(const uint32_t* in, Out* out, uint64_t n, const uint64_t* __restrict__ tile_total,
+                                                          Out* zero_at) {
     __shared__ uint64_t s_wave[4];
-    __shared__ uint64_t s_prefix;
-    __shared__ uint32_t s_tile;
-    const int t = threadIdx.x, lane = t & 63;
-    if (t == 0) {
-        const uint32_t ticket = atomicAdd((uint32_t*)ctl, 1u);
-        if (ticket == tiles - 1) atomicExch((uint32_t*)ctl, 0u);      // every ticket of this scan is out
-        s_tile = ticket;
-    }
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    uint64_t* desc = ctl + 1;
-    if (zero_at && tile == 0 && t == 0) *zero_at = 0;                 // the exclusive scan's leading zero (saves a memset launch)
-    const uint64_t first = (uint64_t)tile * kScanTile + (uint64_t)t * kScanItems;
+    const int t = threadIdx.x;
+    if (zero_at && blockIdx.x == 0 && t == 0) *zero_at = 0;
+    const uint64_t first = (uint64_t)blockIdx.x * kScanTile + (uint64_t)t * kScanItems;
     uint64_t v[kScanItems];
-    load_tile_items<Op>(in, first, n, v);
+    load_tile_items<Op>(in, first, n, v);                             // requested before the totals are added up
+    const uint64_t tile_prefix = tiles_before<Op>(tile_total, blockIdx.x, s_wave);
 #pragma unroll
     for (int i = 1; i < kScanItems; i++) v[i] = Op::apply(v[i - 1], v[i]);
     uint64_t total;
     const uint64_t incl = block_scan_incl<Op>(v[kScanItems - 1], s_wave, total);
-    if (t < 64) {                                                     // wave 0 publishes and looks back
-        if (t == 0)
-            __hip_atomic_store(&desc[tile], desc_pack(total, epoch, tile == 0 ? kDescIncl : kDescAgg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint64_t prefix = Op::id();
-        for (int64_t base = (int64_t)tile - 1; base >= 0; base -= 64) {
-            const int64_t idx = base - lane;
-            uint64_t d = desc_pack(Op::id(), epoch, kDescIncl);       // before tile 0: nothing
-            if (idx >= 0) {
-                do d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while (((d >> 2) & (kDescEpochs - 1)) != epoch || (d & 3) == 0);
-            }
-            const uint64_t done = __ballot((d & 3) == kDescIncl);
-            const int stop = done ? __builtin_ctzll(done) : 63;       // the nearest predecessor that knows its inclusive prefix
-            prefix = Op::apply(prefix, wave_reduce<Op>(lane <= stop ? d >> 12 : Op::id()));
-            if (done) break;
-        }
-        if (t == 0) {
-            if (tile) __hip_atomic_store(&desc[tile], desc_pack(Op::apply(prefix, total), epoch, kDescIncl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_prefix = prefix;
-        }
-    }
-    __syncthreads();
     const uint64_t prev = shfl_up64(incl, 1);
-    uint64_t before = s_prefix;
+    uint64_t before = tile_prefix;
     if (t & 63) before = Op::apply(before, prev);
     else {
 #pragma unroll
@@ -443,9 +400,13 @@ __global__ void __launch_bounds__(256) scan_onepass_kernel(const uint32_t* in, O
         if (first + i < n) out[first + i] = (Out)Op::apply(before, v[i]);
 }
 
-// `tot`: caller-provided workspace of scan_workspace_bytes(n) bytes (one total per tile): the three-launch form, which
-// needs nothing that outlives the call (the entry point that allocates nothing uses it on the static scratch array);
-// nullptr: the one-launch form on the ctx's descriptor buffer (c_desc: swapped with the side stream's by OnSideStream).
+// `tot`: workspace of scan_workspace_bytes(n) bytes (one total per tile); nullptr = the ctx's own (c_tmp, grown on demand).
+// Two launches: tile totals, then the scan proper, every tile adding up the totals before it by itself.  (A one-launch
+// form with decoupled look-back over per-tile descriptors was measured in round 3 and dropped, like the one-sweep sort
+// in round 1 and for the same reason: 1200-2400 tiles of which ~1000 start together, so a late tile adds up hundreds of
+// predecessors' aggregates 64 at a time through agent-scope loads -- sweep stage 0.52 -> 0.59 ms per step, step 5.93 ->
+// 6.02 ms; profiles/r03c_bench_cfg1_onepass_scan_ab.json against ..._three_launch_scan_ab.json.)
+constexpr uint64_t kScanSelfPrefixTiles = 1u << 14;       // beyond: the carry launch (a tile would add up > 16k totals)
 template <class Op, class Out>
 static int scan_impl(bf_ctx* ctx, const uint32_t* in, Out* out, uint64_t n, uint64_t* tot = nullptr, Out* zero_at = nullptr) {
     if (n == 0) {
@@ -453,26 +414,18 @@ static int scan_impl(bf_ctx* ctx, const uint32_t* in, Out* out, uint64_t n, uint
         return BF_OK;
     }
     const uint64_t tiles = (n + kScanTile - 1) / kScanTile;
-    static const bool three = getenv("BREAKFAST_HIP_SCAN3") != nullptr;        // (A/B switch)
-    if (!tot && !three) {
-        if (ctx->c_desc.cap < (tiles + 1) * 8 || ctx->scan_epoch + 1 >= kDescEpochs) {
-            BF_TRY(ensure(ctx, ctx->c_desc, std::max<uint64_t>((tiles + 1) * 8, 1u << 16), false));
-            BF_HIP(ctx, hipMemsetAsync(ctx->c_desc.p, 0, ctx->c_desc.cap, ctx->stream));   // epoch 0 = "never written"
-            ctx->scan_epoch = 0;
-        }
-        const uint32_t epoch = ++ctx->scan_epoch;
-        hipLaunchKernelGGL((scan_onepass_kernel<Op, Out>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, in, out, n,
-                           ctx->c_desc.as<uint64_t>(), epoch, (uint32_t)tiles, zero_at);
-        BF_HIP(ctx, hipGetLastError());
-        return BF_OK;
-    }
     if (!tot) {
         BF_TRY(ensure(ctx, ctx->c_tmp, tiles * 8 + 256, false));
         tot = ctx->c_tmp.as<uint64_t>();
     }
+    static const bool three = getenv("BREAKFAST_HIP_SCAN3") != nullptr;        // (A/B switch)
     hipLaunchKernelGGL((scan_totals_kernel<Op>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, in, n, tot);
-    hipLaunchKernelGGL((scan_carry_kernel<Op>), dim3(1), dim3(256), 0, ctx->stream, tot, tiles);
-    hipLaunchKernelGGL((scan_apply_kernel<Op, Out>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, in, out, n, tot, zero_at);
+    if (tiles <= kScanSelfPrefixTiles && !three) {
+        hipLaunchKernelGGL((scan_apply2_kernel<Op, Out>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, in, out, n, tot, zero_at);
+    } else {
+        hipLaunchKernelGGL((scan_carry_kernel<Op>), dim3(1), dim3(256), 0, ctx->stream, tot, tiles);
+        hipLaunchKernelGGL((scan_apply_kernel<Op, Out>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, in, out, n, tot, zero_at);
+    }
     BF_HIP(ctx, hipGetLastError());
     return BF_OK;
 }

@@ -533,6 +533,7 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
                 nr_g = ctx->out.n_reads; ns_g = ctx->out.n_clusters;
             } else {
                 ClusterGroup grp{ctx->c_gidx.as<uint32_t>() + gb[g], gb[g + 1] - gb[g], cl_base, rd_base, v.n};
+                grp.g = (int)g;
                 BF_TRY(run_cluster(ctx, v, &grp));
                 nr_g = grp.nr; ns_g = grp.ns;
             }

@@ -652,6 +652,52 @@ def test_classes_that_share_a_signature():
     check_against_oracle(g, b, A, flags=BF_FLAG_SORTED_DEDUP)
 
 
+def test_print_order_ties_and_the_fallback_to_the_full_sort():
+    """The print order is (contig, left position, input index of the seed).  The short sort orders on contig and position
+    and puts seeds that share both into input order run by run: 5 clusters at one left position (a run the fix-up handles),
+    90 clusters at another (longer than it handles: the ctx falls back to the two full sorts, for this call and for good),
+    and anchors far beyond their contig's end (a left position outside the short sort's mapped range: fallback as well)."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    A, L = 20, 100
+    g = synth.make_genome([("c0", 400000), ("c1", 400000)], seed=41)
+
+    def case(n_partners, x, bogus=False):
+        seqs, frags, hits = [], [], []
+        for j in range(n_partners):                               # one left breakpoint, many right partners: one class each
+            y = 5000 + 4000 * j
+            while g.seqs[1][y - 1] == g.seqs[0][x]:               # no shared base before the junction: the split scan's
+                y += 1                                            # lowest-k rule (detect.rs:143-146) leaves lpos at x
+            for i in range(3):
+                b = int(rng.integers(A + 5, L - A - 5))
+                read = np.concatenate([g.seqs[0][x - b + 1:x + 1], g.seqs[1][y:y + L - b]])
+                seqs.append(read.tobytes()); frags.append(b"p%d_%d" % (j, i))
+                hits.append((x - b + 2, y + L - A - b + 1, 0, 1, 3))
+        for i in range(3 if bogus else 0):                        # anchors 300 kb past the end of c0: windows of N, one cluster
+            seqs.append(g.seqs[1][1000:1000 + L].tobytes()); frags.append(b"far_%d" % i)
+            hits.append((700000, 1000 + L - A + 1, 0, 1, 3))
+        order = rng.permutation(len(seqs))
+        return engine.make_batch([seqs[i] for i in order], [frags[i] for i in order], [hits[i] for i in order])
+
+    for flags in (0, BF_FLAG_GROUPS_ALWAYS):
+        res, ref = check_against_oracle(g, case(5, 150000), A, flags=flags)
+        assert ref.n_clusters == 5 and len(set(res.clusters["lpos"].tolist())) == 1
+        res, ref = check_against_oracle(g, case(90, 250000), A, flags=flags)
+        assert ref.n_clusters == 90
+        res, ref = check_against_oracle(g, case(4, 100000, bogus=True), A, flags=flags)
+        assert ref.n_clusters == 5
+    # one ctx through all three: the fallback is sticky and the results stay right
+    og = ol.OracleGenome(g.names, g.seqs)
+    eng = engine.Engine(A, 5000, 2)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        for b in (case(5, 150000), case(90, 250000), case(5, 150000), case(4, 100000, bogus=True), case(7, 120000)):
+            eng.reset()
+            eng.submit(b)
+            assert eng.format_sv(eng.finish()) == ol.detect_batch(og, g.names, b, A, 5000, 2).sv
+    finally:
+        eng.close()
+
+
 def test_format_sv_size_query_truncation_and_threads():
     """bf_format_sv: NULL buffer = size query; a short buffer receives a prefix and the full size is still
     returned; a result large enough for the multi-threaded fill equals the oracle's text."""
