@@ -134,11 +134,11 @@ static OwnerView local_view(bf_ctx* ctx) {
     OwnerView v;
     v.n = ctx->n_reads;
     v.key = ctx->d_key.as<uint64_t>(); v.lpos = ctx->d_lpos.as<int32_t>(); v.rpos = ctx->d_rpos.as<int32_t>();
-    v.fhash = ctx->d_fhash.as<uint64_t>(); v.bp = ctx->d_bp.as<uint16_t>(); v.len = ctx->d_len.as<uint16_t>();
+    v.bp = ctx->d_bp.as<uint16_t>(); v.len = ctx->d_len.as<uint16_t>();
     v.flags = ctx->d_flags.as<uint16_t>();
     v.frag = ctx->d_frag.as<uint8_t>(); v.frag_off = ctx->d_frag_off.as<uint64_t>(); v.frag_len = ctx->d_frag_len.as<uint16_t>();
     v.sigx = ctx->d_sigx.as<uint8_t>(); v.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
-    v.info = ctx->d_jrec.as<uint64_t>();
+    v.rw = ctx->d_jrec.as<RecWord>();
     return v;
 }
 static void free_all(bf_ctx* ctx) {
@@ -146,11 +146,11 @@ static void free_all(bf_ctx* ctx) {
         &ctx->d_frag, &ctx->d_frag_off, &ctx->d_hits, &ctx->d_len, &ctx->d_frag_len, &ctx->d_fhash,
         &ctx->d_key, &ctx->d_lpos, &ctx->d_rpos, &ctx->d_bp, &ctx->d_flags, &ctx->d_mask, &ctx->d_jrec, &ctx->d_exact_list,
         &ctx->d_counters, &ctx->d_sigx, &ctx->d_sigx_slot, &ctx->d_send, &ctx->d_part_key, &ctx->d_part_idx,
-        &ctx->d_part_tmp, &ctx->i_key, &ctx->i_lpos, &ctx->i_rpos, &ctx->i_fhash, &ctx->i_bp, &ctx->i_len, &ctx->i_flags,
+        &ctx->d_part_tmp, &ctx->i_key, &ctx->i_lpos, &ctx->i_rpos, &ctx->i_bp, &ctx->i_len, &ctx->i_flags,
         &ctx->i_frag, &ctx->i_frag_off, &ctx->i_frag_len, &ctx->i_sigx, &ctx->i_sigx_slot, &ctx->i_src_rank,
         &ctx->i_src_idx, &ctx->i_jrec, &ctx->c_tmp, &ctx->c_a32, &ctx->c_b32, &ctx->c_c32, &ctx->c_d32, &ctx->c_k64a, &ctx->c_k64b,
         &ctx->c_slpos, &ctx->c_srpos, &ctx->c_reported, &ctx->c_csize, &ctx->c_flag, &ctx->c_scan, &ctx->c_qseed,
-        &ctx->c_qsize, &ctx->c_qoff, &ctx->c_members, &ctx->c_leader, &ctx->c_rep, &ctx->c_qnrep, &ctx->c_ctl, &ctx->c_sel,
+        &ctx->c_qsize, &ctx->c_qoff, &ctx->c_mrec, &ctx->c_mjrec, &ctx->c_leader, &ctx->c_rep, &ctx->c_qnrep, &ctx->c_ctl, &ctx->c_sel,
         &ctx->c_ord, &ctx->c_clusters, &ctx->c_reads, &ctx->c_misc, &ctx->c_joff, &ctx->c_jbytes, &ctx->c_rsrc,
         &ctx->c_tables, &ctx->c_mkey_s, &ctx->c_slot, &ctx->c_big, &ctx->c_cjo, &ctx->c_aoff, &ctx->c_err, &ctx->c_tmp2, &ctx->c_qord, &ctx->c_gidx, &ctx->c_hist, &ctx->c_comp, &ctx->c_bstart, &ctx->c_chunk, &ctx->c_pos2, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
     for (DevBuf* b : all) release(ctx, *b);

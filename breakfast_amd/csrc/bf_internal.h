@@ -115,6 +115,10 @@ __host__ __device__ inline uint32_t info_jrec(uint64_t i) { return (uint32_t)i &
 __host__ __device__ inline uint32_t info_flags(uint64_t i) { return (uint32_t)(i >> 20) & 0x1fu; }
 __host__ __device__ inline uint32_t info_bp(uint64_t i) { return (uint32_t)(i >> 32) & 0xffffu; }
 __host__ __device__ inline uint32_t info_len(uint64_t i) { return (uint32_t)(i >> 48); }
+// ... and that word sits beside the record's 64-bit fragment-id hash, 16 aligned bytes: the wave that enumerates a
+// cluster's members (fill_members_kernel) needs both of every member, and a gather through the sort permutation costs
+// a 128-byte line whatever it uses -- one line per member instead of two (round 3: 2.26 -> 1.2 GB per step).
+struct alignas(16) RecWord { uint64_t info, fhash; };
 
 // ---- wire record of the multi-GPU exchange ---------------------------------------------------
 struct WireHeader {     // 40 B, followed by frag bytes (fixed stride) and optionally 16 raw sig bytes
@@ -193,7 +197,6 @@ struct OwnerView {
     const uint64_t* key = nullptr;
     const int32_t* lpos = nullptr;
     const int32_t* rpos = nullptr;
-    const uint64_t* fhash = nullptr;
     const uint16_t* bp = nullptr;
     const uint16_t* len = nullptr;
     const uint16_t* flags = nullptr;
@@ -204,7 +207,7 @@ struct OwnerView {
     const uint32_t* sigx_slot = nullptr; // record -> slot (only read when the key's sigx bit is set)
     const uint32_t* src_rank = nullptr;  // nullptr = all from this rank
     const uint32_t* src_idx = nullptr;   // nullptr = identity
-    const uint64_t* info = nullptr;      // per record, ONE word for the gathers of dedup and emit: read_info()
+    const RecWord* rw = nullptr;         // per record, ONE 16-byte load for the gathers of the dedup: read_info() word + fragment-id hash
 };
 
 struct HostBuf {                         // pinned host staging (hipHostMalloc): full-rate D2H copies
@@ -317,7 +320,7 @@ struct bf_ctx {
     void* shard = nullptr;                      // bf::Shard (shard.hip): transport and buffers of the in-library sharded path
     bool counts_pending = false;                // ... not yet read back: settle_counts() after the next synchronisation
     bf::DevBuf d_len, d_frag_len, d_fhash;
-    bf::DevBuf d_key, d_lpos, d_rpos, d_bp, d_flags, d_mask, d_jrec;   // d_jrec: read_info() words
+    bf::DevBuf d_key, d_lpos, d_rpos, d_bp, d_flags, d_mask, d_jrec;   // d_jrec: RecWord per read (read_info() word + d_fhash's hash)
     bf::DevBuf d_exact_list, d_counters, d_sigx, d_sigx_slot;
 
     // multi-rank
@@ -329,14 +332,14 @@ struct bf_ctx {
     uint32_t wire_frag_stride = 0, wire_has_sigx = 0, wire_rec_bytes = 0;
     uint64_t n_imported = 0;
     bf::DevBuf d_send, d_part_key, d_part_idx, d_part_tmp;
-    bf::DevBuf i_key, i_lpos, i_rpos, i_fhash, i_bp, i_len, i_flags, i_frag, i_frag_off, i_frag_len, i_sigx,
+    bf::DevBuf i_key, i_lpos, i_rpos, i_bp, i_len, i_flags, i_frag, i_frag_off, i_frag_len, i_sigx,
         i_sigx_slot, i_src_rank, i_src_idx, i_jrec;
     bool reads_on_device = false;               // the finished read table waits in c_reads for bf_result_reads
     uint64_t rsrc_stride = 0;                   // c_rsrc = 4 arrays of this many entries (source rank, source index, record, bytes)
 
     // cluster stage scratch + results
     bf::DevBuf c_tmp, c_a32, c_b32, c_c32, c_d32, c_k64a, c_k64b, c_slpos, c_srpos, c_reported,
-        c_csize, c_flag, c_scan, c_qseed, c_qsize, c_qoff, c_members, c_leader, c_rep, c_qnrep,
+        c_csize, c_flag, c_scan, c_qseed, c_qsize, c_qoff, c_mrec, c_mjrec, c_leader, c_rep, c_qnrep,
         c_ctl, c_sel, c_ord, c_clusters, c_reads, c_misc, c_pos2, c_joff, c_jbytes, c_rsrc, c_tables, c_mkey_s, c_slot, c_big, c_cjo, c_aoff, c_err, c_tmp2, c_qord, c_gidx, c_hist, c_comp, c_bstart, c_chunk;
     bf::ClusterOut out;
     std::vector<uint64_t> render_off_host;

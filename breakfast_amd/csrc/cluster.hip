@@ -275,14 +275,15 @@ constexpr int kMemberHashBits = 16;
 
 struct MemberView {
     const uint32_t* qseed; const uint64_t* qoff;
-    uint32_t* members;      // sorted positions
     // members of clusters above wave_max, compacted (qboff[q] = first compact index of cluster q):
     uint64_t* mkey;         // (cluster number << kMemberHashBits) | low bits of the fragment-id hash
     uint32_t* bslot;        // their member slot
     const uint64_t* qboff;
     uint32_t wave_max;
     uint32_t* mscore;       // longest-flank score per member slot (detect.rs:273-279)
-    const uint64_t* fhash; const uint64_t* info;
+    const RecWord* rw;      // owner record -> {read_info() word, fragment-id hash}: one 16-byte gather per member
+    uint32_t* mrec;         // per member slot: its owner record and the bytes of its junction record, written while the
+    uint32_t* mjrec;        // member's RecWord is at hand, so that emit_kernel reads slot space only and gathers nothing
     // in-wave dedup (WAVE_DEDUP): group leaders' representatives and the clusters' group counts
     const uint32_t* qsize; uint32_t* rep; uint32_t* qnrep;
     const uint8_t* frag; const uint64_t* frag_off; const uint16_t* frag_len;
@@ -323,10 +324,10 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
     const int32_t lp = v.slpos[p], rp = v.srpos[p];
     const bool in_wave = m.qsize[q] <= m.wave_max;
     const uint64_t cbase = in_wave ? 0 : m.qboff[q];
-    auto put = [&](uint64_t slot, uint64_t spos, uint32_t rec) {
-        m.members[slot] = (uint32_t)spos;
-        const uint64_t info = m.info[rec];
-        const uint64_t fh = m.fhash[rec];
+    auto put = [&](uint64_t slot, uint32_t rec) {
+        const RecWord w = m.rw[rec];
+        const uint64_t info = w.info, fh = w.fhash;
+        m.mrec[slot] = rec; m.mjrec[slot] = info_jrec(info);
         const uint32_t l = info_bp(info), r = info_len(info) - l;
         const uint32_t score = min(l, r) * 10000u + max(l, r);       // detect.rs:273-279
         if (in_wave) {
@@ -354,7 +355,7 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
         const uint64_t live_mask = __ballot(live);
         const bool take = live && ks == key && !rpos_far(rs, rp, v.F) && same_sigx(v, key, p, s);
         const uint64_t take_mask = __ballot(take);
-        if (take) put(base + cnt + __popcll(take_mask & ((1ull << lane) - 1)), s, rec);
+        if (take) put(base + cnt + __popcll(take_mask & ((1ull << lane) - 1)), rec);
         cnt += __popcll(take_mask);
         if (live_mask != ~0ull) break;        // the break tests are monotone in sorted order
     }
@@ -483,12 +484,12 @@ __global__ void __launch_bounds__(256) dedup_runs_kernel(uint64_t total_m, const
         const uint32_t sa = sslot[a];
         if (leader[sa] != kNone) continue;
         leader[sa] = sa;
-        const uint32_t ra = f.perm[m.members[sa]];
+        const uint32_t ra = m.mrec[sa];
         uint32_t best = sa, best_score = m.mscore[sa];
         for (uint64_t b = a + 1; b < total_m && skey[b] == key; b++) {
             const uint32_t sb = sslot[b];
             if (leader[sb] != kNone) continue;
-            if (!same_frag(f, ra, f.perm[m.members[sb]])) continue;
+            if (!same_frag(f, ra, m.mrec[sb])) continue;
             leader[sb] = sa;
             if (m.mscore[sb] > best_score) { best = sb; best_score = m.mscore[sb]; }
         }
@@ -575,10 +576,9 @@ struct EmitView {
     const uint32_t* ord;        // output order -> q
     const uint64_t* roff;       // output order -> first supporting read
     const uint32_t* qseed; const uint32_t* qsize; const uint64_t* qoff;
-    const uint32_t* members; const uint32_t* rep;
+    const uint32_t* mrec; const uint32_t* mjrec; const uint32_t* rep;
     const uint64_t* skey; const int32_t* slpos; const int32_t* srpos; const uint32_t* perm;
     const uint32_t* src_rank; const uint32_t* src_idx; const uint64_t* src_base;
-    const uint64_t* info;
     const uint32_t* rank2id; int cb;
     bf_cluster* clusters; bf_read* reads; uint32_t* out_src_rank; uint32_t* out_src_idx; uint32_t* out_rec; uint32_t* out_jrec;
     uint64_t rd_base;           // reads[], out_*[] start at this group's first read: read_begin / read_end count from here
@@ -619,13 +619,11 @@ __global__ void __launch_bounds__(256) emit_kernel(const EmitView e, uint64_t ns
         const uint64_t mask = __ballot(lead);
         if (lead) {
             const uint64_t slot = rbase + cnt + __popcll(mask & ((1ull << lane) - 1));
-            const uint32_t rec = e.perm[e.members[base + rp]];
+            const uint32_t rec = e.mrec[base + rp], jr = e.mjrec[base + rp];      // slot space: no gather (fill_members_kernel)
             uint32_t sr, si; source(rec, sr, si);
             bf_read rd;
             memset(&rd, 0, sizeof rd);
             rd.index = e.src_base[sr] + si;
-            const uint64_t info = e.info[rec];
-            const uint32_t jr = info_jrec(info);
             e.reads[slot] = rd;
             e.out_src_rank[slot] = sr; e.out_src_idx[slot] = si; e.out_rec[slot] = rec; e.out_jrec[slot] = jr;
         }
@@ -639,9 +637,9 @@ __global__ void __launch_bounds__(256) emit_kernel(const EmitView e, uint64_t ns
 // is clustered.  rank32[i] = left contig rank of record i, hist[r] = records of rank r, hist[bins] = sum of all
 // records' junction record bytes (the bound the output buffers are sized with).
 // Sum of the records' junction record bytes (the bound the output buffers are sized with): one atomic per block.
-__global__ void __launch_bounds__(256) record_bytes_kernel(const uint64_t* __restrict__ info, uint64_t n, unsigned long long* sum) {
+__global__ void __launch_bounds__(256) record_bytes_kernel(const RecWord* __restrict__ rw, uint64_t n, unsigned long long* sum) {
     unsigned long long bytes = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) bytes += info_jrec(info[i]);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) bytes += info_jrec(rw[i].info);
     for (int d = 32; d; d >>= 1) bytes += __shfl_down(bytes, d);
     __shared__ unsigned long long w[4];                    // one atomic per block: they all hit one word
     if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = bytes;
@@ -716,7 +714,7 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
     BF_TRY(ensure(ctx, ctx->c_gidx, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_hist, 64 + ctx->n_contigs, false));
     BF_TRY(ensure(ctx, ctx->c_c32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_k64a, n * 8, false));
     BF_HIP(ctx, hipMemsetAsync(ctx->c_hist.p, 0, 8, st));
-    hipLaunchKernelGGL(record_bytes_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, 256), 1024)), dim3(256), 0, st, v.info, n,
+    hipLaunchKernelGGL(record_bytes_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, 256), 1024)), dim3(256), 0, st, v.rw, n,
                        (unsigned long long*)ctx->c_hist.p);
     BF_TRY(mail_fetch(ctx, 0, ctx->c_hist.p));            // read after the wait at the end: no round trip of its own
     if (bounds.size() > 2) {
@@ -1018,15 +1016,16 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
     BF_TRY(scan_u32_to_u64(ctx, ctx->c_qsize.as<uint32_t>(), ctx->c_qoff.as<uint64_t>(), nq));
     BF_TRY(scan_u32_to_u64(ctx, qbig, qboff, nq));
     if (total_m > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "cluster membership list too long (%llu)", (unsigned long long)total_m);
-    BF_TRY(ensure(ctx, ctx->c_members, total_m * 4)); BF_TRY(ensure(ctx, ctx->c_k64a, std::max(total_big, n) * 8, false));
+    BF_TRY(ensure(ctx, ctx->c_mrec, total_m * 4)); BF_TRY(ensure(ctx, ctx->c_mjrec, total_m * 4));
+    BF_TRY(ensure(ctx, ctx->c_k64a, std::max(total_big, n) * 8, false));
     BF_TRY(ensure(ctx, ctx->c_mkey_s, std::max<uint64_t>(total_big, 1) * 8)); BF_TRY(ensure(ctx, ctx->c_slot, std::max<uint64_t>(total_big, 1) * 4 * 2));
     BF_TRY(ensure(ctx, ctx->c_d32, total_m * 4));
     BF_TRY(ensure(ctx, ctx->c_leader, total_m * 4)); BF_TRY(ensure(ctx, ctx->c_rep, total_m * 4));
     MemberView mv{};
     mv.qseed = ctx->c_qseed.as<uint32_t>(); mv.qoff = ctx->c_qoff.as<uint64_t>();
-    mv.members = ctx->c_members.as<uint32_t>(); mv.mkey = ctx->c_k64a.as<uint64_t>(); mv.mscore = ctx->c_d32.as<uint32_t>();
+    mv.mkey = ctx->c_k64a.as<uint64_t>(); mv.mscore = ctx->c_d32.as<uint32_t>();
     mv.bslot = ctx->c_slot.as<uint32_t>(); mv.qboff = qboff; mv.wave_max = wave_max;
-    mv.fhash = v.fhash; mv.info = v.info;
+    mv.rw = v.rw; mv.mrec = ctx->c_mrec.as<uint32_t>(); mv.mjrec = ctx->c_mjrec.as<uint32_t>();
     mv.qsize = ctx->c_qsize.as<uint32_t>(); mv.rep = ctx->c_rep.as<uint32_t>(); mv.qnrep = ctx->c_qnrep.as<uint32_t>();
     mv.frag = v.frag; mv.frag_off = v.frag_off; mv.frag_len = v.frag_len;
     mv.hash_mask = (ctx->cfg.flags & BF_FLAG_WEAK_DEDUP_HASH) ? 0x7ull : ~0ull;
@@ -1151,10 +1150,10 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
     EmitView ev{};
     ev.ord = ctx->c_ord.as<uint32_t>(); ev.roff = ctx->c_scan.as<uint64_t>();
     ev.qseed = ctx->c_qseed.as<uint32_t>(); ev.qsize = ctx->c_qsize.as<uint32_t>(); ev.qoff = ctx->c_qoff.as<uint64_t>();
-    ev.members = ctx->c_members.as<uint32_t>(); ev.rep = ctx->c_rep.as<uint32_t>();
+    ev.mrec = ctx->c_mrec.as<uint32_t>(); ev.mjrec = ctx->c_mjrec.as<uint32_t>(); ev.rep = ctx->c_rep.as<uint32_t>();
     ev.skey = sv.skey; ev.slpos = sv.slpos; ev.srpos = sv.srpos; ev.perm = perm;
     ev.src_rank = v.src_rank; ev.src_idx = v.src_idx; ev.src_base = (const uint64_t*)ctx->c_tables.p;
-    ev.info = v.info; ev.rank2id = d_rank2id; ev.cb = ctx->contig_bits;
+    ev.rank2id = d_rank2id; ev.cb = ctx->contig_bits;
     ev.clusters = ctx->c_clusters.as<bf_cluster>() + cl_base; ev.reads = ctx->c_reads.as<bf_read>() + rd_base;
     ev.out_src_rank = ctx->c_rsrc.as<uint32_t>() + rd_base; ev.out_src_idx = ev.out_src_rank + stride;
     ev.out_rec = ev.out_src_idx + stride; ev.out_jrec = ev.out_rec + stride;
@@ -1198,24 +1197,22 @@ __global__ void bucket_start_kernel(uint64_t* start, const uint32_t* __restrict_
 struct PackView {
     uint64_t n; uint32_t rec_bytes, frag_stride, has_sigx;
     const uint32_t* order;
-    const uint64_t* key; const int32_t* lpos; const int32_t* rpos; const uint64_t* fhash;
+    const uint64_t* key; const int32_t* lpos; const int32_t* rpos;
     const uint16_t* bp; const uint16_t* len; const uint16_t* flags;
     const uint8_t* frag; const uint64_t* frag_off; const uint16_t* frag_len;
     const uint8_t* sigx; const uint32_t* sigx_slot;
-    const uint64_t* info;                                           // read_info() words (localise): junction record bytes
+    const RecWord* rw;                                              // read_info() word (junction record bytes) + fragment-id hash
     uint8_t* out;
 };
-__device__ __forceinline__ uint32_t pack_jrec(const PackView& v, uint32_t i) {
-    return info_jrec(v.info[i]);
-}
 __global__ void __launch_bounds__(256) pack_kernel(const PackView v) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= v.n) return;
     const uint32_t i = v.order[j];
     uint8_t* dst = v.out + j * v.rec_bytes;
     WireHeader h;
-    h.key = v.key[i]; h.lpos = v.lpos[i]; h.rpos = v.rpos[i]; h.fhash = v.fhash[i]; h.src_idx = i;
-    h.bp = v.bp[i]; h.len = v.len[i]; h.frag_len = v.frag_len[i]; h.flags = v.flags[i]; h.jrec = pack_jrec(v, i);
+    const RecWord w = v.rw[i];
+    h.key = v.key[i]; h.lpos = v.lpos[i]; h.rpos = v.rpos[i]; h.fhash = w.fhash; h.src_idx = i;
+    h.bp = v.bp[i]; h.len = v.len[i]; h.frag_len = v.frag_len[i]; h.flags = v.flags[i]; h.jrec = info_jrec(w.info);
     *(WireHeader*)dst = h;
     const uint8_t* f = v.frag + v.frag_off[i];
     for (uint32_t k = 0; k < v.frag_stride; k++) dst[sizeof(WireHeader) + k] = k < h.frag_len ? f[k] : 0;
@@ -1245,9 +1242,10 @@ __global__ void __launch_bounds__(256) pack_lds_kernel(const PackView v) {
         const uint32_t fl = v.frag_len[i];
         rec[0] = key;
         rec[1] = (uint64_t)(uint32_t)v.lpos[i] | ((uint64_t)(uint32_t)v.rpos[i] << 32);
-        rec[2] = v.fhash[i];
+        const RecWord w = v.rw[i];
+        rec[2] = w.fhash;
         rec[3] = (uint64_t)i | ((uint64_t)v.bp[i] << 32) | ((uint64_t)v.len[i] << 48);
-        rec[4] = (uint64_t)(uint16_t)fl | ((uint64_t)v.flags[i] << 16) | ((uint64_t)pack_jrec(v, i) << 32);
+        rec[4] = (uint64_t)(uint16_t)fl | ((uint64_t)v.flags[i] << 16) | ((uint64_t)info_jrec(w.info) << 32);
         const uint8_t* f = v.frag + v.frag_off[i];
         for (uint32_t w = 0; w < fwords; w++) {
             uint64_t x = 0;
@@ -1276,18 +1274,18 @@ __global__ void __launch_bounds__(256) pack_lds_kernel(const PackView v) {
 struct ImportView {
     uint64_t n; uint32_t rec_bytes, frag_stride, has_sigx, n_ranks;
     const uint8_t* in; const uint64_t* src_start;   // n_ranks+1 prefix of src_counts
-    uint64_t* key; int32_t* lpos; int32_t* rpos; uint64_t* fhash; uint16_t* bp; uint16_t* len; uint16_t* flags;
+    uint64_t* key; int32_t* lpos; int32_t* rpos; uint16_t* bp; uint16_t* len; uint16_t* flags;
     uint8_t* frag; uint64_t* frag_off; uint16_t* frag_len; uint8_t* sigx; uint32_t* sigx_slot;
-    uint32_t* src_rank; uint32_t* src_idx; uint64_t* info;
+    uint32_t* src_rank; uint32_t* src_idx; RecWord* rw;
 };
 __global__ void __launch_bounds__(256) import_kernel(const ImportView v) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= v.n) return;
     const uint8_t* src = v.in + j * v.rec_bytes;
     const WireHeader h = *(const WireHeader*)src;
-    v.key[j] = h.key; v.lpos[j] = h.lpos; v.rpos[j] = h.rpos; v.fhash[j] = h.fhash;
+    v.key[j] = h.key; v.lpos[j] = h.lpos; v.rpos[j] = h.rpos;
     v.bp[j] = h.bp; v.len[j] = h.len; v.flags[j] = h.flags; v.frag_len[j] = h.frag_len;
-    v.info[j] = read_info(h.jrec, h.flags, h.bp, h.len);
+    v.rw[j] = RecWord{read_info(h.jrec, h.flags, h.bp, h.len), h.fhash};
     v.frag_off[j] = j * v.frag_stride;
     for (uint32_t k = 0; k < v.frag_stride; k++) v.frag[j * v.frag_stride + k] = src[sizeof(WireHeader) + k];
     v.sigx_slot[j] = (uint32_t)j;
@@ -1309,10 +1307,9 @@ __global__ void __launch_bounds__(256) import_lds_kernel(const ImportView v) {
     const uint64_t* rec = tile + (uint64_t)threadIdx.x * words;
     v.key[j] = rec[0];
     v.lpos[j] = (int32_t)(uint32_t)rec[1]; v.rpos[j] = (int32_t)(uint32_t)(rec[1] >> 32);
-    v.fhash[j] = rec[2];
     v.src_idx[j] = (uint32_t)rec[3]; v.bp[j] = (uint16_t)(rec[3] >> 32); v.len[j] = (uint16_t)(rec[3] >> 48);
     v.frag_len[j] = (uint16_t)rec[4]; v.flags[j] = (uint16_t)(rec[4] >> 16);
-    v.info[j] = read_info((uint32_t)(rec[4] >> 32), (uint32_t)(uint16_t)(rec[4] >> 16), (uint32_t)(uint16_t)(rec[3] >> 32), (uint32_t)(rec[3] >> 48));
+    v.rw[j] = RecWord{read_info((uint32_t)(rec[4] >> 32), (uint32_t)(uint16_t)(rec[4] >> 16), (uint32_t)(uint16_t)(rec[3] >> 32), (uint32_t)(rec[3] >> 48)), rec[2]};
     v.frag_off[j] = j * v.frag_stride;
     uint64_t* fdst = (uint64_t*)(v.frag + j * v.frag_stride);
     for (uint32_t w = 0; w < fwords; w++) fdst[w] = rec[5 + w];
@@ -1358,10 +1355,10 @@ int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint
     PackView pv{};
     pv.n = n; pv.rec_bytes = rec; pv.frag_stride = stride; pv.has_sigx = ctx->wire_has_sigx; pv.order = order;
     pv.key = ctx->d_key.as<uint64_t>(); pv.lpos = ctx->d_lpos.as<int32_t>(); pv.rpos = ctx->d_rpos.as<int32_t>();
-    pv.fhash = ctx->d_fhash.as<uint64_t>(); pv.bp = ctx->d_bp.as<uint16_t>(); pv.len = ctx->d_len.as<uint16_t>();
+    pv.bp = ctx->d_bp.as<uint16_t>(); pv.len = ctx->d_len.as<uint16_t>();
     pv.flags = ctx->d_flags.as<uint16_t>(); pv.frag = ctx->d_frag.as<uint8_t>(); pv.frag_off = ctx->d_frag_off.as<uint64_t>();
     pv.frag_len = ctx->d_frag_len.as<uint16_t>(); pv.sigx = ctx->d_sigx.as<uint8_t>(); pv.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
-    pv.info = ctx->d_jrec.as<uint64_t>();
+    pv.rw = ctx->d_jrec.as<RecWord>();
     pv.out = (uint8_t*)*dev_out;
     if (rec <= kWireLdsMaxRecord && ((uintptr_t)pv.out & 7) == 0)
         hipLaunchKernelGGL(pack_lds_kernel, dim3(grid_for(n, 256)), dim3(256), 256 * rec, st, pv);
@@ -1391,22 +1388,22 @@ int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts) {
     if (ctx->wire_rec_bytes == 0) return fail(ctx, BF_ERR_STATE, "bf_exchange_import before bf_exchange_pack");
     const uint32_t stride = ctx->wire_frag_stride;
     BF_TRY(ensure(ctx, ctx->i_key, n * 8)); BF_TRY(ensure(ctx, ctx->i_lpos, n * 4)); BF_TRY(ensure(ctx, ctx->i_rpos, n * 4));
-    BF_TRY(ensure(ctx, ctx->i_fhash, n * 8)); BF_TRY(ensure(ctx, ctx->i_bp, n * 2)); BF_TRY(ensure(ctx, ctx->i_len, n * 2));
+    BF_TRY(ensure(ctx, ctx->i_bp, n * 2)); BF_TRY(ensure(ctx, ctx->i_len, n * 2));
     BF_TRY(ensure(ctx, ctx->i_flags, n * 2)); BF_TRY(ensure(ctx, ctx->i_frag, std::max<uint64_t>(n * stride, 1)));
     BF_TRY(ensure(ctx, ctx->i_frag_off, n * 8)); BF_TRY(ensure(ctx, ctx->i_frag_len, n * 2));
     BF_TRY(ensure(ctx, ctx->i_sigx, n * 16)); BF_TRY(ensure(ctx, ctx->i_sigx_slot, n * 4));
     BF_TRY(ensure(ctx, ctx->i_src_rank, n * 4)); BF_TRY(ensure(ctx, ctx->i_src_idx, n * 4));
-    BF_TRY(ensure(ctx, ctx->i_jrec, n * 8));
+    BF_TRY(ensure(ctx, ctx->i_jrec, n * sizeof(RecWord)));
     BF_TRY(ensure(ctx, ctx->d_part_tmp, (size_t)(R + 1) * 8));
     BF_HIP(ctx, hipMemcpyAsync(ctx->d_part_tmp.p, start.data(), (size_t)(R + 1) * 8, hipMemcpyHostToDevice, st));
     ImportView v{};
     v.n = n; v.rec_bytes = ctx->wire_rec_bytes; v.frag_stride = stride; v.has_sigx = ctx->wire_has_sigx; v.n_ranks = R;
     v.in = (const uint8_t*)dev_recv; v.src_start = ctx->d_part_tmp.as<uint64_t>();
     v.key = ctx->i_key.as<uint64_t>(); v.lpos = ctx->i_lpos.as<int32_t>(); v.rpos = ctx->i_rpos.as<int32_t>();
-    v.fhash = ctx->i_fhash.as<uint64_t>(); v.bp = ctx->i_bp.as<uint16_t>(); v.len = ctx->i_len.as<uint16_t>();
+    v.bp = ctx->i_bp.as<uint16_t>(); v.len = ctx->i_len.as<uint16_t>();
     v.flags = ctx->i_flags.as<uint16_t>(); v.frag = ctx->i_frag.as<uint8_t>(); v.frag_off = ctx->i_frag_off.as<uint64_t>();
     v.frag_len = ctx->i_frag_len.as<uint16_t>(); v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
-    v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>(); v.info = ctx->i_jrec.as<uint64_t>();
+    v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>(); v.rw = ctx->i_jrec.as<RecWord>();
     Scope t(ctx, "exchange_import");
     if (v.rec_bytes <= kWireLdsMaxRecord && ((uintptr_t)v.in & 7) == 0)
         hipLaunchKernelGGL(import_lds_kernel, dim3(grid_for(n, 256)), dim3(256), 256 * v.rec_bytes, st, v);

@@ -335,7 +335,8 @@ struct LocaliseArgs {
     uint16_t* flags;
     uint64_t* meta;          // render record per read: mask_words mask words + {bp, flags, len}
     int meta_stride;         // u64 per record = mask_words + 1
-    uint64_t* info;          // read_info(): junction record bytes, flags, bp, len in one word for the cluster stage's gathers
+    RecWord* rw;             // read_info() (junction record bytes, flags, bp, len in one word) beside the fragment-id hash:
+    const uint64_t* fhash;   // one 16-byte record per read for the cluster stage's gathers (fhash: read_meta_kernel's output)
     uint32_t* exact_list;
     uint32_t* counters;      // [0] = reads routed to the exact kernel, [1] = raw-signature slots handed out,
                              // [2] = reads whose junction record is text (not packable)
@@ -383,6 +384,7 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
     else { L = (int)(a.seq_off[r + 1] - so); a.len_out[r] = (uint16_t)L; }
     const int A = a.A;
     const bf_hit h = a.hits[r];
+    const uint64_t fh = a.fhash[r];          // (only passed on: it travels beside the info word from here)
     const Oriented o = orient(h, a.contigs);
 
     // forward-strand window starts, 0-based inside the contig (detect.rs:116-131)
@@ -554,7 +556,7 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
 #pragma unroll
     for (int w = 0; w < W; w++) n_exc += (uint32_t)__popcll(rex[w]);
     if (!junction_packable((uint32_t)L, n_exc, 64u * W)) atomicAdd(&a.counters[2], 1u);
-    a.info[r] = read_info(a.by_ref ? junction_ref_bytes((uint32_t)L, n_lower) : junction_record_bytes((uint32_t)L, n_exc, n_lower, 64u * W), fl, (uint32_t)bp, (uint32_t)L);
+    a.rw[r] = RecWord{read_info(a.by_ref ? junction_ref_bytes((uint32_t)L, n_lower) : junction_record_bytes((uint32_t)L, n_exc, n_lower, 64u * W), fl, (uint32_t)bp, (uint32_t)L), fh};
     rec[a.meta_stride - 1] = (uint64_t)(uint16_t)bp | ((uint64_t)fl << 16) | ((uint64_t)(uint16_t)L << 32) | ((uint64_t)n_exc << 48);
     a.flags[r] = fl;
 }
@@ -588,7 +590,8 @@ struct ExactArgs {
     uint32_t by_ref;         // junction records name the read (BF_FLAG_READS_ON_HOST)
     uint8_t* sigx;           // 16 bytes per slot
     uint32_t* sigx_slot;     // read -> slot
-    uint64_t* info;          // read_info() word
+    RecWord* rw;             // read_info() word + fragment-id hash
+    const uint64_t* fhash;
 };
 
 struct ExactRead {
@@ -721,7 +724,7 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
                                    (o.swapped ? kEvSwapped : 0) | kEvExact | (plain ? 0 : kEvSigx));
     a.flags[r] = fl;
     if (!junction_packable((uint32_t)L, n_exc, a.max_packed)) atomicAdd(&a.counters[2], 1u);
-    a.info[r] = read_info(a.by_ref ? junction_ref_bytes((uint32_t)L, n_lower) : junction_record_bytes((uint32_t)L, n_exc, n_lower, a.max_packed), fl, (uint32_t)bp, (uint32_t)L);
+    a.rw[r] = RecWord{read_info(a.by_ref ? junction_ref_bytes((uint32_t)L, n_lower) : junction_record_bytes((uint32_t)L, n_exc, n_lower, a.max_packed), fl, (uint32_t)bp, (uint32_t)L), a.fhash[r]};
     a.meta[(uint64_t)r * (a.mask_words + 1) + a.mask_words] =
         (uint64_t)(uint16_t)bp | ((uint64_t)fl << 16) | ((uint64_t)(uint16_t)L << 32) | ((uint64_t)n_exc << 48);
     }
@@ -733,21 +736,21 @@ __global__ void exact_done_kernel(uint32_t* counters) { counters[3] = counters[0
 // Junction records of surviving reads (format: include/breakfast_hip.h, "Junction records").
 // Record sizes from the render records' last word {bp, flags, len, n_exc}.
 __global__ void __launch_bounds__(256) render_len_kernel(uint64_t n, const uint32_t* __restrict__ idx,
-                                                         const uint64_t* __restrict__ info, uint32_t* __restrict__ out_len) {
+                                                         const RecWord* __restrict__ rw, uint32_t* __restrict__ out_len) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out_len[i] = info_jrec(info[idx[i]]);
+    if (i < n) out_len[i] = info_jrec(rw[idx[i]].info);
 }
 
 // lengths for a caller-supplied (device) index list: an index outside the resident reads is counted,
 // not dereferenced
 __global__ void __launch_bounds__(256) render_len_checked_kernel(uint64_t n, const uint32_t* __restrict__ idx,
-                                                                 const uint64_t* __restrict__ info, uint64_t n_reads,
+                                                                 const RecWord* __restrict__ rw, uint64_t n_reads,
                                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ bad) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t r = idx[i];
     if (r >= n_reads) { out_len[i] = 0; atomicAdd(bad, 1u); return; }
-    out_len[i] = info_jrec(info[r]);
+    out_len[i] = info_jrec(rw[r].info);
 }
 
 // render: 16 lanes per surviving read, 4 reads per wave, 16 reads per block.  The junction string is
@@ -1062,7 +1065,7 @@ int grow_reads(bf_ctx* ctx, uint64_t cap) {
         BF_TRY(ensure(ctx, ctx->d_fhash, cap * 8, true)); BF_TRY(ensure(ctx, ctx->d_key, cap * 8, true));
         BF_TRY(ensure(ctx, ctx->d_lpos, cap * 4, true)); BF_TRY(ensure(ctx, ctx->d_rpos, cap * 4, true));
         BF_TRY(ensure(ctx, ctx->d_bp, cap * 2, true)); BF_TRY(ensure(ctx, ctx->d_flags, cap * 2, true));
-        BF_TRY(ensure(ctx, ctx->d_mask, stride * cap * 8, true)); BF_TRY(ensure(ctx, ctx->d_jrec, cap * 8, true));
+        BF_TRY(ensure(ctx, ctx->d_mask, stride * cap * 8, true)); BF_TRY(ensure(ctx, ctx->d_jrec, cap * sizeof(RecWord), true));
         BF_TRY(ensure(ctx, ctx->d_exact_list, cap * 4, true)); BF_TRY(ensure(ctx, ctx->d_sigx_slot, cap * 4, true));
         BF_TRY(ensure(ctx, ctx->d_sigx, cap * 16, true));
     }
@@ -1120,7 +1123,7 @@ int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len) {
     BF_TRY(ensure(ctx, ctx->d_fhash, cap * 8, keep)); BF_TRY(ensure(ctx, ctx->d_key, cap * 8, keep));
     BF_TRY(ensure(ctx, ctx->d_lpos, cap * 4, keep)); BF_TRY(ensure(ctx, ctx->d_rpos, cap * 4, keep));
     BF_TRY(ensure(ctx, ctx->d_bp, cap * 2, keep)); BF_TRY(ensure(ctx, ctx->d_flags, cap * 2, keep));
-    BF_TRY(ensure(ctx, ctx->d_mask, (size_t)(Wm + 1) * cap * 8, keep)); BF_TRY(ensure(ctx, ctx->d_jrec, cap * 8, keep));
+    BF_TRY(ensure(ctx, ctx->d_mask, (size_t)(Wm + 1) * cap * 8, keep)); BF_TRY(ensure(ctx, ctx->d_jrec, cap * sizeof(RecWord), keep));
     BF_TRY(ensure(ctx, ctx->d_exact_list, cap * 4, keep)); BF_TRY(ensure(ctx, ctx->d_sigx_slot, cap * 4, keep));
     // raw signature bytes: one 16-byte slot per read at most (handed out with an atomic counter by both kernels)
     BF_TRY(ensure(ctx, ctx->d_sigx, (size_t)cap * 16, keep));
@@ -1154,7 +1157,7 @@ int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len) {
     a.sigx = ctx->d_sigx.as<uint8_t>(); a.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
     a.key = ctx->d_key.as<uint64_t>(); a.lpos = ctx->d_lpos.as<int32_t>(); a.rpos = ctx->d_rpos.as<int32_t>();
     a.bp = ctx->d_bp.as<uint16_t>(); a.flags = ctx->d_flags.as<uint16_t>(); a.meta = ctx->d_mask.as<uint64_t>();
-    a.meta_stride = (int)Wm + 1; a.info = ctx->d_jrec.as<uint64_t>();
+    a.meta_stride = (int)Wm + 1; a.rw = ctx->d_jrec.as<RecWord>(); a.fhash = ctx->d_fhash.as<uint64_t>();
     a.exact_list = ctx->d_exact_list.as<uint32_t>(); a.counters = ctx->d_counters.as<uint32_t>();
     {
         Scope t(ctx, "localise");
@@ -1189,7 +1192,7 @@ int run_localise(bf_ctx* ctx, bool defer_counts, bool all) {
         e.contigs = ctx->g_contigs.as<ContigDev>(); e.raw = ctx->g_raw.as<uint8_t>();
         e.key = ctx->d_key.as<uint64_t>(); e.lpos = ctx->d_lpos.as<int32_t>(); e.rpos = ctx->d_rpos.as<int32_t>();
         e.bp = ctx->d_bp.as<uint16_t>(); e.flags = ctx->d_flags.as<uint16_t>(); e.meta = ctx->d_mask.as<uint64_t>();
-        e.mask_words = (int)Wm; e.max_packed = 64u * W; e.by_ref = (ctx->cfg.flags & BF_FLAG_READS_ON_HOST) ? 1u : 0u; e.info = ctx->d_jrec.as<uint64_t>(); e.sigx = ctx->d_sigx.as<uint8_t>(); e.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
+        e.mask_words = (int)Wm; e.max_packed = 64u * W; e.by_ref = (ctx->cfg.flags & BF_FLAG_READS_ON_HOST) ? 1u : 0u; e.rw = ctx->d_jrec.as<RecWord>(); e.fhash = ctx->d_fhash.as<uint64_t>(); e.sigx = ctx->d_sigx.as<uint8_t>(); e.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
         Scope t(ctx, "localise_exact");
         const unsigned blocks = (unsigned)std::min<uint64_t>(grid_for(n * 64, 256), 16384);   // oversubscribed: entries differ in length
         hipLaunchKernelGGL(localise_exact_kernel, dim3(blocks), dim3(256), 0, ctx->stream, e);
@@ -1221,7 +1224,7 @@ int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf&
     Scope t(ctx, "render_offsets");
     if (!d_sizes) {
         hipLaunchKernelGGL(render_len_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
-                           ctx->d_jrec.as<uint64_t>(), ctx->c_misc.as<uint32_t>());
+                           ctx->d_jrec.as<RecWord>(), ctx->c_misc.as<uint32_t>());
         d_sizes = ctx->c_misc.as<uint32_t>();
     }
     BF_TRY(scan_u32_to_u64(ctx, d_sizes, d_off.as<uint64_t>(), n));
@@ -1278,7 +1281,7 @@ int render_range_at(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local
 
 int render_sizes_checked(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint32_t* d_len, uint32_t* d_bad) {
     if (n) hipLaunchKernelGGL(render_len_checked_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
-                              ctx->d_jrec.as<uint64_t>(), ctx->n_reads, d_len, d_bad);
+                              ctx->d_jrec.as<RecWord>(), ctx->n_reads, d_len, d_bad);
     BF_HIP(ctx, hipGetLastError());
     return BF_OK;
 }
@@ -1301,7 +1304,7 @@ int render_dev(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint64_t* d
     {
         Scope t(ctx, "render_offsets");
         hipLaunchKernelGGL(render_len_checked_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
-                           ctx->d_jrec.as<uint64_t>(), ctx->n_reads, d_len, d_bad);
+                           ctx->d_jrec.as<RecWord>(), ctx->n_reads, d_len, d_bad);
         BF_TRY(scan_u32_to_u64(ctx, d_len, d_off, n));
     }
     uint32_t bad = 0;
@@ -1364,7 +1367,7 @@ static int render_dev_static(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_id
     // written for [0, n) before they are read
     BF_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
     hipLaunchKernelGGL(render_len_checked_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, d_local_idx,
-                       ctx->d_jrec.as<uint64_t>(), ctx->n_reads, d_len, d_bad);
+                       ctx->d_jrec.as<RecWord>(), ctx->n_reads, d_len, d_bad);
     BF_TRY(scan_u32_to_u64_ws(ctx, d_len, d_off, n, d_scan));
     // read-backs through the ctx's pinned words (a copy to pageable memory may stage through memory the runtime allocates)
     volatile uint32_t* hw = ctx->h_counts + 8;

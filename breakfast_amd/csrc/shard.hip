@@ -484,12 +484,12 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
     OwnerView v;
     v.n = ctx->n_imported;
     v.key = ctx->i_key.as<uint64_t>(); v.lpos = ctx->i_lpos.as<int32_t>(); v.rpos = ctx->i_rpos.as<int32_t>();
-    v.fhash = ctx->i_fhash.as<uint64_t>(); v.bp = ctx->i_bp.as<uint16_t>(); v.len = ctx->i_len.as<uint16_t>();
+    v.bp = ctx->i_bp.as<uint16_t>(); v.len = ctx->i_len.as<uint16_t>();
     v.flags = ctx->i_flags.as<uint16_t>();
     v.frag = ctx->i_frag.as<uint8_t>(); v.frag_off = ctx->i_frag_off.as<uint64_t>(); v.frag_len = ctx->i_frag_len.as<uint16_t>();
     v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
     v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>();
-    v.info = ctx->i_jrec.as<uint64_t>();
+    v.rw = ctx->i_jrec.as<RecWord>();
     ctx->clustered = false; ctx->reads_on_device = false;
     ctx->out.n_clusters = ctx->out.n_reads = 0; ctx->n_evidence = v.n;
 
