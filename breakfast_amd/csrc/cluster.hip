@@ -222,25 +222,29 @@ __global__ void __launch_bounds__(256) sweep_walk_kernel(const SweepView v, uint
 constexpr unsigned kFlagGrid = 1024;
 __global__ void __launch_bounds__(256) flag_ge_kernel(uint32_t* flag, const uint32_t* __restrict__ val, uint32_t thr, uint64_t n,
                                                       uint32_t wave_max, unsigned long long* sums,
-                                                      const uint32_t* __restrict__ idx = nullptr) {
+                                                      const uint32_t* __restrict__ idx = nullptr, unsigned int* n_wide = nullptr) {
     unsigned long long s_all = 0, s_big = 0;
+    unsigned int wide = 0;                                           // flagged values above 64 (fill_members_kernel<4>'s clusters)
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         const uint32_t c = val[idx ? idx[i] : i];
         const bool f = c >= thr;
         flag[i] = f ? 1u : 0u;
-        if (f) { s_all += c; if (c > wave_max) s_big += c; }
+        if (f) { s_all += c; if (c > wave_max) s_big += c; wide |= c > 64u ? 1u : 0u; }
     }
+    const bool any_wide = __ballot(wide != 0) != 0;
     for (int d = 32; d; d >>= 1) { s_all += __shfl_down(s_all, d); s_big += __shfl_down(s_big, d); }
     // one pair of atomics per BLOCK: they all hit the same two words and are served one after the other (with one pair
     // per wave the 8192 atomics of a launch, not its 40 MB of traffic, set the kernel's time: 75 us for 5M records)
     __shared__ unsigned long long w_all[4], w_big[4];
-    if ((threadIdx.x & 63) == 0) { w_all[threadIdx.x >> 6] = s_all; w_big[threadIdx.x >> 6] = s_big; }
+    __shared__ unsigned int w_wide[4];
+    if ((threadIdx.x & 63) == 0) { w_all[threadIdx.x >> 6] = s_all; w_big[threadIdx.x >> 6] = s_big; w_wide[threadIdx.x >> 6] = any_wide; }
     __syncthreads();
     if (threadIdx.x == 0) {
         s_all = w_all[0] + w_all[1] + w_all[2] + w_all[3];
         s_big = w_big[0] + w_big[1] + w_big[2] + w_big[3];
         if (s_all) atomicAdd(&sums[0], s_all);
         if (s_big) atomicAdd(&sums[1], s_big);
+        if (n_wide && (w_wide[0] | w_wide[1] | w_wide[2] | w_wide[3])) atomicOr(n_wide, 1u);
     }
 }
 // Clusters of up to wave_max <= kWaveDedupMax members are de-duplicated by the wave that enumerates them
@@ -290,16 +294,33 @@ struct MemberView {
     uint64_t hash_mask;     // all ones; a few bits under BF_FLAG_WEAK_DEDUP_HASH (tests: forces the byte-wise redo)
 };
 
-__device__ __forceinline__ bool same_frag_bytes(const MemberView& m, uint32_t ra, uint32_t rb) {
-    // lengths and offsets in one round trip (not the offsets only after the lengths have come back)
-    const uint32_t la = m.frag_len[ra], lb = m.frag_len[rb];
-    const uint64_t oa = m.frag_off[ra], ob = m.frag_off[rb];
-    if (la != lb) return false;
-    const uint8_t* a = m.frag + oa;
-    const uint8_t* b = m.frag + ob;
-    uint32_t diff = 0;                       // no early exit: the hashes already agree, the ids almost surely too
-    for (uint32_t k = 0; k < la; k++) diff |= (uint32_t)(a[k] ^ b[k]);
+// Two fragment ids byte for byte.  The wave that calls this sits in a chain of round trips to memory, so the compare is
+// shaped for few of them: both lengths and both offsets in one, then the first 32 bytes of both ids as eight 8-byte words
+// in flight together (ids are rarely longer; the words past an id's end are read and masked -- the id buffers end in 64
+// spare bytes), then 8 bytes a step for the rest.  (Round 2's form -- lengths, then offsets, then a loop that waited for
+// every two bytes -- was a dozen dependent round trips: ~18 us of a wave's life, most of fill_members_kernel's time.)
+__device__ __forceinline__ uint64_t load_u64_any(const uint8_t* p) { uint64_t x; __builtin_memcpy(&x, p, 8); return x; }
+__device__ __forceinline__ uint64_t head_bytes_mask(uint32_t len, uint32_t at) {      // bytes [at, at + 8) that lie below len
+    const uint32_t nb = len > at ? min(len - at, 8u) : 0u;
+    return nb >= 8u ? ~0ull : ((1ull << (8u * nb)) - 1ull);
+}
+__device__ __forceinline__ bool same_id_bytes(const uint8_t* __restrict__ frag, const uint64_t* __restrict__ frag_off,
+                                              const uint16_t* __restrict__ frag_len, uint32_t ra, uint32_t rb) {
+    const uint32_t la = frag_len[ra], lb = frag_len[rb];
+    const uint64_t oa = frag_off[ra], ob = frag_off[rb];
+    const uint8_t* a = frag + oa;
+    const uint8_t* b = frag + ob;
+    uint64_t xa[4], xb[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) { xa[w] = load_u64_any(a + 8 * w); xb[w] = load_u64_any(b + 8 * w); }
+    uint64_t diff = (uint64_t)(la ^ lb);
+#pragma unroll
+    for (int w = 0; w < 4; w++) diff |= (xa[w] ^ xb[w]) & head_bytes_mask(la, 8u * w);
+    for (uint32_t k = 32; k < la; k += 8) diff |= (load_u64_any(a + k) ^ load_u64_any(b + k)) & head_bytes_mask(la, k);
     return diff == 0;
+}
+__device__ __forceinline__ bool same_frag_bytes(const MemberView& m, uint32_t ra, uint32_t rb) {
+    return same_id_bytes(m.frag, m.frag_off, m.frag_len, ra, rb);
 }
 
 // One wave per qualifying cluster: re-enumerate the seed's members in sweep order.
@@ -310,19 +331,28 @@ __device__ __forceinline__ bool same_frag_bytes(const MemberView& m, uint32_t ra
 // instead of a radix sort of all member slots by (cluster, hash) and a pass over the sorted runs.  The members of
 // larger clusters (duplicate-heavy libraries pile thousands of reads on one junction) are written, compacted,
 // for exactly that sort.
+// Two instantiations share the enumeration: R = 1 takes the clusters of up to 64 members (a member per lane, everything
+// in registers: ~50 VGPRs, eight waves a SIMD -- the kernel lives on round trips to memory, so waves in flight are what
+// counts), R = kWaveDedupMax / 64 the larger ones (several members per lane, and the clusters above wave_max, which it
+// only enumerates); a wave whose cluster belongs to the other one leaves at once.  The second is launched only when the
+// host knows of such clusters (flag_ge_kernel counts them).
+template <int R>
 __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, const MemberView m, uint64_t nq) {
-    __shared__ uint64_t s_fh[4][kWaveDedupMax];
-    __shared__ uint32_t s_sc[4][kWaveDedupMax];
-    __shared__ uint32_t s_rc[4][kWaveDedupMax];
-    __shared__ uint32_t s_ld[4][kWaveDedupMax];
+    constexpr uint32_t kCap = 64u * R;
+    __shared__ uint64_t s_fh[4][kCap];
+    __shared__ uint32_t s_sc[4][kCap];
+    __shared__ uint32_t s_rc[4][kCap];
+    __shared__ uint32_t s_ld[R > 1 ? 4 : 1][R > 1 ? kCap : 1];
     const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
     if (q >= nq) return;
+    const uint32_t size = m.qsize[q];
+    const bool in_wave = size <= m.wave_max;
+    if ((R == 1) != (in_wave && size <= 64u)) return;                // the other instantiation's cluster (wave-uniform)
     const uint64_t p = m.qseed[q];
     const uint64_t base = m.qoff[q];
     const uint64_t key = v.skey[p];
     const int32_t lp = v.slpos[p], rp = v.srpos[p];
-    const bool in_wave = m.qsize[q] <= m.wave_max;
     const uint64_t cbase = in_wave ? 0 : m.qboff[q];
     auto put = [&](uint64_t slot, uint32_t rec) {
         const RecWord w = m.rw[rec];
@@ -332,7 +362,7 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
         const uint32_t score = min(l, r) * 10000u + max(l, r);       // detect.rs:273-279
         if (in_wave) {
             const uint32_t i = (uint32_t)(slot - base);
-            if (i < kWaveDedupMax) { s_fh[wv][i] = fh; s_sc[wv][i] = score; s_rc[wv][i] = rec; }
+            if (i < kCap) { s_fh[wv][i] = fh; s_sc[wv][i] = score; s_rc[wv][i] = rec; }
         } else {
             const uint64_t ci = cbase + (slot - base);
             m.mkey[ci] = (q << kMemberHashBits) | (fh & ((1ull << kMemberHashBits) - 1));
@@ -365,8 +395,50 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t c = (uint32_t)min(cnt, (uint64_t)kWaveDedupMax);   // == qsize[q]
-    constexpr int R = kWaveDedupMax / 64;
+    const uint32_t c = (uint32_t)min(cnt, (uint64_t)kCap);           // == qsize[q]
+    if constexpr (R == 1) {
+        // The usual cluster: a member per lane, everything in registers.  The kernel is bound by the instructions of the
+        // loop over the members (one broadcast + compare per member: ~110k clusters x ~40 members a step), so this
+        // loop is as short as it gets -- two v_readlane for the j-th member's hash, no LDS word to wait for, no guards
+        // for further rounds -- and the loop over the representatives only visits the members that joined a group.
+        const uint32_t i = (uint32_t)lane;
+        const bool in = i < c;
+        const uint64_t f = in ? s_fh[wv][i] & m.hash_mask : 0;
+        const uint32_t rcl = in ? s_rc[wv][i] : 0, sc = in ? s_sc[wv][i] : 0;
+        const int flo = (int)(uint32_t)f, fhi = (int)(uint32_t)(f >> 32);
+        const uint32_t cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        uint32_t l = i;
+        for (uint32_t j = 0; j + 1 < cu; j++) {
+            const int jl = __builtin_amdgcn_readlane(flo, (int)j), jh = __builtin_amdgcn_readlane(fhi, (int)j);
+            const bool cand = i > j && in && l == i && flo == jl && fhi == jh;
+            l = cand ? j : l;
+        }
+        bool verified = true;
+        if (in && l != i) verified = same_frag_bytes(m, rcl, s_rc[wv][l]);
+        if (__ballot(!verified)) {                                   // two ids with one hash: bytes, pair by pair
+            l = i;
+            for (uint32_t j = 0; j + 1 < cu; j++) {
+                const int jl = __builtin_amdgcn_readlane(flo, (int)j), jh = __builtin_amdgcn_readlane(fhi, (int)j);
+                const bool cand = i > j && in && l == i && flo == jl && fhi == jh;
+                bool same = false;
+                if (cand) same = same_frag_bytes(m, rcl, s_rc[wv][j]);
+                l = same ? j : l;
+            }
+        }
+        uint32_t best = i, bs = sc;
+        uint64_t jm = __ballot(in && l != i);                        // ascending: the first maximum wins (strict >, detect.rs:280)
+        while (jm) {
+            const int i2 = __builtin_ctzll(jm);
+            jm &= jm - 1;
+            const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)l, i2), si = (uint32_t)__builtin_amdgcn_readlane((int)sc, i2);
+            if (i == li && si > bs) { bs = si; best = (uint32_t)i2; }
+        }
+        const bool leads = in && l == i;
+        if (in) m.rep[base + i] = leads ? best : kNone;
+        const uint32_t groups = (uint32_t)__popcll(__ballot(leads));
+        if (lane == 0) m.qnrep[q] = groups;
+        return;
+    } else {
     const int rounds = (int)((c + 63) >> 6);
     uint64_t fh[R]; uint32_t ld[R], rc[R];
 #pragma unroll
@@ -444,18 +516,14 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
         groups += (uint32_t)__popcll(__ballot(leads));
     }
     if (lane == 0) m.qnrep[q] = groups;
+    }
 }
 
 struct FragView {
     const uint32_t* perm; const uint8_t* frag; const uint64_t* frag_off; const uint16_t* frag_len;
 };
 __device__ __forceinline__ bool same_frag(const FragView& f, uint32_t ra, uint32_t rb) {
-    const uint32_t la = f.frag_len[ra];
-    if (la != f.frag_len[rb]) return false;
-    const uint8_t* a = f.frag + f.frag_off[ra];
-    const uint8_t* b = f.frag + f.frag_off[rb];
-    for (uint32_t k = 0; k < la; k++) if (a[k] != b[k]) return false;
-    return true;
+    return same_id_bytes(f.frag, f.frag_off, f.frag_len, ra, rb);
 }
 
 // Fragment-id groups (remove_frag_id_duplicates, detect.rs:247-287) without the reference's O(c^2):
@@ -961,6 +1029,7 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
     BF_TRY(ensure(ctx, ctx->c_flag, n * 4)); BF_TRY(ensure(ctx, ctx->c_scan, (n + 1) * 8));
     uint64_t nq = 0;
     uint64_t totals[2] = {0, 0};
+    bool wide_clusters = false;                            // some qualifying cluster has more than 64 members (fill_members_kernel<4>)
     const uint32_t wave_max = (ctx->cfg.flags & BF_FLAG_SORTED_DEDUP) ? 0u : kWaveDedupMax;
     unsigned long long* sums = nullptr;
     {
@@ -987,14 +1056,16 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
                                ctx->c_csize.as<uint32_t>(), small_list, big_list, counts, list_blocks);
         }
         hipLaunchKernelGGL(flag_ge_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, B), kFlagGrid)), dim3(B), 0, st,
-                           ctx->c_flag.as<uint32_t>(), ctx->c_csize.as<uint32_t>(), min_evidence, n, wave_max, sums);
+                           ctx->c_flag.as<uint32_t>(), ctx->c_csize.as<uint32_t>(), min_evidence, n, wave_max, sums, (const uint32_t*)nullptr, counts + 13);
         BF_TRY(scan_u32_to_u64(ctx, ctx->c_flag.as<uint32_t>(), ctx->c_scan.as<uint64_t>(), n));
         // members of the qualifying clusters, and of those too large for the in-wave dedup; the number of qualifying
         // clusters; the records class_order set aside: one wait for all of them (mailbox)
         BF_TRY(mail_fetch(ctx, 0, sums, 2));
         BF_TRY(mail_fetch(ctx, 2, ctx->c_scan.as<uint64_t>() + n));
+        BF_TRY(mail_fetch(ctx, 4, counts + 12));            // (word 13: a qualifying cluster has more than 64 members)
         BF_SYNC(ctx, st);
         totals[0] = ctx->h_mail[0]; totals[1] = ctx->h_mail[1]; nq = ctx->h_mail[2];
+        wide_clusters = (ctx->h_mail[4] >> 32) != 0;
         if (!wait_over && ctx->h_mail[3] != 0) { ctx->saw_overflow = true; *redo = true; return BF_OK; }
         BF_TRY(settle_counts(ctx));                       // the localise counters came along with this synchronisation
     }
@@ -1036,7 +1107,9 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
             BF_HIP(ctx, hipMemsetAsync(ctx->c_leader.p, 0xff, total_m * 4, st));
             BF_HIP(ctx, hipMemsetAsync(ctx->c_rep.p, 0xff, total_m * 4, st));
         }
-        hipLaunchKernelGGL(fill_members_kernel, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, sv, mv, nq);
+        hipLaunchKernelGGL(fill_members_kernel<1>, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, sv, mv, nq);
+        if (wide_clusters || total_big)
+            hipLaunchKernelGGL(fill_members_kernel<kWaveDedupMax / 64>, dim3(grid_for(nq * 64, B)), dim3(B), 0, st, sv, mv, nq);
         if (total_big) {
             uint32_t* slot_in = mv.bslot; uint32_t* slot_s = slot_in + total_big;
             unsigned qbits = 1; while ((1ull << qbits) < nq) qbits++;
@@ -1389,7 +1462,7 @@ int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts) {
     const uint32_t stride = ctx->wire_frag_stride;
     BF_TRY(ensure(ctx, ctx->i_key, n * 8)); BF_TRY(ensure(ctx, ctx->i_lpos, n * 4)); BF_TRY(ensure(ctx, ctx->i_rpos, n * 4));
     BF_TRY(ensure(ctx, ctx->i_bp, n * 2)); BF_TRY(ensure(ctx, ctx->i_len, n * 2));
-    BF_TRY(ensure(ctx, ctx->i_flags, n * 2)); BF_TRY(ensure(ctx, ctx->i_frag, std::max<uint64_t>(n * stride, 1)));
+    BF_TRY(ensure(ctx, ctx->i_flags, n * 2)); BF_TRY(ensure(ctx, ctx->i_frag, n * stride + 64));          // (same_id_bytes reads whole words past an id's end)
     BF_TRY(ensure(ctx, ctx->i_frag_off, n * 8)); BF_TRY(ensure(ctx, ctx->i_frag_len, n * 2));
     BF_TRY(ensure(ctx, ctx->i_sigx, n * 16)); BF_TRY(ensure(ctx, ctx->i_sigx_slot, n * 4));
     BF_TRY(ensure(ctx, ctx->i_src_rank, n * 4)); BF_TRY(ensure(ctx, ctx->i_src_idx, n * 4));

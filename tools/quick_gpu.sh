@@ -10,8 +10,9 @@ rc=$?; tail -4 $out/tests.log
 if [ $rc -ne 0 ]; then echo "tests failed ($rc)"; exit $rc; fi
 timeout -k 10 200 python bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-h2h > $out/bench.json 2> $out/bench.log || exit 1
 timeout -k 10 200 python bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-h2h --exchange > $out/bench_x.json 2> $out/bench_x.log || exit 1
+timeout -k 10 200 python bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-h2h --one-stream > $out/bench_1s.json 2> $out/bench_1s.log || exit 1
 python - <<PY
 import json
-for f in ("bench", "bench_x"):
+for f in ("bench", "bench_x", "bench_1s"):
     d = json.load(open("$out/%s.json" % f)); print(f, d["ms_per_step"], d["stage_ms"])
 PY
