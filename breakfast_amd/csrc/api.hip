@@ -83,6 +83,11 @@ int ensure(bf_ctx* ctx, DevBuf& b, size_t bytes, bool keep) {
     return BF_OK;
 }
 
+int wide_words(bf_ctx* ctx, size_t n, uint64_t** out) {
+    BF_TRY(ensure_host(ctx, ctx->h_wide, std::max<size_t>(n, 512) * 8));
+    *out = ctx->h_wide.as<uint64_t>();
+    return BF_OK;
+}
 int ensure_host(bf_ctx* ctx, HostBuf& b, size_t bytes) {
     if (bytes <= b.cap && b.p) return BF_OK;
     if (b.p) {
@@ -147,14 +152,14 @@ static void free_all(bf_ctx* ctx) {
         &ctx->d_key, &ctx->d_lpos, &ctx->d_rpos, &ctx->d_bp, &ctx->d_flags, &ctx->d_mask, &ctx->d_jrec, &ctx->d_exact_list,
         &ctx->d_counters, &ctx->d_sigx, &ctx->d_sigx_slot, &ctx->d_send, &ctx->d_part_key, &ctx->d_part_idx,
         &ctx->d_part_tmp, &ctx->i_key, &ctx->i_lpos, &ctx->i_rpos, &ctx->i_bp, &ctx->i_len, &ctx->i_flags,
-        &ctx->i_frag, &ctx->i_frag_off, &ctx->i_frag_len, &ctx->i_sigx, &ctx->i_sigx_slot, &ctx->i_src_rank,
-        &ctx->i_src_idx, &ctx->i_jrec, &ctx->c_tmp, &ctx->c_a32, &ctx->c_b32, &ctx->c_c32, &ctx->c_d32, &ctx->c_k64a, &ctx->c_k64b,
+        &ctx->i_frag, &ctx->i_frag_off, &ctx->i_frag_len, &ctx->i_sigx, &ctx->i_sigx_slot, &ctx->i_src,
+        &ctx->i_jrec, &ctx->c_tmp, &ctx->c_a32, &ctx->c_b32, &ctx->c_c32, &ctx->c_d32, &ctx->c_k64a, &ctx->c_k64b,
         &ctx->c_slpos, &ctx->c_srpos, &ctx->c_reported, &ctx->c_csize, &ctx->c_flag, &ctx->c_scan, &ctx->c_qseed,
         &ctx->c_qsize, &ctx->c_qoff, &ctx->c_mrec, &ctx->c_mjrec, &ctx->c_leader, &ctx->c_rep, &ctx->c_qnrep, &ctx->c_ctl, &ctx->c_sel,
         &ctx->c_ord, &ctx->c_clusters, &ctx->c_reads, &ctx->c_misc, &ctx->c_joff, &ctx->c_jbytes, &ctx->c_rsrc,
         &ctx->c_tables, &ctx->c_mkey_s, &ctx->c_slot, &ctx->c_big, &ctx->c_cjo, &ctx->c_aoff, &ctx->c_err, &ctx->c_tmp2, &ctx->c_qord, &ctx->c_gidx, &ctx->c_hist, &ctx->c_comp, &ctx->c_bstart, &ctx->c_chunk, &ctx->c_pos2, &ctx->r_idx, &ctx->r_off, &ctx->r_bytes};
     for (DevBuf* b : all) release(ctx, *b);
-    HostBuf* hosts[] = {&ctx->out.clusters, &ctx->out.reads, &ctx->out.src, &ctx->out.junction, &ctx->out.cjo};
+    HostBuf* hosts[] = {&ctx->out.clusters, &ctx->out.reads, &ctx->out.src, &ctx->out.junction, &ctx->out.cjo, &ctx->h_wide};
     for (HostBuf* h : hosts) { if (h->p) (void)hipHostFree(h->p); h->p = nullptr; h->cap = 0; }
 }
 

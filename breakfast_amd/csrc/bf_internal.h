@@ -205,8 +205,8 @@ struct OwnerView {
     const uint16_t* frag_len = nullptr;
     const uint8_t* sigx = nullptr;       // 16 raw signature bytes per slot
     const uint32_t* sigx_slot = nullptr; // record -> slot (only read when the key's sigx bit is set)
-    const uint32_t* src_rank = nullptr;  // nullptr = all from this rank
-    const uint32_t* src_idx = nullptr;   // nullptr = identity
+    const uint64_t* src = nullptr;       // imported records: source rank << 32 | index on that rank, ONE word (emit gathers it
+                                         // per supporting read); nullptr = all from this rank, record i is read i
     const RecWord* rw = nullptr;         // per record, ONE 16-byte load for the gathers of the dedup: read_info() word + fragment-id hash
 };
 
@@ -314,6 +314,8 @@ struct bf_ctx {
     bool order_full = false;                    // the short print-order sort met something it does not handle (long tie runs, a
                                                 // position outside its mapped range): the ctx uses the full two-sort order from then on
     bool saw_overflow = false;                  // a chunk too large for the LDS sort has come up: class_order waits for the count again
+    bf::HostBuf h_wide;                         // pinned, grown on demand (wide_words): longer read-backs that ride on a wait the
+                                                // path makes anyway -- the imported view's contig histogram, per-rank words
     uint32_t* h_counts = nullptr;               // pinned (bf_ctx_create): words 0-2 the localise kernels' counters on their way
                                                 // to the three fields above, words 8-11 the read-backs of bf_render_junctions_dev_static
     void* scratch = nullptr;                    // this device's copy of the static scratch array (localise.hip, scratch_setup)
@@ -333,7 +335,7 @@ struct bf_ctx {
     uint64_t n_imported = 0;
     bf::DevBuf d_send, d_part_key, d_part_idx, d_part_tmp;
     bf::DevBuf i_key, i_lpos, i_rpos, i_bp, i_len, i_flags, i_frag, i_frag_off, i_frag_len, i_sigx,
-        i_sigx_slot, i_src_rank, i_src_idx, i_jrec;
+        i_sigx_slot, i_src, i_jrec;
     bool reads_on_device = false;               // the finished read table waits in c_reads for bf_result_reads
     uint64_t rsrc_stride = 0;                   // c_rsrc = 4 arrays of this many entries (source rank, source index, record, bytes)
 
@@ -395,6 +397,8 @@ inline int mail_fetch(bf_ctx* ctx, int slot, const void* d_src, int n = 1) {
     return BF_OK;
 }
 int ensure(bf_ctx* ctx, DevBuf& b, size_t bytes, bool keep = false);
+// n 64-bit words of pinned host memory for a read-back (valid until the next call with a larger n: ask before queueing copies)
+int wide_words(bf_ctx* ctx, size_t n, uint64_t** out);
 int ensure_host(bf_ctx* ctx, HostBuf& b, size_t bytes);
 void release(bf_ctx* ctx, DevBuf& b);
 
@@ -452,7 +456,10 @@ int rank_histogram(bf_ctx* ctx, const OwnerView& v, std::vector<uint64_t>& hist)
 int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* g = nullptr);   // fills ctx->out (without junction text)
 int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint64_t dev_send_bytes, uint64_t* counts,
                   void** dev_out, uint32_t* record_bytes);
-int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts);
+// rank_hist: the imported records per left contig rank, counted behind the import (same wait); dev_self: where the records
+// of source rank `self` are read instead of their place in dev_recv (the rank's own piece, left in its send buffer)
+int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts, std::vector<uint64_t>* rank_hist = nullptr,
+               const uint8_t* dev_self = nullptr, uint32_t self = 0);
 // primitives.hip -------------------------------------------------------------------------------
 // stable LSD radix sort of (key, value) pairs on key bits [begin_bit, end_bit); result in kout/vout, inputs kept
 int radix_sort_pairs(bf_ctx* ctx, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n,

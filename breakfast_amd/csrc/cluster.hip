@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(256) count_groups_kernel(uint64_t nq, const ui
 
 struct OrderView {
     const uint32_t* qseed; const uint64_t* skey; const int32_t* slpos; const uint32_t* perm;
-    const uint32_t* src_rank; const uint32_t* src_idx; int cb;
+    const uint64_t* src; int cb;
 };
 // The short print-order sort.  The order is (contig rank, lpos as the wrapped usize, input index of the seed): 5 + 32 + 24
 // and more significant bits, eight 8-bit passes in two sorts of ~50k keys each, sixteen launches at the latency floor --
@@ -606,8 +606,7 @@ __global__ void cluster_keys_short_kernel(const OrderView o, uint64_t* kpos, uin
     if ((lp >= 0 && m >= top - kNegRoom) || (lp < 0 && lp < -kNegRoom)) { atomicOr(so.flag, 1u); m = 0; }
     const uint64_t rank = (o.skey[p] >> key_rank_shift(o.cb)) - so.rank_lo;
     kpos[k] = (rank << so.pos_bits) | (uint64_t)m;
-    const uint64_t sr = o.src_rank ? o.src_rank[rec] : 0, si = o.src_idx ? o.src_idx[rec] : rec;
-    kidx[k] = (sr << 32) | si;
+    kidx[k] = o.src ? o.src[rec] : (uint64_t)rec;
 }
 // qord[] is in (rank, position) order, stable on the sorted-space order of the seeds; a run of equal keys is put into
 // input-index order by the thread at its head
@@ -637,8 +636,7 @@ __global__ void cluster_keys_kernel(const OrderView o, const uint32_t* __restric
     const uint32_t p = o.qseed[sel ? sel[k] : k];
     const uint32_t rec = o.perm[p];
     kpos[k] = ((o.skey[p] >> key_rank_shift(o.cb)) << 32) | (uint32_t)o.slpos[p];
-    const uint64_t sr = o.src_rank ? o.src_rank[rec] : 0, si = o.src_idx ? o.src_idx[rec] : rec;
-    kidx[k] = (sr << 32) | si;
+    kidx[k] = o.src ? o.src[rec] : (uint64_t)rec;
 }
 struct EmitView {
     const uint32_t* ord;        // output order -> q
@@ -646,7 +644,7 @@ struct EmitView {
     const uint32_t* qseed; const uint32_t* qsize; const uint64_t* qoff;
     const uint32_t* mrec; const uint32_t* mjrec; const uint32_t* rep;
     const uint64_t* skey; const int32_t* slpos; const int32_t* srpos; const uint32_t* perm;
-    const uint32_t* src_rank; const uint32_t* src_idx; const uint64_t* src_base;
+    const uint64_t* src; const uint64_t* src_base;
     const uint32_t* rank2id; int cb;
     bf_cluster* clusters; bf_read* reads; uint32_t* out_src_rank; uint32_t* out_src_idx; uint32_t* out_rec; uint32_t* out_jrec;
     uint64_t rd_base;           // reads[], out_*[] start at this group's first read: read_begin / read_end count from here
@@ -663,7 +661,8 @@ __global__ void __launch_bounds__(256) emit_kernel(const EmitView e, uint64_t ns
     const uint32_t c = e.qsize[q];
     const uint64_t rbase = e.roff[k];
     auto source = [&](uint32_t rec, uint32_t& sr, uint32_t& si) {
-        sr = e.src_rank ? e.src_rank[rec] : 0; si = e.src_idx ? e.src_idx[rec] : rec;
+        const uint64_t w = e.src ? e.src[rec] : (uint64_t)rec;
+        sr = (uint32_t)(w >> 32); si = (uint32_t)w;
     };
     if (lane == 0) {
         const uint32_t p = e.qseed[q];
@@ -739,19 +738,27 @@ __global__ void __launch_bounds__(256) rank_hist_kernel(unsigned long long* __re
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < bins; b += 256) if (h[b]) atomicAdd(&hist[bin0 + b], (unsigned long long)h[b]);
 }
-int rank_histogram(bf_ctx* ctx, const OwnerView& v, std::vector<uint64_t>& hist) {
-    hist.assign(ctx->n_contigs, 0);
-    if (v.n == 0) return BF_OK;
+// queued on the ctx's stream; the counts are in *h_hist (pinned) after the next wait for it
+static int rank_histogram_queue(bf_ctx* ctx, const uint64_t* d_key, uint64_t n, uint64_t** h_hist) {
     const hipStream_t st = ctx->stream;
+    BF_TRY(wide_words(ctx, ctx->n_contigs, h_hist));
     BF_TRY(ensure(ctx, ctx->c_bstart, std::max<size_t>((size_t)ctx->n_contigs * 8, 64), false));
     BF_HIP(ctx, hipMemsetAsync(ctx->c_bstart.p, 0, (size_t)ctx->n_contigs * 8, st));
     for (uint32_t bin0 = 0; bin0 < ctx->n_contigs; bin0 += kRankHistMax)
-        hipLaunchKernelGGL(rank_hist_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(v.n, 256), 512)), dim3(256), 0, st,
-                           (unsigned long long*)ctx->c_bstart.p, v.key, key_rank_shift(ctx->contig_bits), (1u << ctx->contig_bits) - 1, bin0,
-                           std::min(kRankHistMax, ctx->n_contigs - bin0), v.n);
+        hipLaunchKernelGGL(rank_hist_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, 256), 512)), dim3(256), 0, st,
+                           (unsigned long long*)ctx->c_bstart.p, d_key, key_rank_shift(ctx->contig_bits), (1u << ctx->contig_bits) - 1, bin0,
+                           std::min(kRankHistMax, ctx->n_contigs - bin0), n);
     BF_HIP(ctx, hipGetLastError());
-    BF_HIP(ctx, hipMemcpyAsync(hist.data(), ctx->c_bstart.p, (size_t)ctx->n_contigs * 8, hipMemcpyDeviceToHost, st));
-    BF_SYNC(ctx, st);
+    BF_HIP(ctx, hipMemcpyAsync(*h_hist, ctx->c_bstart.p, (size_t)ctx->n_contigs * 8, hipMemcpyDeviceToHost, st));
+    return BF_OK;
+}
+int rank_histogram(bf_ctx* ctx, const OwnerView& v, std::vector<uint64_t>& hist) {
+    hist.assign(ctx->n_contigs, 0);
+    if (v.n == 0) return BF_OK;
+    uint64_t* h = nullptr;
+    BF_TRY(rank_histogram_queue(ctx, v.key, v.n, &h));
+    BF_SYNC(ctx, ctx->stream);
+    hist.assign(h, h + ctx->n_contigs);
     return BF_OK;
 }
 
@@ -760,9 +767,9 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
     const uint64_t n = v.n;
     const hipStream_t st = ctx->stream;
     bounds.assign(1, 0); bounds.push_back(n);
-    *record_bytes = 0;
+    if (record_bytes) *record_bytes = 0;
     const std::vector<uint64_t>& rank_hist = view_hist ? *view_hist : ctx->rank_hist;
-    if (max_groups < 2 || n == 0 || (v.src_rank && !view_hist) || rank_hist.size() != ctx->n_contigs) return BF_OK;
+    if (max_groups < 2 || n == 0 || (v.src && !view_hist) || rank_hist.size() != ctx->n_contigs) return BF_OK;
     uint64_t counted = 0;
     for (uint64_t c : rank_hist) counted += c;
     if (counted != n) return fail(ctx, BF_ERR_STATE, "contig histogram of %llu reads for %llu evidence records", (unsigned long long)counted, (unsigned long long)n);
@@ -781,10 +788,12 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
     bounds.push_back(n);
     BF_TRY(ensure(ctx, ctx->c_gidx, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_hist, 64 + ctx->n_contigs, false));
     BF_TRY(ensure(ctx, ctx->c_c32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_k64a, n * 8, false));
-    BF_HIP(ctx, hipMemsetAsync(ctx->c_hist.p, 0, 8, st));
-    hipLaunchKernelGGL(record_bytes_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, 256), 1024)), dim3(256), 0, st, v.rw, n,
-                       (unsigned long long*)ctx->c_hist.p);
-    BF_TRY(mail_fetch(ctx, 0, ctx->c_hist.p));            // read after the wait at the end: no round trip of its own
+    if (record_bytes) {                                   // (the sharded path's records stay with their sources: no bound to compute)
+        BF_HIP(ctx, hipMemsetAsync(ctx->c_hist.p, 0, 8, st));
+        hipLaunchKernelGGL(record_bytes_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, 256), 1024)), dim3(256), 0, st, v.rw, n,
+                           (unsigned long long*)ctx->c_hist.p);
+        BF_TRY(mail_fetch(ctx, 0, ctx->c_hist.p));        // read after the wait at the end: no round trip of its own
+    }
     if (bounds.size() > 2) {
         const unsigned shift = (unsigned)key_rank_shift(ctx->contig_bits);
         {
@@ -802,7 +811,7 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
         }
     }
     BF_SYNC(ctx, st);                                     // (group_of is read by the copy above until here)
-    *record_bytes = ctx->h_mail[0];
+    if (record_bytes) *record_bytes = ctx->h_mail[0];
     BF_TRY(settle_counts(ctx));                           // the localise counters came along with this synchronisation
     return BF_OK;
 }
@@ -1133,7 +1142,7 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
         const hipStream_t as = ctx->stream;
         uint64_t* kpos = ctx->c_misc.as<uint64_t>();
         uint64_t* kidx = kpos + nq; uint64_t* kpos2 = kidx + nq; uint64_t* kidx2 = kpos2 + nq;
-        OrderView ov{ctx->c_qseed.as<uint32_t>(), sv.skey, sv.slpos, perm, v.src_rank, v.src_idx, ctx->contig_bits};
+        OrderView ov{ctx->c_qseed.as<uint32_t>(), sv.skey, sv.slpos, perm, v.src, ctx->contig_bits};
         // values = q; c_b32 / c_c32 are free since the sweep
         uint32_t* va = ctx->c_b32.as<uint32_t>(); uint32_t* vb = ctx->c_c32.as<uint32_t>();
         if (!ctx->order_full) {
@@ -1154,7 +1163,7 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
             hipLaunchKernelGGL(cluster_keys_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, ov, (const uint32_t*)nullptr, kpos, kidx, va, nq);
             // significant bits of (source rank << 32 | source index): on one rank the index alone, below n
             unsigned idx_bits = 64;
-            if (!v.src_rank) { idx_bits = 1; while (idx_bits < 32 && (1ull << idx_bits) < v.n) idx_bits++; }
+            if (!v.src) { idx_bits = 1; while (idx_bits < 32 && (1ull << idx_bits) < v.n) idx_bits++; }
             else { unsigned rb = 1; while ((1u << rb) < ctx->n_ranks) rb++; idx_bits = 32 + rb; }
             BF_TRY(sort_pairs<uint64_t>(ctx, kidx, kidx2, va, vb, nq, 0, idx_bits));
             hipLaunchKernelGGL(gather_key_kernel, dim3(grid_for(nq, B)), dim3(B), 0, as, kpos2, kpos, vb, nq);
@@ -1225,7 +1234,7 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
     ev.qseed = ctx->c_qseed.as<uint32_t>(); ev.qsize = ctx->c_qsize.as<uint32_t>(); ev.qoff = ctx->c_qoff.as<uint64_t>();
     ev.mrec = ctx->c_mrec.as<uint32_t>(); ev.mjrec = ctx->c_mjrec.as<uint32_t>(); ev.rep = ctx->c_rep.as<uint32_t>();
     ev.skey = sv.skey; ev.slpos = sv.slpos; ev.srpos = sv.srpos; ev.perm = perm;
-    ev.src_rank = v.src_rank; ev.src_idx = v.src_idx; ev.src_base = (const uint64_t*)ctx->c_tables.p;
+    ev.src = v.src; ev.src_base = (const uint64_t*)ctx->c_tables.p;
     ev.rank2id = d_rank2id; ev.cb = ctx->contig_bits;
     ev.clusters = ctx->c_clusters.as<bf_cluster>() + cl_base; ev.reads = ctx->c_reads.as<bf_read>() + rd_base;
     ev.out_src_rank = ctx->c_rsrc.as<uint32_t>() + rd_base; ev.out_src_idx = ev.out_src_rank + stride;
@@ -1347,14 +1356,15 @@ __global__ void __launch_bounds__(256) pack_lds_kernel(const PackView v) {
 struct ImportView {
     uint64_t n; uint32_t rec_bytes, frag_stride, has_sigx, n_ranks;
     const uint8_t* in; const uint64_t* src_start;   // n_ranks+1 prefix of src_counts
+    const uint8_t* self_in; uint64_t self_begin, self_end;   // records [self_begin, self_end) lie at self_in instead (may be empty)
     uint64_t* key; int32_t* lpos; int32_t* rpos; uint16_t* bp; uint16_t* len; uint16_t* flags;
     uint8_t* frag; uint64_t* frag_off; uint16_t* frag_len; uint8_t* sigx; uint32_t* sigx_slot;
-    uint32_t* src_rank; uint32_t* src_idx; RecWord* rw;
+    uint64_t* src; RecWord* rw;
 };
 __global__ void __launch_bounds__(256) import_kernel(const ImportView v) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= v.n) return;
-    const uint8_t* src = v.in + j * v.rec_bytes;
+    const uint8_t* src = (j >= v.self_begin && j < v.self_end) ? v.self_in + (j - v.self_begin) * v.rec_bytes : v.in + j * v.rec_bytes;
     const WireHeader h = *(const WireHeader*)src;
     v.key[j] = h.key; v.lpos[j] = h.lpos; v.rpos[j] = h.rpos;
     v.bp[j] = h.bp; v.len[j] = h.len; v.flags[j] = h.flags; v.frag_len[j] = h.frag_len;
@@ -1365,22 +1375,30 @@ __global__ void __launch_bounds__(256) import_kernel(const ImportView v) {
     if (v.has_sigx) for (int k = 0; k < 16; k++) v.sigx[j * 16 + k] = src[sizeof(WireHeader) + v.frag_stride + k];
     uint32_t r = 0;
     while (r + 1 < v.n_ranks && j >= v.src_start[r + 1]) r++;
-    v.src_rank[j] = r; v.src_idx[j] = h.src_idx;
+    v.src[j] = ((uint64_t)r << 32) | h.src_idx;
 }
 
 __global__ void __launch_bounds__(256) import_lds_kernel(const ImportView v) {
     extern __shared__ uint64_t tile[];
     const uint32_t words = v.rec_bytes >> 3, fwords = v.frag_stride >> 3;
     const uint64_t j0 = (uint64_t)blockIdx.x * 256, j = j0 + threadIdx.x;
-    const uint64_t in_tile = min((uint64_t)256, v.n - j0) * words;
-    const uint64_t* in = (const uint64_t*)v.in + j0 * words;
-    for (uint64_t t = threadIdx.x; t < in_tile; t += 256) tile[t] = in[t];
+    const uint64_t n_tile = min((uint64_t)256, v.n - j0), in_tile = n_tile * words;
+    if (j0 >= v.self_end || j0 + n_tile <= v.self_begin || (j0 >= v.self_begin && j0 + n_tile <= v.self_end)) {
+        // (nearly every tile: all of it from one buffer)
+        const uint64_t* in = j0 >= v.self_begin && j0 < v.self_end ? (const uint64_t*)v.self_in + (j0 - v.self_begin) * words : (const uint64_t*)v.in + j0 * words;
+        for (uint64_t t = threadIdx.x; t < in_tile; t += 256) tile[t] = in[t];
+    } else {
+        for (uint64_t t = threadIdx.x; t < in_tile; t += 256) {
+            const uint64_t jj = j0 + t / words, w = t % words;
+            tile[t] = (jj >= v.self_begin && jj < v.self_end) ? ((const uint64_t*)v.self_in)[(jj - v.self_begin) * words + w] : ((const uint64_t*)v.in)[jj * words + w];
+        }
+    }
     __syncthreads();
     if (j >= v.n) return;
     const uint64_t* rec = tile + (uint64_t)threadIdx.x * words;
     v.key[j] = rec[0];
     v.lpos[j] = (int32_t)(uint32_t)rec[1]; v.rpos[j] = (int32_t)(uint32_t)(rec[1] >> 32);
-    v.src_idx[j] = (uint32_t)rec[3]; v.bp[j] = (uint16_t)(rec[3] >> 32); v.len[j] = (uint16_t)(rec[3] >> 48);
+    v.bp[j] = (uint16_t)(rec[3] >> 32); v.len[j] = (uint16_t)(rec[3] >> 48);
     v.frag_len[j] = (uint16_t)rec[4]; v.flags[j] = (uint16_t)(rec[4] >> 16);
     v.rw[j] = RecWord{read_info((uint32_t)(rec[4] >> 32), (uint32_t)(uint16_t)(rec[4] >> 16), (uint32_t)(uint16_t)(rec[3] >> 32), (uint32_t)(rec[3] >> 48)), rec[2]};
     v.frag_off[j] = j * v.frag_stride;
@@ -1390,7 +1408,7 @@ __global__ void __launch_bounds__(256) import_lds_kernel(const ImportView v) {
     if (v.has_sigx) { uint64_t* sd = (uint64_t*)(v.sigx + j * 16); sd[0] = rec[5 + fwords]; sd[1] = rec[6 + fwords]; }
     uint32_t r = 0;
     while (r + 1 < v.n_ranks && j >= v.src_start[r + 1]) r++;
-    v.src_rank[j] = r;
+    v.src[j] = ((uint64_t)r << 32) | (uint32_t)rec[3];
 }
 
 int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint64_t dev_send_bytes, uint64_t* counts,
@@ -1450,7 +1468,8 @@ int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint
     return BF_OK;
 }
 
-int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts) {
+int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts, std::vector<uint64_t>* rank_hist, const uint8_t* dev_self, uint32_t self) {
+    if (rank_hist) rank_hist->assign(ctx->n_contigs, 0);
     const uint32_t R = ctx->n_ranks;
     hipStream_t st = ctx->stream;
     std::vector<uint64_t> start(R + 1, 0);
@@ -1465,25 +1484,30 @@ int run_import(bf_ctx* ctx, const void* dev_recv, const uint64_t* src_counts) {
     BF_TRY(ensure(ctx, ctx->i_flags, n * 2)); BF_TRY(ensure(ctx, ctx->i_frag, n * stride + 64));          // (same_id_bytes reads whole words past an id's end)
     BF_TRY(ensure(ctx, ctx->i_frag_off, n * 8)); BF_TRY(ensure(ctx, ctx->i_frag_len, n * 2));
     BF_TRY(ensure(ctx, ctx->i_sigx, n * 16)); BF_TRY(ensure(ctx, ctx->i_sigx_slot, n * 4));
-    BF_TRY(ensure(ctx, ctx->i_src_rank, n * 4)); BF_TRY(ensure(ctx, ctx->i_src_idx, n * 4));
+    BF_TRY(ensure(ctx, ctx->i_src, n * 8));
     BF_TRY(ensure(ctx, ctx->i_jrec, n * sizeof(RecWord)));
     BF_TRY(ensure(ctx, ctx->d_part_tmp, (size_t)(R + 1) * 8));
     BF_HIP(ctx, hipMemcpyAsync(ctx->d_part_tmp.p, start.data(), (size_t)(R + 1) * 8, hipMemcpyHostToDevice, st));
     ImportView v{};
     v.n = n; v.rec_bytes = ctx->wire_rec_bytes; v.frag_stride = stride; v.has_sigx = ctx->wire_has_sigx; v.n_ranks = R;
     v.in = (const uint8_t*)dev_recv; v.src_start = ctx->d_part_tmp.as<uint64_t>();
+    v.self_in = dev_self; v.self_begin = v.self_end = 0;
+    if (dev_self && self < R) { v.self_begin = start[self]; v.self_end = start[self + 1]; }
     v.key = ctx->i_key.as<uint64_t>(); v.lpos = ctx->i_lpos.as<int32_t>(); v.rpos = ctx->i_rpos.as<int32_t>();
     v.bp = ctx->i_bp.as<uint16_t>(); v.len = ctx->i_len.as<uint16_t>();
     v.flags = ctx->i_flags.as<uint16_t>(); v.frag = ctx->i_frag.as<uint8_t>(); v.frag_off = ctx->i_frag_off.as<uint64_t>();
     v.frag_len = ctx->i_frag_len.as<uint16_t>(); v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
-    v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>(); v.rw = ctx->i_jrec.as<RecWord>();
+    v.src = ctx->i_src.as<uint64_t>(); v.rw = ctx->i_jrec.as<RecWord>();
     Scope t(ctx, "exchange_import");
-    if (v.rec_bytes <= kWireLdsMaxRecord && ((uintptr_t)v.in & 7) == 0)
+    if (v.rec_bytes <= kWireLdsMaxRecord && ((uintptr_t)v.in & 7) == 0 && ((uintptr_t)v.self_in & 7) == 0)
         hipLaunchKernelGGL(import_lds_kernel, dim3(grid_for(n, 256)), dim3(256), 256 * v.rec_bytes, st, v);
     else
         hipLaunchKernelGGL(import_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, v);
     BF_HIP(ctx, hipGetLastError());
+    uint64_t* h_hist = nullptr;
+    if (rank_hist) BF_TRY(rank_histogram_queue(ctx, v.key, n, &h_hist));
     BF_SYNC(ctx, st);   // dev_recv may be released by the caller on return
+    if (rank_hist) rank_hist->assign(h_hist, h_hist + ctx->n_contigs);
     return BF_OK;
 }
 
@@ -1524,25 +1548,19 @@ __global__ void request_keys_kernel(uint32_t* __restrict__ key, uint32_t* __rest
     key[i] = c * W + src_rank[i];
     val[i] = (uint32_t)i;
 }
-__global__ void request_gather_kernel(uint32_t* __restrict__ req, uint32_t* __restrict__ len, const uint32_t* __restrict__ order,
-                                      const uint32_t* __restrict__ src_idx, const uint32_t* __restrict__ jrec, uint64_t nr) {
+// ... and, in the same launch (its first threads), start[k] = first position whose sorted key is >= k (k = groups: the end)
+__global__ void request_gather_kernel(uint32_t* __restrict__ req, const uint32_t* __restrict__ order, const uint32_t* __restrict__ src_idx,
+                                      uint64_t nr, uint64_t* __restrict__ start, const uint32_t* __restrict__ skey, uint32_t groups) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nr) return;
-    const uint32_t i = order[j];
-    req[j] = src_idx[i];
-    len[j] = jrec[i];
-}
-// start[k] = first position whose key is >= k (k = groups: the end), bytes[k] = arrival offset there
-__global__ void request_bounds_kernel(uint64_t* __restrict__ start, uint64_t* __restrict__ bytes, const uint32_t* __restrict__ skey,
-                                      const uint64_t* __restrict__ aoff, uint64_t nr, uint32_t groups) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > groups) return;
-    uint64_t lo = 0, hi = nr;
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (skey[mid] < k) lo = mid + 1; else hi = mid;
+    if (j <= groups) {
+        uint64_t lo = 0, hi = nr;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (skey[mid] < j) lo = mid + 1; else hi = mid;
+        }
+        start[j] = lo;
     }
-    start[k] = lo; bytes[k] = aoff[lo];
+    if (j < nr) req[j] = src_idx[order[j]];
 }
 // The same for supporting reads [rd_base, rd_base + nr) of a result that is appended group by group (one piece):
 // d_req[j] = source index of the j-th request in (source rank, result order); start[s] = first request to rank s.
@@ -1553,21 +1571,16 @@ int order_requests_range(bf_ctx* ctx, uint64_t rd_base, uint64_t nr, uint32_t* d
     const hipStream_t st = ctx->stream;
     BF_TRY(ensure(ctx, ctx->c_a32, nr * 4, false)); BF_TRY(ensure(ctx, ctx->c_b32, nr * 4, false));
     BF_TRY(ensure(ctx, ctx->c_c32, nr * 4, false)); BF_TRY(ensure(ctx, ctx->c_d32, nr * 4, false));
-    BF_TRY(ensure(ctx, ctx->c_aoff, (nr + 1) * 8 + (size_t)(W + 1) * 16 + nr * 4 + 16));
-    uint64_t* aoff = ctx->c_aoff.as<uint64_t>();
-    uint64_t* start = aoff + nr + 1; uint64_t* bytes = start + W + 1;
-    uint32_t* len = (uint32_t*)(bytes + W + 1);
+    BF_TRY(ensure(ctx, ctx->c_aoff, (size_t)(W + 1) * 8 + 64));
+    uint64_t* start = ctx->c_aoff.as<uint64_t>();
     const uint32_t* src = ctx->c_rsrc.as<uint32_t>() + rd_base;     // out_src_rank, out_src_idx, out_rec, out_jrec: `stride` apart
     hipLaunchKernelGGL(request_keys_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, st, ctx->c_a32.as<uint32_t>(),
                        ctx->c_c32.as<uint32_t>(), src, nr, 1u, W);
     unsigned bits = 1; while ((1u << bits) < W) bits++;
     BF_TRY(sort_pairs<uint32_t>(ctx, ctx->c_a32.as<uint32_t>(), ctx->c_b32.as<uint32_t>(), ctx->c_c32.as<uint32_t>(),
                                 ctx->c_d32.as<uint32_t>(), nr, 0, bits));
-    hipLaunchKernelGGL(request_gather_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, st, d_req, len, ctx->c_d32.as<uint32_t>(),
-                       src + stride, src + 3 * stride, nr);
-    BF_TRY(scan_u32_to_u64(ctx, len, aoff, nr));
-    hipLaunchKernelGGL(request_bounds_kernel, dim3(grid_for(W + 1, 256)), dim3(256), 0, st, start, bytes,
-                       ctx->c_b32.as<uint32_t>(), aoff, nr, W);
+    hipLaunchKernelGGL(request_gather_kernel, dim3(grid_for(std::max<uint64_t>(nr, W + 1), 256)), dim3(256), 0, st, d_req, ctx->c_d32.as<uint32_t>(),
+                       src + stride, nr, start, ctx->c_b32.as<uint32_t>(), W);
     BF_HIP(ctx, hipGetLastError());
     *d_start = start;
     return BF_OK;

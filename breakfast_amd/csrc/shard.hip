@@ -87,30 +87,41 @@ struct Transport {
     virtual int all_gather(bf_ctx* ctx, const uint64_t* in, uint32_t k, uint64_t* out) = 0;
     // bytes[s * n + d] = what rank s sends to rank d (every rank passes the same matrix); the send buffer holds the
     // pieces for ranks 0..n-1 back to back, the receive buffer gets the pieces from ranks 0..n-1 back to back.
-    // Device pointers; queued on (or completed before returning to) the ctx's stream.
-    virtual int all_to_all(bf_ctx* ctx, const uint8_t* d_send, uint8_t* d_recv, const uint64_t* bytes) = 0;
+    // Device pointers; queued on (or completed before returning to) the ctx's stream.  skip_self: the rank's own piece is
+    // not copied (its place in the receive buffer stays as it was): the caller reads it from the send buffer.
+    virtual int all_to_all(bf_ctx* ctx, const uint8_t* d_send, uint8_t* d_recv, const uint64_t* bytes, bool skip_self = false) = 0;
 };
 
 struct RcclTransport : Transport {
     ncclComm_t comm = nullptr;
     DevBuf d_ctl;
-    ~RcclTransport() override { if (comm) (void)rccl().CommDestroy(comm); if (d_ctl.p) (void)hipFree(d_ctl.p); }
+    HostBuf h_ctl;                        // pinned: the control words go up and come back without a staging copy
+    ~RcclTransport() override {
+        if (comm) (void)rccl().CommDestroy(comm);
+        if (d_ctl.p) (void)hipFree(d_ctl.p);
+        if (h_ctl.p) (void)hipHostFree(h_ctl.p);
+    }
     int all_gather(bf_ctx* ctx, const uint64_t* in, uint32_t k, uint64_t* out) override {
         BF_TRY(ensure(ctx, d_ctl, (size_t)(n + 1) * k * 8));
+        BF_TRY(ensure_host(ctx, h_ctl, (size_t)(n + 1) * k * 8));
         uint64_t* d_in = d_ctl.as<uint64_t>();
         uint64_t* d_out = d_in + k;
-        BF_HIP(ctx, hipMemcpyAsync(d_in, in, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream));
+        uint64_t* h_in = h_ctl.as<uint64_t>();
+        uint64_t* h_out = h_in + k;
+        memcpy(h_in, in, (size_t)k * 8);
+        BF_HIP(ctx, hipMemcpyAsync(d_in, h_in, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream));
         BF_NCCL(ctx, rccl().AllGather(d_in, d_out, k, ncclUint64, comm, ctx->stream));
-        BF_HIP(ctx, hipMemcpyAsync(out, d_out, (size_t)n * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+        BF_HIP(ctx, hipMemcpyAsync(h_out, d_out, (size_t)n * k * 8, hipMemcpyDeviceToHost, ctx->stream));
         BF_SYNC(ctx, ctx->stream);
+        memcpy(out, h_out, (size_t)n * k * 8);
         return BF_OK;
     }
-    int all_to_all(bf_ctx* ctx, const uint8_t* d_send, uint8_t* d_recv, const uint64_t* bytes) override {
+    int all_to_all(bf_ctx* ctx, const uint8_t* d_send, uint8_t* d_recv, const uint64_t* bytes, bool skip_self) override {
         uint64_t so = 0, ro = 0;
         std::vector<uint64_t> soff(n), roff(n);
         for (uint32_t r = 0; r < n; r++) { soff[r] = so; roff[r] = ro; so += bytes[(size_t)rank * n + r]; ro += bytes[(size_t)r * n + rank]; }
         const uint64_t self = bytes[(size_t)rank * n + rank];
-        if (self) BF_HIP(ctx, hipMemcpyAsync(d_recv + roff[rank], d_send + soff[rank], self, hipMemcpyDeviceToDevice, ctx->stream));
+        if (self && !skip_self) BF_HIP(ctx, hipMemcpyAsync(d_recv + roff[rank], d_send + soff[rank], self, hipMemcpyDeviceToDevice, ctx->stream));
         if (n > 1) {
             BF_NCCL(ctx, rccl().GroupStart());
             // an error inside the group is remembered, the group is closed whatever happened (an open group would swallow
@@ -193,7 +204,7 @@ struct HostTransport : Transport {
         if (trace_on()) trace_line(ctx, "leave", "host all_gather", "", 0);
         return BF_OK;
     }
-    int all_to_all(bf_ctx* ctx, const uint8_t* d_send, uint8_t* d_recv, const uint64_t* bytes) override {
+    int all_to_all(bf_ctx* ctx, const uint8_t* d_send, uint8_t* d_recv, const uint64_t* bytes, bool skip_self) override {
         if (trace_on()) trace_line(ctx, "enter", "host all_to_all", "", 0);
         // rounds: every rank stages at most slot_bytes of its send buffer per round; all ranks run the same number
         std::vector<uint64_t> total(n, 0), recv_off(n, 0);
@@ -214,7 +225,7 @@ struct HostTransport : Transport {
                 for (uint32_t d = 0; d < rank; d++) a += bytes[(size_t)s * n + d];
                 const uint64_t b = a + bytes[(size_t)s * n + rank];
                 const uint64_t lo = std::max(a, w0), hi = std::min(b, w0 + slot_bytes);
-                if (lo < hi)
+                if (lo < hi && !(skip_self && s == rank))
                     BF_HIP(ctx, hipMemcpyAsync(d_recv + recv_off[s] + (lo - a), slot(s) + (lo - w0), hi - lo, hipMemcpyHostToDevice, ctx->stream));
             }
             BF_SYNC(ctx, ctx->stream);
@@ -260,19 +271,25 @@ static int grow_host_keep(bf_ctx* ctx, HostBuf& b, size_t used, size_t need) {
 // place[i] = (source rank, slot in that source's record list) of supporting read i: the reads sorted by source rank
 // are position j = order^-1(i); the slot counts from the first request of this owner to that source
 // src[i] = the source rank alone: all the host needs to walk the records in the order they were asked for
+// (slot_base comes by value, a word per rank: a table the host has just computed needs no copy and no wait this way)
+constexpr uint32_t kMaxShardRanks = 256;
+struct RankWords { uint64_t w[kMaxShardRanks + 1]; };
 __global__ void place_kernel(bf_place* __restrict__ place, uint8_t* __restrict__ src, const uint32_t* __restrict__ order,
-                             const uint32_t* __restrict__ skey, const uint64_t* __restrict__ start, const uint64_t* __restrict__ slot_base, uint64_t nr) {
+                             const uint32_t* __restrict__ skey, const uint64_t* __restrict__ start, const RankWords slot_base, uint64_t nr) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nr) return;
     const uint32_t s = skey[j];
-    place[order[j]] = bf_place{s, (uint32_t)(slot_base[s] + (j - start[s]))};
+    place[order[j]] = bf_place{s, (uint32_t)(slot_base.w[s] + (j - start[s]))};
     src[order[j]] = (uint8_t)s;
 }
 
-// out[k] = off[pos[k]]: the record offsets at the boundaries between the owners' request lists
-__global__ void pick_block_offsets_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ off, const uint64_t* __restrict__ pos, uint32_t n) {
+// out[k] = off[pos[k]]: the record offsets at the boundaries between the owners' request lists (k <= n_ranks), then at the
+// chunk boundaries the render and its copies go by (out[n_ranks + 1 + c] = off[n * c / n_chunks]): one launch, one copy
+__global__ void pick_block_offsets_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ off, const RankWords pos, uint32_t n_ranks,
+                                          uint64_t n, int n_chunks) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) out[k] = off[pos[k]];
+    if (k <= n_ranks) out[k] = off[pos.w[k]];
+    else if (k <= n_ranks + 1 + (uint32_t)n_chunks) out[k] = off[n * (uint64_t)(k - n_ranks - 1) / n_chunks];
 }
 
 inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
@@ -471,28 +488,12 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
     BF_TRY(ensure(ctx, sh->d_recv, std::max<uint64_t>(n_owned, 1) * rec));
     {
         Scope t(ctx, "exchange_alltoall");
-        BF_TRY(tr->all_to_all(ctx, (const uint8_t*)d_packed, sh->d_recv.as<uint8_t>(), bytes.data()));
+        // (the rank's own records are not copied: the import reads them where the pack left them)
+        BF_TRY(tr->all_to_all(ctx, (const uint8_t*)d_packed, sh->d_recv.as<uint8_t>(), bytes.data(), true));
     }
+    uint64_t self_off = 0;
+    for (uint32_t d = 0; d < me; d++) self_off += bytes[(size_t)me * W + d];
     ctx->src_index_base = sh->bases;
-    BF_TRY(run_import(ctx, sh->d_recv.p, src_counts.data()));
-
-    // 4.-7. the owner's cluster stage (detect.rs:190-231, 247-287), a few contig ranks at a time like bf_finish on one
-    //       GPU: when a group is clustered its supporting reads are requested from their source ranks, and the sources
-    //       render and copy those records to their host memory WHILE the owners cluster the next group.  Every rank
-    //       runs the same number of groups (agreed from the exchange counts every rank knows; a rank whose records
-    //       cut into fewer groups takes part in the remaining rounds with nothing to ask for).
-    OwnerView v;
-    v.n = ctx->n_imported;
-    v.key = ctx->i_key.as<uint64_t>(); v.lpos = ctx->i_lpos.as<int32_t>(); v.rpos = ctx->i_rpos.as<int32_t>();
-    v.bp = ctx->i_bp.as<uint16_t>(); v.len = ctx->i_len.as<uint16_t>();
-    v.flags = ctx->i_flags.as<uint16_t>();
-    v.frag = ctx->i_frag.as<uint8_t>(); v.frag_off = ctx->i_frag_off.as<uint64_t>(); v.frag_len = ctx->i_frag_len.as<uint16_t>();
-    v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
-    v.src_rank = ctx->i_src_rank.as<uint32_t>(); v.src_idx = ctx->i_src_idx.as<uint32_t>();
-    v.rw = ctx->i_jrec.as<RecWord>();
-    ctx->clustered = false; ctx->reads_on_device = false;
-    ctx->out.n_clusters = ctx->out.n_reads = 0; ctx->n_evidence = v.n;
-
     uint64_t max_owned = 0;
     for (uint32_t d = 0; d < W; d++) {
         uint64_t owned = 0;
@@ -508,16 +509,35 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
     // 7.97 -- a group costs some sixty launches, two collectives and five host round trips.  (While a place and an offset
     // per read still travelled the copy was the longer part either way and groups bought nothing: 9.19 against 9.24.)
     else if (max_owned >= (1ull << 22)) G = 2;
+    std::vector<uint64_t> hist;                                      // imported records per left contig rank: counted behind the import
+    BF_TRY(run_import(ctx, sh->d_recv.p, src_counts.data(), G > 1 ? &hist : nullptr, (const uint8_t*)d_packed + self_off, me));
+
+    // 4.-7. the owner's cluster stage (detect.rs:190-231, 247-287), a few contig ranks at a time like bf_finish on one
+    //       GPU: when a group is clustered its supporting reads are requested from their source ranks, and the sources
+    //       render and copy those records to their host memory WHILE the owners cluster the next group.  Every rank
+    //       runs the same number of groups (agreed from the exchange counts every rank knows; a rank whose records
+    //       cut into fewer groups takes part in the remaining rounds with nothing to ask for).
+    OwnerView v;
+    v.n = ctx->n_imported;
+    v.key = ctx->i_key.as<uint64_t>(); v.lpos = ctx->i_lpos.as<int32_t>(); v.rpos = ctx->i_rpos.as<int32_t>();
+    v.bp = ctx->i_bp.as<uint16_t>(); v.len = ctx->i_len.as<uint16_t>();
+    v.flags = ctx->i_flags.as<uint16_t>();
+    v.frag = ctx->i_frag.as<uint8_t>(); v.frag_off = ctx->i_frag_off.as<uint64_t>(); v.frag_len = ctx->i_frag_len.as<uint16_t>();
+    v.sigx = ctx->i_sigx.as<uint8_t>(); v.sigx_slot = ctx->i_sigx_slot.as<uint32_t>();
+    v.src = ctx->i_src.as<uint64_t>();
+    v.rw = ctx->i_jrec.as<RecWord>();
+    ctx->clustered = false; ctx->reads_on_device = false;
+    ctx->out.n_clusters = ctx->out.n_reads = 0; ctx->n_evidence = v.n;
+
     std::vector<uint64_t> gb{0, v.n};
-    if (G > 1 && v.n) {
-        std::vector<uint64_t> hist;
-        uint64_t unused = 0;
-        BF_TRY(rank_histogram(ctx, v, hist));
-        BF_TRY(cluster_groups(ctx, v, G, gb, &unused, &hist));
-    }
+    if (G > 1 && v.n) BF_TRY(cluster_groups(ctx, v, G, gb, nullptr, &hist));
     const size_t my_groups = gb.size() - 1;
 
-    std::vector<uint64_t> req_counts(W), start(W + 1), rm((size_t)W * W), ctl(W), recv_before(W, 0), pick(2 * (size_t)W + 2);
+    std::vector<uint64_t> req_counts(W), rm((size_t)W * W), recv_before(W, 0);
+    RankWords ctl{}, pick{};
+    constexpr int kMaxChunks = 8;
+    uint64_t* h_words = nullptr;                                     // pinned read-backs: W + 1 starts; W + 1 block offsets + chunk offsets
+    BF_TRY(wide_words(ctx, 2 * (size_t)W + 4 + kMaxChunks, &h_words));
     uint64_t cl_base = 0, rd_base = 0, n_in = 0, rec_total = 0;
     sh->block_off.assign((size_t)G * W + 1, 0);
     sh->group_read_begin.assign((size_t)G + 1, 0);
@@ -544,9 +564,9 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
         BF_TRY(ensure(ctx, sh->d_req_out, std::max<uint64_t>(nr_g, 1) * 4));
         if (nr_g) {
             BF_TRY(order_requests_range(ctx, rd_base, nr_g, sh->d_req_out.as<uint32_t>(), &d_start));
-            BF_HIP(ctx, hipMemcpyAsync(start.data(), d_start, (size_t)(W + 1) * 8, hipMemcpyDeviceToHost, st));
+            BF_HIP(ctx, hipMemcpyAsync(h_words, d_start, (size_t)(W + 1) * 8, hipMemcpyDeviceToHost, st));
             BF_SYNC(ctx, st);
-            for (uint32_t s2 = 0; s2 < W; s2++) req_counts[s2] = start[s2 + 1] - start[s2];
+            for (uint32_t s2 = 0; s2 < W; s2++) req_counts[s2] = h_words[s2 + 1] - h_words[s2];
         }
         BF_TRY(tr->all_gather(ctx, req_counts.data(), W, rm.data()));   // rm[o * W + s] = requests of owner o to source s
         // slots: a source lists what it was asked in earlier groups, then this group's requests of owner 0, owner 1, ...
@@ -554,19 +574,16 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
         for (uint32_t s2 = 0; s2 < W; s2++) {
             uint64_t before = recv_before[s2];
             for (uint32_t o = 0; o < me; o++) before += rm[(size_t)o * W + s2];
-            ctl[s2] = before;
+            ctl.w[s2] = before;
         }
         for (uint32_t o = 0; o < W; o++) n_in_g += rm[(size_t)o * W + me];
         if (n_in + n_in_g > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "sharded path: %llu junction requests for one rank", (unsigned long long)(n_in + n_in_g));
         if (nr_g) {
             BF_TRY(ensure(ctx, sh->d_place, (rd_base + nr_g) * sizeof(bf_place), true));
             BF_TRY(ensure(ctx, sh->d_src, rd_base + nr_g, true));
-            BF_TRY(ensure(ctx, sh->d_small, (size_t)(W + 1) * 8));
-            BF_HIP(ctx, hipMemcpyAsync(sh->d_small.p, ctl.data(), (size_t)W * 8, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(place_kernel, dim3(grid_for(nr_g, 256)), dim3(256), 0, st, sh->d_place.as<bf_place>() + rd_base,
-                               sh->d_src.as<uint8_t>() + rd_base, ctx->c_d32.as<uint32_t>(), ctx->c_b32.as<uint32_t>(), d_start, sh->d_small.as<uint64_t>(), nr_g);
+                               sh->d_src.as<uint8_t>() + rd_base, ctx->c_d32.as<uint32_t>(), ctx->c_b32.as<uint32_t>(), d_start, ctl, nr_g);
             BF_HIP(ctx, hipGetLastError());
-            BF_SYNC(ctx, st);                                        // (ctl is reused by the next group)
         }
         // the request lists go to the sources (4 bytes a read), appended to what came in earlier groups
         for (uint32_t o = 0; o < W; o++) for (uint32_t s2 = 0; s2 < W; s2++) bytes[(size_t)o * W + s2] = rm[(size_t)o * W + s2] * 4;
@@ -578,33 +595,35 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
         // the source's side: render the requested reads' junction records (detect.rs:155-162) and copy them to THIS rank's
         // host memory, chunk by chunk behind the next chunk's render (and behind the owners' next group)
         if (n_in_g) {
-            constexpr int kMaxChunks = 8;
             const int nc = n_in_g >= (1u << 16) ? (G > 1 ? 2 : kMaxChunks) : 1;
             uint64_t off[kMaxChunks + 1];
             const uint32_t* d_idx = sh->d_req_in.as<uint32_t>() + n_in;
             BF_TRY(ensure(ctx, ctx->r_idx, n_in_g * 4 + 16));
+            BF_TRY(ensure(ctx, sh->d_roff_g, (n_in_g + 1) * 8));
+            BF_TRY(ensure(ctx, sh->d_pick, ((size_t)W + 4 + kMaxChunks) * 8));
             uint32_t* d_len = ctx->r_idx.as<uint32_t>();
             uint32_t* d_bad = d_len + n_in_g;
             BF_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, st));
             BF_TRY(render_sizes_checked(ctx, n_in_g, d_idx, d_len, d_bad));
-            BF_TRY(render_prepare(ctx, n_in_g, d_idx, sh->d_roff_g, nc, off, d_len));
-            // where owner o's requests of this round begin among the records (the first W + 1 words: positions, the rest: offsets)
-            BF_TRY(ensure(ctx, sh->d_pick, (2 * (size_t)W + 2) * 8));
-            pick[0] = 0;
-            for (uint32_t o = 0; o < W; o++) pick[o + 1] = pick[o] + rm[(size_t)o * W + me];
-            BF_HIP(ctx, hipMemcpyAsync(sh->d_pick.p, pick.data(), (size_t)(W + 1) * 8, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(pick_block_offsets_kernel, dim3(grid_for(W + 1, 256)), dim3(256), 0, st, sh->d_pick.as<uint64_t>() + (W + 1),
-                               sh->d_roff_g.as<uint64_t>(), sh->d_pick.as<uint64_t>(), W + 1);
+            BF_TRY(scan_u32_to_u64(ctx, d_len, sh->d_roff_g.as<uint64_t>(), n_in_g));
+            // where owner o's requests of this round begin among the records, and where the render's chunks do: one launch,
+            // one copy, one wait (the positions go by value)
+            pick.w[0] = 0;
+            for (uint32_t o = 0; o < W; o++) pick.w[o + 1] = pick.w[o] + rm[(size_t)o * W + me];
+            hipLaunchKernelGGL(pick_block_offsets_kernel, dim3(grid_for(W + 2 + nc, 256)), dim3(256), 0, st, sh->d_pick.as<uint64_t>(),
+                               sh->d_roff_g.as<uint64_t>(), pick, W, n_in_g, nc);
             BF_HIP(ctx, hipGetLastError());
-            BF_HIP(ctx, hipMemcpyAsync(pick.data() + (W + 1), sh->d_pick.as<uint64_t>() + (W + 1), (size_t)(W + 1) * 8, hipMemcpyDeviceToHost, st));
-            uint32_t bad = 0;
-            BF_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+            uint64_t* h_pick = h_words + W + 1;
+            BF_HIP(ctx, hipMemcpyAsync(h_pick, sh->d_pick.as<uint64_t>(), ((size_t)W + 2 + nc) * 8, hipMemcpyDeviceToHost, st));
+            BF_HIP(ctx, hipMemcpyAsync(h_pick + W + 2 + nc, d_bad, 4, hipMemcpyDeviceToHost, st));
             BF_SYNC(ctx, st);
+            const uint32_t bad = (uint32_t)h_pick[W + 2 + nc];
             if (bad) return fail(ctx, BF_ERR_HIP, "sharded path: %u requested reads are not resident on rank %u", bad, me);
+            for (int c = 0; c <= nc; c++) off[c] = h_pick[W + 1 + c];
             const uint64_t total_g = off[nc];
-            if (pick[(size_t)W + 1] != 0 || pick[2 * (size_t)W + 1] != total_g)
+            if (h_pick[0] != 0 || h_pick[W] != total_g || off[0] != 0)
                 return fail(ctx, BF_ERR_HIP, "sharded path: the record offsets of round %u do not span its %llu bytes", g, (unsigned long long)total_g);
-            for (uint32_t o = 0; o < W; o++) sh->block_off[(size_t)g * W + o] = rec_total + pick[(size_t)W + 1 + o];
+            for (uint32_t o = 0; o < W; o++) sh->block_off[(size_t)g * W + o] = rec_total + h_pick[o];
             BF_TRY(ensure(ctx, sh->d_rbytes, std::max<uint64_t>(rec_total + total_g, 1), true));
             BF_TRY(grow_host_keep(ctx, sh->h_rbytes, rec_total, rec_total + total_g));
             BF_TRY(ensure(ctx, sh->d_roff, (n_in + n_in_g + 1) * 8, true));
