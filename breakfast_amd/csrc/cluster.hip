@@ -1313,31 +1313,20 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackView v) {
 // kWireLdsMaxRecord bytes (fragment ids of up to 200 bytes), i.e. practically always.
 constexpr uint32_t kWireLdsMaxRecord = 256;
 
-__global__ void __launch_bounds__(256) pack_lds_kernel(const PackView v) {
-    extern __shared__ uint64_t tile[];
-    const uint32_t words = v.rec_bytes >> 3, fwords = v.frag_stride >> 3;
-    const uint64_t j0 = (uint64_t)blockIdx.x * 256, j = j0 + threadIdx.x;
-    if (j < v.n) {
-        const uint32_t i = v.order[j];
-        uint64_t* rec = tile + (uint64_t)threadIdx.x * words;
+__device__ __forceinline__ void build_wire_record(const PackView& v, uint32_t i, uint64_t* rec) {
+    const uint32_t fwords = v.frag_stride >> 3;
+    {
         const uint64_t key = v.key[i];
         const uint32_t fl = v.frag_len[i];
         rec[0] = key;
         rec[1] = (uint64_t)(uint32_t)v.lpos[i] | ((uint64_t)(uint32_t)v.rpos[i] << 32);
-        const RecWord w = v.rw[i];
-        rec[2] = w.fhash;
+        const RecWord rwd = v.rw[i];
+        rec[2] = rwd.fhash;
         rec[3] = (uint64_t)i | ((uint64_t)v.bp[i] << 32) | ((uint64_t)v.len[i] << 48);
-        rec[4] = (uint64_t)(uint16_t)fl | ((uint64_t)v.flags[i] << 16) | ((uint64_t)info_jrec(w.info) << 32);
+        rec[4] = (uint64_t)(uint16_t)fl | ((uint64_t)v.flags[i] << 16) | ((uint64_t)info_jrec(rwd.info) << 32);
+        // the id as whole words, zero beyond its end (the id buffer ends in 64 spare bytes: bf_submit)
         const uint8_t* f = v.frag + v.frag_off[i];
-        for (uint32_t w = 0; w < fwords; w++) {
-            uint64_t x = 0;
-#pragma unroll
-            for (uint32_t b = 0; b < 8; b++) {
-                const uint32_t k = 8 * w + b;
-                if (k < fl) x |= (uint64_t)f[k] << (8 * b);
-            }
-            rec[5 + w] = x;
-        }
+        for (uint32_t w = 0; w < fwords; w++) rec[5 + w] = 8 * w < fl ? load_u64_any(f + 8 * w) & head_bytes_mask(fl, 8 * w) : 0ull;
         if (v.has_sigx) {
             uint64_t s0 = 0, s1 = 0;
             if ((key >> kKeySigxBit) & 1) {
@@ -1347,10 +1336,84 @@ __global__ void __launch_bounds__(256) pack_lds_kernel(const PackView v) {
             rec[5 + fwords] = s0; rec[6 + fwords] = s1;
         }
     }
+}
+__global__ void __launch_bounds__(256) pack_lds_kernel(const PackView v) {
+    extern __shared__ uint64_t tile[];
+    const uint32_t words = v.rec_bytes >> 3;
+    const uint64_t j0 = (uint64_t)blockIdx.x * 256, j = j0 + threadIdx.x;
+    if (j < v.n) build_wire_record(v, v.order[j], tile + (uint64_t)threadIdx.x * words);
     __syncthreads();
     const uint64_t in_tile = min((uint64_t)256, v.n - j0) * words;
     uint64_t* out = (uint64_t*)v.out + j0 * words;
     for (uint64_t t = threadIdx.x; t < in_tile; t += 256) out[t] = tile[t];
+}
+
+// The partition without a sort and without a gather: count -> scan -> scatter.  Every workgroup takes 256 consecutive
+// records; pack_count_kernel leaves its records per owner in cnt[owner * n_blocks + block]; an exclusive scan over that
+// array (owner-major) is, for every (owner, block), the position among ALL records sent of the block's first record for
+// that owner: the owners' pieces back to back, the source's order kept inside a piece (detect.rs:193-198: ties fall in
+// input order).  pack_scatter_kernel then builds its 256 records in LDS, ordered by (owner, input order) -- a lane's place
+// among its wave's records for the same owner from ballots, the waves' counts from LDS --, and writes every owner's run
+// to its place with coalesced stores.  The records are read once, in input order (round 2's form sorted (owner, index)
+// pairs and gathered the records through the order: with W owners, W interleaved walks over every input array).
+constexpr uint32_t kScatterMaxRanks = 64;
+__global__ void __launch_bounds__(256) pack_count_kernel(uint32_t* __restrict__ cnt, const uint64_t* __restrict__ key, uint32_t W, uint64_t n,
+                                                         uint32_t n_blocks) {
+    __shared__ uint32_t c[kScatterMaxRanks];
+    if (threadIdx.x < W) c[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&c[(uint32_t)(mix64(key[i]) % W)], 1u);
+    __syncthreads();
+    if (threadIdx.x < W) cnt[(uint64_t)threadIdx.x * n_blocks + blockIdx.x] = c[threadIdx.x];
+}
+// per_owner[o] = records for owner o (o < W), from the scanned counts
+__global__ void pack_totals_kernel(uint64_t* __restrict__ per_owner, const uint64_t* __restrict__ off, uint32_t W, uint32_t n_blocks) {
+    const uint32_t o = threadIdx.x;
+    if (o < W) per_owner[o] = off[(uint64_t)(o + 1) * n_blocks] - off[(uint64_t)o * n_blocks];
+}
+__global__ void __launch_bounds__(256) pack_scatter_kernel(const PackView v, const uint64_t* __restrict__ off, uint32_t W, uint32_t n_blocks) {
+    extern __shared__ uint64_t tile[];                       // 256 records, then the small tables
+    const uint32_t words = v.rec_bytes >> 3;
+    uint32_t* wcnt = (uint32_t*)(tile + 256 * (uint64_t)words);     // [4][W]: a wave's records per owner
+    uint32_t* pre = wcnt + 4 * W;                                   // [W + 1]: where owner o's run starts in the tile
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (uint32_t k = t; k < 4 * W; k += 256) wcnt[k] = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + t;
+    const bool valid = i < v.n;
+    const uint32_t o = valid ? (uint32_t)(mix64(v.key[i]) % W) : 0u;
+    uint32_t rank = 0;
+    uint64_t todo = __ballot(valid);
+    while (todo) {                                           // one round per owner present in the wave
+        const int lead = __builtin_ctzll(todo);
+        const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)o, lead);
+        const uint64_t m = __ballot(valid && o == o0);
+        if (valid && o == o0) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (lane == lead) wcnt[wv * W + o0] = (uint32_t)__popcll(m);
+        todo &= ~m;
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < W; k++) { pre[k] = run; run += wcnt[k] + wcnt[W + k] + wcnt[2 * W + k] + wcnt[3 * W + k]; }
+        pre[W] = run;
+    }
+    __syncthreads();
+    if (valid) {
+        uint32_t at = pre[o] + rank;
+        for (int w = 0; w < wv; w++) at += wcnt[w * W + o];
+        build_wire_record(v, (uint32_t)i, tile + (uint64_t)at * words);
+    }
+    __syncthreads();
+    const uint32_t in_tile = pre[W] * words;
+    uint64_t* out = (uint64_t*)v.out;
+    for (uint32_t x = t; x < in_tile; x += 256) {
+        const uint32_t r = x / words, w = x - r * words;
+        uint32_t lo = 0, hi = W;                             // the owner whose run holds tile record r: pre[lo] <= r < pre[lo + 1]
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= r) lo = mid; else hi = mid; }
+        out[(off[(uint64_t)lo * n_blocks + blockIdx.x] + (r - pre[lo])) * words + w] = tile[x];
+    }
 }
 
 struct ImportView {
@@ -1432,6 +1495,34 @@ int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint
     }
     if (n == 0) return BF_OK;
     Scope t(ctx, "exchange_pack");
+    PackView pv{};
+    pv.n = n; pv.rec_bytes = rec; pv.frag_stride = stride; pv.has_sigx = ctx->wire_has_sigx; pv.order = nullptr;
+    pv.key = ctx->d_key.as<uint64_t>(); pv.lpos = ctx->d_lpos.as<int32_t>(); pv.rpos = ctx->d_rpos.as<int32_t>();
+    pv.bp = ctx->d_bp.as<uint16_t>(); pv.len = ctx->d_len.as<uint16_t>();
+    pv.flags = ctx->d_flags.as<uint16_t>(); pv.frag = ctx->d_frag.as<uint8_t>(); pv.frag_off = ctx->d_frag_off.as<uint64_t>();
+    pv.frag_len = ctx->d_frag_len.as<uint16_t>(); pv.sigx = ctx->d_sigx.as<uint8_t>(); pv.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
+    pv.rw = ctx->d_jrec.as<RecWord>();
+    pv.out = (uint8_t*)*dev_out;
+    const bool sorted_pack = getenv("BREAKFAST_HIP_SORTED_PACK") != nullptr;    // (A/B switch and test hook: the round-2 form; read on every call)
+    const size_t lds = (size_t)256 * rec + (size_t)(4 * R + R + 1) * 4;
+    if (R <= kScatterMaxRanks && lds <= 65536 && ((uintptr_t)pv.out & 7) == 0 && n < (1ull << 32) && !sorted_pack) {
+        const uint32_t nb = (uint32_t)grid_for(n, 256);
+        const uint64_t cells = (uint64_t)R * nb;
+        BF_TRY(ensure(ctx, ctx->d_part_key, cells * 4 + 64)); BF_TRY(ensure(ctx, ctx->d_part_idx, (cells + 1) * 8));
+        BF_TRY(ensure(ctx, ctx->d_part_tmp, (size_t)(R + 1) * 8));
+        uint32_t* cnt = ctx->d_part_key.as<uint32_t>(); uint64_t* off = ctx->d_part_idx.as<uint64_t>();
+        uint64_t* h_counts = nullptr;
+        BF_TRY(wide_words(ctx, R, &h_counts));
+        hipLaunchKernelGGL(pack_count_kernel, dim3(nb), dim3(256), 0, st, cnt, pv.key, R, n, nb);
+        BF_TRY(scan_u32_to_u64(ctx, cnt, off, cells));
+        hipLaunchKernelGGL(pack_totals_kernel, dim3(1), dim3(std::max(64u, R)), 0, st, ctx->d_part_tmp.as<uint64_t>(), off, R, nb);
+        BF_HIP(ctx, hipMemcpyAsync(h_counts, ctx->d_part_tmp.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(pack_scatter_kernel, dim3(nb), dim3(256), lds, st, pv, off, R, nb);
+        BF_HIP(ctx, hipGetLastError());
+        BF_SYNC(ctx, st);
+        for (uint32_t r = 0; r < R; r++) counts[r] = h_counts[r];
+        return BF_OK;
+    }
     BF_TRY(ensure(ctx, ctx->d_part_key, n * 4 * 2)); BF_TRY(ensure(ctx, ctx->d_part_idx, n * 4 * 2));
     BF_TRY(ensure(ctx, ctx->d_part_tmp, (size_t)(R + 1) * 8));
     uint32_t* own = ctx->d_part_key.as<uint32_t>(); uint32_t* own_s = own + n;
@@ -1443,14 +1534,7 @@ int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint
     std::vector<uint64_t> start(R + 1, n);
     BF_HIP(ctx, hipMemcpyAsync(ctx->d_part_tmp.p, start.data(), (size_t)(R + 1) * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(bucket_start_kernel, dim3(grid_for(n, B)), dim3(B), 0, st, ctx->d_part_tmp.as<uint64_t>(), own_s, n);
-    PackView pv{};
-    pv.n = n; pv.rec_bytes = rec; pv.frag_stride = stride; pv.has_sigx = ctx->wire_has_sigx; pv.order = order;
-    pv.key = ctx->d_key.as<uint64_t>(); pv.lpos = ctx->d_lpos.as<int32_t>(); pv.rpos = ctx->d_rpos.as<int32_t>();
-    pv.bp = ctx->d_bp.as<uint16_t>(); pv.len = ctx->d_len.as<uint16_t>();
-    pv.flags = ctx->d_flags.as<uint16_t>(); pv.frag = ctx->d_frag.as<uint8_t>(); pv.frag_off = ctx->d_frag_off.as<uint64_t>();
-    pv.frag_len = ctx->d_frag_len.as<uint16_t>(); pv.sigx = ctx->d_sigx.as<uint8_t>(); pv.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
-    pv.rw = ctx->d_jrec.as<RecWord>();
-    pv.out = (uint8_t*)*dev_out;
+    pv.order = order;
     if (rec <= kWireLdsMaxRecord && ((uintptr_t)pv.out & 7) == 0)
         hipLaunchKernelGGL(pack_lds_kernel, dim3(grid_for(n, 256)), dim3(256), 256 * rec, st, pv);
     else

@@ -281,6 +281,30 @@ def test_eight_ranks_uneven_empty_shards_and_a_hot_class():
         assert merged(g, results, 20) == ref.sv
 
 
+def test_the_pack_that_sorts_and_the_pack_that_scatters_agree(monkeypatch):
+    """run_partition packs by count -> scan -> scatter; the round-2 form (sort (owner, index) pairs, gather the records) stays
+    as the fallback for more than 64 ranks or records that do not fit LDS.  Both through five ranks with an empty shard and
+    a hot class, reads with N (signatures that travel with their raw bytes): the merged table equals the oracle's."""
+    contigs = [("chr1", 90000), ("chr10", 70000), ("chr2", 80000), ("chrX", 60000)]
+    g = synth.make_genome(contigs, seed=61, n_runs=[(0, 30000, 400), (2, 40000, 700), (3, 20000, 300)])
+    spec = synth.ReadSpec(n_reads=3000, read_len=100, anchor_len=20, n_events=60, singleton_frac=0.2, mate_frac=0.6,
+                          hot_frac=0.3, hot_events=2, seed=67, margin=300)
+    b = synth.make_reads(g, spec)
+    n = b.n
+    ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, 20, 5000, 2)
+    assert ref.n_clusters > 10
+    cuts = [0, n // 4, n // 4, n // 2, n - 1, n]
+    parts = [b.slice(cuts[r], cuts[r + 1]) if cuts[r + 1] > cuts[r] else None for r in range(5)]
+    for sorted_pack in (False, True):
+        if sorted_pack:
+            monkeypatch.setenv("BREAKFAST_HIP_SORTED_PACK", "1")
+        else:
+            monkeypatch.delenv("BREAKFAST_HIP_SORTED_PACK", raising=False)
+        results = run_as_threads(g, parts, cuts[:5], 20, slot_bytes=1 << 16)
+        assert sum(x.n_evidence for x in results) == n
+        assert merged(g, results, 20) == ref.sv
+
+
 def test_two_ranks_at_half_a_million_reads():
     contigs, gk, spec = synth.config(1, scale=0.05, genome_scale=0.05)      # 500k reads, 154 Mb genome, 25 contigs
     spec.margin = 10000 + 2 * spec.read_len + 128
