@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-read known-answer tables for five hazard fixtures, derived WITHOUT either oracle.
+"""Per-read and per-cluster known-answer tables for twelve hazard fixtures, derived WITHOUT either oracle.
 
 The reference holds no vectors, so what pins the two restatements of detect.rs under
 oracle/ is what this repository derives itself.  kat_survey was derived by hand in the survey.  This script is the
@@ -14,10 +14,18 @@ pencil-and-paper method of that derivation written down once, for fixtures too l
   * one read (hz_contig_ends read 0) was also derived entirely by hand from detect.rs:105-187 and the FASTA text
     (DESIGN.md section 2 shows the work); the script must reproduce that row, see HAND_ROW below.
 
+  * clusters are not found by walking the reference's two loops (detect.rs:203-227) either, but from their fixed point
+    written as set comprehensions (derive_clusters below): compat(p, s) = every test of :214-223 as one predicate;
+    because the evidence is sorted by (chr, pos), the two `break` tests are monotone and a seed's cluster is simply
+    {p} + {s after p : compat(p, s)} -- reported or not, which is the reference's quirk (:225 pushes without looking at
+    reported[s]); the seeds are the reads no EARLIER SEED is compatible with; pairing (detect.rs:79-87) is "a 3p line
+    counts iff the nearest 5p line before it carries the same read number".
+
 Output: tests/golden/hand_tables.json -- literal numbers and strings per read (input order of the paired reads):
-swapped, mm[A..L-A-1], bp, lpos, rpos, junction, signature; and for hz_dedup_min_evidence the surviving reads of
-every printed cluster (detect.rs:247-287: groups by fragment id, score min(l,r)*10000+max(l,r), first maximum).
-tests/test_hand_tables.py checks BOTH restatements and the GPU against the committed file.
+swapped, mm[A..L-A-1], bp, lpos, rpos, junction, signature; and per fixture the printed clusters: seed, members in
+sweep order, and the reads that survive remove_frag_id_duplicates (detect.rs:247-287: groups by fragment id, score
+min(l,r)*10000+max(l,r), first maximum) -- from which tests/test_hand_tables.py writes the expected .sv text.
+It checks BOTH restatements, the committed .sv files and the GPU against the committed tables.
 
 Run:  python tests/golden/derive_tables.py        (rewrites hand_tables.json; the diff must be empty)
 """
@@ -25,7 +33,12 @@ import json
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FIXTURES = ["hz_tie_lowest_k", "hz_len_2a", "hz_contig_ends", "hz_ref_alphabet", "hz_dedup_min_evidence"]
+FIXTURES = ["hz_tie_lowest_k", "hz_len_2a", "hz_contig_ends", "hz_ref_alphabet", "hz_dedup_min_evidence",
+            # the clustering quirks (round 3): a read an earlier seed reported joins a later seed's cluster; reorientation
+            # on one contig; coordinates that wrap below zero (printed and sorted as usize); unpaired lines; reads of
+            # several lengths in one class; min_evidence 0 and 1 (singletons print)
+            "hz_two_clusters", "hz_same_chr_swap", "hz_wrapped_coords", "hz_pairing", "hz_mixed_lengths",
+            "hz_min_evidence_0", "hz_min_evidence_1"]
 
 # bio 0.39 alphabets::dna::complement (Cargo.toml:14): identity except these letters, both cases
 _A, _B = "AGCTYRWSKMDVHBN", "TCGARYWSMKHBDVN"
@@ -57,14 +70,19 @@ def window(contig: bytes, start: int, L: int) -> bytes:
 
 
 def pairs(path):
-    """(fragment id, sequence, (strand, chr, pos), (mstrand, mchr, mpos)) per 5p/3p pair that the pairing rule of
-    detect.rs:79-87 accepts (these five fixtures have no unpaired lines)."""
+    """(fragment id, sequence, (strand, chr, pos), (mstrand, mchr, mpos)) per 3p line that the pairing rule of
+    detect.rs:79-87 accepts: the nearest 5p line before it carries the same read number (a 5p line without its 3p, a
+    3p line after another read's 5p, or two 3p lines of one read after their 5p all follow from that)."""
     lines = [l for l in open(path, "rb").read().split(b"\n") if l]
-    assert len(lines) % 2 == 0
-    for l5, l3 in zip(lines[0::2], lines[1::2]):
-        h5, s5, c5, p5 = l5.split(b"\t")
+    kind = [l[:2] for l in lines]
+    num = [int(l.split(b":")[1]) for l in lines]
+    assert all(k in (b"5p", b"3p") for k in kind)
+    for i, l3 in enumerate(lines):
+        before = [j for j in range(i) if kind[j] == b"5p"]
+        if kind[i] != b"3p" or not before or num[before[-1]] != num[i]:
+            continue
+        h5, s5, c5, p5 = lines[before[-1]].split(b"\t")
         h3, s3, c3, p3 = l3.split(b"\t")
-        assert h5.startswith(b"5p:") and h3.startswith(b"3p:") and h5.split(b":")[1] == h3.split(b":")[1]
         _, _, frag, seq = h3.split(b":")[:4]
         yield frag, seq, (s5 == b"+", c5, int(p5)), (s3 == b"+", c3, int(p3))
 
@@ -93,37 +111,41 @@ def derive(name):
         rows.append({"frag": frag.decode(), "swapped": swapped, "mm": mm, "bp": bp, "lpos": lpos % 2 ** 64, "rpos": rpos % 2 ** 64,
                      "strand": st, "mstrand": mst, "chr": ch.decode(), "mchr": mch.decode(),
                      "junction": junction.decode(), "signature": signature.decode(), "len": L})
-    out = {"args": [A, F, E], "reads": rows}
-    if name == "hz_dedup_min_evidence":
-        out["clusters"] = dedup_clusters(rows, F, E)
-    return out
+    return {"args": [A, F, E], "reads": rows, "clusters": derive_clusters(rows, F, E)}
 
 
-def dedup_clusters(rows, F, E):
-    """For this fixture every read of a junction shares (chr, strands, mchr, signature) and sits within max_frag_len, so
-    a cluster is simply the reads of one junction in sorted order (asserted); what is derived here is
-    remove_frag_id_duplicates (detect.rs:247-287) and the two min_evidence tests (:229, :231)."""
-    order = sorted(range(len(rows)), key=lambda i: (rows[i]["chr"].encode(), rows[i]["lpos"]))     # stable, detect.rs:193-198
-    klass = lambda r: (r["chr"], r["strand"], r["mchr"], r["mstrand"], r["signature"])
-    clusters, seen = [], set()
-    for i in order:
-        if i in seen:
-            continue
-        members = [j for j in order if klass(rows[j]) == klass(rows[i])]
-        assert all(abs(rows[j]["lpos"] - rows[i]["lpos"]) <= F and abs(rows[j]["rpos"] - rows[i]["rpos"]) <= F for j in members)
-        seen.update(members)
+def derive_clusters(rows, F, E):
+    """The printed clusters (detect.rs:193-241) as a fixed point, not as the reference's loops.
+    order: the evidence sorted stably by (chr bytes, pos as usize).  For p before s in that order,
+      compat(p, s) = same chr, pos[s] - pos[p] <= F, same mchr, |mpos[s] - mpos[p]| <= F as i64, same strands, same signature
+    (:214-223; the first two are the loop's `break` tests, monotone in sorted order, so "until the first failure" and
+    "everywhere" select the same reads).  A seed is a read that no earlier SEED is compatible with (:205, :226: only seeds
+    report); a seed's cluster is itself and every later read compatible with it, whether an earlier seed already
+    reported that read or not (:225).  Then the two min_evidence tests (:229, :231) around remove_frag_id_duplicates."""
+    n = len(rows)
+    order = sorted(range(n), key=lambda i: (rows[i]["chr"].encode(), rows[i]["lpos"]))            # stable; lpos is the wrapped usize
+    i64 = lambda x: x - 2 ** 64 if x >= 2 ** 63 else x
+    def compat(p, s):
+        a, b = rows[order[p]], rows[order[s]]
+        return (a["chr"] == b["chr"] and b["lpos"] - a["lpos"] <= F and a["mchr"] == b["mchr"] and
+                abs(i64(b["rpos"]) - i64(a["rpos"])) <= F and a["strand"] == b["strand"] and a["mstrand"] == b["mstrand"] and
+                a["signature"] == b["signature"])
+    seeds = []
+    for p in range(n):                                     # (a definition by recursion on p, evaluated in order)
+        if not any(compat(q, p) for q in seeds):
+            seeds.append(p)
+    score = lambda m: min(rows[m]["bp"], rows[m]["len"] - rows[m]["bp"]) * 10000 + max(rows[m]["bp"], rows[m]["len"] - rows[m]["bp"])
+    clusters = []
+    for p in seeds:
+        members = [order[p]] + [order[s] for s in range(p + 1, n) if compat(p, s)]
         if len(members) < E:
             continue
         kept = []
-        for j in members:                                  # representative at the slot of the group's first member
+        for j in members:                                  # a group's representative stands at the slot of its first member
             group = [m for m in members if rows[m]["frag"] == rows[j]["frag"]]
             if group[0] != j:
                 continue
-            score = lambda m: min(rows[m]["bp"], rows[m]["len"] - rows[m]["bp"]) * 10000 + max(rows[m]["bp"], rows[m]["len"] - rows[m]["bp"])
-            best = group[0]
-            for m in group[1:]:
-                if score(m) > score(best):                 # strict: the first maximum stays
-                    best = m
+            best = max(group, key=lambda m: (score(m), -group.index(m)))       # the first maximum (strict >, :280)
             kept.append(best)
         if len(kept) >= E:
             clusters.append({"seed": members[0], "members": members, "kept": kept})
@@ -139,7 +161,7 @@ def main():
     path = os.path.join(HERE, "hand_tables.json")
     json.dump(tables, open(path, "w"), indent=1, sort_keys=True)
     for name, t in tables.items():
-        print("%-24s %d reads%s" % (name, len(t["reads"]), ", %d clusters" % len(t["clusters"]) if "clusters" in t else ""))
+        print("%-24s %d reads, %d clusters" % (name, len(t["reads"]), len(t["clusters"])))
 
 
 if __name__ == "__main__":
