@@ -1094,7 +1094,7 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
     BF_TRY(ensure(ctx, ctx->c_misc, nq * 8 * 4));
     BF_HIP(ctx, hipEventRecord(ctx->ev[9], st));          // the seeds are known: the side stream may order them (queued below)
     BF_TRY(scan_u32_to_u64(ctx, ctx->c_qsize.as<uint32_t>(), ctx->c_qoff.as<uint64_t>(), nq));
-    BF_TRY(scan_u32_to_u64(ctx, qbig, qboff, nq));
+    if (total_big) BF_TRY(scan_u32_to_u64(ctx, qbig, qboff, nq));      // (no cluster above wave_max: nothing reads the offsets)
     if (total_m > 0xfffffff0ull) return fail(ctx, BF_ERR_RANGE, "cluster membership list too long (%llu)", (unsigned long long)total_m);
     BF_TRY(ensure(ctx, ctx->c_mrec, total_m * 4)); BF_TRY(ensure(ctx, ctx->c_mjrec, total_m * 4));
     BF_TRY(ensure(ctx, ctx->c_k64a, std::max(total_big, n) * 8, false));
