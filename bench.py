@@ -281,6 +281,22 @@ def main():
         h2h["pageable"] = timed(batch, "host-to-host, pageable batches, %s reads" % args.reads)
         h2h["pageable"]["input"] = "the same batch in ordinary numpy arrays, staged by the library's host threads"
         if args.reads == "packed":
+            # the same reads at two bits a base on PCIe (bf_submit_packed2: expanded to the resident 4-bit form on the device,
+            # behind every uploaded piece), pinned and pageable
+            t5 = time.time()
+            two = engine.pack2_batch(batch)
+            del pinned
+            pinned = eng.pin_batch(two)
+            log(rank, "batch packed to 2-bit codes (%d exceptions) and copied into bf_host_alloc memory in %.1fs" % (two.exc_read.size, time.time() - t5))
+            keep_in, keep_wire = in_bytes, on_wire
+            in_bytes = nbytes(two)
+            on_wire = in_bytes - two.seq_off.nbytes - two.frag_off.nbytes + 2 * two.n
+            h2h["two_bit_reads"] = timed(pinned, "host-to-host, pinned batches, 2-bit reads")
+            h2h["two_bit_reads"].update({"input": "bf_submit_packed2: 2 bits a base + exceptions for the bases that are none of ACGT",
+                                         "input_bytes": int(in_bytes), "wire_bytes": int(on_wire), "pcie_bound_ms": round(on_wire / 55e9 * 1e3, 2)})
+            h2h["two_bit_reads"]["pageable"] = timed(two, "host-to-host, pageable batches, 2-bit reads")
+            in_bytes, on_wire = keep_in, keep_wire
+            del two
             # the same with ASCII reads (bf_submit): a caller that does not pack
             in_bytes_ascii = nbytes(ascii_batch)
             del pinned

@@ -147,7 +147,7 @@ static OwnerView local_view(bf_ctx* ctx) {
     return v;
 }
 static void free_all(bf_ctx* ctx) {
-    DevBuf* all[] = {&ctx->g_blocks, &ctx->g_exc, &ctx->g_raw, &ctx->g_coarse, &ctx->g_coarse2, &ctx->g_contigs, &ctx->d_seq, &ctx->d_seq_off,
+    DevBuf* all[] = {&ctx->g_blocks, &ctx->g_exc, &ctx->g_raw, &ctx->g_coarse, &ctx->g_coarse2, &ctx->g_contigs, &ctx->d_seq, &ctx->d_seq2, &ctx->d_exc_read, &ctx->d_exc_pos, &ctx->d_exc_code, &ctx->d_seq_off,
         &ctx->d_frag, &ctx->d_frag_off, &ctx->d_hits, &ctx->d_len, &ctx->d_frag_len, &ctx->d_fhash,
         &ctx->d_key, &ctx->d_lpos, &ctx->d_rpos, &ctx->d_bp, &ctx->d_flags, &ctx->d_mask, &ctx->d_jrec, &ctx->d_exact_list,
         &ctx->d_counters, &ctx->d_sigx, &ctx->d_sigx_slot, &ctx->d_send, &ctx->d_part_key, &ctx->d_part_idx,
@@ -579,7 +579,7 @@ int bf_reset(bf_ctx* ctx) {
     ctx->off_pending.clear();
     ctx->host_reads.clear();
     ctx->rank_hist.assign(ctx->n_contigs, 0);
-    ctx->n_reads = 0; ctx->seq_bytes = 0; ctx->frag_bytes = 0;
+    ctx->n_reads = 0; ctx->seq_bytes = 0; ctx->frag_bytes = 0; ctx->seq2_bytes = 0; ctx->n_exc = 0;
     ctx->max_len = 0; ctx->min_len = 0xffffffffu; ctx->max_frag = 0;
     ctx->localised = false; ctx->imported = false; ctx->clustered = false; ctx->n_imported = 0; ctx->n_exact = 0;
     ctx->out.n_clusters = ctx->out.n_reads = ctx->out.junction_size = 0;
@@ -609,16 +609,19 @@ struct SubmitJob {
     uint64_t a, b;
 };
 
-struct BatchView {          // bf_batch or bf_packed_batch
+struct BatchView {          // bf_batch, bf_packed_batch or bf_packed2_batch
     uint64_t n_reads;
-    const uint8_t* seq_bytes; const uint64_t* seq_off; const uint16_t* seq_len;     // seq_len: 4-bit reads only
+    const uint8_t* seq_bytes; const uint64_t* seq_off; const uint16_t* seq_len;     // seq_len: 4-bit and 2-bit reads only
     const uint8_t* frag_bytes; const uint64_t* frag_off; const bf_hit* hits;
+    bool two_bit = false;                                   // seq_bytes holds 2-bit codes: uploaded to d_seq2, expanded on the device
+    uint64_t n_exc = 0; const uint32_t* exc_read = nullptr; const uint16_t* exc_pos = nullptr; const uint8_t* exc_code = nullptr;
 };
 
 struct SubmitShared {
     bf_ctx* ctx; const BatchView* bat;
     uint64_t r_base;       // first read of the piece inside the batch
-    uint64_t n0, seq0, frag0;          // resident reads / bytes before the BATCH
+    uint64_t n0, seq0, frag0;          // resident reads / bytes before the BATCH (2-bit batches: seq0 counts d_seq2's bytes)
+    uint64_t nib = 0;                  // 2-bit batches: 4-bit bytes the piece's reads will take (summed by the jobs)
     bool hits_direct;
     uint8_t* wide = nullptr;           // piece-wide pinned buffer for the rebased offsets (batches in bf_host_alloc memory)
     uint64_t p0 = 0, p1 = 0;           // the piece
@@ -653,6 +656,7 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
     if (hipSetDevice(ctx->device) != hipSuccess) { sh->error(0, BF_ERR_HIP, "hipSetDevice failed in a staging thread"); return; }
     bf_ctx::StageSlot& sl = ctx->slots[slot_id];
     uint32_t mx = 0, mn = 0xffffffffu, mf = 0;
+    uint64_t nib = 0;
     std::vector<uint64_t> hist(ctx->n_contigs, 0);
     for (size_t j; (j = sh->next.fetch_add(1)) < sh->jobs.size();) {
         const SubmitJob& job = sh->jobs[j];
@@ -683,13 +687,15 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
                 if (sb < sa || fb < fa) { sh->error(i, BF_ERR_INVALID, "bf_submit: offsets not monotone at read %llu", (unsigned long long)i); ok = false; break; }
                 uint64_t L = sb - sa;
                 const uint64_t fl = fb - fa;
-                if (b->seq_len) {                                // 4-bit codes: ceil(L / 2) bytes hold the L bases
+                if (b->seq_len) {                                // 4-bit codes: ceil(L / 2) bytes hold the L bases; 2-bit: ceil(L / 4)
                     L = b->seq_len[i];
-                    if (sb - sa != (L + 1) / 2) {
-                        sh->error(i, BF_ERR_INVALID, "bf_submit_packed: read %llu has %llu bases in %llu bytes (expected %llu)", (unsigned long long)i,
-                                  (unsigned long long)L, (unsigned long long)(sb - sa), (unsigned long long)((L + 1) / 2));
+                    const uint64_t want = b->two_bit ? (L + 3) / 4 : (L + 1) / 2;
+                    if (sb - sa != want) {
+                        sh->error(i, BF_ERR_INVALID, "%s: read %llu has %llu bases in %llu bytes (expected %llu)", b->two_bit ? "bf_submit_packed2" : "bf_submit_packed",
+                                  (unsigned long long)i, (unsigned long long)L, (unsigned long long)(sb - sa), (unsigned long long)want);
                         ok = false; break;
                     }
+                    nib += (L + 1) / 2;
                     ll[i - job.a] = (uint16_t)L;
                     fls[i - job.a] = (uint16_t)std::min<uint64_t>(fb - fa, 65535);
                 }
@@ -722,7 +728,7 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
                 e = hipMemcpyAsync(ctx->d_hits.as<bf_hit>() + sh->n0 + job.a, hh, cnt * sizeof(bf_hit), hipMemcpyHostToDevice, ctx->in_stream);
         } else {
             const uint8_t* src = job.kind == 1 ? b->seq_bytes + b->seq_off[0] : b->frag_bytes + b->frag_off[0];
-            uint8_t* dst = job.kind == 1 ? ctx->d_seq.as<uint8_t>() + sh->seq0 : ctx->d_frag.as<uint8_t>() + sh->frag0;
+            uint8_t* dst = job.kind == 1 ? (b->two_bit ? ctx->d_seq2.as<uint8_t>() : ctx->d_seq.as<uint8_t>()) + sh->seq0 : ctx->d_frag.as<uint8_t>() + sh->frag0;
             memcpy(sl.p, src + job.a, job.b - job.a);
             e = hipMemcpyAsync(dst + job.a, sl.p, job.b - job.a, hipMemcpyHostToDevice, ctx->in_stream);
         }
@@ -732,6 +738,7 @@ static void submit_worker(SubmitShared* sh, int slot_id) {
     }
     std::lock_guard<std::mutex> g(sh->mu);
     sh->mx = std::max(sh->mx, mx); sh->mn = std::min(sh->mn, mn); sh->mf = std::max(sh->mf, mf);
+    sh->nib += nib;
     for (uint32_t r = 0; r < ctx->n_contigs; r++) sh->hist[r] += hist[r];
 }
 
@@ -822,6 +829,29 @@ int bf_submit_packed(bf_ctx* ctx, const bf_packed_batch* b) {
     return submit_impl(ctx, &v);
 }
 
+int bf_submit_packed2(bf_ctx* ctx, const bf_packed2_batch* b) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!b) return fail(ctx, BF_ERR_INVALID, "bf_submit_packed2: null batch");
+    if (b->n_reads && !b->seq_len) return fail(ctx, BF_ERR_INVALID, "bf_submit_packed2: null seq_len");
+    if (ctx->cfg.flags & BF_FLAG_READS_ON_HOST)
+        return fail(ctx, BF_ERR_STATE, "bf_submit_packed2 with BF_FLAG_READS_ON_HOST: records that name a read are expanded from 4-bit or ASCII arrays");
+    if (ctx->n_reads && !ctx->packed_reads && b->n_reads) return fail(ctx, BF_ERR_STATE, "bf_submit_packed2 after bf_submit: a ctx holds its reads in one form; call bf_reset first");
+    if (b->n_exceptions && (!b->exc_read || !b->exc_pos || !b->exc_code)) return fail(ctx, BF_ERR_INVALID, "bf_submit_packed2: null exception array");
+    if (b->n_reads > 0xffffffffull) return fail(ctx, BF_ERR_RANGE, "bf_submit_packed2: more than 2^32-1 reads in one batch");
+    for (uint64_t j = 0; j < b->n_exceptions; j++) {        // (a per cent of the reads at most: checked here, in order)
+        const uint32_t r = b->exc_read[j], c = b->exc_code[j];
+        if (r >= b->n_reads || b->exc_pos[j] >= b->seq_len[r])
+            return fail(ctx, BF_ERR_INVALID, "bf_submit_packed2: exception %llu names base %u of read %u (the batch has %llu reads)", (unsigned long long)j, b->exc_pos[j], r, (unsigned long long)b->n_reads);
+        if (c > 15 || c == 1 || c == 2 || c == 4 || c == 8)
+            return fail(ctx, BF_ERR_INVALID, "bf_submit_packed2: exception %llu has code %u (any of 0..15 but A, C, G, T = 1, 2, 4, 8)", (unsigned long long)j, c);
+        if (j && (b->exc_read[j - 1] > r || (b->exc_read[j - 1] == r && b->exc_pos[j - 1] >= b->exc_pos[j])))
+            return fail(ctx, BF_ERR_INVALID, "bf_submit_packed2: exceptions not ascending by (read, position) at %llu", (unsigned long long)j);
+    }
+    BatchView v{b->n_reads, b->seq_2bit, b->seq_off, b->seq_len, b->frag_bytes, b->frag_off, b->hits};
+    v.two_bit = true; v.n_exc = b->n_exceptions; v.exc_read = b->exc_read; v.exc_pos = b->exc_pos; v.exc_code = b->exc_code;
+    return submit_impl(ctx, &v);
+}
+
 static int submit_impl(bf_ctx* ctx, const BatchView* b) {
     BF_TRACE_CALL(ctx);
     if (ctx->n_contigs == 0) return fail(ctx, BF_ERR_STATE, "bf_submit before bf_genome_set");
@@ -834,7 +864,17 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
     const uint64_t sb = b->seq_off[m] - b->seq_off[0], fb = b->frag_off[m] - b->frag_off[0];
     if (fb && !b->frag_bytes) return fail(ctx, BF_ERR_INVALID, "bf_submit: null frag_bytes");
     BF_HIP(ctx, hipSetDevice(ctx->device));
-    BF_TRY(reserve_input(ctx, ctx->n_reads + m, ctx->seq_bytes + sb, ctx->frag_bytes + fb));
+    // (2-bit batches: sb counts 2-bit bytes; the reads will take at most twice that as 4-bit codes, ceil(L/2) <= 2 ceil(L/4))
+    BF_TRY(reserve_input(ctx, ctx->n_reads + m, ctx->seq_bytes + (b->two_bit ? 2 * sb : sb), ctx->frag_bytes + fb));
+    if (b->two_bit) {
+        if (ctx->seq2_bytes + sb + 64 > ctx->d_seq2.cap || !ctx->d_seq2.p || ctx->n_exc + b->n_exc > ctx->d_exc_read.cap / 4 || !ctx->d_exc_read.p) {
+            BF_SYNC(ctx, ctx->in_stream);                   // nothing may move under a queued upload or an expansion
+            BF_SYNC(ctx, ctx->stream);
+            BF_TRY(ensure(ctx, ctx->d_seq2, std::max<uint64_t>(ctx->seq2_bytes + sb + 64, ctx->d_seq2.cap * 2), true));
+            const uint64_t ne = std::max<uint64_t>({ctx->n_exc + b->n_exc, ctx->d_exc_read.cap / 4 * 2, (uint64_t)4096});
+            BF_TRY(ensure(ctx, ctx->d_exc_read, ne * 4, true)); BF_TRY(ensure(ctx, ctx->d_exc_pos, ne * 2, true)); BF_TRY(ensure(ctx, ctx->d_exc_code, ne, true));
+        }
+    }
     const bool seq_direct = is_pinned(ctx, b->seq_bytes + b->seq_off[0], sb);
     const bool frag_direct = fb == 0 || is_pinned(ctx, b->frag_bytes + b->frag_off[0], fb);
     // "h2d" in bf_kernel_times: from this call's first upload to its last, on the copy-in stream
@@ -856,7 +896,26 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
         }
     } timer{ctx, t_a, t_b};
     SubmitShared sh;
-    sh.ctx = ctx; sh.bat = b; sh.n0 = ctx->n_reads; sh.seq0 = ctx->seq_bytes; sh.frag0 = ctx->frag_bytes;
+    sh.ctx = ctx; sh.bat = b; sh.n0 = ctx->n_reads; sh.seq0 = b->two_bit ? ctx->seq2_bytes : ctx->seq_bytes; sh.frag0 = ctx->frag_bytes;
+    uint8_t* const d_seq_in = b->two_bit ? ctx->d_seq2.as<uint8_t>() : ctx->d_seq.as<uint8_t>();
+    uint64_t nib_before = 0;                                // 2-bit batches: 4-bit bytes of the pieces before this one
+    if (b->two_bit && b->n_exc) {
+        // the exceptions of the whole batch go up first (a pinned slot at a time), with the reads' resident numbers
+        if (ctx->slots.empty()) ctx->slots.resize(std::max<uint32_t>(ctx->host_threads, 1));
+        bf_ctx::StageSlot& sl = ctx->slots[0];
+        const uint64_t per = kStageSlotBytes / 8;
+        for (uint64_t a = 0; a < b->n_exc; a += per) {
+            const uint64_t cnt = std::min<uint64_t>(per, b->n_exc - a);
+            if (!slot_ready(ctx, sl)) return fail(ctx, BF_ERR_NOMEM, "pinned staging memory is not available");
+            uint32_t* er = (uint32_t*)sl.p; uint16_t* ep = (uint16_t*)(er + cnt); uint8_t* ec = (uint8_t*)(ep + cnt);
+            for (uint64_t j = 0; j < cnt; j++) { er[j] = (uint32_t)(sh.n0 + b->exc_read[a + j]); ep[j] = b->exc_pos[a + j]; ec[j] = b->exc_code[a + j]; }
+            BF_HIP(ctx, hipMemcpyAsync(ctx->d_exc_read.as<uint32_t>() + ctx->n_exc + a, er, cnt * 4, hipMemcpyHostToDevice, ctx->in_stream));
+            BF_HIP(ctx, hipMemcpyAsync(ctx->d_exc_pos.as<uint16_t>() + ctx->n_exc + a, ep, cnt * 2, hipMemcpyHostToDevice, ctx->in_stream));
+            BF_HIP(ctx, hipMemcpyAsync(ctx->d_exc_code.as<uint8_t>() + ctx->n_exc + a, ec, cnt, hipMemcpyHostToDevice, ctx->in_stream));
+            BF_HIP(ctx, hipEventRecord(sl.ev, ctx->in_stream));
+            sl.used = true;
+        }
+    }
     sh.hits_direct = is_pinned(ctx, b->hits, m * sizeof(bf_hit));
     sh.hist.assign(ctx->n_contigs, 0);
     if (ctx->slots.size() < ctx->host_threads) ctx->slots.resize(ctx->host_threads);
@@ -878,7 +937,7 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
         // the host threads below check this piece's offsets and hits.  (Nothing of a batch is resident before its
         // last piece has passed: these copies only touch memory beyond n_reads.)
         if (seq_direct && se > sa)
-            BF_HIP(ctx, hipMemcpyAsync(ctx->d_seq.as<uint8_t>() + sh.seq0 + sa, b->seq_bytes + b->seq_off[0] + sa, se - sa, hipMemcpyHostToDevice, ctx->in_stream));
+            BF_HIP(ctx, hipMemcpyAsync(d_seq_in + sh.seq0 + sa, b->seq_bytes + b->seq_off[0] + sa, se - sa, hipMemcpyHostToDevice, ctx->in_stream));
         if (frag_direct && fe > fa)
             BF_HIP(ctx, hipMemcpyAsync(ctx->d_frag.as<uint8_t>() + sh.frag0 + fa, b->frag_bytes + b->frag_off[0] + fa, fe - fa, hipMemcpyHostToDevice, ctx->in_stream));
         if (sh.hits_direct)
@@ -894,7 +953,7 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
         if (!seq_direct) for (uint64_t a = sa; a < se; a += job_bytes) sh.jobs.push_back(SubmitJob{1, a, std::min(se, a + job_bytes)});
         if (!frag_direct) for (uint64_t a = fa; a < fe; a += job_bytes) sh.jobs.push_back(SubmitJob{2, a, std::min(fe, a + job_bytes)});
         // a batch wholly in bf_host_alloc memory: the threads write one piece-wide set of arrays, uploaded in four copies
-        sh.wide = nullptr; sh.p0 = p0; sh.p1 = p1;
+        sh.wide = nullptr; sh.p0 = p0; sh.p1 = p1; sh.nib = 0;
         bf_ctx::WideSlot* ws = nullptr;
         if (seq_direct && frag_direct) {
             ws = &ctx->wide[ctx->wide_next++ & 1];
@@ -940,7 +999,16 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
         if (mn < 2 * ctx->cfg.anchor_len && p0) ctx->n_localised = 0;
         if (mn < 2 * ctx->cfg.anchor_len)
             return fail(ctx, BF_ERR_RANGE, "a read of length %u is shorter than 2 * anchor_len = %u (detect.rs:311 never emits such reads)", mn, 2 * ctx->cfg.anchor_len);
-        if (b->seq_len) ctx->off_pending.push_back(bf_ctx::OffsetPiece{sh.n0 + p0, sh.n0 + p1, sh.seq0 + sa, sh.frag0 + fa});
+        if (b->seq_len && !b->two_bit) ctx->off_pending.push_back(bf_ctx::OffsetPiece{sh.n0 + p0, sh.n0 + p1, sh.seq0 + sa, sh.frag0 + fa});
+        if (b->two_bit) {
+            bf_ctx::OffsetPiece pc{sh.n0 + p0, sh.n0 + p1, ctx->seq_bytes + nib_before, sh.frag0 + fa};
+            pc.two_bit = true; pc.seq2_base = sh.seq0 + sa;
+            pc.exc0 = ctx->n_exc + (uint64_t)(std::lower_bound(b->exc_read, b->exc_read + b->n_exc, (uint32_t)p0) - b->exc_read);
+            pc.exc1 = ctx->n_exc + (uint64_t)(std::lower_bound(b->exc_read, b->exc_read + b->n_exc, (uint32_t)std::min<uint64_t>(p1, 0xffffffffull)) - b->exc_read);
+            if (p1 > 0xffffffffull) pc.exc1 = ctx->n_exc + b->n_exc;
+            ctx->off_pending.push_back(pc);
+            nib_before += sh.nib;
+        }
         if (p1 < m && eager) {
             // a finished piece in the middle of a large batch: localise it behind its upload.  (The batch becomes
             // resident only when its last piece has been checked; a rejected batch drops the evidence again.)
@@ -952,7 +1020,9 @@ static int submit_impl(bf_ctx* ctx, const BatchView* b) {
     }
     if (ctx->cfg.flags & BF_FLAG_READS_ON_HOST)              // the caller keeps these arrays for the results to point into
         ctx->host_reads.push_back(bf_ctx::HostReads{ctx->n_reads, m, b->seq_bytes, b->seq_off, b->seq_len});
-    ctx->n_reads += m; ctx->seq_bytes += sb; ctx->frag_bytes += fb;
+    ctx->n_reads += m; ctx->frag_bytes += fb;
+    if (b->two_bit) { ctx->seq_bytes += nib_before; ctx->seq2_bytes += sb; ctx->n_exc += b->n_exc; }
+    else ctx->seq_bytes += sb;
     ctx->max_len = mx; ctx->min_len = mn; ctx->max_frag = mf;
     ctx->localised = false; ctx->imported = false; ctx->consumed = false;
     if (ctx->rank_hist.size() != ctx->n_contigs) ctx->rank_hist.assign(ctx->n_contigs, 0);

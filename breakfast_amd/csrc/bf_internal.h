@@ -265,7 +265,9 @@ struct bf_ctx {
     std::vector<StageSlot> slots;               // one per host thread, kStageSlotBytes each (allocated on first use)
     // 4-bit batches: the offsets are not uploaded, the device rebuilds them from the lengths (a read takes ceil(len / 2)
     // bytes, fragment ids lie back to back): reads [r0, r1) start at these byte offsets; done before anything reads them
-    struct OffsetPiece { uint64_t r0, r1, seq_base, frag_base; };
+    // (two_bit: the piece came as 2-bit codes -- bf_submit_packed2 --, its bytes lie at d_seq2 + seq2_base and are expanded
+    //  to 4-bit codes at seq_base once the offsets are there; exceptions [exc0, exc1) of the resident list are its own)
+    struct OffsetPiece { uint64_t r0, r1, seq_base, frag_base; bool two_bit = false; uint64_t seq2_base = 0, exc0 = 0, exc1 = 0; };
     std::vector<OffsetPiece> off_pending;
     struct WideSlot { uint8_t* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
     WideSlot wide[2];                           // piece-wide offset staging for batches in bf_host_alloc memory, used in turn
@@ -298,6 +300,9 @@ struct bf_ctx {
     bool packed_reads = false;                  // d_seq holds 4-bit base codes (bf_submit_packed), d_len came with them
     uint64_t n_reads = 0;
     uint64_t seq_bytes = 0, frag_bytes = 0;
+    uint64_t seq2_bytes = 0, n_exc = 0;          // bf_submit_packed2: 2-bit bytes uploaded since bf_reset (kept until then: a
+                                                // piece is expanded by the stream that localises it), exceptions resident
+    bf::DevBuf d_seq2, d_exc_read, d_exc_pos, d_exc_code;
     uint32_t max_len = 0, min_len = 0xffffffffu, max_frag = 0;
     bf::DevBuf d_seq, d_seq_off, d_frag, d_frag_off, d_hits;
     // derived by localise
@@ -422,7 +427,7 @@ int genome_pack(bf_ctx* ctx);                       // raw image -> blocks + coa
 int run_localise(bf_ctx* ctx, bool defer_counts = false, bool all = true);   // read_meta + packed + exact kernels; all = false:
                                                     // only the reads bf_submit has not localised behind their upload yet
 int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len);
-int offsets_from_lengths(bf_ctx* ctx, uint64_t n_uploaded);   // 4-bit batches: rebuilds the offset arrays of the uploaded pieces   // bf_submit: the packed kernel over reads [n_localised, n)
+int offsets_from_lengths(bf_ctx* ctx, uint64_t n_uploaded, uint32_t max_len);   // 4-bit batches: rebuilds the offset arrays of the uploaded pieces   // bf_submit: the packed kernel over reads [n_localised, n)
 int grow_reads(bf_ctx* ctx, uint64_t cap);          // per-read arrays for `cap` reads, contents kept
 int settle_counts(bf_ctx* ctx);                     // n_exact / n_sigx / n_text_records valid on return
 int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, int n_chunks, uint64_t* chunk_off,

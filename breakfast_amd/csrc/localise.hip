@@ -1076,15 +1076,57 @@ int grow_reads(bf_ctx* ctx, uint64_t cap) {
 // 4-bit batches come without their offset arrays (16 of a read's 121 bytes on PCIe): a read takes ceil(len / 2) bytes
 // and fragment ids lie back to back, so an exclusive scan of the lengths of an uploaded piece, started at the piece's
 // first byte (known on the host), IS the offset array.  Per piece and array: widen, scan, add the base.
+// halve: 0 = the length itself (fragment ids), 1 = ceil(len / 2) (4-bit codes), 2 = ceil(len / 4) (2-bit codes)
 __global__ void widen_lengths_kernel(uint32_t* __restrict__ out, const uint16_t* __restrict__ len, uint64_t n, int halve) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = halve ? ((uint32_t)len[i] + 1u) >> 1 : (uint32_t)len[i];
+    if (i < n) out[i] = halve == 2 ? ((uint32_t)len[i] + 3u) >> 2 : halve ? ((uint32_t)len[i] + 1u) >> 1 : (uint32_t)len[i];
+}
+// bf_submit_packed2: a piece that crossed PCIe at two bits a base becomes the resident 4-bit form (BAM codes: A = 1, C = 2,
+// G = 4, T = 8 = 1 << code; two bases a byte, high nibble first).  One lane per 16 bases of a read: four bytes in (bits
+// 2(k & 3).. of byte k >> 2 hold base k), eight bytes out; lanes of one read touch consecutive bytes on both sides.  The
+// last group of a read writes only the bytes the read has and leaves the padding nibble of an odd length zero.
+__global__ void __launch_bounds__(256) expand_2bit_kernel(uint8_t* __restrict__ out, const uint64_t* __restrict__ out_off /* per read, absolute */,
+                                                          const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off /* per read, from 0 */,
+                                                          const uint16_t* __restrict__ len, uint64_t n, uint32_t groups) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r = x / groups;
+    const uint32_t g = (uint32_t)(x - r * groups);
+    if (r >= n) return;
+    const uint32_t L = len[r];
+    if (16u * g >= L) return;
+    const uint32_t nb = min(16u, L - 16u * g);                       // bases of this group
+    const uint8_t* src = in + in_off[r] + 4u * g;
+    uint32_t w;                                                      // (whole word: d_seq2 ends in 64 spare bytes; bits past nb are masked below)
+    __builtin_memcpy(&w, src, 4);
+    uint64_t o = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+        const uint32_t hi = 1u << ((w >> (4u * j)) & 3u), lo = 1u << ((w >> (4u * j + 2u)) & 3u);
+        const uint32_t byte = (2u * j < nb ? hi << 4 : 0u) | (2u * j + 1u < nb ? lo : 0u);
+        o |= (uint64_t)byte << (8u * j);
+    }
+    uint8_t* dst = out + out_off[r] + 8u * g;
+    if (nb == 16u) __builtin_memcpy(dst, &o, 8);
+    else for (uint32_t k = 0; k < (nb + 1u) >> 1; k++) dst[k] = (uint8_t)(o >> (8u * k));
+}
+// ... and the bases that are none of ACGT put in place: exception j names (read, position, 4-bit code).  A nibble is
+// cleared and set with two atomics on its aligned word: two exceptions may share a byte, never a nibble.
+__global__ void patch_exceptions_kernel(uint8_t* __restrict__ seq, const uint64_t* __restrict__ seq_off, const uint32_t* __restrict__ exc_read,
+                                        const uint16_t* __restrict__ exc_pos, const uint8_t* __restrict__ exc_code, uint64_t n) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t pos = exc_pos[j];
+    const uint64_t at = seq_off[exc_read[j]] + (pos >> 1);
+    const uint32_t shift = 8u * (uint32_t)((uintptr_t)(seq + at) & 3u) + ((pos & 1u) ? 0u : 4u);
+    unsigned int* word = (unsigned int*)((uintptr_t)(seq + at) & ~(uintptr_t)3);
+    atomicAnd(word, ~(0xfu << shift));
+    atomicOr(word, ((uint32_t)exc_code[j] & 0xfu) << shift);
 }
 __global__ void add_base_kernel(uint64_t* __restrict__ off, uint64_t base, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) off[i] += base;
 }
-int offsets_from_lengths(bf_ctx* ctx, uint64_t n_uploaded) {
+int offsets_from_lengths(bf_ctx* ctx, uint64_t n_uploaded, uint32_t max_len) {
     size_t done = 0;
     for (const bf_ctx::OffsetPiece& pc : ctx->off_pending) {
         if (pc.r1 > n_uploaded) break;
@@ -1096,6 +1138,19 @@ int offsets_from_lengths(bf_ctx* ctx, uint64_t n_uploaded) {
             hipLaunchKernelGGL(widen_lengths_kernel, dim3(grid_for(m, 256)), dim3(256), 0, ctx->stream, ctx->c_a32.as<uint32_t>(), len, m, which ? 0 : 1);
             BF_TRY(scan_u32_to_u64(ctx, ctx->c_a32.as<uint32_t>(), off, m));                   // m + 1 entries, from 0
             hipLaunchKernelGGL(add_base_kernel, dim3(grid_for(m + 1, 256)), dim3(256), 0, ctx->stream, off, which ? pc.frag_base : pc.seq_base, m + 1);
+        }
+        if (pc.two_bit && m) {                               // the piece's bytes are 2-bit codes in d_seq2: expand, patch
+            BF_TRY(ensure(ctx, ctx->c_scan, (m + 1) * 8, false));
+            const uint16_t* len = ctx->d_len.as<uint16_t>() + pc.r0;
+            hipLaunchKernelGGL(widen_lengths_kernel, dim3(grid_for(m, 256)), dim3(256), 0, ctx->stream, ctx->c_a32.as<uint32_t>(), len, m, 2);
+            BF_TRY(scan_u32_to_u64(ctx, ctx->c_a32.as<uint32_t>(), ctx->c_scan.as<uint64_t>(), m));
+            const uint32_t groups = (std::max<uint32_t>(max_len, 1) + 15u) / 16u;
+            hipLaunchKernelGGL(expand_2bit_kernel, dim3(grid_for(m * groups, 256)), dim3(256), 0, ctx->stream, ctx->d_seq.as<uint8_t>(),
+                               ctx->d_seq_off.as<uint64_t>() + pc.r0, ctx->d_seq2.as<uint8_t>() + pc.seq2_base, ctx->c_scan.as<uint64_t>(), len, m, groups);
+            if (pc.exc1 > pc.exc0)
+                hipLaunchKernelGGL(patch_exceptions_kernel, dim3(grid_for(pc.exc1 - pc.exc0, 256)), dim3(256), 0, ctx->stream, ctx->d_seq.as<uint8_t>(),
+                                   ctx->d_seq_off.as<uint64_t>(), ctx->d_exc_read.as<uint32_t>() + pc.exc0, ctx->d_exc_pos.as<uint16_t>() + pc.exc0,
+                                   ctx->d_exc_code.as<uint8_t>() + pc.exc0, pc.exc1 - pc.exc0);
         }
         BF_HIP(ctx, hipGetLastError());
         done++;
@@ -1133,7 +1188,7 @@ int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len) {
         BF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));
         ctx->in_pending = false;
     }
-    BF_TRY(offsets_from_lengths(ctx, n));
+    BF_TRY(offsets_from_lengths(ctx, n, max_len));
 
     {
         Scope t(ctx, "read_meta");

@@ -46,3 +46,28 @@ int64_t bf_synth_pack_fixed(uint8_t* out, const uint8_t* seq, int64_t n, int64_t
     }
     return bad;
 }
+
+/* engine.pack2_batch for reads of one length: BAM 4-bit codes -> 2-bit codes (A C G T = 0 1 2 3, base k in bits 2(k & 3)..
+ * of byte k >> 2, every read on a byte).  Returns the number of bases that are none of the four (the caller then takes
+ * the general path, which lists them); the output is complete only when that is zero. */
+int64_t bf_synth_pack2_fixed(uint8_t* out, const uint8_t* nib, int64_t n, int64_t L) {
+    static const uint8_t two[16] = {255, 0, 1, 255, 2, 255, 255, 255, 3, 255, 255, 255, 255, 255, 255, 255};
+    const int64_t nb4 = (L + 1) / 2, nb2 = (L + 3) / 4;
+    int64_t bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (int64_t r = 0; r < n; r++) {
+        const uint8_t* s = nib + r * nb4;
+        uint8_t* o = out + r * nb2;
+        for (int64_t b = 0; b < nb2; b++) {
+            uint8_t x = 0;
+            for (int64_t j = 0; j < 4 && 4 * b + j < L; j++) {
+                const int64_t k = 4 * b + j;
+                const uint8_t c = two[(k & 1) ? (s[k >> 1] & 15) : (s[k >> 1] >> 4)];
+                bad += c == 255;
+                x |= (uint8_t)((c & 3) << (2 * j));
+            }
+            o[b] = x;
+        }
+    }
+    return bad;
+}

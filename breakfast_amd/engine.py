@@ -51,6 +51,12 @@ class BfPackedBatch(C.Structure):
                 ("frag_bytes", C.c_void_p), ("frag_off", C.c_void_p), ("hits", C.c_void_p)]
 
 
+class BfPacked2Batch(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("seq_2bit", C.c_void_p), ("seq_off", C.c_void_p), ("seq_len", C.c_void_p),
+                ("n_exceptions", C.c_uint64), ("exc_read", C.c_void_p), ("exc_pos", C.c_void_p), ("exc_code", C.c_void_p),
+                ("frag_bytes", C.c_void_p), ("frag_off", C.c_void_p), ("hits", C.c_void_p)]
+
+
 class BfResult(C.Structure):
     _fields_ = [("n_evidence", C.c_uint64), ("n_clusters", C.c_uint64), ("n_reads", C.c_uint64),
                 ("clusters", C.c_void_p), ("reads", C.c_void_p), ("junction_bytes", C.c_void_p),
@@ -102,7 +108,7 @@ ABI_SYMBOLS = [
     "bf_evidence_fetch", "bf_kernel_times", "bf_stats", "bf_junction_text", "bf_junction_text_of", "bf_result_junction_text",
     "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
     "bf_host_alloc", "bf_host_free", "bf_submit_wait", "bf_reserve",
-    "bf_genome_begin", "bf_genome_write", "bf_genome_fill", "bf_genome_end", "bf_submit_packed",
+    "bf_genome_begin", "bf_genome_write", "bf_genome_fill", "bf_genome_end", "bf_submit_packed", "bf_submit_packed2",
     "bf_shard_unique_id", "bf_shard_init_rccl", "bf_shard_init_host", "bf_shard_finish", "bf_shard_result_places", "bf_shard_format_sv",
     "bf_shard_format_sv_names",
 ]
@@ -149,6 +155,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_genome_fill.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, FILL_FN, vp]
     lib.bf_submit.argtypes = [vp, C.POINTER(BfBatch)]
     lib.bf_submit_packed.argtypes = [vp, C.POINTER(BfPackedBatch)]
+    lib.bf_submit_packed2.argtypes = [vp, C.POINTER(BfPacked2Batch)]
     lib.bf_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     lib.bf_host_free.argtypes = [vp, vp]
     lib.bf_submit_wait.argtypes = [vp]
@@ -294,6 +301,70 @@ def pack_batch(b: Batch, chunk: int = 1 << 20, threads: int = 0) -> PackedBatch:
             one(a)
     return PackedBatch(out, boff.astype(np.uint64), lens.astype(np.uint16), np.ascontiguousarray(b.frag_bytes, np.uint8),
                        np.ascontiguousarray(b.frag_off, np.uint64), np.ascontiguousarray(b.hits, HIT_DTYPE))
+
+
+@dataclass
+class Packed2Batch:
+    """A Batch with the reads at two bits a base = bf_packed2_batch: A C G T = 0 1 2 3, four bases a byte (base k in bits
+    2(k & 3).. of byte k >> 2), every read on a byte; the other bases as exceptions (read, position, BAM 4-bit code)."""
+    seq_2bit: np.ndarray     # uint8
+    seq_off: np.ndarray      # uint64 byte offsets, n+1
+    seq_len: np.ndarray      # uint16, n
+    exc_read: np.ndarray     # uint32, ascending
+    exc_pos: np.ndarray      # uint16
+    exc_code: np.ndarray     # uint8
+    frag_bytes: np.ndarray
+    frag_off: np.ndarray
+    hits: np.ndarray
+
+    @property
+    def n(self) -> int:
+        return int(self.hits.shape[0])
+
+
+def pack2_batch(pb: PackedBatch, chunk: int = 1 << 18) -> Packed2Batch:
+    """4-bit codes -> 2-bit codes + exceptions (what a parser that classifies every base anyway would produce)."""
+    n = pb.n
+    lens = np.ascontiguousarray(pb.seq_len, np.uint16).astype(np.int64)
+    so4 = np.ascontiguousarray(pb.seq_off, np.uint64).astype(np.int64)
+    nb2 = (lens + 3) // 4
+    off2 = np.zeros(n + 1, np.int64)
+    np.cumsum(nb2, out=off2[1:])
+    out = np.zeros(int(off2[-1]), np.uint8)
+    nib = np.ascontiguousarray(pb.seq_nibbles, np.uint8)
+    if n and int(lens.min()) == int(lens.max()) and int(so4[0]) == 0:
+        from . import synth                                  # reads of one length, all plain ACGT: the C helper, when it is built
+        fast = synth.fast_lib()
+        if fast is not None and hasattr(fast, "bf_synth_pack2_fixed") and fast.bf_synth_pack2_fixed(out.ctypes.data, nib.ctypes.data, n, int(lens[0])) == 0:
+            return Packed2Batch(out, off2.astype(np.uint64), lens.astype(np.uint16), np.zeros(0, np.uint32), np.zeros(0, np.uint16), np.zeros(0, np.uint8),
+                                np.ascontiguousarray(pb.frag_bytes, np.uint8), np.ascontiguousarray(pb.frag_off, np.uint64),
+                                np.ascontiguousarray(pb.hits, HIT_DTYPE))
+        out[:] = 0
+    two = np.zeros(16, np.uint8)
+    two[[1, 2, 4, 8]] = [0, 1, 2, 3]
+    plain = np.zeros(16, bool)
+    plain[[1, 2, 4, 8]] = True
+    er, ep, ec = [], [], []
+    for a in range(0, n, chunk):
+        e = min(n, a + chunk)
+        ln = lens[a:e]
+        tot = int(ln.sum())
+        if tot == 0:
+            continue
+        read = np.repeat(np.arange(e - a, dtype=np.int64), ln)
+        first = np.zeros(e - a, np.int64)
+        np.cumsum(ln[:-1], out=first[1:])
+        k = np.arange(tot, dtype=np.int64) - first[read]
+        byte4 = nib[so4[a:e][read] + (k >> 1)]
+        code = np.where((k & 1) == 0, byte4 >> 4, byte4 & 15).astype(np.uint8)
+        np.add.at(out, off2[a:e][read] + (k >> 2), (two[code] << (2 * (k & 3)).astype(np.uint8)).astype(np.uint8))
+        bad = ~plain[code]
+        if bad.any():
+            er.append((read[bad] + a).astype(np.uint32)); ep.append(k[bad].astype(np.uint16)); ec.append(code[bad])
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+    return Packed2Batch(out, off2.astype(np.uint64), lens.astype(np.uint16), cat(er, np.uint32), cat(ep, np.uint16), cat(ec, np.uint8),
+                        np.ascontiguousarray(pb.frag_bytes, np.uint8), np.ascontiguousarray(pb.frag_off, np.uint64),
+                        np.ascontiguousarray(pb.hits, HIT_DTYPE))
 
 
 @dataclass
@@ -487,6 +558,8 @@ class Engine:
     def submit(self, b) -> None:
         if isinstance(b, PackedBatch):
             return self.submit_packed(b)
+        if isinstance(b, Packed2Batch):
+            return self.submit_packed2(b)
         arrs = [np.ascontiguousarray(b.seq_bytes, np.uint8), np.ascontiguousarray(b.seq_off, np.uint64),
                 np.ascontiguousarray(b.frag_bytes, np.uint8), np.ascontiguousarray(b.frag_off, np.uint64),
                 np.ascontiguousarray(b.hits, HIT_DTYPE)]
@@ -503,6 +576,16 @@ class Engine:
         self._check(self.lib.bf_submit_packed(self.h, C.byref(cb)))
         if self.flags & BF_FLAG_READS_ON_HOST:
             self._kept_reads.append(arrs)
+
+    def submit_packed2(self, b: Packed2Batch) -> None:
+        arrs = [np.ascontiguousarray(b.seq_2bit, np.uint8), np.ascontiguousarray(b.seq_off, np.uint64),
+                np.ascontiguousarray(b.seq_len, np.uint16), np.ascontiguousarray(b.exc_read, np.uint32),
+                np.ascontiguousarray(b.exc_pos, np.uint16), np.ascontiguousarray(b.exc_code, np.uint8),
+                np.ascontiguousarray(b.frag_bytes, np.uint8), np.ascontiguousarray(b.frag_off, np.uint64),
+                np.ascontiguousarray(b.hits, HIT_DTYPE)]
+        p = [a.ctypes.data for a in arrs]
+        cb = BfPacked2Batch(b.n, p[0], p[1], p[2], int(arrs[3].shape[0]), p[3], p[4], p[5], p[6], p[7], p[8])
+        self._check(self.lib.bf_submit_packed2(self.h, C.byref(cb)))
 
     def host_alloc(self, nbytes: int, dtype=np.uint8) -> np.ndarray:
         """A numpy array over bf_host_alloc memory (pinned; owned by the ctx, valid until close())."""
@@ -523,6 +606,9 @@ class Engine:
         if isinstance(b, PackedBatch):
             return PackedBatch(pin(b.seq_nibbles, np.uint8), pin(b.seq_off, np.uint64), pin(b.seq_len, np.uint16),
                                pin(b.frag_bytes, np.uint8), pin(b.frag_off, np.uint64), pin(b.hits, HIT_DTYPE))
+        if isinstance(b, Packed2Batch):                    # (the exception arrays are copied by the call: they stay where they are)
+            return Packed2Batch(pin(b.seq_2bit, np.uint8), pin(b.seq_off, np.uint64), pin(b.seq_len, np.uint16), b.exc_read, b.exc_pos,
+                                b.exc_code, pin(b.frag_bytes, np.uint8), pin(b.frag_off, np.uint64), pin(b.hits, HIT_DTYPE))
         return Batch(pin(b.seq_bytes, np.uint8), pin(b.seq_off, np.uint64), pin(b.frag_bytes, np.uint8),
                      pin(b.frag_off, np.uint64), pin(b.hits, HIT_DTYPE))
 

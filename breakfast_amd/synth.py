@@ -54,6 +54,9 @@ def fast_lib():
                 lib.bf_synth_fill.argtypes = [C.c_void_p] * 10 + [C.c_int64, C.c_int64, C.c_void_p]
                 lib.bf_synth_pack_fixed.restype = C.c_int64
                 lib.bf_synth_pack_fixed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+                if hasattr(lib, "bf_synth_pack2_fixed"):
+                    lib.bf_synth_pack2_fixed.restype = C.c_int64
+                    lib.bf_synth_pack2_fixed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
                 _fast = lib
             except OSError:
                 _fast = False

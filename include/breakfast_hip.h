@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 12
+#define BF_ABI_VERSION 13
 
 enum {
     BF_OK = 0,
@@ -225,6 +225,31 @@ typedef struct {
     const bf_hit*   hits;
 } bf_packed_batch;
 int bf_submit_packed(bf_ctx* ctx, const bf_packed_batch* batch);
+
+/* The same reads at TWO bits a base on PCIe (round 3; what crosses the link is the longest part of a host-to-host step,
+ * and a read is > 99 % plain ACGT): A = 0, C = 1, G = 2, T = 3, four bases a byte, base k of a read in bits 2(k & 3) and
+ * 2(k & 3) + 1 of its byte k >> 2; every read starts on a byte and takes ceil(len / 4) bytes (seq_off: BYTE offsets).
+ * The bases that are none of the four travel beside the stream as exceptions {read, position, BAM 4-bit code}, ascending
+ * by (read, position); the stream holds any code there.  The ctx keeps its reads as 4-bit codes, as after
+ * bf_submit_packed (the two calls may be mixed): every uploaded piece is expanded on the device behind its upload, the
+ * exceptions patched in, before the per-read kernels see it -- results are those of bf_submit_packed on the same reads.
+ * Same hand-over rules as bf_submit (asynchronous; arrays in bf_host_alloc memory are uploaded from where they lie; the
+ * three exception arrays are copied before the call returns).  Not with BF_FLAG_READS_ON_HOST (records that name a read
+ * are expanded from 4-bit or ASCII arrays).  No counterpart in the reference (detect.rs:91 holds reads as ASCII). */
+typedef struct {
+    uint64_t        n_reads;
+    const uint8_t*  seq_2bit;
+    const uint64_t* seq_off;      /* n_reads+1 byte offsets into seq_2bit */
+    const uint16_t* seq_len;      /* n_reads: bases per read */
+    uint64_t        n_exceptions;
+    const uint32_t* exc_read;     /* n_exceptions: read index inside this batch, ascending */
+    const uint16_t* exc_pos;      /* ... base position inside the read, ascending within a read */
+    const uint8_t*  exc_code;     /* ... BAM 4-bit code of that base: any of 0..15 except 1, 2, 4, 8 (A, C, G, T) */
+    const uint8_t*  frag_bytes;
+    const uint64_t* frag_off;
+    const bf_hit*   hits;
+} bf_packed2_batch;
+int bf_submit_packed2(bf_ctx* ctx, const bf_packed2_batch* batch);
 
 /* Pinned host memory for batches (bf_submit uploads from it without staging).  Owned by the ctx: freed by
  * bf_host_free or bf_ctx_destroy.  These two calls may come from any thread, also while another thread is inside

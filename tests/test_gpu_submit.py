@@ -234,6 +234,100 @@ def test_a_rejected_4bit_batch_leaves_the_ctx_as_it_was():
         eng.close()
 
 
+@pytest.mark.parametrize("piece", [0, 1000, 4097])
+@pytest.mark.parametrize("sizes", [(10 ** 9,), (1, 7, 5000, 300, 12000)])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_reads_at_two_bits_a_base_give_the_oracle_bytes(piece, sizes, pinned):
+    """bf_submit_packed2: two bits a base on PCIe, the bases that are none of ACGT as exceptions, expanded to the resident
+    4-bit form behind every uploaded piece.  Odd read lengths (123: a last 2-bit byte with three bases, a padding nibble),
+    N in one read in five hundred bases, every cut into batches and pieces, pinned or pageable; batches alternate between
+    the 4-bit and the 2-bit call (one ctx, one resident form): the .sv is the oracle's, and the resident bytes are the ones
+    bf_submit_packed would have left (same evidence, same junction strings, through both localise kernels)."""
+    g, b = case(L=123, upper=True, n_frac=0.002)
+    ref = oracle_sv(g, b)
+    eng = engine.Engine(20, 5000, 2, piece_reads=piece, host_threads=4)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        held, n_exc = [], 0
+        for k, (a, e) in enumerate(cuts_for(b.n, sizes)):
+            part = engine.pack_batch(b.slice(a, e))
+            if k % 3 != 2:
+                part = engine.pack2_batch(part)
+                n_exc += int(part.exc_read.size)
+            if pinned:
+                part = eng.pin_batch(part)
+                held.append(part)
+            eng.submit(part)
+        assert n_exc > 100
+        res = eng.finish()
+        assert res.n_evidence == b.n
+        assert eng.format_sv(res) == ref
+        assert eng.format_sv(eng.finish()) == ref
+    finally:
+        eng.close()
+
+
+def test_two_bit_reads_leave_the_evidence_of_four_bit_reads():
+    g, b = case(L=150, upper=True, n_frac=0.003)
+    pb = engine.pack_batch(b)
+    outs = []
+    for form, flags in ((pb, 0), (engine.pack2_batch(pb), 0), (engine.pack2_batch(pb), BF_FLAG_FORCE_EXACT)):
+        eng = engine.Engine(20, 5000, 2, piece_reads=3001, host_threads=3, flags=flags | BF_FLAG_KEEP_EVIDENCE)
+        try:
+            eng.set_genome(g.names, g.seqs)
+            eng.submit(form)
+            res = eng.finish()
+            ev = eng.evidence()
+            by, off = eng.render_junctions(np.arange(b.n, dtype=np.uint32))
+            outs.append((eng.format_sv(res), {k: ev[k].copy() for k in ("bp", "lpos", "rpos", "class_key", "mask")}, by.tobytes(), off.copy()))
+        finally:
+            eng.close()
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and o[2] == outs[0][2] and np.array_equal(o[3], outs[0][3])
+        for k in ("bp", "lpos", "rpos", "mask"):
+            assert np.array_equal(o[1][k], outs[0][1][k]), k
+    assert np.array_equal(outs[1][1]["class_key"], outs[0][1]["class_key"])
+
+
+def test_a_rejected_2bit_batch_leaves_the_ctx_as_it_was():
+    import dataclasses
+    g, b = case(upper=True, n_frac=0.002)
+    good, bad = engine.pack2_batch(engine.pack_batch(b.slice(0, 10000))), engine.pack2_batch(engine.pack_batch(b.slice(10000, 20000)))
+    assert bad.exc_read.size > 10
+    eng = engine.Engine(20, 5000, 2, piece_reads=1500, host_threads=3)
+    try:
+        eng.set_genome(g.names, g.seqs)
+        eng.submit(good)
+        ln = bad.seq_len.copy(); ln[4000] += 4                             # a length that does not match its bytes
+        with pytest.raises(engine.BreakfastError) as e:
+            eng.submit(dataclasses.replace(bad, seq_len=ln))
+        assert e.value.code == -1 and "read 4000 " in str(e.value)
+        for field, j, value, what in (("exc_code", 3, 4, "code 4"), ("exc_code", 3, 16, "code 16"), ("exc_pos", 5, 60000, "names base"),
+                                      ("exc_read", 2, 10000, "names base"), ("exc_read", 7, 0, "not ascending")):
+            arr = getattr(bad, field).copy(); arr[j] = value
+            with pytest.raises(engine.BreakfastError) as e:
+                eng.submit(dataclasses.replace(bad, **{field: arr}))
+            assert e.value.code == -1 and what in str(e.value), str(e.value)
+        assert eng.stats()[0] == good.n
+        assert eng.format_sv(eng.finish()) == oracle_sv(g, b.slice(0, 10000))
+        eng.submit(bad)
+        eng.submit(engine.pack_batch(b.slice(20000, b.n)))                 # a 4-bit batch behind two 2-bit ones
+        assert eng.format_sv(eng.finish()) == oracle_sv(g, b)
+        eng.reset()
+        eng.submit(bad)                                                    # after a reset the 2-bit scratch starts over
+        assert eng.format_sv(eng.finish()) == oracle_sv(g, b.slice(10000, 20000))
+    finally:
+        eng.close()
+    roh = engine.Engine(20, 5000, 2, flags=engine.BF_FLAG_READS_ON_HOST)
+    try:
+        roh.set_genome(g.names, g.seqs)
+        with pytest.raises(engine.BreakfastError) as e:
+            roh.submit(good)
+        assert e.value.code == -4 and "READS_ON_HOST" in str(e.value)
+    finally:
+        roh.close()
+
+
 def test_pageable_batches_may_be_freed_on_return_and_pinned_ones_after_the_wait():
     g, b = case()
     ref = oracle_sv(g, b)
