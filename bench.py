@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=1, help="index into BASELINE.json configs (default 1)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink reads AND genome (smoke runs only)")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=6_000_000, help="reads in the CPU baseline sample (0 = skip; the default is about 11 s of one core)")
     ap.add_argument("--variant", choices=["fused", "exact"], default="fused",
                     help="the localise stage: the packed kernel (shipped), or every read through the byte-exact kernel (diagnostic)")
     ap.add_argument("--exchange", action="store_true",

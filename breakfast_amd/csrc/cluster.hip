@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(256) fill_members_kernel(const SweepView v, co
 }
 
 struct FragView {
-    const uint32_t* perm; const uint8_t* frag; const uint64_t* frag_off; const uint16_t* frag_len;
+    const uint8_t* frag; const uint64_t* frag_off; const uint16_t* frag_len;
 };
 __device__ __forceinline__ bool same_frag(const FragView& f, uint32_t ra, uint32_t rb) {
     return same_id_bytes(f.frag, f.frag_off, f.frag_len, ra, rb);
@@ -1109,7 +1109,7 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
     mv.qsize = ctx->c_qsize.as<uint32_t>(); mv.rep = ctx->c_rep.as<uint32_t>(); mv.qnrep = ctx->c_qnrep.as<uint32_t>();
     mv.frag = v.frag; mv.frag_off = v.frag_off; mv.frag_len = v.frag_len;
     mv.hash_mask = (ctx->cfg.flags & BF_FLAG_WEAK_DEDUP_HASH) ? 0x7ull : ~0ull;
-    FragView fv{perm, v.frag, v.frag_off, v.frag_len};
+    FragView fv{v.frag, v.frag_off, v.frag_len};
     {
         Scope t(ctx, "dedup");
         if (total_big) {                                 // the sorted-run kernels find their slots untouched

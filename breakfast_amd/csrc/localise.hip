@@ -1286,8 +1286,11 @@ int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf&
     // the chunk boundaries in ONE small copy (nine separate 8-byte copies cost 30 us each)
     uint64_t* d_pick = (uint64_t*)(ctx->c_misc.as<uint8_t>() + ((n * 4 + 15) & ~(size_t)15));
     hipLaunchKernelGGL(pick_offsets_kernel, dim3(1), dim3(64), 0, ctx->stream, d_off.as<uint64_t>(), n, n_chunks, d_pick);
-    BF_HIP(ctx, hipMemcpyAsync(chunk_off, d_pick, (size_t)(n_chunks + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    // ... into the ctx's pinned mailbox (a copy into the caller's pageable array is staged by the runtime: a round trip more)
+    if (n_chunks + 1 > kMailWords - 8) return fail(ctx, BF_ERR_RANGE, "render_prepare: %d chunks", n_chunks);
+    BF_TRY(mail_fetch(ctx, 8, d_pick, n_chunks + 1));
     BF_SYNC(ctx, ctx->stream);
+    for (int c = 0; c <= n_chunks; c++) chunk_off[c] = ctx->h_mail[8 + c];
     return BF_OK;
 }
 

@@ -239,7 +239,7 @@ struct HostTransport : Transport {
 struct Shard {
     Transport* tr = nullptr;
     std::vector<uint64_t> bases;                // index_base of every rank
-    DevBuf d_send, d_recv, d_req_out, d_req_in, d_place, d_src, d_small, d_pick, d_roff, d_roff_g, d_rbytes;
+    DevBuf d_send, d_recv, d_req_out, d_req_in, d_place, d_src, d_pick, d_roff, d_roff_g, d_rbytes;
     HostBuf h_places, h_src, h_roff, h_rbytes;
     std::vector<uint64_t> block_off, group_read_begin;      // what the last bf_shard_finish's result points at
     uint64_t last_nr = 0, last_n_in = 0;                    // sizes of the tables left on the device
@@ -326,7 +326,7 @@ int shard_attach(bf_ctx* ctx, Transport* tr, uint32_t rank, uint32_t n_ranks, ui
 void shard_destroy(bf_ctx* ctx) {
     Shard* sh = shard_of(ctx);
     if (!sh) return;
-    DevBuf* bufs[] = {&sh->d_send, &sh->d_recv, &sh->d_req_out, &sh->d_req_in, &sh->d_place, &sh->d_src, &sh->d_small, &sh->d_pick, &sh->d_roff, &sh->d_roff_g, &sh->d_rbytes};
+    DevBuf* bufs[] = {&sh->d_send, &sh->d_recv, &sh->d_req_out, &sh->d_req_in, &sh->d_place, &sh->d_src, &sh->d_pick, &sh->d_roff, &sh->d_roff_g, &sh->d_rbytes};
     for (DevBuf* b : bufs) release(ctx, *b);
     HostBuf* hosts[] = {&sh->h_places, &sh->h_src, &sh->h_roff, &sh->h_rbytes};
     for (HostBuf* h : hosts) { if (h->p) (void)hipHostFree(h->p); h->p = nullptr; h->cap = 0; }
