@@ -1081,16 +1081,26 @@ static int clusterise_in_groups(bf_ctx* ctx, const OwnerView& v, bool* done) {
     // (bf_config.reserved[0] overrides; measured on configs[1], round 3: 2 groups 5.69 ms, 3: 5.42, 4: 5.55)
     const uint32_t fit = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(v.n / 3300000, 2), kMaxGroups);
     const uint32_t want = ctx->cfg.reserved[0] ? std::min<uint32_t>(ctx->cfg.reserved[0], 64u) : fit;
-    BF_TRY(cluster_groups(ctx, v, want, gb, &bound));
-    if (gb.size() <= 2) return BF_OK;                              // one contig holds it all: nothing to pipeline
-    // every output buffer at its final size before the first copy is queued: nothing may move under a copy
-    BF_TRY(ensure(ctx, ctx->c_jbytes, bound ? bound : 1, false));
-    BF_TRY(ensure_host(ctx, ctx->out.junction, bound));
+    BF_TRY(cluster_groups(ctx, v, want, gb, true));
+    if (gb.size() <= 2) {                                          // one contig holds it all: nothing to pipeline
+        BF_SYNC(ctx, ctx->stream);                                 // (the cut's kernels and its read-back are through)
+        return BF_OK;
+    }
     uint64_t cl_base = 0, rd_base = 0, byte_base = 0;
+    bool sized = false;
     for (size_t g = 0; g + 1 < gb.size(); g++) {
         ClusterGroup grp{ctx->c_gidx.as<uint32_t>() + gb[g], gb[g + 1] - gb[g], cl_base, rd_base, v.n};
         grp.g = (int)g;
         BF_TRY(run_cluster(ctx, v, &grp));
+        if (!sized) {
+            // every output buffer at its final size before the first copy is queued: nothing may move under a copy.  The
+            // bound (all records' bytes) came along with the first group's waits (cluster_groups itself waits for nothing)
+            if (grp.m == 0) BF_SYNC(ctx, ctx->stream);             // (a group without evidence returns before its first wait)
+            bound = ctx->h_mail[kMailRecordBytes];
+            BF_TRY(ensure(ctx, ctx->c_jbytes, bound ? bound : 1, false));
+            BF_TRY(ensure_host(ctx, ctx->out.junction, bound));
+            sized = true;
+        }
         if (!grp.nr) continue;
         const uint64_t stride = ctx->rsrc_stride;
         const uint32_t* d_idx = ctx->c_rsrc.as<uint32_t>() + stride + rd_base;       // out_src_idx of this group

@@ -396,6 +396,7 @@ struct TraceCall {
 #define BF_TRACE_CALL(ctx) bf::TraceCall trace_call_(ctx, __func__)
 
 constexpr int kMailWords = 32;
+constexpr int kMailRecordBytes = 6;    // cluster_groups leaves the sum of all records' junction record bytes here
 // queues the copy of n 64-bit device words into mailbox slots [slot, slot + n); valid after the next wait for ctx->stream
 inline int mail_fetch(bf_ctx* ctx, int slot, const void* d_src, int n = 1) {
     BF_HIP(ctx, hipMemcpyAsync(ctx->h_mail + slot, d_src, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -455,8 +456,11 @@ struct ClusterGroup {
     uint64_t ns = 0, nr = 0;           // out: clusters and supporting reads this group added
     int g = -1;                        // the group's number in the cut cluster_groups made (ctx->group_ranks[g]: its contig ranks)
 };
-int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::vector<uint64_t>& bounds, uint64_t* record_bytes,
-                   const std::vector<uint64_t>* view_hist = nullptr);   // view_hist: records per left contig rank of an imported view
+// Queues the cut; waits for nothing.  want_record_bytes: the sum of all records' junction record bytes is on its way to
+// ctx->h_mail[kMailRecordBytes] (valid after the caller's next wait for ctx->stream).  view_hist: records per left contig rank
+// of an imported view.
+int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::vector<uint64_t>& bounds, bool want_record_bytes,
+                   const std::vector<uint64_t>* view_hist = nullptr);
 int rank_histogram(bf_ctx* ctx, const OwnerView& v, std::vector<uint64_t>& hist);
 int run_cluster(bf_ctx* ctx, const OwnerView& v, ClusterGroup* g = nullptr);   // fills ctx->out (without junction text)
 int run_partition(bf_ctx* ctx, const bf_wire_local& agreed, void* dev_send, uint64_t dev_send_bytes, uint64_t* counts,

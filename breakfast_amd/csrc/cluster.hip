@@ -713,10 +713,17 @@ __global__ void __launch_bounds__(256) record_bytes_kernel(const RecWord* __rest
     __syncthreads();
     if (threadIdx.x == 0 && w[0] + w[1] + w[2] + w[3]) atomicAdd(sum, w[0] + w[1] + w[2] + w[3]);
 }
+// (a group is a run of contig ranks: its number is how many groups start at or below the record's rank.  The first ranks
+//  come by value -- a table the host has just made needs no copy and no wait this way)
+struct GroupCuts { uint32_t n; uint32_t first_rank[255]; };
 __global__ void group_id_kernel(uint32_t* __restrict__ gid, uint32_t* __restrict__ iota, const uint64_t* __restrict__ key,
-                                const uint8_t* __restrict__ group_of_rank, int shift, uint32_t mask, uint64_t n) {
+                                const GroupCuts cuts, int shift, uint32_t mask, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { gid[i] = group_of_rank[(uint32_t)(key[i] >> shift) & mask]; iota[i] = (uint32_t)i; }
+    if (i >= n) return;
+    const uint32_t r = (uint32_t)(key[i] >> shift) & mask;
+    uint32_t g = 0;
+    for (uint32_t k = 1; k < cuts.n; k++) g += cuts.first_rank[k] <= r ? 1u : 0u;
+    gid[i] = g; iota[i] = (uint32_t)i;
 }
 // -> bounds: positions in c_gidx (record ids ordered by contig rank, input order inside) where the groups start;
 // one group (bounds = {0, n}) when there is nothing to gain.  The reads per left contig rank are known on the host
@@ -762,12 +769,11 @@ int rank_histogram(bf_ctx* ctx, const OwnerView& v, std::vector<uint64_t>& hist)
     return BF_OK;
 }
 
-int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::vector<uint64_t>& bounds, uint64_t* record_bytes,
+int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::vector<uint64_t>& bounds, bool want_record_bytes,
                    const std::vector<uint64_t>* view_hist) {
     const uint64_t n = v.n;
     const hipStream_t st = ctx->stream;
     bounds.assign(1, 0); bounds.push_back(n);
-    if (record_bytes) *record_bytes = 0;
     const std::vector<uint64_t>& rank_hist = view_hist ? *view_hist : ctx->rank_hist;
     if (max_groups < 2 || n == 0 || (v.src && !view_hist) || rank_hist.size() != ctx->n_contigs) return BF_OK;
     uint64_t counted = 0;
@@ -776,10 +782,8 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
     // cut after the rank where the running count passes the next multiple of n / max_groups
     bounds.assign(1, 0);
     uint64_t run = 0;
-    std::vector<uint8_t> group_of(ctx->n_contigs, 0);
     ctx->group_ranks.clear();
     for (uint32_t r = 0; r < ctx->n_contigs; r++) {
-        group_of[r] = (uint8_t)(bounds.size() - 1);
         if (ctx->group_ranks.size() < bounds.size()) ctx->group_ranks.emplace_back(r, r);
         ctx->group_ranks.back().second = r;
         run += rank_hist[r];
@@ -788,11 +792,11 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
     bounds.push_back(n);
     BF_TRY(ensure(ctx, ctx->c_gidx, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_hist, 64 + ctx->n_contigs, false));
     BF_TRY(ensure(ctx, ctx->c_c32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_k64a, n * 8, false));
-    if (record_bytes) {                                   // (the sharded path's records stay with their sources: no bound to compute)
+    if (want_record_bytes) {                              // (the sharded path's records stay with their sources: no bound to compute)
         BF_HIP(ctx, hipMemsetAsync(ctx->c_hist.p, 0, 8, st));
         hipLaunchKernelGGL(record_bytes_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(n, 256), 1024)), dim3(256), 0, st, v.rw, n,
                            (unsigned long long*)ctx->c_hist.p);
-        BF_TRY(mail_fetch(ctx, 0, ctx->c_hist.p));        // read after the wait at the end: no round trip of its own
+        BF_TRY(mail_fetch(ctx, kMailRecordBytes, ctx->c_hist.p));      // the caller reads it after its next wait (no round trip here)
     }
     if (bounds.size() > 2) {
         const unsigned shift = (unsigned)key_rank_shift(ctx->contig_bits);
@@ -800,19 +804,19 @@ int cluster_groups(bf_ctx* ctx, const OwnerView& v, uint32_t max_groups, std::ve
             // record ids ordered by GROUP, input order inside: a group's ids ascend, so what reads the records through them
             // walks memory once (ordered by rank, a group was a dozen interleaved walks: 835 MB fetched for 60 MB used)
             BF_TRY(ensure(ctx, ctx->c_a32, n * 4, false)); BF_TRY(ensure(ctx, ctx->c_b32, n * 4, false));
-            uint8_t* d_tab = ctx->c_hist.as<uint8_t>() + 64;
-            BF_HIP(ctx, hipMemcpyAsync(d_tab, group_of.data(), ctx->n_contigs, hipMemcpyHostToDevice, st));
+            GroupCuts cuts{};
+            cuts.n = (uint32_t)ctx->group_ranks.size();
+            for (uint32_t g = 0; g < cuts.n; g++) cuts.first_rank[g] = ctx->group_ranks[g].first;
             hipLaunchKernelGGL(group_id_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, ctx->c_b32.as<uint32_t>(), ctx->c_c32.as<uint32_t>(), v.key,
-                               d_tab, (int)shift, (1u << ctx->contig_bits) - 1, n);
+                               cuts, (int)shift, (1u << ctx->contig_bits) - 1, n);
             unsigned gbits = 1;
             while ((1u << gbits) < bounds.size() - 1) gbits++;
             BF_TRY(sort_pairs<uint32_t>(ctx, ctx->c_b32.as<uint32_t>(), ctx->c_a32.as<uint32_t>(), ctx->c_c32.as<uint32_t>(),
                                         ctx->c_gidx.as<uint32_t>(), n, 0, gbits));
         }
     }
-    BF_SYNC(ctx, st);                                     // (group_of is read by the copy above until here)
-    if (record_bytes) *record_bytes = ctx->h_mail[0];
-    BF_TRY(settle_counts(ctx));                           // the localise counters came along with this synchronisation
+    // no wait here: the first group's cluster stage waits soon enough (the byte bound and the localise counters ride on it)
+    BF_HIP(ctx, hipGetLastError());
     return BF_OK;
 }
 // ---- sorted space without a full sort: class partition + chunk sort ----------------------------------

@@ -530,7 +530,7 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
     ctx->out.n_clusters = ctx->out.n_reads = 0; ctx->n_evidence = v.n;
 
     std::vector<uint64_t> gb{0, v.n};
-    if (G > 1 && v.n) BF_TRY(cluster_groups(ctx, v, G, gb, nullptr, &hist));
+    if (G > 1 && v.n) BF_TRY(cluster_groups(ctx, v, G, gb, false, &hist));
     const size_t my_groups = gb.size() - 1;
 
     std::vector<uint64_t> req_counts(W), rm((size_t)W * W), recv_before(W, 0);
