@@ -88,10 +88,16 @@ def pairs(path):
 
 
 def derive(name):
-    g = fasta(os.path.join(HERE, name + ".fa"))
     A, F, E = (int(x) for x in open(os.path.join(HERE, name + ".args")).read().split())
+    return derive_files(os.path.join(HERE, name + ".fa"), os.path.join(HERE, name + ".bowtie"), A, F, E)
+
+
+def derive_files(fa_path, bowtie_path, A, F, E):
+    """The tables of any (FASTA, Bowtie output, options) triple: the fixtures above, and the random cases of
+    tests/test_hand_tables.py::test_independent_derivation_on_random_cases."""
+    g = fasta(fa_path)
     rows = []
-    for frag, seq, (st, ch, pos), (mst, mch, mpos) in pairs(os.path.join(HERE, name + ".bowtie")):
+    for frag, seq, (st, ch, pos), (mst, mch, mpos) in pairs(bowtie_path):
         L = len(seq)
         swapped = ch > mch or (ch == mch and pos > mpos)                       # detect.rs:108
         if swapped:

@@ -87,6 +87,60 @@ def test_clusters_against_the_tables(name):
     assert ol.detect_text(ol.OracleGenome.from_fasta(fa), lines, A, F, E).sv == want
 
 
+def sv_from_table(t):
+    out = [SV_HEADER]
+    for c in t["clusters"]:
+        s = t["reads"][c["seed"]]
+        out.append(b"%s\t%s\t%d\t\t%s\t%s\t%d\t\t%s\t\t\n" % (
+            s["chr"].encode(), b"+" if s["strand"] else b"-", s["lpos"], s["mchr"].encode(), b"+" if s["mstrand"] else b"-", s["rpos"],
+            b";".join(t["reads"][k]["junction"].encode() for k in c["kept"])))
+    return b"".join(out)
+
+
+def random_case(seed, tmp_path):
+    """A small synthetic case with everything the path distinguishes: both strands, same-contig and cross-contig events,
+    mates that share a fragment id, piles on a hot junction, N runs and soft-masked stretches in the genome, N in reads,
+    contigs whose names sort unlike their order -> (fasta path, bowtie path, A, F, E)."""
+    from breakfast_amd import synth
+    rng = np.random.default_rng(seed)
+    contigs = [("chr2", 30000), ("chr10", 26000), ("chrX", 22000)]
+    g = synth.make_genome(contigs, seed=1000 + seed, end_n=int(rng.integers(0, 40)),
+                          n_runs=[(0, 9000, 400), (2, 5000, 120)], lower_runs=[(1, 8000, 5000)])
+    A = int(rng.choice([12, 20]))
+    L = int(rng.choice([2 * A + 8, 75, 100]))
+    spec = synth.ReadSpec(n_reads=int(rng.integers(60, 220)), read_len=L, anchor_len=A, n_events=int(rng.integers(3, 12)),
+                          singleton_frac=0.25, mate_frac=0.5, hot_frac=0.2, hot_events=1, subst_rate=0.02, n_rate=0.003,
+                          seed=2000 + seed, margin=int(rng.choice([0, 300])))
+    b = synth.make_reads(g, spec)
+    fa, bt = tmp_path / ("r%d.fa" % seed), tmp_path / ("r%d.bowtie" % seed)
+    fa.write_bytes(g.fasta())
+    bt.write_bytes(synth.bowtie_lines_slow(b, g.names))
+    return str(fa), str(bt), A, int(rng.choice([300, 5000])), int(rng.choice([1, 2, 3]))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_independent_derivation_on_random_cases(seed, tmp_path):
+    """The derivation of tests/golden/derive_tables.py (flanks as slices, closed-form mm[k], clusters as a fixed point,
+    dedup from ids and scores; no code shared with oracle/) against BOTH restatements on random cases, not only on the
+    twelve fixtures: per-read rows and the printed table."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("derive_tables", os.path.join(GOLDEN, "derive_tables.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fa, bt, A, F, E = random_case(seed, tmp_path)
+    t = mod.derive_files(fa, bt, A, F, E)
+    assert len(t["reads"]) >= 50
+    fa_bytes, lines = open(fa, "rb").read(), open(bt, "rb").read()
+    ev = po.consume_lines(po.parse_fasta(fa_bytes), lines.split(b"\n")[:-1], A)
+    assert len(ev) == len(t["reads"])
+    for e, r in zip(ev, t["reads"]):
+        assert (e.swapped, e.bp, e.pos, e.mpos, e.sequence, e.signature) == (
+            r["swapped"], r["bp"], r["lpos"], r["rpos"], r["junction"].encode(), r["signature"].encode())
+    want = sv_from_table(t)
+    assert po.detect(fa_bytes, lines.split(b"\n")[:-1], A, F, E) == want
+    assert ol.detect_text(ol.OracleGenome.from_fasta(fa_bytes), lines, A, F, E).sv == want
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(TABLES))
 def test_gpu_against_the_tables(name):
