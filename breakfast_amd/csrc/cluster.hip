@@ -859,20 +859,22 @@ __global__ void class_bucket_start_kernel(uint32_t* __restrict__ bstart, const u
     if (j == m - 1) for (uint32_t x = b + 1; x <= mask + 1; x++) bstart[x] = (uint32_t)m;
 }
 // cstart[c] = where chunk c begins (c <= n_chunks; cstart[n_chunks] = m); osize[c] = its size if it is too large for LDS
-__global__ void chunk_table_kernel(uint32_t* __restrict__ cstart, uint32_t* __restrict__ osize, const uint32_t* __restrict__ bstart,
-                                   uint32_t n_buckets, uint32_t n_chunks, uint32_t m) {
+// cfirst[c] = that first bucket's number (n_buckets when there is none): chunk c's buckets are [cfirst[c], cfirst[c + 1])
+__global__ void chunk_table_kernel(uint32_t* __restrict__ cstart, uint32_t* __restrict__ osize, uint32_t* __restrict__ cfirst,
+                                   const uint32_t* __restrict__ bstart, uint32_t n_buckets, uint32_t n_chunks, uint32_t m) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c > n_chunks) return;
-    auto first_at_or_after = [&](uint64_t pos) -> uint32_t {      // start of the first bucket that starts at or after pos
-        if (pos >= m) return m;
+    auto first_at_or_after = [&](uint64_t pos) -> uint32_t {      // the first bucket that starts at or after pos
+        if (pos >= m) return n_buckets;
         uint32_t lo = 0, hi = n_buckets;                           // bstart is non-decreasing, bstart[n_buckets] = m
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (bstart[mid] >= pos) hi = mid; else lo = mid + 1; }
-        return bstart[lo];
+        return lo;
     };
-    const uint32_t s = first_at_or_after((uint64_t)c * kChunkBase);
-    cstart[c] = s;
+    const uint32_t b = first_at_or_after((uint64_t)c * kChunkBase);
+    const uint32_t s = bstart[b];                                  // (bstart[n_buckets] = m)
+    cstart[c] = s; cfirst[c] = b;
     if (c < n_chunks) {
-        const uint32_t e = first_at_or_after((uint64_t)(c + 1) * kChunkBase);
+        const uint32_t e = bstart[first_at_or_after((uint64_t)(c + 1) * kChunkBase)];
         osize[c] = e - s > kChunkCap ? e - s : 0u;
     }
 }
@@ -883,9 +885,76 @@ __device__ __forceinline__ void put_sorted(const SortedOut& o, uint64_t at, uint
     o.srpos[at] = (int32_t)x.b;
     o.perm[at] = x.a;
 }
+// A bucket of up to 64 R records sorted by ONE WAVE in registers: element e = 64 r + lane, a bitonic network on (comp,
+// position in the bucket) whose steps with a stride below 64 exchange lanes (three 32-bit lane permutes: no LDS memory,
+// no bank conflicts, no workgroup barrier) and whose longer strides are compare-exchanges between a lane's own registers.
+// A bucket holds whole signatures and the order of the signatures among themselves is never used, so sorting bucket by
+// bucket IS the chunk's sort, and a bucket's records stay in its own range.  The payload is fetched through the sorted
+// position (a bucket is a few KB: cache hits).
+constexpr uint32_t kWaveBucketMax = 256;
+// (NB buckets at a time, their networks independent of each other: a second bucket's chain of lane permutes fills the gaps
+//  of the first.)  The sort key is ONE 64-bit word: inside a bucket the low `bits` signature bits are the bucket's number,
+//  the same for every record, so their place holds the record's position in the bucket instead (below 256 <= 2^bits):
+//  key = signature's other bits | lpos | position -- unique, so a compare-exchange is one 64-bit compare and two selects,
+//  and a lane exchange two permutes (the kernel is bound by these instructions: 41k waves x 21-33 steps a launch).
+template <int R, int NB>
+__device__ __forceinline__ void wave_sort_buckets(const uint64_t* __restrict__ comp, const RsV3* __restrict__ val, const SortedOut& out,
+                                                  const uint32_t (&s_)[NB], const uint32_t (&size_)[NB], const uint64_t (&out_base_)[NB],
+                                                  const uint32_t (&bucket_)[NB], int bits, int lane) {
+    uint64_t key[NB * R];
+    const uint32_t low = (1u << bits) - 1u;
+#pragma unroll
+    for (int q = 0; q < NB * R; q++) {
+        const uint32_t e = 64u * (q % R) + lane;
+        if (e < size_[q / R]) {
+            const uint64_t c = comp[s_[q / R] + e];
+            key[q] = ((c >> (32 + bits)) << (32 + bits)) | ((uint64_t)(uint32_t)c << bits) | e;
+        } else key[q] = ~0ull;                                       // padding: above every record (a position is never all ones)
+    }
+#pragma unroll
+    for (uint32_t k = 2; k <= 64u * R; k <<= 1) {
+#pragma unroll
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {                                           // partner = another register of this lane
+                const int jj = (int)(j >> 6);
+#pragma unroll
+                for (int q = 0; q < NB * R; q++) {
+                    const int r = q % R;
+                    if (r & jj) continue;
+                    const int p = q | jj;                            // (R is a power of two: q | jj stays inside q's bucket)
+                    const bool asc = ((64u * r + lane) & k) == 0;
+                    const uint64_t a = key[q], b = key[p];
+                    const bool sw = (a > b) == asc;
+                    key[q] = sw ? b : a; key[p] = sw ? a : b;
+                }
+            } else {                                                 // partner = lane ^ j, same register
+                const bool lower = (lane & j) == 0;
+#pragma unroll
+                for (int q = 0; q < NB * R; q++) {
+                    const bool want_min = lower == (((64u * (q % R) + lane) & k) == 0);   // the lower lane of an ascending pair keeps the smaller
+                    const uint32_t plo = (uint32_t)__shfl_xor((int)(uint32_t)key[q], (int)j), phi = (uint32_t)__shfl_xor((int)(uint32_t)(key[q] >> 32), (int)j);
+                    const uint64_t pk = ((uint64_t)phi << 32) | plo;
+                    key[q] = ((key[q] > pk) == want_min) ? pk : key[q];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NB * R; q++) {
+        const uint32_t e = 64u * (q % R) + lane;
+        if (e < size_[q / R]) {
+            const uint64_t k_ = key[q];
+            const uint32_t li = (uint32_t)k_ & low, lpos = (uint32_t)(k_ >> bits);
+            const uint32_t sig = ((uint32_t)(k_ >> (32 + bits)) << bits) | (bucket_[q / R] & low);
+            put_sorted(out, out_base_[q / R] + e, ((uint64_t)sig << 32) | lpos, val[s_[q / R] + li]);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) chunk_sort_kernel(const uint32_t* __restrict__ cstart, const uint64_t* __restrict__ obefore,
                                                          const uint64_t* __restrict__ comp, const RsV3* __restrict__ val, SortedOut out,
-                                                         uint64_t* __restrict__ side_comp, RsV3* __restrict__ side_val) {
+                                                         uint64_t* __restrict__ side_comp, RsV3* __restrict__ side_val,
+                                                         const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ cfirst, int bits) {
     __shared__ uint64_t s_comp[kChunkCap];
     __shared__ uint32_t s_li[kChunkCap];
     __shared__ RsV3 s_v[kChunkCap];
@@ -903,6 +972,50 @@ __global__ void __launch_bounds__(256) chunk_sort_kernel(const uint32_t* __restr
             put_sorted(out, tail + ob + r, cc, vv);
         }
         return;
+    }
+    {
+        // The chunk's buckets are [b0, b1) (chunk_table_kernel).  When none of them is longer than kWaveBucketMax the waves
+        // take the non-empty ones in turn and sort them in registers; a chunk with a longer bucket (a signature with hundreds
+        // of records) goes through the LDS network below as a whole.  Every wave reads the bucket starts itself, 64 to a
+        // load (no walk from one start to the next: each step of such a walk is a round trip, and a dozen of them were
+        // longer than the sort).
+        const uint32_t b0 = cfirst[c], b1 = cfirst[c + 1];
+        const int lane = (int)(t & 63u), wv = (int)(t >> 6);
+        uint32_t longest = 0;
+        for (uint32_t base = b0; base < b1; base += 64) {
+            const uint32_t b = base + lane;
+            const uint32_t bn = b < b1 ? bstart[b + 1] - bstart[b] : 0u;
+            longest = max(longest, bn);
+        }
+        for (int o = 32; o > 0; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
+        if (longest <= kWaveBucketMax && bits >= 8) {                // block-uniform: every wave saw the same starts
+            uint32_t ps[2] = {0, 0}, pn[2] = {0, 0}, pb[2] = {0, 0}; // buckets of up to 64 records wait for a partner
+            uint64_t po[2] = {0, 0};
+            int held = 0;
+            uint32_t seen = 0;                                       // non-empty buckets before this round
+            for (uint32_t base = b0; base < b1; base += 64) {
+                const uint32_t b = base + lane;
+                const uint32_t my_s = b < b1 ? bstart[b] : 0u, my_n = b < b1 ? bstart[b + 1] - my_s : 0u;
+                uint64_t todo = __ballot(my_n != 0);
+                for (; todo; todo &= todo - 1, seen++) {
+                    if ((seen & 3u) != (uint32_t)wv) continue;
+                    const int src = __builtin_ctzll(todo);
+                    const uint32_t bs = (uint32_t)__builtin_amdgcn_readlane((int)my_s, src), bn = (uint32_t)__builtin_amdgcn_readlane((int)my_n, src);
+                    const uint64_t ob_ = (uint64_t)bs - ob;
+                    if (bn <= 64) {
+                        ps[held] = bs; pn[held] = bn; po[held] = ob_; pb[held] = base + (uint32_t)src;
+                        if (++held == 2) { wave_sort_buckets<1, 2>(comp, val, out, ps, pn, po, pb, bits, lane); held = 0; }
+                        continue;
+                    }
+                    const uint32_t s1[1] = {bs}, n1[1] = {bn}, b1_[1] = {base + (uint32_t)src};
+                    const uint64_t o1[1] = {ob_};
+                    if (bn <= 128) wave_sort_buckets<2, 1>(comp, val, out, s1, n1, o1, b1_, bits, lane);
+                    else wave_sort_buckets<4, 1>(comp, val, out, s1, n1, o1, b1_, bits, lane);
+                }
+            }
+            if (held) { pn[1] = 0; wave_sort_buckets<1, 2>(comp, val, out, ps, pn, po, pb, bits, lane); }     // (an empty partner: all padding)
+            return;
+        }
     }
     uint32_t P = 64;
     while (P < size) P <<= 1;
@@ -951,11 +1064,12 @@ static int class_order(bf_ctx* ctx, const OwnerView& v, const uint32_t* idx, uin
     // (read on every call on purpose: the tests change it between engines of one process)
     const uint32_t n_buckets = 1u << bits;
     const uint32_t n_chunks = (uint32_t)((m + kChunkBase - 1) / kChunkBase);
-    // chunk table: cstart u32[n_chunks + 1] | osize u32[n_chunks] | obefore u64[n_chunks + 1]
+    // chunk table: cstart u32[n_chunks + 1] | osize u32[n_chunks] | obefore u64[n_chunks + 1] | cfirst u32[n_chunks + 1]
     const size_t off_osize = ((size_t)(n_chunks + 1) * 4 + 255) & ~(size_t)255;
     const size_t off_obefore = (off_osize + (size_t)n_chunks * 4 + 255) & ~(size_t)255;
+    const size_t off_cfirst = (off_obefore + (size_t)(n_chunks + 1) * 8 + 255) & ~(size_t)255;
     const size_t comp_bytes = (m * 8 + 255) & ~(size_t)255;
-    BF_TRY(ensure(ctx, ctx->c_chunk, off_obefore + (size_t)(n_chunks + 1) * 8, false));
+    BF_TRY(ensure(ctx, ctx->c_chunk, off_cfirst + (size_t)(n_chunks + 1) * 4, false));
     BF_TRY(ensure(ctx, ctx->c_bstart, (size_t)(n_buckets + 1) * 4, false));
     BF_TRY(ensure(ctx, ctx->c_comp, comp_bytes + m * sizeof(RsV3), false));       // partitioned: comp, then the payload
     BF_TRY(ensure(ctx, ctx->c_pos2, m * sizeof(RsV3), false));
@@ -964,13 +1078,15 @@ static int class_order(bf_ctx* ctx, const OwnerView& v, const uint32_t* idx, uin
     uint32_t* cstart = ctx->c_chunk.as<uint32_t>();
     uint32_t* osize = (uint32_t*)(ctx->c_chunk.as<uint8_t>() + off_osize);
     uint64_t* obefore = (uint64_t*)(ctx->c_chunk.as<uint8_t>() + off_obefore);
+    uint32_t* cfirst = (uint32_t*)(ctx->c_chunk.as<uint8_t>() + off_cfirst);
     hipLaunchKernelGGL(comp_build_kernel, dim3(grid_for(m, B)), dim3(B), 0, st, comp_in, val_in, idx, v.key, v.lpos, v.rpos, m);
     BF_TRY(radix_sort_kv3(ctx, comp_in, comp_s, val_in, val_s, m, 32, 32 + (unsigned)bits));
     hipLaunchKernelGGL(class_bucket_start_kernel, dim3(grid_for(m, B)), dim3(B), 0, st, ctx->c_bstart.as<uint32_t>(), comp_s, m, bits);
-    hipLaunchKernelGGL(chunk_table_kernel, dim3(grid_for(n_chunks + 1, B)), dim3(B), 0, st, cstart, osize, ctx->c_bstart.as<uint32_t>(),
+    hipLaunchKernelGGL(chunk_table_kernel, dim3(grid_for(n_chunks + 1, B)), dim3(B), 0, st, cstart, osize, cfirst, ctx->c_bstart.as<uint32_t>(),
                        n_buckets, n_chunks, (uint32_t)m);
     BF_TRY(scan_u32_to_u64(ctx, osize, obefore, n_chunks));
-    hipLaunchKernelGGL(chunk_sort_kernel, dim3(n_chunks), dim3(256), 0, st, cstart, obefore, comp_s, val_s, out, comp_in, val_in);
+    hipLaunchKernelGGL(chunk_sort_kernel, dim3(n_chunks), dim3(256), 0, st, cstart, obefore, comp_s, val_s, out, comp_in, val_in,
+                       ctx->c_bstart.as<uint32_t>(), cfirst, bits);
     BF_HIP(ctx, hipGetLastError());
     uint64_t n_over = 0;
     if (!wait_over) {                                   // the caller reads mailbox slot 3 at its next wait (usually zero)
