@@ -244,6 +244,33 @@ def test_class_order_chunks_that_overflow(bits, monkeypatch):
     check_against_oracle(g, b, 20, flags=BF_FLAG_FORCE_EXACT)
 
 
+@pytest.mark.parametrize("bits", ["", "12", "8", "7"])
+def test_buckets_sorted_by_one_wave_in_registers(bits, monkeypatch):
+    """The chunk sort's register form: a bucket (the records of a few signatures) of up to 64, 128 or 256 records is sorted
+    by one wave, one, two or four records a lane, on one 64-bit key whose low bits hold the record's position in the bucket.
+    Junctions with ~40, ~100 and ~200 reads each (every size class, ties on lpos broken by input order), with 65536, 4096
+    and 256 buckets (fewer buckets = more signatures per bucket: 8 bits leave exactly the room a position needs), and with
+    128 buckets (no room: the LDS network takes every chunk).  Against the oracle, in one go and in contig groups."""
+    if bits:
+        monkeypatch.setenv("BREAKFAST_HIP_BUCKET_BITS", bits)
+    contigs = [("chr1", 300000), ("chr10", 200000), ("chr2", 250000)]
+    g = synth.make_genome(contigs, seed=25)
+    parts, base = [], 0
+    for n_reads, n_events, seed in ((4000, 100, 81), (6000, 60, 82), (8000, 40, 83), (3000, 1500, 84)):
+        parts.append(synth.make_reads(g, synth.ReadSpec(n_reads=n_reads, read_len=100, anchor_len=20, n_events=n_events, singleton_frac=0.0,
+                                                        mate_frac=0.3, seed=seed, margin=300, frag_base=base)))
+        base += n_reads
+    import test_gpu_submit as tgs
+    pieces = []                                                    # the size classes interleaved in input order
+    for k in range(16):
+        pieces += [p.slice(k * p.n // 16, (k + 1) * p.n // 16) for p in parts]
+    b = tgs.concat(pieces)
+    res, ref = check_against_oracle(g, b, 20)
+    sizes = (res.clusters["read_end"] - res.clusters["read_begin"]).astype(np.int64)
+    assert sizes.max() > 128 and (sizes < 64).any()
+    check_against_oracle(g, b, 20, flags=BF_FLAG_GROUPS_ALWAYS)
+
+
 def test_scaled_config_exact_kernel_only():
     contigs, gk, spec = synth.config(1, scale=0.0005, genome_scale=0.002)
     g = synth.make_genome(contigs, **gk)
