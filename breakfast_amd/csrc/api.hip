@@ -147,7 +147,7 @@ static OwnerView local_view(bf_ctx* ctx) {
     return v;
 }
 static void free_all(bf_ctx* ctx) {
-    DevBuf* all[] = {&ctx->g_blocks, &ctx->g_exc, &ctx->g_raw, &ctx->g_coarse, &ctx->g_coarse2, &ctx->g_contigs, &ctx->d_seq, &ctx->d_seq2, &ctx->d_exc_read, &ctx->d_exc_pos, &ctx->d_exc_code, &ctx->d_seq_off,
+    DevBuf* all[] = {&ctx->g_blocks, &ctx->g_exc, &ctx->g_raw, &ctx->g_lower, &ctx->g_run_start, &ctx->g_run_byte, &ctx->g_coarse, &ctx->g_coarse2, &ctx->g_contigs, &ctx->d_seq, &ctx->d_seq2, &ctx->d_exc_read, &ctx->d_exc_pos, &ctx->d_exc_code, &ctx->d_seq_off,
         &ctx->d_frag, &ctx->d_frag_off, &ctx->d_hits, &ctx->d_len, &ctx->d_frag_len, &ctx->d_fhash,
         &ctx->d_key, &ctx->d_lpos, &ctx->d_rpos, &ctx->d_bp, &ctx->d_flags, &ctx->d_mask, &ctx->d_jrec, &ctx->d_exact_list,
         &ctx->d_counters, &ctx->d_sigx, &ctx->d_sigx_slot, &ctx->d_send, &ctx->d_part_key, &ctx->d_part_idx,
@@ -542,6 +542,30 @@ int bf_genome_end(bf_ctx* ctx) {
         BF_TRY(localise_uploaded(ctx, ctx->n_reads, ctx->max_len));
     }
     return BF_OK;
+}
+
+int bf_genome_read(bf_ctx* ctx, uint32_t contig, uint64_t offset, uint64_t n, uint8_t* out) {
+    if (!ctx) return BF_ERR_INVALID;
+    BF_TRACE_CALL(ctx);
+    if (!ctx->genome_ready) return fail(ctx, BF_ERR_STATE, "bf_genome_read before bf_genome_end");
+    if (contig >= ctx->n_contigs || offset > ctx->contig_host[contig].len || n > ctx->contig_host[contig].len - offset)
+        return fail(ctx, BF_ERR_RANGE, "bf_genome_read: piece outside its contig");
+    if (n == 0) return BF_OK;
+    if (!out) return fail(ctx, BF_ERR_INVALID, "bf_genome_read: null output");
+    BF_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf tmp;
+    const uint64_t piece = 64u << 20;
+    BF_TRY(ensure(ctx, tmp, std::min(n, piece)));
+    int rc = BF_OK;
+    for (uint64_t a = 0; a < n && rc == BF_OK; a += piece) {
+        const uint64_t m = std::min(piece, n - a);
+        rc = genome_unpack(ctx, ctx->contig_host[contig].goff + offset + a, m, tmp.as<uint8_t>());
+        if (rc == BF_OK && (hipMemcpyAsync(out + a, tmp.p, m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                            hipStreamSynchronize(ctx->stream) != hipSuccess))
+            rc = fail(ctx, BF_ERR_HIP, "bf_genome_read: copy to the host failed");
+    }
+    release(ctx, tmp);
+    return rc;
 }
 
 int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint8_t* const* seqs,

@@ -49,6 +49,37 @@ __host__ __device__ inline uint64_t block_image_slots(uint64_t n_blocks) { retur
 __host__ __device__ inline uint64_t exc_slot(uint64_t b) { return ((b >> 3) << 4) + (b & 7); }
 __host__ __device__ inline uint64_t exc_image_slots(uint64_t n_blocks) { return ((n_blocks >> 3) + 2) << 4; }
 
+// The reference keeps every byte of the FASTA (detect.rs:48-56) and compares bytes (detect.rs:137-145, :223).  The raw
+// image (one byte per base: 3.1 GB of hg38's 5.4 GB resident) is gone after the pack: a byte is rebuilt from its 2-bit
+// code ((byte >> 1) & 3: A C T G = 0 1 2 3 in either case), its exception bit, a plane "one of acgt", and for every
+// other byte (N, n, IUPAC, anything) a table of the runs of equal such bytes, sorted by start, searched by bisection
+// (hg38: a few hundred runs of N).  Only the byte-exact kernel and signatures with a byte outside ACGT ask.
+struct GenomeBytes {
+    const GenomeBlock* blocks;
+    const uint64_t* exc;         // overlapping lines, exc_slot()
+    const uint64_t* lower;       // one word per 64-base block, bit k = base k is one of "acgt"
+    const uint64_t* run_start;   // global base offsets, ascending
+    const uint8_t* run_byte;
+    uint32_t n_runs;
+#ifdef __HIPCC__
+    __device__ __forceinline__ uint8_t at(uint64_t g) const {
+        const uint64_t b = g >> 6;
+        const int k = (int)(g & 63);
+        const GenomeBlock w = blocks[block_slot(b)];
+        const uint32_t code = (uint32_t)((w.lo >> k) & 1) | ((uint32_t)((w.hi >> k) & 1) << 1);
+        const uint32_t plain = 0x47544341u >> (8 * code);                 // "ACTG"
+        if (!((exc[exc_slot(b)] >> k) & 1)) return (uint8_t)plain;
+        if ((lower[b] >> k) & 1) return (uint8_t)(plain | 0x20);
+        uint32_t lo_ = 0, hi_ = n_runs;                                   // last run that starts at or before g
+        while (lo_ < hi_) {
+            const uint32_t mid = (lo_ + hi_) >> 1;
+            if (run_start[mid] <= g) lo_ = mid + 1; else hi_ = mid;
+        }
+        return lo_ ? run_byte[lo_ - 1] : (uint8_t)'N';
+    }
+#endif
+};
+
 struct ContigDev {      // 16 B, indexed by contig id
     uint64_t goff;      // global base offset of the contig's first base (multiple of 64)
     uint32_t len;
@@ -253,7 +284,9 @@ struct bf_ctx {
     std::vector<uint32_t> contig_by_rank;       // rank -> id
     std::vector<bf::ContigDev> contig_host;
     uint64_t genome_bases = 0;                  // padded total (multiple of 64)
-    bf::DevBuf g_blocks, g_exc, g_raw, g_coarse, g_coarse2, g_contigs;
+    bf::DevBuf g_blocks, g_exc, g_raw, g_coarse, g_coarse2, g_contigs;     // g_raw: only between bf_genome_begin and bf_genome_end
+    bf::DevBuf g_lower, g_run_start, g_run_byte;
+    uint32_t n_runs = 0;
 
     // host -> device hand-over (bf_submit): uploads run on in_stream from pinned memory -- the caller's own when it
     // came from bf_host_alloc, else a ring of pinned staging slots filled by a few host threads -- and the reads
@@ -424,6 +457,7 @@ struct OnSideStream {
 };
 
 // localise.hip ----------------------------------------------------------------------------------
+int genome_unpack(bf_ctx* ctx, uint64_t g0, uint64_t n, uint8_t* dev_out);    // the bytes of global offsets [g0, g0 + n)
 int genome_pack(bf_ctx* ctx);                       // raw image -> blocks + coarse bitmap
 int run_localise(bf_ctx* ctx, bool defer_counts = false, bool all = true);   // read_meta + packed + exact kernels; all = false:
                                                     // only the reads bf_submit has not localised behind their upload yet

@@ -37,16 +37,12 @@ __device__ __forceinline__ bool is_acgt(uint8_t c) { return c == 'A' || c == 'C'
 // ---------------------------------------------------------------------------------------------
 // genome_pack: thread t packs bases [64t, 64t+64).  A wave's 64 exception flags form one word
 // of the coarse bitmap (ballot), so block t's flag is bit t%64 of coarse[t/64].
-__global__ void __launch_bounds__(256) genome_pack_kernel(const uint8_t* __restrict__ raw,
-                                                          GenomeBlock* __restrict__ blocks,
-                                                          uint64_t* __restrict__ exc_plane,
-                                                          uint64_t* __restrict__ coarse,
-                                                          uint32_t* __restrict__ coarse2,
-                                                          uint64_t n_blocks /* multiple of 64 */) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_blocks) return;  // whole waves only: n_blocks and blockDim are multiples of 64
+struct PackedBlock { uint64_t lo, hi, ex, lw, st; };       // st: bases that start a run of equal bytes outside ACGTacgt
+
+__device__ __forceinline__ PackedBlock pack_block(const uint8_t* __restrict__ raw, uint64_t t) {
     const uint4* src = (const uint4*)(raw + t * 64);
-    uint64_t lo = 0, hi = 0, ex = 0;
+    PackedBlock o{0, 0, 0, 0, 0};
+    uint8_t prev = t ? raw[t * 64 - 1] : (uint8_t)'A';
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint4 v = src[q];
@@ -58,12 +54,31 @@ __global__ void __launch_bounds__(256) genome_pack_kernel(const uint8_t* __restr
                 const uint8_t c = (uint8_t)(wds[d] >> (8 * b));
                 const int k = q * 16 + d * 4 + b;
                 const uint64_t code = (c >> 1) & 3;
-                lo |= (code & 1) << k;
-                hi |= (code >> 1) << k;
-                ex |= (uint64_t)!is_acgt(c) << k;
+                const bool upper = is_acgt(c), lower = is_acgt((uint8_t)(c ^ 0x20)) && (c & 0x20);
+                o.lo |= (code & 1) << k;
+                o.hi |= (code >> 1) << k;
+                o.ex |= (uint64_t)!upper << k;
+                o.lw |= (uint64_t)lower << k;
+                o.st |= (uint64_t)(!upper && !lower && c != prev) << k;
+                prev = c;
             }
         }
     }
+    return o;
+}
+
+__global__ void __launch_bounds__(256) genome_pack_kernel(const uint8_t* __restrict__ raw,
+                                                          GenomeBlock* __restrict__ blocks,
+                                                          uint64_t* __restrict__ exc_plane,
+                                                          uint64_t* __restrict__ lower_plane,
+                                                          uint64_t* __restrict__ coarse,
+                                                          uint32_t* __restrict__ coarse2,
+                                                          uint32_t* __restrict__ wave_runs,
+                                                          uint64_t n_blocks /* multiple of 64 */) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_blocks) return;  // whole waves only: n_blocks and blockDim are multiples of 64
+    const PackedBlock o = pack_block(raw, t);
+    const uint64_t lo = o.lo, hi = o.hi, ex = o.ex;
     // overlapping lines: block t is the lower-half slot t%4 of line t/4 and the upper-half slot of line t/4 - 1
     blocks[block_slot(t)] = GenomeBlock{lo, hi};
     if (t >= 4) blocks[block_slot(t - 4) + 4] = GenomeBlock{lo, hi};
@@ -71,11 +86,36 @@ __global__ void __launch_bounds__(256) genome_pack_kernel(const uint8_t* __restr
         exc_plane[exc_slot(t)] = ex;
         if (t >= 8) exc_plane[exc_slot(t - 8) + 8] = ex;
     }
+    lower_plane[t] = o.lw;
     const uint64_t flags = __ballot(ex != 0);
+    uint32_t runs = (uint32_t)__popcll(o.st);
+    if (__ballot(runs != 0)) for (int d = 32; d > 0; d >>= 1) runs += (uint32_t)__shfl_xor((int)runs, d);
     if ((threadIdx.x & 63) == 0) {
         coarse[t >> 6] = flags;
         // second level: one bit per coarse word (4096 bases); zero-initialised, set bits are rare
         if (flags) atomicOr(&coarse2[t >> 11], 1u << ((t >> 6) & 31));
+        wave_runs[t >> 6] = runs;
+    }
+}
+
+// second pass over the waves that hold run starts: the table {start, byte}, in ascending order of start
+__global__ void __launch_bounds__(256) genome_runs_kernel(const uint8_t* __restrict__ raw, const uint32_t* __restrict__ wave_runs,
+                                                          const uint64_t* __restrict__ wave_off, uint64_t* __restrict__ run_start,
+                                                          uint8_t* __restrict__ run_byte, uint64_t n_blocks) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_blocks || wave_runs[t >> 6] == 0) return;          // wave-uniform
+    uint64_t st = pack_block(raw, t).st;
+    const uint32_t mine = (uint32_t)__popcll(st);
+    uint32_t incl = mine;                                         // inclusive prefix over the wave's lanes
+    const int lane = threadIdx.x & 63;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += up; }
+    uint64_t at = wave_off[t >> 6] + (incl - mine);
+    while (st) {
+        const int k = __ffsll((long long)st) - 1;
+        st &= st - 1;
+        run_start[at] = t * 64 + (uint64_t)k;
+        run_byte[at] = raw[t * 64 + (uint64_t)k];
+        at++;
     }
 }
 
@@ -147,6 +187,13 @@ __device__ __forceinline__ void load_window_exc(const uint64_t* __restrict__ exc
     for (int i = 0; i <= W; i++) x[i] = p[i];
 #pragma unroll
     for (int w = 0; w < W; w++) ex[w] = (x[w] >> sh) | ((x[w + 1] << 1) << (63 - sh));
+}
+
+// bits of the lower-case plane for the 8 bases from g on (bit j = base g + j); the plane ends in a spare word
+__device__ __forceinline__ uint32_t lower8(const uint64_t* __restrict__ lower, uint64_t g) {
+    const uint64_t w0 = lower[g >> 6], w1 = lower[(g >> 6) + 1];
+    const int sh = (int)(g & 63);
+    return (uint32_t)((w0 >> sh) | ((w1 << 1) << (63 - sh))) & 0xffu;
 }
 
 // 32-bit stand-in for a signature that holds a non-ACGT byte (the sweep compares the 16 raw bytes)
@@ -325,7 +372,7 @@ struct LocaliseArgs {
     const uint64_t* coarse;
     const uint32_t* coarse2;
     const uint64_t* exc;          // exception plane (overlapping lines), read only by flagged windows
-    const uint8_t* raw;           // raw genome bytes, read only for signatures that hold a non-ACGT byte
+    GenomeBytes gb;               // raw genome bytes, rebuilt only for signatures that hold a non-ACGT byte
     uint8_t* sigx;                // 16 raw signature bytes per slot
     uint32_t* sigx_slot;          // read -> slot
     uint64_t* key;
@@ -515,14 +562,28 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
     if (sigx) {
         // a signature byte outside ACGT: the class is decided on the 16 raw bytes (case-sensitive,
         // detect.rs:223); the key carries their hash and the bytes are kept aside for the sweep
+        // Codes and exception bits of the sixteen bases are in registers (oriented, complemented); what is missing is
+        // which of the exceptions are one of "acgt" (the complement of a lower-case letter is lower case: one 8-bit
+        // window of the lower-case plane per side, in genome order) and the bytes that are neither (bisection).
         uint8_t sb[16];
-        const uint8_t* lraw = a.raw + o.c.goff;
-        const uint8_t* rraw = a.raw + o.mc.goff;
+        const uint64_t lg0 = o.c.goff + (uint64_t)(o.strand ? o.pos - 1 + (bp - 8) : o.pos + A - 2 - (bp - 1));     // detect.rs:118,121
+        const uint64_t rg0 = o.mc.goff + (uint64_t)(o.mstrand ? o.mpos + A - L - 1 + bp : o.mpos + L - 2 - (bp + 7));  // :127,130
+        uint32_t llw = lower8(a.gb.lower, lg0), rlw = lower8(a.gb.lower, rg0);
+        if (!o.strand) llw = __brev(llw) >> 24;
+        if (!o.mstrand) rlw = __brev(rlw) >> 24;
+        const uint32_t lx = extract8<W>(lex, bp - 8), rx = extract8<W>(qex, bp);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int kl = bp - 8 + k, kr = bp + k;
-            const uint8_t cl = o.strand ? lraw[o.pos - 1 + kl] : comp_byte(lraw[o.pos + A - 2 - kl]);          // detect.rs:118,121
-            const uint8_t cr = o.mstrand ? rraw[o.mpos + A - L - 1 + kr] : comp_byte(rraw[o.mpos + L - 2 - kr]);   // :127,130
+            const uint32_t lcode = ((sig >> k) & 1) | (((sig >> (8 + k)) & 1) << 1), rcode = ((sig >> (16 + k)) & 1) | (((sig >> (24 + k)) & 1) << 1);
+            uint8_t cl = (uint8_t)(0x47544341u >> (8 * lcode)), cr = (uint8_t)(0x47544341u >> (8 * rcode));         // "ACTG"
+            if ((lx >> k) & 1) {
+                if ((llw >> k) & 1) cl |= 0x20;
+                else { const uint8_t c = a.gb.at(o.strand ? lg0 + k : lg0 + 7 - k); cl = o.strand ? c : comp_byte(c); }
+            }
+            if ((rx >> k) & 1) {
+                if ((rlw >> k) & 1) cr |= 0x20;
+                else { const uint8_t c = a.gb.at(o.mstrand ? rg0 + k : rg0 + 7 - k); cr = o.mstrand ? c : comp_byte(c); }
+            }
             sb[k] = cl; sb[8 + k] = cr;
         }
         sig = sigx_hash(sb);
@@ -562,7 +623,7 @@ __global__ void __launch_bounds__(256) localise_fast_kernel(const LocaliseArgs a
 }
 
 // ---------------------------------------------------------------------------------------------
-// Byte-exact path: one wave per routed read, straight from the raw images.  Handles windows that
+// Byte-exact path: one wave per routed read, on the bytes of the FASTA (rebuilt: GenomeBytes).  Handles windows that
 // leave the contig (-> 'N', detect.rs:118-130), reference bytes outside ACGT (soft-masked, N,
 // IUPAC), and reads longer than the packed path's 64*W.
 struct ExactArgs {
@@ -578,7 +639,7 @@ struct ExactArgs {
     const uint16_t* len;     // read lengths when the reads are 4-bit codes
     uint32_t packed;
     const ContigDev* contigs;
-    const uint8_t* raw;
+    GenomeBytes gb;
     uint64_t* key;
     int32_t* lpos;
     int32_t* rpos;
@@ -597,19 +658,20 @@ struct ExactArgs {
 struct ExactRead {
     const uint8_t* seq; uint64_t so; bool packed; int L; bool swapped;
     __device__ __forceinline__ uint8_t raw_base(int k) const { return base_at(seq, so, k, packed); }
-    const uint8_t* lraw; int64_t llen; int64_t lbase; bool lfwd;
-    const uint8_t* rraw; int64_t rlen; int64_t rbase; bool rfwd;
+    GenomeBytes gb;
+    uint64_t lgoff; int64_t llen; int64_t lbase; bool lfwd;
+    uint64_t rgoff; int64_t rlen; int64_t rbase; bool rfwd;
     __device__ __forceinline__ uint8_t s(int k) const {
         return swapped ? comp_byte(raw_base(L - 1 - k)) : raw_base(k);
     }
     __device__ __forceinline__ uint8_t left(int k) const {
         const int64_t i = lfwd ? lbase + k : lbase - k;
-        const uint8_t c = (i >= 0 && i < llen) ? lraw[i] : (uint8_t)'N';
+        const uint8_t c = (i >= 0 && i < llen) ? gb.at(lgoff + (uint64_t)i) : (uint8_t)'N';
         return lfwd ? c : comp_byte(c);
     }
     __device__ __forceinline__ uint8_t right(int k) const {
         const int64_t i = rfwd ? rbase + k : rbase - k;
-        const uint8_t c = (i >= 0 && i < rlen) ? rraw[i] : (uint8_t)'N';
+        const uint8_t c = (i >= 0 && i < rlen) ? gb.at(rgoff + (uint64_t)i) : (uint8_t)'N';
         return rfwd ? c : comp_byte(c);
     }
 };
@@ -634,9 +696,9 @@ __global__ void __launch_bounds__(256) localise_exact_kernel(const ExactArgs a) 
     x.L = a.packed ? (int)a.len[r] : (int)(a.seq_off[r + 1] - a.seq_off[r]);
     x.swapped = o.swapped;
     const int L = x.L;
-    x.lraw = a.raw + o.c.goff; x.llen = o.c.len; x.lfwd = o.strand;
+    x.gb = a.gb; x.lgoff = o.c.goff; x.llen = o.c.len; x.lfwd = o.strand;
     x.lbase = o.strand ? o.pos - 1 : o.pos + A - 2;                 // detect.rs:118,121
-    x.rraw = a.raw + o.mc.goff; x.rlen = o.mc.len; x.rfwd = o.mstrand;
+    x.rgoff = o.mc.goff; x.rlen = o.mc.len; x.rfwd = o.mstrand;
     x.rbase = o.mstrand ? o.mpos + A - L - 1 : o.mpos + L - 2;      // detect.rs:127,130
     const int n_chunks = (L + 63) >> 6;
 
@@ -1020,10 +1082,52 @@ static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)(
 
 int genome_pack(bf_ctx* ctx) {
     const uint64_t n_blocks = ctx->genome_bases / 64;     // multiple of 64 by construction
+    const uint64_t n_waves = n_blocks / 64;
     Scope t(ctx, "genome_pack");
+    DevBuf wave_runs, wave_off;
+    BF_TRY(ensure(ctx, ctx->g_lower, (n_blocks + 1) * 8));
+    BF_HIP(ctx, hipMemsetAsync(ctx->g_lower.as<uint64_t>() + n_blocks, 0, 8, ctx->stream));
+    BF_TRY(ensure(ctx, wave_runs, n_waves * 4));
+    if (int rc = ensure(ctx, wave_off, (n_waves + 1) * 8)) { release(ctx, wave_runs); return rc; }
+    auto done = [&](int rc) { release(ctx, wave_runs); release(ctx, wave_off); return rc; };
     hipLaunchKernelGGL(genome_pack_kernel, dim3(grid_for(n_blocks, 256)), dim3(256), 0, ctx->stream,
-                       ctx->g_raw.as<uint8_t>(), ctx->g_blocks.as<GenomeBlock>(), ctx->g_exc.as<uint64_t>(),
-                       ctx->g_coarse.as<uint64_t>(), ctx->g_coarse2.as<uint32_t>(), n_blocks);
+                       ctx->g_raw.as<uint8_t>(), ctx->g_blocks.as<GenomeBlock>(), ctx->g_exc.as<uint64_t>(), ctx->g_lower.as<uint64_t>(),
+                       ctx->g_coarse.as<uint64_t>(), ctx->g_coarse2.as<uint32_t>(), wave_runs.as<uint32_t>(), n_blocks);
+    if (hipGetLastError() != hipSuccess) return done(fail(ctx, BF_ERR_HIP, "genome_pack_kernel failed to launch"));
+    // the bytes that are none of ACGTacgt, as runs: count per wave -> offsets -> the table, sized exactly
+    if (int rc = scan_u32_to_u64(ctx, wave_runs.as<uint32_t>(), wave_off.as<uint64_t>(), n_waves)) return done(rc);
+    uint64_t total = 0;
+    if (hipMemcpyAsync(&total, wave_off.as<uint64_t>() + n_waves, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return done(fail(ctx, BF_ERR_HIP, "genome_pack: reading the run count back failed"));
+    if (total > 0xfffffff0ull) return done(fail(ctx, BF_ERR_RANGE, "the genome holds %llu runs of bytes outside ACGTacgt; the supported maximum is 2^32 - 16", (unsigned long long)total));
+    ctx->n_runs = (uint32_t)total;
+    if (int rc = ensure(ctx, ctx->g_run_start, (total + 1) * 8)) return done(rc);
+    if (int rc = ensure(ctx, ctx->g_run_byte, total + 16)) return done(rc);
+    if (total) {
+        hipLaunchKernelGGL(genome_runs_kernel, dim3(grid_for(n_blocks, 256)), dim3(256), 0, ctx->stream,
+                           ctx->g_raw.as<uint8_t>(), wave_runs.as<uint32_t>(), wave_off.as<uint64_t>(),
+                           ctx->g_run_start.as<uint64_t>(), ctx->g_run_byte.as<uint8_t>(), n_blocks);
+        if (hipGetLastError() != hipSuccess) return done(fail(ctx, BF_ERR_HIP, "genome_runs_kernel failed to launch"));
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return done(fail(ctx, BF_ERR_HIP, "genome_pack failed"));
+    release(ctx, ctx->g_raw);                             // every byte can be rebuilt from what is resident now
+    return done(BF_OK);
+}
+
+static GenomeBytes genome_bytes(const bf_ctx* ctx) {
+    return GenomeBytes{ctx->g_blocks.as<GenomeBlock>(), ctx->g_exc.as<uint64_t>(), ctx->g_lower.as<uint64_t>(),
+                       ctx->g_run_start.as<uint64_t>(), ctx->g_run_byte.as<uint8_t>(), ctx->n_runs};
+}
+
+__global__ void __launch_bounds__(256) genome_unpack_kernel(const GenomeBytes gb, uint64_t g0, uint64_t n, uint8_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gb.at(g0 + i);
+}
+
+int genome_unpack(bf_ctx* ctx, uint64_t g0, uint64_t n, uint8_t* dev_out) {
+    if (n == 0) return BF_OK;
+    hipLaunchKernelGGL(genome_unpack_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, genome_bytes(ctx), g0, n, dev_out);
     BF_HIP(ctx, hipGetLastError());
     return BF_OK;
 }
@@ -1208,7 +1312,7 @@ int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len) {
     a.by_ref = (ctx->cfg.flags & BF_FLAG_READS_ON_HOST) ? 1u : 0u;
     a.blocks = ctx->g_blocks.as<GenomeBlock>(); a.coarse = ctx->g_coarse.as<uint64_t>();
     a.coarse2 = ctx->g_coarse2.as<uint32_t>();
-    a.exc = ctx->g_exc.as<uint64_t>(); a.raw = ctx->g_raw.as<uint8_t>();
+    a.exc = ctx->g_exc.as<uint64_t>(); a.gb = genome_bytes(ctx);
     a.sigx = ctx->d_sigx.as<uint8_t>(); a.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();
     a.key = ctx->d_key.as<uint64_t>(); a.lpos = ctx->d_lpos.as<int32_t>(); a.rpos = ctx->d_rpos.as<int32_t>();
     a.bp = ctx->d_bp.as<uint16_t>(); a.flags = ctx->d_flags.as<uint16_t>(); a.meta = ctx->d_mask.as<uint64_t>();
@@ -1244,7 +1348,7 @@ int run_localise(bf_ctx* ctx, bool defer_counts, bool all) {
         e.counters = ctx->d_counters.as<uint32_t>(); e.hits = ctx->d_hits.as<bf_hit>();
         e.seq = ctx->d_seq.as<uint8_t>(); e.seq_off = ctx->d_seq_off.as<uint64_t>();
         e.len = ctx->d_len.as<uint16_t>(); e.packed = ctx->packed_reads ? 1u : 0u;
-        e.contigs = ctx->g_contigs.as<ContigDev>(); e.raw = ctx->g_raw.as<uint8_t>();
+        e.contigs = ctx->g_contigs.as<ContigDev>(); e.gb = genome_bytes(ctx);
         e.key = ctx->d_key.as<uint64_t>(); e.lpos = ctx->d_lpos.as<int32_t>(); e.rpos = ctx->d_rpos.as<int32_t>();
         e.bp = ctx->d_bp.as<uint16_t>(); e.flags = ctx->d_flags.as<uint16_t>(); e.meta = ctx->d_mask.as<uint64_t>();
         e.mask_words = (int)Wm; e.max_packed = 64u * W; e.by_ref = (ctx->cfg.flags & BF_FLAG_READS_ON_HOST) ? 1u : 0u; e.rw = ctx->d_jrec.as<RecWord>(); e.fhash = ctx->d_fhash.as<uint64_t>(); e.sigx = ctx->d_sigx.as<uint8_t>(); e.sigx_slot = ctx->d_sigx_slot.as<uint32_t>();

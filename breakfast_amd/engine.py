@@ -108,7 +108,7 @@ ABI_SYMBOLS = [
     "bf_evidence_fetch", "bf_kernel_times", "bf_stats", "bf_junction_text", "bf_junction_text_of", "bf_result_junction_text",
     "bf_junction_record_bound", "bf_junction_record_bytes", "bf_result_reads",
     "bf_host_alloc", "bf_host_free", "bf_submit_wait", "bf_reserve",
-    "bf_genome_begin", "bf_genome_write", "bf_genome_fill", "bf_genome_end", "bf_submit_packed", "bf_submit_packed2",
+    "bf_genome_begin", "bf_genome_write", "bf_genome_fill", "bf_genome_end", "bf_genome_read", "bf_submit_packed", "bf_submit_packed2",
     "bf_shard_unique_id", "bf_shard_init_rccl", "bf_shard_init_host", "bf_shard_finish", "bf_shard_result_places", "bf_shard_format_sv",
     "bf_shard_format_sv_names",
 ]
@@ -153,6 +153,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_genome_write.argtypes = [vp, C.c_uint32, C.c_uint64, vp, C.c_uint64]
     lib.bf_genome_end.argtypes = [vp]
     lib.bf_genome_fill.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, FILL_FN, vp]
+    lib.bf_genome_read.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, vp]
     lib.bf_submit.argtypes = [vp, C.POINTER(BfBatch)]
     lib.bf_submit_packed.argtypes = [vp, C.POINTER(BfPackedBatch)]
     lib.bf_submit_packed2.argtypes = [vp, C.POINTER(BfPacked2Batch)]
@@ -522,6 +523,12 @@ class Engine:
         c_seqs = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
         c_lens = (C.c_uint64 * n)(*[a.size for a in arrs])
         self._check(self.lib.bf_genome_set(self.h, n, c_names, c_seqs, c_lens))
+
+    def genome_read(self, contig: int, offset: int, n: int) -> np.ndarray:
+        """bf_genome_read: the bytes of a piece of a contig, rebuilt from the packed images."""
+        out = np.empty(n, np.uint8)
+        self._check(self.lib.bf_genome_read(self.h, contig, offset, n, out.ctypes.data if n else None))
+        return out
 
     def set_genome_in_pieces(self, names: Sequence[bytes], seqs: Sequence[np.ndarray], piece: int = 1 << 20,
                              fill: bool = False, order=None) -> None:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 13
+#define BF_ABI_VERSION 14
 
 enum {
     BF_OK = 0,
@@ -174,7 +174,8 @@ int bf_abi_version(void);
 
 /* Replaces the genome HashMap, detect.rs:48-56 + lookups at :115/:124.  Takes each contig's bytes
  * exactly as stored in the FASTA (case preserved).  Packs them on the GPU into the resident
- * 2-bit block image + exception map + raw byte image.  Contig order by byte-wise name compare
+ * 2-bit block image + exception map + a plane "one of acgt" + a table of the runs of every other byte; the bytes
+ * themselves are released after the pack (every one of them can be rebuilt: bf_genome_read).  Contig order by byte-wise name compare
  * (Rust String Ord, detect.rs:108,194) is derived here.  Inputs may be freed on return. */
 int bf_genome_set(bf_ctx* ctx, uint32_t n_contigs, const char* const* names,
                   const uint8_t* const* seqs, const uint64_t* lens);
@@ -191,6 +192,10 @@ int bf_genome_write(bf_ctx* ctx, uint32_t contig, uint64_t offset, const uint8_t
 typedef void (*bf_fill_fn)(void* user, uint8_t* dst, uint64_t n);
 int bf_genome_fill(bf_ctx* ctx, uint32_t contig, uint64_t offset, uint64_t n, bf_fill_fn fill, void* user);
 int bf_genome_end(bf_ctx* ctx);
+/* The bytes of a piece of a contig as the ctx holds them after bf_genome_end: out[0..n) = what bf_genome_write was
+ * given for [offset, offset + n), case and every byte outside ACGT included (the reference's genome[chr][i],
+ * detect.rs:118-130; rebuilt on the device from the packed form, copied to `out` in host memory).  For checks. */
+int bf_genome_read(bf_ctx* ctx, uint32_t contig, uint64_t offset, uint64_t n, uint8_t* out);
 
 /* ---- the hot path -------------------------------------------------------------------------- */
 

@@ -369,6 +369,71 @@ def test_genome_in_pieces_any_order_and_filled_in_place(fill):
         eng.close()
 
 
+def genome_of_every_byte(rng, n):
+    """ACGT with soft-masked stretches, N runs of every kind of length (across 64-base blocks and 4096-base waves of the
+    pack kernel), isolated IUPAC letters in both cases, and bytes no FASTA should hold but the reference would keep."""
+    s = rng.choice(np.frombuffer(b"ACGT", np.uint8), n)
+    for _ in range(n // 3000 + 3):                                  # soft-masked stretches
+        a = int(rng.integers(0, n)); m = int(rng.integers(1, 700))
+        s[a:a + m] |= 0x20
+    for m in (1, 2, 63, 64, 65, 127, 128, 129, 4095, 4096, 4097, 9000):     # runs of one byte
+        for c in b"Nn":
+            if m < n // 4:
+                a = int(rng.integers(0, n - m)); s[a:a + m] = c
+    for _ in range(n // 500 + 5):                                   # single letters and short mixed runs
+        a = int(rng.integers(0, n)); m = int(rng.integers(1, 6))
+        s[a:a + m] = rng.choice(np.frombuffer(b"RYKMSWBDHVNrykmswbdhvn*-.Xx", np.uint8), min(m, n - a))
+    for a in (0, 63, 64, n - 1, n - 64):                            # block edges
+        if 0 <= a < n: s[a] = ord("N")
+    return s
+
+
+def test_every_byte_of_the_genome_can_be_rebuilt():
+    """The raw image is released after the pack (2-bit codes + exception plane + lower-case plane + a table of the runs of
+    every other byte stay): bf_genome_read must give back the bytes bf_genome_write was given, whatever they are; and the
+    byte-exact kernel and the raw signatures, which ask for such bytes, still agree with the oracle on such a genome."""
+    rng = np.random.default_rng(77)
+    lens = [200000, 1, 63, 64, 65, 4096, 4097, 131072 + 5, 70000]
+    names = [b"c%02d" % i for i in range(len(lens))]
+    seqs = [genome_of_every_byte(rng, n) for n in lens]
+    seqs.append(np.full(10000, ord("N"), np.uint8)); names.append(b"allN")
+    seqs.append(np.frombuffer(b"ACGT" * 2500, np.uint8).copy()); names.append(b"plain")
+    eng = engine.Engine(20, 5000, 2)
+    try:
+        eng.set_genome_in_pieces(names, seqs, piece=33333, order=lambda n: rng.permutation(n))
+        for c, s in enumerate(seqs):
+            assert np.array_equal(eng.genome_read(c, 0, s.size), s), names[c]
+        assert np.array_equal(eng.genome_read(0, 12345, 4099), seqs[0][12345:12345 + 4099])
+        assert eng.genome_read(0, 200000, 0).size == 0
+        with pytest.raises(engine.BreakfastError):
+            eng.genome_read(0, 199999, 2)
+        eng.set_genome(names[:3], seqs[:3])                           # a second genome in the same ctx
+        assert np.array_equal(eng.genome_read(0, 0, seqs[0].size), seqs[0])
+    finally:
+        eng.close()
+    # reads cut out of such a genome (upper-cased, as a sequencer gives them): windows over N runs, lower case and IUPAC
+    big = [0, 7, 8]
+    g = synth.Genome([names[i] for i in big], [seqs[i] for i in big])
+    spec = synth.ReadSpec(n_reads=6000, read_len=100, anchor_len=20, n_events=150, singleton_frac=0.3, seed=9, margin=300)
+    b = synth.make_reads(g, spec)
+    low = (b.seq_bytes >= ord("a")) & (b.seq_bytes <= ord("z"))
+    b.seq_bytes[low] &= np.uint8(0xDF)
+    ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, 20, 5000, 2)
+    assert ref.n_clusters > 0
+    for flags in (0, engine.BF_FLAG_FORCE_EXACT):
+        e2 = engine.Engine(20, 5000, 2, flags=flags | engine.BF_FLAG_KEEP_EVIDENCE)
+        try:
+            e2.set_genome(g.names, g.seqs)
+            e2.submit(b)
+            assert e2.format_sv(e2.finish()) == ref.sv
+            if flags == 0:
+                ev = e2.evidence()
+                assert ((ev["flags"] & engine.BF_EV_SIGX) != 0).sum() > 50, "no raw signatures built by the packed kernel"
+                assert ((ev["flags"] & engine.BF_EV_EXACT) != 0).sum() < b.n
+        finally:
+            e2.close()
+
+
 def test_genome_fill_limits():
     eng = engine.Engine(20, 5000, 2)
     try:
