@@ -147,7 +147,7 @@ static OwnerView local_view(bf_ctx* ctx) {
     return v;
 }
 static void free_all(bf_ctx* ctx) {
-    DevBuf* all[] = {&ctx->g_blocks, &ctx->g_exc, &ctx->g_raw, &ctx->g_lower, &ctx->g_run_start, &ctx->g_run_byte, &ctx->g_coarse, &ctx->g_coarse2, &ctx->g_contigs, &ctx->d_seq, &ctx->d_seq2, &ctx->d_exc_read, &ctx->d_exc_pos, &ctx->d_exc_code, &ctx->d_seq_off,
+    DevBuf* all[] = {&ctx->g_blocks, &ctx->g_exc, &ctx->g_raw, &ctx->g_lower, &ctx->g_run_start, &ctx->g_run_byte, &ctx->g_lower_start, &ctx->g_lower_len, &ctx->g_run_len, &ctx->g_coarse, &ctx->g_coarse2, &ctx->g_contigs, &ctx->d_seq, &ctx->d_seq2, &ctx->d_exc_read, &ctx->d_exc_pos, &ctx->d_exc_code, &ctx->d_seq_off,
         &ctx->d_frag, &ctx->d_frag_off, &ctx->d_hits, &ctx->d_len, &ctx->d_frag_len, &ctx->d_fhash,
         &ctx->d_key, &ctx->d_lpos, &ctx->d_rpos, &ctx->d_bp, &ctx->d_flags, &ctx->d_mask, &ctx->d_jrec, &ctx->d_exact_list,
         &ctx->d_counters, &ctx->d_sigx, &ctx->d_sigx_slot, &ctx->d_send, &ctx->d_part_key, &ctx->d_part_idx,
@@ -420,6 +420,14 @@ constexpr uint32_t kGenomeSlots = 16;
 static_assert(kStageSlotBytes == BF_GENOME_FILL_MAX, "bf_genome_fill hands out one staging slot");
 
 int bf_genome_begin(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint64_t* lens) {
+    return genome_begin(ctx, n_contigs, names, lens, false);
+}
+
+int bf_genome_begin_image(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint64_t* lens) {
+    return genome_begin(ctx, n_contigs, names, lens, true);
+}
+
+extern "C++" int bf::genome_begin(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint64_t* lens, bool image) {
     if (!ctx) return BF_ERR_INVALID;
     BF_TRACE_CALL(ctx);
     if (!names || !lens || n_contigs == 0) return fail(ctx, BF_ERR_INVALID, "bf_genome_begin: null/empty argument");
@@ -454,7 +462,8 @@ int bf_genome_begin(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, c
     if (total / 64 >= 0x7ffffff0ull) return fail(ctx, BF_ERR_RANGE, "genome too large: %llu bases (limit 2^37)", (unsigned long long)total);
     ctx->genome_bases = total;
     const uint64_t n_blocks = total / 64;
-    BF_TRY(ensure(ctx, ctx->g_raw, total + 4096));
+    ctx->genome_image = image;
+    BF_TRY(ensure(ctx, ctx->g_raw, image ? n_blocks * sizeof(GenomeBlock) + 64 : total + 4096));
     BF_TRY(ensure(ctx, ctx->g_blocks, block_image_slots(n_blocks) * sizeof(GenomeBlock)));
     BF_TRY(ensure(ctx, ctx->g_exc, exc_image_slots(n_blocks) * 8));
     BF_TRY(ensure(ctx, ctx->g_coarse, (n_blocks / 64 + 4) * 8));
@@ -462,7 +471,8 @@ int bf_genome_begin(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, c
     BF_TRY(ensure(ctx, ctx->g_contigs, (size_t)n_contigs * sizeof(ContigDev)));
     // on the copy-in stream, so that the pieces written behind them land on cleared memory
     const hipStream_t is = ctx->in_stream;
-    BF_HIP(ctx, hipMemsetAsync(ctx->g_raw.p, 'A', total + 4096, is));   // padding is never compared
+    if (image) BF_HIP(ctx, hipMemsetAsync(ctx->g_raw.p, 0, n_blocks * sizeof(GenomeBlock) + 64, is));
+    else BF_HIP(ctx, hipMemsetAsync(ctx->g_raw.p, 'A', total + 4096, is));   // padding is never compared
     BF_HIP(ctx, hipMemsetAsync(ctx->g_blocks.p, 0, block_image_slots(n_blocks) * sizeof(GenomeBlock), is));
     BF_HIP(ctx, hipMemsetAsync(ctx->g_exc.p, 0, exc_image_slots(n_blocks) * 8, is));
     BF_HIP(ctx, hipMemsetAsync(ctx->g_coarse.p, 0, (n_blocks / 64 + 4) * 8, is));
@@ -484,13 +494,23 @@ static int genome_write_impl(bf_ctx* ctx, uint32_t contig, uint64_t offset, cons
         return code;
     };
     if (ctx->n_contigs == 0 || ctx->genome_ready) return bad(BF_ERR_STATE, "bf_genome_write outside bf_genome_begin .. bf_genome_end");
+    if (ctx->genome_image) return bad(BF_ERR_STATE, "bf_genome_write after bf_genome_begin_image: this genome comes as an image (bf_genome_set_image)");
     if (contig >= ctx->n_contigs || offset > ctx->contig_host[contig].len || n > ctx->contig_host[contig].len - offset)
         return bad(BF_ERR_RANGE, "bf_genome_write: piece outside its contig");
     if (n == 0) return BF_OK;
     if (!bytes && !fill) return bad(BF_ERR_INVALID, "bf_genome_write: null bytes");
     if (fill && n > kStageSlotBytes) return bad(BF_ERR_RANGE, "bf_genome_fill: a piece of more than BF_GENOME_FILL_MAX bytes");
+    return genome_stage(ctx, ctx->g_raw.as<uint8_t>() + ctx->contig_host[contig].goff + offset, bytes, n, fill, user);
+}
+
+// n bytes to device memory `dst` through the genome's pinned slots, on the copy-in stream.  Thread-safe.
+extern "C++" int bf::genome_stage(bf_ctx* ctx, uint8_t* dst, const uint8_t* bytes, uint64_t n, bf_fill_fn fill, void* user) {
+    auto bad = [&](int code, const char* msg) {
+        std::lock_guard<std::mutex> g(ctx->genome_mu);
+        if (!ctx->genome_err_code) { ctx->genome_err_code = code; ctx->genome_err = msg; }
+        return code;
+    };
     if (hipSetDevice(ctx->device) != hipSuccess) return bad(BF_ERR_HIP, "hipSetDevice failed");
-    uint8_t* dst = ctx->g_raw.as<uint8_t>() + ctx->contig_host[contig].goff + offset;
     for (uint64_t a = 0; a < n; a += kStageSlotBytes) {
         const uint64_t len = std::min<uint64_t>(kStageSlotBytes, n - a);
         bf_ctx::GenomeSlot& sl = ctx->gslots[ctx->gslot_next.fetch_add(1) % kGenomeSlots];
@@ -532,7 +552,7 @@ int bf_genome_end(bf_ctx* ctx) {
     // the pack kernel runs on the main stream behind every piece
     BF_HIP(ctx, hipEventRecord(ctx->ev_in, ctx->in_stream));
     BF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));
-    BF_TRY(genome_pack(ctx));
+    BF_TRY(ctx->genome_image ? genome_from_image(ctx) : genome_pack(ctx));
     BF_SYNC(ctx, ctx->stream);
     ctx->genome_ready = true;
     // reads that arrived while the genome was still on its way

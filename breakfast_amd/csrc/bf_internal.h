@@ -287,6 +287,10 @@ struct bf_ctx {
     bf::DevBuf g_blocks, g_exc, g_raw, g_coarse, g_coarse2, g_contigs;     // g_raw: only between bf_genome_begin and bf_genome_end
     bf::DevBuf g_lower, g_run_start, g_run_byte;
     uint32_t n_runs = 0;
+    // hand-over as a packed image (bf_genome_set_image): g_raw stages the plain blocks, the runs come as they are
+    bool genome_image = false;
+    bf::DevBuf g_lower_start, g_lower_len, g_run_len;         // released at bf_genome_end
+    uint64_t n_lower_runs = 0;
 
     // host -> device hand-over (bf_submit): uploads run on in_stream from pinned memory -- the caller's own when it
     // came from bf_host_alloc, else a ring of pinned staging slots filled by a few host threads -- and the reads
@@ -458,7 +462,10 @@ struct OnSideStream {
 
 // localise.hip ----------------------------------------------------------------------------------
 int genome_unpack(bf_ctx* ctx, uint64_t g0, uint64_t n, uint8_t* dev_out);    // the bytes of global offsets [g0, g0 + n)
-int genome_pack(bf_ctx* ctx);                       // raw image -> blocks + coarse bitmap
+int genome_pack(bf_ctx* ctx);
+int genome_from_image(bf_ctx* ctx);                 // plain blocks + runs -> the same resident images
+int genome_begin(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint64_t* lens, bool image);
+int genome_stage(bf_ctx* ctx, uint8_t* dst, const uint8_t* bytes, uint64_t n, bf_fill_fn fill, void* user);                       // raw image -> blocks + coarse bitmap
 int run_localise(bf_ctx* ctx, bool defer_counts = false, bool all = true);   // read_meta + packed + exact kernels; all = false:
                                                     // only the reads bf_submit has not localised behind their upload yet
 int localise_uploaded(bf_ctx* ctx, uint64_t n, uint32_t max_len);

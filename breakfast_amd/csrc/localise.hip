@@ -1115,6 +1115,92 @@ int genome_pack(bf_ctx* ctx) {
     return done(BF_OK);
 }
 
+// The same images from a packed genome image (genome_image.hip): thread t takes block t's two code words as they are and
+// builds its words of the lower-case and exception planes from the runs that reach into it (bisection for the first such
+// run; runs ascend and do not overlap -- damaged tables can set wrong bits, never touch memory outside the arrays).
+__device__ __forceinline__ uint64_t run_bits(const uint64_t* __restrict__ start, const uint32_t* __restrict__ len, uint64_t n, uint64_t g0) {
+    uint64_t lo = 0, hi = n;                                           // first run that ends after g0
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (start[mid] + len[mid] <= g0) lo = mid + 1; else hi = mid;
+    }
+    uint64_t bits = 0;
+    for (uint64_t i = lo; i < n; i++) {
+        const uint64_t s = start[i];
+        if (s >= g0 + 64) break;
+        const uint64_t e = min(s + (uint64_t)len[i], g0 + 64), a = max(s, g0);
+        if (e > a) bits |= low_mask((int)(e - g0)) & ~low_mask((int)(a - g0));
+    }
+    return bits;
+}
+
+__global__ void __launch_bounds__(256) genome_image_kernel(const GenomeBlock* __restrict__ plain,
+                                                           const uint64_t* __restrict__ lower_start, const uint32_t* __restrict__ lower_len, uint64_t n_lower,
+                                                           const uint64_t* __restrict__ other_start, const uint32_t* __restrict__ other_len, uint64_t n_other,
+                                                           GenomeBlock* __restrict__ blocks, uint64_t* __restrict__ exc_plane,
+                                                           uint64_t* __restrict__ lower_plane, uint64_t* __restrict__ coarse,
+                                                           uint32_t* __restrict__ coarse2, uint32_t* __restrict__ bad, uint64_t n_blocks) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_blocks) return;  // whole waves only
+    const GenomeBlock b = plain[t];
+    blocks[block_slot(t)] = b;
+    if (t >= 4) blocks[block_slot(t - 4) + 4] = b;
+    const uint64_t lw = run_bits(lower_start, lower_len, n_lower, t * 64), ot = run_bits(other_start, other_len, n_other, t * 64);
+    const uint64_t ex = lw | ot;
+    if (lw & ot) atomicOr(bad, 1u);                      // a base in a run of both kinds: not an image this library wrote
+    if (ex) {
+        exc_plane[exc_slot(t)] = ex;
+        if (t >= 8) exc_plane[exc_slot(t - 8) + 8] = ex;
+    }
+    lower_plane[t] = lw;
+    const uint64_t flags = __ballot(ex != 0);
+    if ((threadIdx.x & 63) == 0) {
+        coarse[t >> 6] = flags;
+        if (flags) atomicOr(&coarse2[t >> 11], 1u << ((t >> 6) & 31));
+    }
+}
+
+// runs ascend, do not overlap and end inside the genome
+__global__ void __launch_bounds__(256) runs_check_kernel(const uint64_t* __restrict__ start, const uint32_t* __restrict__ len, uint64_t n,
+                                                         uint64_t genome_bases, uint32_t* __restrict__ bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t e = start[i] + len[i];
+    if (len[i] == 0 || e > genome_bases || (i + 1 < n && start[i + 1] < e)) atomicOr(bad, 2u);
+}
+
+int genome_from_image(bf_ctx* ctx) {
+    const uint64_t n_blocks = ctx->genome_bases / 64;
+    Scope t(ctx, "genome_pack");
+    DevBuf bad;
+    BF_TRY(ensure(ctx, ctx->g_lower, (n_blocks + 1) * 8));
+    BF_TRY(ensure(ctx, bad, 16));
+    auto done = [&](int rc) {
+        release(ctx, bad); release(ctx, ctx->g_raw); release(ctx, ctx->g_lower_start); release(ctx, ctx->g_lower_len); release(ctx, ctx->g_run_len);
+        if (rc != BF_OK) ctx->n_contigs = 0;              // the staged image is gone: the next genome starts with its own begin
+        return rc;
+    };
+    uint32_t h_bad = 0;
+    const uint64_t nl = ctx->n_lower_runs, no = ctx->n_runs;
+    bool ok = hipMemsetAsync(ctx->g_lower.as<uint64_t>() + n_blocks, 0, 8, ctx->stream) == hipSuccess &&
+              hipMemsetAsync(bad.p, 0, 16, ctx->stream) == hipSuccess;
+    if (ok) {
+        if (nl) hipLaunchKernelGGL(runs_check_kernel, dim3(grid_for(nl, 256)), dim3(256), 0, ctx->stream, ctx->g_lower_start.as<uint64_t>(), ctx->g_lower_len.as<uint32_t>(), nl, ctx->genome_bases, bad.as<uint32_t>());
+        if (no) hipLaunchKernelGGL(runs_check_kernel, dim3(grid_for(no, 256)), dim3(256), 0, ctx->stream, ctx->g_run_start.as<uint64_t>(), ctx->g_run_len.as<uint32_t>(), no, ctx->genome_bases, bad.as<uint32_t>());
+        hipLaunchKernelGGL(genome_image_kernel, dim3(grid_for(n_blocks, 256)), dim3(256), 0, ctx->stream, ctx->g_raw.as<GenomeBlock>(),
+                           ctx->g_lower_start.as<uint64_t>(), ctx->g_lower_len.as<uint32_t>(), nl,
+                           ctx->g_run_start.as<uint64_t>(), ctx->g_run_len.as<uint32_t>(), no,
+                           ctx->g_blocks.as<GenomeBlock>(), ctx->g_exc.as<uint64_t>(), ctx->g_lower.as<uint64_t>(),
+                           ctx->g_coarse.as<uint64_t>(), ctx->g_coarse2.as<uint32_t>(), bad.as<uint32_t>(), n_blocks);
+        ok = hipGetLastError() == hipSuccess &&
+             hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    if (!ok) return done(fail(ctx, BF_ERR_HIP, "building the genome from its image failed"));
+    if (h_bad) return done(fail(ctx, BF_ERR_INVALID, "the genome image is damaged (its runs %s)", (h_bad & 2) ? "do not ascend or leave the genome" : "overlap"));
+    return done(BF_OK);
+}
+
 static GenomeBytes genome_bytes(const bf_ctx* ctx) {
     return GenomeBytes{ctx->g_blocks.as<GenomeBlock>(), ctx->g_exc.as<uint64_t>(), ctx->g_lower.as<uint64_t>(),
                        ctx->g_run_start.as<uint64_t>(), ctx->g_run_byte.as<uint8_t>(), ctx->n_runs};

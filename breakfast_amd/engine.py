@@ -111,6 +111,8 @@ ABI_SYMBOLS = [
     "bf_genome_begin", "bf_genome_write", "bf_genome_fill", "bf_genome_end", "bf_genome_read", "bf_submit_packed", "bf_submit_packed2",
     "bf_shard_unique_id", "bf_shard_init_rccl", "bf_shard_init_host", "bf_shard_finish", "bf_shard_result_places", "bf_shard_format_sv",
     "bf_shard_format_sv_names",
+    "bf_genome_image_write", "bf_genome_image_open", "bf_genome_image_info", "bf_genome_image_close", "bf_genome_begin_image",
+    "bf_genome_set_image",
 ]
 
 _lib = None
@@ -154,6 +156,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_genome_end.argtypes = [vp]
     lib.bf_genome_fill.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, FILL_FN, vp]
     lib.bf_genome_read.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, vp]
+    lib.bf_genome_image_write.argtypes = [C.c_char_p, C.c_uint32, vp, vp, vp, C.c_uint64, C.c_int64, C.c_uint32]
+    lib.bf_genome_image_open.argtypes = [C.c_char_p, C.c_uint64, C.c_int64, C.POINTER(vp)]
+    lib.bf_genome_image_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
+    lib.bf_genome_image_close.argtypes = [vp]
+    lib.bf_genome_image_close.restype = None
+    lib.bf_genome_begin_image.argtypes = [vp, C.c_uint32, vp, vp]
+    lib.bf_genome_set_image.argtypes = [vp, vp]
     lib.bf_submit.argtypes = [vp, C.POINTER(BfBatch)]
     lib.bf_submit_packed.argtypes = [vp, C.POINTER(BfPackedBatch)]
     lib.bf_submit_packed2.argtypes = [vp, C.POINTER(BfPacked2Batch)]
@@ -481,6 +490,47 @@ def make_batch(seqs: Sequence[bytes], frags: Sequence[bytes],
                  np.frombuffer(b"".join(frags), np.uint8).copy(), fo, h)
 
 
+def write_genome_image(path: str, names: Sequence[bytes], seqs: Sequence[np.ndarray], src_size: int = 0, src_mtime_ns: int = 0,
+                       threads: int = 0) -> None:
+    """bf_genome_image_write: host only (no GPU is touched)."""
+    lib = load_library()
+    n = len(names)
+    arrs = [np.ascontiguousarray(np.frombuffer(s, np.uint8) if isinstance(s, (bytes, bytearray)) else s, dtype=np.uint8) for s in seqs]
+    c_names = (C.c_char_p * n)(*[bytes(x) for x in names])
+    c_seqs = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
+    c_lens = (C.c_uint64 * n)(*[a.size for a in arrs])
+    rc = lib.bf_genome_image_write(os.fsencode(path), n, c_names, c_seqs, c_lens, src_size, src_mtime_ns, threads)
+    if rc < 0:
+        raise BreakfastError(rc, (lib.bf_last_error(None) or b"").decode())
+
+
+class GenomeImage:
+    """bf_genome_image_open / _info / _close."""
+
+    def __init__(self, path: str, src_size: int = 0, src_mtime_ns: int = 0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.bf_genome_image_open(os.fsencode(path), src_size, src_mtime_ns, C.byref(self.h))
+        if rc < 0:
+            raise BreakfastError(rc, (self.lib.bf_last_error(None) or b"").decode())
+        n, names, lens, up = C.c_uint32(), C.POINTER(C.c_char_p)(), C.POINTER(C.c_uint64)(), C.c_uint64()
+        self.lib.bf_genome_image_info(self.h, C.byref(n), C.byref(names), C.byref(lens), C.byref(up))
+        self.names = [names[i] for i in range(n.value)]
+        self.lens = [int(lens[i]) for i in range(n.value)]
+        self.upload_bytes = int(up.value)
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.bf_genome_image_close(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """One bf_ctx = one GPU.  Mirrors the stages of detect::main (detect.rs:39-242)."""
 
@@ -523,6 +573,14 @@ class Engine:
         c_seqs = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
         c_lens = (C.c_uint64 * n)(*[a.size for a in arrs])
         self._check(self.lib.bf_genome_set(self.h, n, c_names, c_seqs, c_lens))
+
+    def set_genome_image(self, img: "GenomeImage", begin_first: bool = False) -> None:
+        """bf_genome_set_image (begin_first: bf_genome_begin_image before it, as a caller does that submits reads meanwhile)."""
+        self.contig_names = list(img.names)
+        if begin_first:
+            n = len(img.names)
+            self._check(self.lib.bf_genome_begin_image(self.h, n, (C.c_char_p * n)(*img.names), (C.c_uint64 * n)(*img.lens)))
+        self._check(self.lib.bf_genome_set_image(self.h, img.h))
 
     def genome_read(self, contig: int, offset: int, n: int) -> np.ndarray:
         """bf_genome_read: the bytes of a piece of a contig, rebuilt from the packed images."""

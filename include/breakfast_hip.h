@@ -35,7 +35,8 @@ enum {
     BF_ERR_HIP = -3,         /* a HIP runtime call failed                           */
     BF_ERR_STATE = -4,       /* call sequence violated (e.g. submit before genome)  */
     BF_ERR_RANGE = -5,       /* value outside the supported range (see limits)      */
-    BF_ERR_NOMEM = -6
+    BF_ERR_NOMEM = -6,
+    BF_ERR_IO = -7           /* a file cannot be read or written, or is not what was asked for (genome images) */
 };
 
 /* Supported ranges (violations -> BF_ERR_RANGE / BF_ERR_INVALID, never silent truncation):
@@ -196,6 +197,30 @@ int bf_genome_end(bf_ctx* ctx);
  * given for [offset, offset + n), case and every byte outside ACGT included (the reference's genome[chr][i],
  * detect.rs:118-130; rebuilt on the device from the packed form, copied to `out` in host memory).  For checks. */
 int bf_genome_read(bf_ctx* ctx, uint32_t contig, uint64_t offset, uint64_t n, uint8_t* out);
+
+/* ---- the genome as a packed image ------------------------------------------------------------
+ * No counterpart in the reference, which reads the FASTA on every run (detect.rs:48-56); the counterpart in its
+ * world is Bowtie's index beside the FASTA.  An image holds what the GPU keeps of a genome -- 2 bits a base, the runs
+ * of lower-case letters, the runs of every other byte -- so that 0.8 GB instead of hg38's 3.1 GB cross PCIe and nothing
+ * of the FASTA is read, joined or packed again.  Every byte of the FASTA can be rebuilt from it (bf_genome_read): the
+ * results are the same bytes.  The format is described in breakfast_amd/csrc/genome_image.hip.
+ *
+ * bf_genome_image_write: host only (no GPU is touched), `threads` workers (0 = chosen from the machine).  src_size and
+ * src_mtime_ns name the file the contigs came from (st_size, st_mtim in ns; 0, 0 = unnamed): bf_genome_image_open
+ * refuses an image whose source does not match the values it is given (0, 0 = do not check).  The file is written
+ * beside its target and renamed when complete.
+ * bf_genome_image_open maps and checks the file; the tables bf_genome_image_info returns live until _close.
+ * bf_genome_set_image = bf_genome_set from an image.  Reads may be submitted while it runs on another thread when
+ * bf_genome_begin_image has fixed the (same) contig table before.  Messages of the calls without a ctx: bf_last_error(NULL). */
+typedef struct bf_genome_image bf_genome_image;
+int bf_genome_image_write(const char* path, uint32_t n_contigs, const char* const* names, const uint8_t* const* seqs,
+                          const uint64_t* lens, uint64_t src_size, int64_t src_mtime_ns, uint32_t threads);
+int bf_genome_image_open(const char* path, uint64_t src_size, int64_t src_mtime_ns, bf_genome_image** out);
+int bf_genome_image_info(const bf_genome_image* img, uint32_t* n_contigs, const char* const** names, const uint64_t** lens,
+                         uint64_t* upload_bytes);
+void bf_genome_image_close(bf_genome_image* img);
+int bf_genome_begin_image(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint64_t* lens);
+int bf_genome_set_image(bf_ctx* ctx, const bf_genome_image* img);
 
 /* ---- the hot path -------------------------------------------------------------------------- */
 

@@ -2,6 +2,8 @@
 every uploaded piece (the reference consumes reads as they arrive, detect.rs:76-188).  However a read set is cut
 into batches and pieces, pinned or pageable, the .sv must be the oracle's, byte for byte.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -432,6 +434,87 @@ def test_every_byte_of_the_genome_can_be_rebuilt():
                 assert ((ev["flags"] & engine.BF_EV_EXACT) != 0).sum() < b.n
         finally:
             e2.close()
+
+
+@pytest.mark.parametrize("begin_first", [False, True])
+def test_genome_from_its_image(tmp_path, begin_first):
+    """bf_genome_image_write -> bf_genome_image_open -> bf_genome_set_image: the resident genome is the one bf_genome_set
+    builds from the bytes (every byte read back; the oracle's stdout on reads over N runs, lower case and IUPAC letters,
+    packed kernel and byte-exact kernel), with 0.26 of the bytes on the wire."""
+    import test_genome_image as tgi
+    names, seqs = tgi.case_genome(seed=21)
+    path = str(tmp_path / "g.bf2bit")
+    engine.write_genome_image(path, names, seqs)
+    img = engine.GenomeImage(path)
+    assert img.upload_bytes < 0.4 * sum(s.size for s in seqs)          # (a genome dense in odd bytes; hg38: 0.27)
+    big = [0, 7, 8, 9]
+    g = synth.Genome([names[i] for i in big], [seqs[i] for i in big])
+    spec = synth.ReadSpec(n_reads=6000, read_len=100, anchor_len=20, n_events=150, singleton_frac=0.3, seed=9, margin=300)
+    b = synth.make_reads(g, spec)
+    low = (b.seq_bytes >= ord("a")) & (b.seq_bytes <= ord("z"))
+    b.seq_bytes[low] &= np.uint8(0xDF)
+    b.hits["contig5"] = np.asarray(big, np.uint32)[b.hits["contig5"]]          # contig ids of the whole genome
+    b.hits["contig3"] = np.asarray(big, np.uint32)[b.hits["contig3"]]
+    ref = ol.detect_batch(ol.OracleGenome(names, seqs), names, b, 20, 5000, 2)
+    assert ref.n_clusters > 0
+    try:
+        for flags in (0, engine.BF_FLAG_FORCE_EXACT):
+            eng = engine.Engine(20, 5000, 2, flags=flags)
+            try:
+                if begin_first:
+                    eng.set_genome(names[:2], seqs[:2])                        # another genome first: the ctx starts over
+                eng.set_genome_image(img, begin_first=begin_first)
+                for c, s_ in enumerate(seqs):
+                    assert np.array_equal(eng.genome_read(c, 0, s_.size), s_), names[c]
+                eng.submit(b)
+                assert eng.format_sv(eng.finish()) == ref.sv
+                eng.reset()
+                eng.set_genome(names, seqs)                                    # and back to the bytes
+                eng.submit(b)
+                assert eng.format_sv(eng.finish()) == ref.sv
+            finally:
+                eng.close()
+    finally:
+        img.close()
+
+
+def test_damaged_images_are_refused_by_the_device_checks(tmp_path):
+    """Tables that pass the file checks (sizes, sections) but do not ascend, overlap or leave the genome."""
+    import struct
+    import test_genome_image as tgi
+    names, seqs = tgi.case_genome(seed=22)
+    path = str(tmp_path / "g.bf2bit")
+    engine.write_genome_image(path, names, seqs)
+    raw = bytearray(open(path, "rb").read())
+    f = tgi.HEADER.unpack(bytes(raw[:192]))
+    n_lower, n_other, off_lower_start, off_other_start = f[6], f[7], f[13], f[15]
+    assert n_lower > 10 and n_other > 10
+
+    def with_word(off, value):
+        d = bytearray(raw); d[off:off + 8] = struct.pack("<Q", value); return bytes(d)
+    first_other = struct.unpack("<Q", raw[off_other_start:off_other_start + 8])[0]
+    cases = {"descending": with_word(off_lower_start + 8 * 5, 0), "outside": with_word(off_lower_start + 8 * (n_lower - 1), 1 << 40),
+             "both_kinds": with_word(off_lower_start, first_other)}
+    eng = engine.Engine(20, 5000, 2)
+    try:
+        for name, data in cases.items():
+            p = str(tmp_path / name)
+            open(p, "wb").write(data)
+            img = engine.GenomeImage(p)
+            with pytest.raises(engine.BreakfastError) as e:
+                eng.set_genome_image(img)
+            assert "damaged" in str(e.value), name
+            img.close()
+        img = engine.GenomeImage(path)                                         # the ctx is still good for a sound image
+        eng.set_genome_image(img)
+        assert np.array_equal(eng.genome_read(0, 0, seqs[0].size), seqs[0])
+        img.close()
+        with pytest.raises(engine.BreakfastError):                             # bytes after bf_genome_begin_image
+            n = len(names)
+            eng._check(eng.lib.bf_genome_begin_image(eng.h, n, (C.c_char_p * n)(*names), (C.c_uint64 * n)(*[x.size for x in seqs])))
+            eng._check(eng.lib.bf_genome_write(eng.h, 0, 0, seqs[0].ctypes.data, 10))
+    finally:
+        eng.close()
 
 
 def test_genome_fill_limits():
