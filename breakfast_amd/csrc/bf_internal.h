@@ -398,7 +398,7 @@ struct bf_ctx {
     bf::Timing timing;
     void* timing_pending = nullptr;             // std::vector<PendingEvent>* (api.hip)
     bf::DevBuf r_idx, r_off, r_bytes;           // bf_render_junctions staging
-    uint64_t device_bytes = 0;
+    std::atomic<uint64_t> device_bytes{0};       // (bf_genome_write_image allocates beside bf_submit)
 };
 
 namespace bf {

@@ -406,6 +406,23 @@ static bool can_reread(int fd) {
     return fd > 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
 }
 
+// The packed image of <genome>.fa, if `breakfast-hip index` has made one and the FASTA has not changed since (size and
+// modification time are kept in the image): 0.27 of the bytes go to the GPU and the FASTA is not read at all.
+static std::string genome_image_path(const std::string& genome_path) { return genome_path + ".bf2bit"; }
+static int64_t mtime_ns(const struct stat& st) { return (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec; }
+static bf_genome_image* open_genome_image(const std::string& genome_path) {
+    if (getenv("BREAKFAST_HIP_NO_IMAGE")) return nullptr;                       // (A/B switch)
+    struct stat st;
+    if (stat((genome_path + ".fa").c_str(), &st) != 0) return nullptr;          // the FASTA path reports it
+    bf_genome_image* img = nullptr;
+    if (bf_genome_image_open(genome_image_path(genome_path).c_str(), (uint64_t)st.st_size, mtime_ns(st), &img) != BF_OK) {
+        if (access(genome_image_path(genome_path).c_str(), F_OK) == 0)
+            fprintf(stderr, "WARNING: %s (reading the FASTA instead; `breakfast-hip index` makes a new image)\n", bf_last_error(nullptr));
+        return nullptr;
+    }
+    return img;
+}
+
 // `breakfast-hip detect --gpus=N`: the reads are parsed into host memory, cut into N contiguous input ranges (the
 // reference's tie-breaks are input order, detect.rs:193-198, so rank r must hold the reads before rank r+1's), and
 // every range is driven by its own thread and ctx through the library's sharded path.  Rows are merged for printing
@@ -420,11 +437,18 @@ static int detect_sharded(const bf_config& cfg0, const std::vector<int>& devices
     char shm_name[64];
     snprintf(shm_name, sizeof shm_name, "/breakfast_hip_%d", (int)getpid());
 
-    Fasta fa = read_fasta(genome_path + ".fa", threads);
+    bf_genome_image* image = open_genome_image(genome_path);
+    Fasta fa;
+    if (!image) fa = read_fasta(genome_path + ".fa", threads);
     fprintf(stderr, "Reading reference genome into memory...\n");
-    timing.lap("fasta_load");
+    timing.lap(image ? "image_open" : "fasta_load");
     hits::ContigIndex contigs;
     std::vector<const char*> names; std::vector<const uint8_t*> seqs;
+    if (image) {
+        uint32_t n = 0; const char* const* nm = nullptr;
+        bf_genome_image_info(image, &n, &nm, nullptr, nullptr);
+        for (uint32_t i = 0; i < n; i++) { names.push_back(nm[i]); contigs.add(nm[i], i); }
+    }
     for (size_t i = 0; i < fa.names.size(); i++) {
         names.push_back(fa.names[i].c_str());
         seqs.push_back((const uint8_t*)fa.seqs[i].get());
@@ -486,7 +510,7 @@ static int detect_sharded(const bf_config& cfg0, const std::vector<int>& devices
             // 1. everything local: ctx, genome, this rank's reads (bf_last_error(NULL) is per thread)
             bool ok = check(bf_ctx_create(&cfg, &ctxs[r]));
             ctx = ctxs[r];
-            ok = ok && check(bf_genome_set(ctx, (uint32_t)names.size(), names.data(), seqs.data(), fa.lens.data()));
+            ok = ok && check(image ? bf_genome_set_image(ctx, image) : bf_genome_set(ctx, (uint32_t)names.size(), names.data(), seqs.data(), fa.lens.data()));
             for (size_t k = 0; ok && k < all.size(); k++) {          // the parts of the parsed batches inside [lo, hi)
                 const uint64_t a = std::max(lo, first[k]), b = std::min(hi, first[k + 1]);
                 if (a < b) ok = check(submit_parsed(ctx, all[k], a - first[k], b - first[k]));
@@ -514,6 +538,7 @@ static int detect_sharded(const bf_config& cfg0, const std::vector<int>& devices
     write_all(1, out.get(), (size_t)size);
     timing.lap("write_stdout");
     for (bf_ctx* c : ctxs) bf_ctx_destroy(c);
+    bf_genome_image_close(image);
     return 0;
 }
 
@@ -535,18 +560,20 @@ int main(int argc, char** argv) {
     if (argc >= 2 && strcmp(argv[1], "annotate") == 0) return annotate_main(argc, argv);    // main.rs:27
     const bool anchors_only = argc >= 2 && strcmp(argv[1], "anchors") == 0;
     const bool hits_only = argc >= 2 && strcmp(argv[1], "hits") == 0;
-    if (argc < 2 || (strcmp(argv[1], "detect") != 0 && !anchors_only && !hits_only)) {
+    const bool index_only = argc >= 2 && strcmp(argv[1], "index") == 0;
+    if (argc < 2 || (strcmp(argv[1], "detect") != 0 && !anchors_only && !hits_only && !index_only)) {
         fputs("\nBreakfast is a software for detecting chromosomal rearrangements in DNA/RNA sequencing data.\n\n"
               "Usage:\n  breakfast-hip detect [options] <bam_file> <genome>\n  breakfast-hip filter [options] <sample_sheet>\n"
               "  breakfast-hip annotate <sv_path> <bed_path>\n  breakfast-hip anchors [--anchor-len=N] <bam_file>\n"
-              "  breakfast-hip hits [--threads=N] [--block-bytes=N] <hits_file> <genome>\n", stderr);
+              "  breakfast-hip hits [--threads=N] [--block-bytes=N] <hits_file> <genome>\n"
+              "  breakfast-hip index [--threads=N] <genome>      (writes <genome>.bf2bit beside <genome>.fa; detect uses it)\n", stderr);
         return -1;
     }
     // `detect` does its work in a child process, started before anything touches the GPU.  When the output is written
     // the child says so and the parent returns; releasing 10 GB of device memory, the pinned buffers and the runtime
     // (0.18 s for configs[1], most of it inside the driver after exit) then happens behind the caller's back instead of
     // in front of it.  A child that ends without saying so hands its exit status on.  BREAKFAST_HIP_NO_DETACH=1: one process.
-    if (!anchors_only && !hits_only && !getenv("BREAKFAST_HIP_NO_DETACH")) {
+    if (!anchors_only && !hits_only && !index_only && !getenv("BREAKFAST_HIP_NO_DETACH")) {
         int pfd[2];
         if (pipe2(pfd, O_CLOEXEC) == 0) {                   // (not for Bowtie to inherit)
             fflush(stdout); fflush(stderr);
@@ -625,6 +652,24 @@ int main(int argc, char** argv) {
             bam::dispatch_reads(*bam, stdout, cfg.anchor_len);
         } catch (const std::exception& e) { error("Failed reading BAM record: %s", e.what()); }   // common.rs:64
         fflush(stdout);
+        return 0;
+    }
+    if (index_only) {
+        // <genome>.fa -> <genome>.bf2bit, the packed image `detect` hands to the GPU instead of the FASTA (host work only)
+        if (pos.size() != 1) error("Invalid arguments.\nUsage:\n  breakfast-hip index [--threads=N] <genome>");
+        const std::string fa_path = pos[0] + ".fa";
+        struct stat st;
+        if (stat(fa_path.c_str(), &st) != 0) error("Genome FASTA file %s could not be read.", fa_path.c_str());
+        Fasta fa = read_fasta(fa_path, threads);
+        if (fa.names.empty()) error("Genome FASTA file %s holds no sequences.", fa_path.c_str());
+        timing.lap("fasta_load");
+        std::vector<const char*> names; std::vector<const uint8_t*> seqs;
+        for (size_t i = 0; i < fa.names.size(); i++) { names.push_back(fa.names[i].c_str()); seqs.push_back((const uint8_t*)fa.seqs[i].get()); }
+        if (bf_genome_image_write(genome_image_path(pos[0]).c_str(), (uint32_t)names.size(), names.data(), seqs.data(), fa.lens.data(),
+                                  (uint64_t)st.st_size, mtime_ns(st), (uint32_t)threads) != BF_OK)
+            error("%s", bf_last_error(nullptr));
+        timing.lap("pack_and_write");
+        timing.print();
         return 0;
     }
     if (hits_only) {
@@ -742,12 +787,22 @@ int main(int argc, char** argv) {
         double ctx_at = 0, ready_at = 0, first_submit_at = 0;      // seconds since the process started (--timing)
         auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - timing.t0).count(); };
         std::thread ctx_thread([&] { if (bf_ctx_create(&cfg, &ctx) != BF_OK) ctx_error = bf_last_error(nullptr); ctx_at = since_start(); });
-        auto fs = scan_fasta(genome_path + ".fa", threads);
+        bf_genome_image* image = open_genome_image(genome_path);
+        std::unique_ptr<FastaScan> fs;
+        if (!image) fs = scan_fasta(genome_path + ".fa", threads);
         if (announce) fprintf(stderr, "Reading reference genome into memory...\n");
-        timing.lap("fasta_scan");
+        timing.lap(image ? "image_open" : "fasta_scan");
         hits::ContigIndex contigs;
         std::vector<const char*> names;
-        for (size_t i = 0; i < fs->names.size(); i++) { names.push_back(fs->names[i].c_str()); contigs.add(fs->names[i], (uint32_t)i); }
+        const uint64_t* contig_lens = nullptr;
+        if (image) {
+            uint32_t n = 0; const char* const* nm = nullptr;
+            bf_genome_image_info(image, &n, &nm, &contig_lens, nullptr);
+            for (uint32_t i = 0; i < n; i++) { names.push_back(nm[i]); contigs.add(nm[i], i); }
+        } else {
+            for (size_t i = 0; i < fs->names.size(); i++) { names.push_back(fs->names[i].c_str()); contigs.add(fs->names[i], (uint32_t)i); }
+            contig_lens = fs->lens.data();
+        }
         if (names.empty()) error("Genome FASTA file %s.fa holds no sequences.", genome_path.c_str());
         contigs.build();
         // half of the threads parse, a quarter joins and uploads the FASTA, the rest is for bf_submit's checks, the submit
@@ -769,7 +824,8 @@ int main(int argc, char** argv) {
         std::thread genome_thread([&] {
             ctx_thread.join();
             if (!ctx) error("%s", ctx_error.c_str());
-            if (bf_genome_begin(ctx, (uint32_t)names.size(), names.data(), fs->lens.data()) != BF_OK) error("%s", bf_last_error(ctx));
+            if ((image ? bf_genome_begin_image(ctx, (uint32_t)names.size(), names.data(), contig_lens)
+                       : bf_genome_begin(ctx, (uint32_t)names.size(), names.data(), contig_lens)) != BF_OK) error("%s", bf_last_error(ctx));
             // a hit list in a file: the resident arrays are sized once from a sample of its first lines (growing them
             // later waits for all queued work and copies what is there)
             struct stat hst;
@@ -801,7 +857,8 @@ int main(int argc, char** argv) {
             { std::lock_guard<std::mutex> g(gpu_mu); gpu_ready = true; }
             gpu_cv.notify_all();
             const auto t0 = std::chrono::steady_clock::now();
-            stream_fasta(*fs, g_threads, ctx);
+            if (image) (void)bf_genome_write_image(ctx, image);          // (bf_genome_end repeats its error)
+            else stream_fasta(*fs, g_threads, ctx);
             genome_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         });
 
@@ -867,6 +924,7 @@ int main(int argc, char** argv) {
                 { std::lock_guard<std::mutex> g(mu); queue.clear(); done = true; cv.notify_all(); }
                 submitter.join();
                 genome_thread.join();
+                bf_genome_image_close(image);
                 spent.clear(); in_flight.clear();          // they live in the ctx's pinned memory
                 popt.allocator = nullptr;
                 bf_ctx_destroy(ctx);
@@ -888,6 +946,7 @@ int main(int argc, char** argv) {
         genome_thread.join();
         if (bf_genome_end(ctx) != BF_OK) error("%s", bf_last_error(ctx));
         fs.reset();                                                 // the genome now lives in HBM
+        bf_genome_image_close(image);
         timing.lap("genome_to_hbm_tail");
         timing.add("  genome_stream_beside_the_parser", genome_s);
 

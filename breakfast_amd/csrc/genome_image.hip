@@ -7,6 +7,7 @@
 //   bf_genome_image_write   host only: contigs -> file
 //   bf_genome_image_open    maps and checks a file (size and sections, the source's size and mtime)
 //   bf_genome_set_image     uploads it (pinned slots, a few host threads) and builds the resident planes on the GPU
+//                           (= bf_genome_begin_image + bf_genome_write_image + bf_genome_end)
 //
 // File (little-endian, sections 64-byte aligned): header, contig lengths u64[n], name offsets u32[n+1], names,
 // blocks {lo u64, hi u64}[n_blocks] (bit k of lo/hi = bit 0/1 of the code (byte >> 1) & 3 of base 64*block + k; contig i
@@ -284,15 +285,15 @@ int bf_genome_image_info(const bf_genome_image* img, uint32_t* n_contigs, const 
     return BF_OK;
 }
 
-int bf_genome_set_image(bf_ctx* ctx, const bf_genome_image* img) {
+int bf_genome_write_image(bf_ctx* ctx, const bf_genome_image* img) {
     if (!ctx) return BF_ERR_INVALID;
-    if (!img) return fail(ctx, BF_ERR_INVALID, "bf_genome_set_image: null image");
+    if (!img) return fail(ctx, BF_ERR_INVALID, "bf_genome_write_image: null image");
     const ImageHeader& h = img->h;
-    // after a bf_genome_begin with this very contig table (reads may already be on their way) or by itself
     bool begun = ctx->n_contigs == h.n_contigs && !ctx->genome_ready && ctx->genome_image;
     for (uint32_t i = 0; begun && i < h.n_contigs; i++)
         begun = ctx->contig_names[i] == img->name_store[i] && ctx->contig_host[i].len == img->lens[i];
-    if (!begun) BF_TRY(genome_begin(ctx, h.n_contigs, img->names.data(), img->lens, true));
+    if (!begun) return fail(ctx, BF_ERR_STATE, "bf_genome_write_image: not after a bf_genome_begin_image with this image's contigs");
+    // (no kernel reads these before bf_genome_end; bf_submit touches none of them)
     BF_TRY(ensure(ctx, ctx->g_lower_start, 8 * h.n_lower + 16)); BF_TRY(ensure(ctx, ctx->g_lower_len, 4 * h.n_lower + 16));
     BF_TRY(ensure(ctx, ctx->g_run_start, 8 * h.n_other + 16)); BF_TRY(ensure(ctx, ctx->g_run_len, 4 * h.n_other + 16));
     BF_TRY(ensure(ctx, ctx->g_run_byte, h.n_other + 16));
@@ -308,7 +309,13 @@ int bf_genome_set_image(bf_ctx* ctx, const bf_genome_image* img) {
     add(ctx->g_run_byte.p, h.off_other_byte, h.n_other);
     const size_t nt = std::max<size_t>(1, std::min<size_t>(ctx->host_threads, pieces.size()));
     std::atomic<size_t> next{0};
-    auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < pieces.size();) if (genome_stage(ctx, pieces[k].dst, pieces[k].src, pieces[k].n, nullptr, nullptr) != BF_OK) return; };
+    std::atomic<int> rc{BF_OK};
+    auto work = [&] {
+        for (size_t k; (k = next.fetch_add(1)) < pieces.size();) {
+            const int r = genome_stage(ctx, pieces[k].dst, pieces[k].src, pieces[k].n, nullptr, nullptr);
+            if (r != BF_OK) { rc = r; return; }
+        }
+    };
     if (nt <= 1) work();
     else {
         std::vector<std::thread> pool;
@@ -317,7 +324,16 @@ int bf_genome_set_image(bf_ctx* ctx, const bf_genome_image* img) {
     }
     ctx->n_lower_runs = h.n_lower;
     ctx->n_runs = (uint32_t)h.n_other;
-    return bf_genome_end(ctx);
+    return rc.load();               // (the message is kept for bf_genome_end, like bf_genome_write's)
+}
+
+int bf_genome_set_image(bf_ctx* ctx, const bf_genome_image* img) {
+    if (!ctx) return BF_ERR_INVALID;
+    if (!img) return fail(ctx, BF_ERR_INVALID, "bf_genome_set_image: null image");
+    BF_TRY(genome_begin(ctx, img->h.n_contigs, img->names.data(), img->lens, true));
+    const int rc = bf_genome_write_image(ctx, img);
+    const int rc_end = bf_genome_end(ctx);
+    return rc != BF_OK ? rc : rc_end;
 }
 
 }  // extern "C"

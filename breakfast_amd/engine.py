@@ -112,7 +112,7 @@ ABI_SYMBOLS = [
     "bf_shard_unique_id", "bf_shard_init_rccl", "bf_shard_init_host", "bf_shard_finish", "bf_shard_result_places", "bf_shard_format_sv",
     "bf_shard_format_sv_names",
     "bf_genome_image_write", "bf_genome_image_open", "bf_genome_image_info", "bf_genome_image_close", "bf_genome_begin_image",
-    "bf_genome_set_image",
+    "bf_genome_write_image", "bf_genome_set_image",
 ]
 
 _lib = None
@@ -163,6 +163,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.bf_genome_image_close.restype = None
     lib.bf_genome_begin_image.argtypes = [vp, C.c_uint32, vp, vp]
     lib.bf_genome_set_image.argtypes = [vp, vp]
+    lib.bf_genome_write_image.argtypes = [vp, vp]
     lib.bf_submit.argtypes = [vp, C.POINTER(BfBatch)]
     lib.bf_submit_packed.argtypes = [vp, C.POINTER(BfPackedBatch)]
     lib.bf_submit_packed2.argtypes = [vp, C.POINTER(BfPacked2Batch)]
@@ -575,12 +576,15 @@ class Engine:
         self._check(self.lib.bf_genome_set(self.h, n, c_names, c_seqs, c_lens))
 
     def set_genome_image(self, img: "GenomeImage", begin_first: bool = False) -> None:
-        """bf_genome_set_image (begin_first: bf_genome_begin_image before it, as a caller does that submits reads meanwhile)."""
+        """bf_genome_set_image (begin_first: in its three steps, as a caller does that submits reads meanwhile)."""
         self.contig_names = list(img.names)
         if begin_first:
             n = len(img.names)
             self._check(self.lib.bf_genome_begin_image(self.h, n, (C.c_char_p * n)(*img.names), (C.c_uint64 * n)(*img.lens)))
-        self._check(self.lib.bf_genome_set_image(self.h, img.h))
+            self._check(self.lib.bf_genome_write_image(self.h, img.h))
+            self._check(self.lib.bf_genome_end(self.h))
+        else:
+            self._check(self.lib.bf_genome_set_image(self.h, img.h))
 
     def genome_read(self, contig: int, offset: int, n: int) -> np.ndarray:
         """bf_genome_read: the bytes of a piece of a contig, rebuilt from the packed images."""

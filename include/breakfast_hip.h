@@ -210,8 +210,10 @@ int bf_genome_read(bf_ctx* ctx, uint32_t contig, uint64_t offset, uint64_t n, ui
  * refuses an image whose source does not match the values it is given (0, 0 = do not check).  The file is written
  * beside its target and renamed when complete.
  * bf_genome_image_open maps and checks the file; the tables bf_genome_image_info returns live until _close.
- * bf_genome_set_image = bf_genome_set from an image.  Reads may be submitted while it runs on another thread when
- * bf_genome_begin_image has fixed the (same) contig table before.  Messages of the calls without a ctx: bf_last_error(NULL). */
+ * bf_genome_set_image = bf_genome_set from an image; in steps, for a caller that submits reads meanwhile:
+ * bf_genome_begin_image (for bf_genome_begin: the contig table bf_genome_image_info gave), bf_genome_write_image (for the
+ * bf_genome_write calls: uploads everything, from any one thread, beside bf_submit on others), bf_genome_end.
+ * Messages of the calls without a ctx: bf_last_error(NULL). */
 typedef struct bf_genome_image bf_genome_image;
 int bf_genome_image_write(const char* path, uint32_t n_contigs, const char* const* names, const uint8_t* const* seqs,
                           const uint64_t* lens, uint64_t src_size, int64_t src_mtime_ns, uint32_t threads);
@@ -220,6 +222,7 @@ int bf_genome_image_info(const bf_genome_image* img, uint32_t* n_contigs, const 
                          uint64_t* upload_bytes);
 void bf_genome_image_close(bf_genome_image* img);
 int bf_genome_begin_image(bf_ctx* ctx, uint32_t n_contigs, const char* const* names, const uint64_t* lens);
+int bf_genome_write_image(bf_ctx* ctx, const bf_genome_image* img);
 int bf_genome_set_image(bf_ctx* ctx, const bf_genome_image* img);
 
 /* ---- the hot path -------------------------------------------------------------------------- */

@@ -447,6 +447,40 @@ def test_cli_driver_reproduces_golden(name, form, tmp_path):
     assert p.stderr.count(b"Reading reference genome into memory...") == 1
 
 
+@pytest.mark.parametrize("form", ["", "--devices=0,0"])
+@pytest.mark.parametrize("name", ["kat_survey", "hz_ref_alphabet", "hz_wrapped_coords", "hz_read_n_iupac"])
+def test_cli_driver_with_a_genome_image(name, form, tmp_path):
+    """`breakfast-hip index <genome>` writes <genome>.bf2bit beside <genome>.fa; `detect` then hands the image to the GPU
+    instead of reading the FASTA (--timing names the phase), with the same stdout; an image whose FASTA has changed since
+    is left aside with a warning, and the FASTA is read."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import GOLDEN, ROOT
+    exe = os.path.join(ROOT, "breakfast_amd", "csrc", "breakfast-hip")
+    fa, lines, (A, F, E), sv = load_golden(name)
+    prefix = str(tmp_path / "genome")
+    shutil.copy(os.path.join(GOLDEN, name + ".fa"), prefix + ".fa")
+    argv = [exe, "detect", "--timing", "--anchor-len=%d" % A, "--max-frag-len=%d" % F, "--min-evidence=%d" % E] + form.split() + \
+           ["--anchor-hits=%s.bowtie" % os.path.join(GOLDEN, name), "unused.bam", prefix]
+    p = subprocess.run(argv, capture_output=True, timeout=120)
+    assert p.returncode == 0 and p.stdout == sv and b"image_open" not in p.stderr, p.stderr.decode()
+    q = subprocess.run([exe, "index", prefix], capture_output=True, timeout=120)
+    assert q.returncode == 0 and q.stdout == b"", q.stderr.decode()
+    assert sorted(os.listdir(tmp_path)) == ["genome.bf2bit", "genome.fa"]
+    p = subprocess.run(argv, capture_output=True, timeout=120)
+    assert p.returncode == 0 and p.stdout == sv and b"image_open" in p.stderr, p.stderr.decode()
+    assert b"fasta_scan" not in p.stderr and b"fasta_load" not in p.stderr
+    p = subprocess.run(argv, capture_output=True, timeout=120, env=dict(os.environ, BREAKFAST_HIP_NO_IMAGE="1"))
+    assert p.returncode == 0 and p.stdout == sv and b"image_open" not in p.stderr
+    st = os.stat(prefix + ".fa")
+    os.utime(prefix + ".fa", ns=(st.st_atime_ns, st.st_mtime_ns + 1000))            # the FASTA was touched after the image was made
+    p = subprocess.run(argv, capture_output=True, timeout=120)
+    assert p.returncode == 0 and p.stdout == sv and b"image_open" not in p.stderr and b"WARNING: " in p.stderr and b"stale" in p.stderr
+    q = subprocess.run([exe, "index", str(tmp_path / "absent")], capture_output=True, timeout=120)
+    assert q.returncode == 255 and q.stderr.startswith(b"ERROR: ")
+
+
 def test_cli_driver_error_convention(tmp_path):
     import os
     import subprocess
