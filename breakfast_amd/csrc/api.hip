@@ -1162,8 +1162,13 @@ static int clusterise_in_groups(bf_ctx* ctx, const OwnerView& v, bool* done) {
             if (off[c + 1] > off[c]) {
                 BF_HIP(ctx, hipEventRecord(ctx->ev[1 + c], ctx->stream));
                 BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[1 + c], 0));
+                // (diagnosis: BREAKFAST_HIP_TIME_COPIES=1 puts every record copy's own duration into bf_kernel_times as "d2h")
+                static const bool time_copies = getenv("BREAKFAST_HIP_TIME_COPIES") != nullptr;
+                hipEvent_t t_a = nullptr, t_b = nullptr;
+                if (time_copies && hipEventCreate(&t_a) == hipSuccess && hipEventCreate(&t_b) == hipSuccess) (void)hipEventRecord(t_a, ctx->copy_stream);
                 BF_HIP(ctx, hipMemcpyAsync(ctx->out.junction.as<uint8_t>() + byte_base + off[c], ctx->c_jbytes.as<uint8_t>() + byte_base + off[c],
                                            off[c + 1] - off[c], hipMemcpyDeviceToHost, ctx->copy_stream));
+                if (t_a && t_b && hipEventRecord(t_b, ctx->copy_stream) == hipSuccess) pending(ctx).push_back(PendingEvent{"d2h", t_a, t_b});
             }
         }
         BF_TRY(patch_reads_off(ctx, ctx->c_joff.as<uint64_t>(), grp.nr, rd_base, byte_base));   // the table, for bf_result_reads
