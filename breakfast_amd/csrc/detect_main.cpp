@@ -776,6 +776,7 @@ int main(int argc, char** argv) {
     if (const char* e = getenv("BREAKFAST_HIP_STAGE_THREADS")) cfg.reserved[1] = (uint32_t)std::max(1, atoi(e));
     bf_ctx* ctx = nullptr;
     double genome_s = 0, submit_s = 0;
+    size_t longest_name = 0;                      // of the contigs (bounds a row's length when the table is rendered)
     // one attempt at "genome + reads into the GPU"; false when the reads have to be taken as ASCII after all
     bool announce = true;
     auto load_inputs = [&]() -> bool {
@@ -804,6 +805,7 @@ int main(int argc, char** argv) {
             contig_lens = fs->lens.data();
         }
         if (names.empty()) error("Genome FASTA file %s.fa holds no sequences.", genome_path.c_str());
+        for (const char* nm : names) longest_name = std::max(longest_name, strlen(nm));
         contigs.build();
         // half of the threads parse, a quarter joins and uploads the FASTA, the rest is for bf_submit's checks, the submit
         // thread and the reader (measured with 16 threads: 8 + 4 + 4 gives 0.285-0.294 s, 11 + 3 + 3 gives 0.298-0.306 s)
@@ -868,7 +870,10 @@ int main(int argc, char** argv) {
         // parsed batches go to a submit thread through a short queue (in input order: one producer, one consumer), so that
         // the thread that pairs lines across block boundaries is not held up while a batch is staged for the GPU
         submit_s = 0;
-        if (!getenv("BREAKFAST_HIP_PARSER_THREADS")) popt.threads = std::max(1, threads >= 8 ? threads / 2 : threads - g_threads);
+        // (with a genome image nothing joins FASTA lines: the uploader's copies take 35 ms of a quarter of the threads, the
+        // parser gets the rest but one -- 16 threads: 11 parse, parse_and_submit 0.141-0.150 -> 0.124-0.127 s)
+        if (!getenv("BREAKFAST_HIP_PARSER_THREADS"))
+            popt.threads = image ? std::max(1, threads - std::max(2, threads / 4) - 1) : std::max(1, threads >= 8 ? threads / 2 : threads - g_threads);
         {
             std::mutex mu;
             std::condition_variable cv;
@@ -973,7 +978,6 @@ int main(int argc, char** argv) {
         const int slices = nc >= 4096 ? 8 : 1;
         const size_t hdr = strlen("CHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tCHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tSUPPORTING READS\tSIGNATURE\tNOTES\n");
         std::vector<std::unique_ptr<char[]>> bufs((size_t)slices);
-        std::vector<int64_t> sizes((size_t)slices, 0);
         auto slice = [&](int k) {
             bf_result part = res;
             const uint64_t c0 = nc * (uint64_t)k / slices, c1 = nc * (uint64_t)(k + 1) / slices;
@@ -982,22 +986,44 @@ int main(int argc, char** argv) {
             part.cluster_junction_off = res.cluster_junction_off ? res.cluster_junction_off + c0 : nullptr;
             return part;
         };
+        // A slice's text is at most 4 bytes per record byte (two bytes of a record are eight bases) plus a '|' and a ';' per
+        // read, plus a row's fixed part per cluster: a buffer of that size is filled by ONE bf_format_sv call (a size query
+        // first would decode every record once more: 17 of 59 ms on configs[1]); untouched memory costs nothing.
         std::thread writer;
+        double fill_s = 0, wait_s = 0;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
         for (int k = 0; k < slices; k++) {
             const bf_result part = slice(k);
-            const int64_t size = bf_format_sv(ctx, &part, nullptr, 0);
+            const auto t1 = now();
+            uint64_t rec_bytes = res.junction_size, n_rd = res.n_reads;
+            if (res.cluster_junction_off && part.n_clusters) {
+                rec_bytes = part.cluster_junction_off[part.n_clusters] - part.cluster_junction_off[0];
+                n_rd = part.clusters[part.n_clusters - 1].read_end - part.clusters[0].read_begin;
+            } else if (!part.n_clusters) { rec_bytes = 0; n_rd = 0; }
+            const uint64_t bound = hdr + 4 * rec_bytes + 2 * n_rd + part.n_clusters * (2 * longest_name + 64) + 64;
+            bufs[k].reset(new char[(size_t)bound]);
+            const int64_t size = bf_format_sv(ctx, &part, bufs[k].get(), bound);
             if (size < 0) error("could not render the result");
-            bufs[k].reset(new char[(size_t)size + 1]);
-            if (bf_format_sv(ctx, &part, bufs[k].get(), (uint64_t)size) != size) error("could not render the result");
-            sizes[k] = size;
+            if ((uint64_t)size > bound) {                          // (the bound is generous; if it ever is not: the exact size)
+                bufs[k].reset(new char[(size_t)size + 1]);
+                if (bf_format_sv(ctx, &part, bufs[k].get(), (uint64_t)size) != size) error("could not render the result");
+            }
+            const auto t2 = now();
             if (writer.joinable()) writer.join();
+            const auto t3 = now();
+            fill_s += secs(t1, t2); wait_s += secs(t2, t3);
             const char* p = bufs[k].get() + (k ? hdr : 0);       // every slice starts with the header line: once is enough
             const size_t len = (size_t)size - (k ? hdr : 0);
             writer = std::thread([p, len] { write_all(1, p, len); });
         }
+        const auto t4 = now();
         if (writer.joinable()) writer.join();
+        wait_s += secs(t4, now());
+        timing.lap("format_and_write");
+        timing.add("  of_which_formatting", fill_s);
+        timing.add("  of_which_waiting_for_the_writer", wait_s);
     }
-    timing.lap("format_and_write");
     if (getenv("BREAKFAST_HIP_TEARDOWN")) { bf_ctx_destroy(ctx); timing.lap("teardown"); }
     timing.print();
     // everything is written: the process ends here and the driver reclaims the GPU memory
