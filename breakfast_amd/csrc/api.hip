@@ -1350,28 +1350,26 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t 
             off[c + 1] = sz;
         }
     };
-    {
-        const uint64_t nt = r->n_reads < (1u << 16) ? 1 : std::min<uint64_t>(max_threads, nc);
-        if (nt <= 1) sizes(0, nc);
-        else {
-            std::vector<std::thread> pool;
-            for (uint64_t t = 0; t < nt; t++) pool.emplace_back(sizes, nc * t / nt, nc * (t + 1) / nt);
-            for (auto& th : pool) th.join();
+    // One team of threads for both passes (sizes, then -- once thread 0 has added them up -- the text): a thread is started
+    // once per call, which is what a caller that renders the table slice by slice pays per slice.
+    const uint64_t nt = r->n_reads < (1u << 16) ? 1 : std::min<uint64_t>(max_threads, nc);
+    uint64_t total = 0;
+    bool do_fill = false;
+    std::vector<uint64_t> cut(nt + 1, 0);                // the text pass's ranges: equal bytes per thread
+    auto add_up = [&] {
+        off[0] = hdr;
+        for (uint64_t c = 0; c < nc; c++) off[c + 1] += off[c];
+        total = off[nc];
+        do_fill = buf && cap >= total && !bad;
+        uint64_t c0 = 0;
+        for (uint64_t t = 0; t < nt; t++) {
+            const uint64_t want = hdr + (total - hdr) * (t + 1) / nt;
+            uint64_t c1 = t + 1 == nt ? nc : (uint64_t)(std::upper_bound(off.begin(), off.end(), want) - off.begin());
+            c1 = std::min(std::max(c1, c0), nc);
+            cut[t + 1] = c1;
+            c0 = c1;
         }
-        if (bad) return BF_ERR_INVALID;
-    }
-    off[0] = hdr;
-    for (uint64_t c = 0; c < nc; c++) off[c + 1] += off[c];
-    const uint64_t total = off[nc];
-    if (!buf) return (int64_t)total;
-    if (cap < total) {                                   // truncated copy, as documented: size is still returned
-        std::string tmp((size_t)total, '\0');
-        const int64_t n = bf_format_sv(ctx, r, tmp.data(), total);
-        if (n < 0) return n;
-        memcpy(buf, tmp.data(), (size_t)cap);
-        return (int64_t)total;
-    }
-    memcpy(buf, kSvHeader, hdr);
+    };
     auto fill = [&](uint64_t c0, uint64_t c1) {
         for (uint64_t c = c0; c < c1; c++) {
             const bf_cluster& cl = r->clusters[c];
@@ -1395,19 +1393,42 @@ int64_t bf_format_sv(const bf_ctx* ctx, const bf_result* r, char* buf, uint64_t 
             *p++ = '\t'; *p++ = '\t'; *p++ = '\n';                                      // detect.rs:240
         }
     };
-    const uint64_t nt = total < (8u << 20) ? 1 : std::min<uint64_t>(max_threads, nc);
-    if (nt <= 1) { fill(0, nc); return (int64_t)total; }
-    std::vector<std::thread> pool;
-    uint64_t c0 = 0;
-    for (uint64_t t = 0; t < nt; t++) {                  // equal bytes per thread
-        const uint64_t want = hdr + (total - hdr) * (t + 1) / nt;
-        uint64_t c1 = t + 1 == nt ? nc : (uint64_t)(std::upper_bound(off.begin(), off.end(), want) - off.begin());
-        c1 = std::min(std::max(c1, c0), nc);
-        pool.emplace_back(fill, c0, c1);
-        c0 = c1;
+    if (nt <= 1) {
+        sizes(0, nc);
+        if (bad) return BF_ERR_INVALID;
+        add_up();
+        if (do_fill) { memcpy(buf, kSvHeader, hdr); fill(0, nc); }
+    } else {
+        std::atomic<uint64_t> arrived{0};
+        std::atomic<bool> go{false};
+        auto member = [&](uint64_t t) {
+            sizes(nc * t / nt, nc * (t + 1) / nt);
+            if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == nt) {       // the last one in adds up for all
+                if (!bad) add_up();
+                go.store(true, std::memory_order_release);
+            } else {
+                for (uint32_t spins = 0; !go.load(std::memory_order_acquire); spins++)
+                    if (spins > 64) std::this_thread::yield();
+            }
+            if (do_fill) {
+                if (t == 0) memcpy(buf, kSvHeader, hdr);
+                fill(cut[t], cut[t + 1]);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (uint64_t t = 1; t < nt; t++) pool.emplace_back(member, t);
+        member(0);
+        for (auto& th : pool) th.join();
+        if (bad) return BF_ERR_INVALID;
     }
-    for (auto& th : pool) th.join();
-    return (int64_t)total;
+    if (!buf || do_fill) return (int64_t)total;
+    {                                                        // cap < total: truncated copy, as documented; the size is still returned
+        std::string tmp((size_t)total, '\0');
+        const int64_t n = bf_format_sv(ctx, r, tmp.data(), total);
+        if (n < 0) return n;
+        memcpy(buf, tmp.data(), (size_t)cap);
+        return (int64_t)total;
+    }
 }
 
 int64_t bf_junction_text(const uint8_t* record, uint64_t avail, char* buf, uint64_t cap) {

@@ -975,7 +975,8 @@ int main(int argc, char** argv) {
     fflush(stdout);
     {
         const uint64_t nc = res.n_clusters;
-        const int slices = nc >= 4096 ? 8 : 1;
+        int slices = nc >= 4096 ? 8 : 1;
+        if (const char* e = getenv("BREAKFAST_HIP_SV_SLICES")) slices = std::max(1, std::min(64, atoi(e)));    // (A/B switch)
         const size_t hdr = strlen("CHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tCHROM\tSTRAND\tPOSITION\tNEARBY FEATURES\tSUPPORTING READS\tSIGNATURE\tNOTES\n");
         std::vector<std::unique_ptr<char[]>> bufs((size_t)slices);
         auto slice = [&](int k) {
@@ -1010,11 +1011,11 @@ int main(int argc, char** argv) {
                 if (bf_format_sv(ctx, &part, bufs[k].get(), (uint64_t)size) != size) error("could not render the result");
             }
             const auto t2 = now();
+            const char* p = bufs[k].get() + (k ? hdr : 0);       // every slice starts with the header line: once is enough
+            const size_t len = (size_t)size - (k ? hdr : 0);
             if (writer.joinable()) writer.join();
             const auto t3 = now();
             fill_s += secs(t1, t2); wait_s += secs(t2, t3);
-            const char* p = bufs[k].get() + (k ? hdr : 0);       // every slice starts with the header line: once is enough
-            const size_t len = (size_t)size - (k ? hdr : 0);
             writer = std::thread([p, len] { write_all(1, p, len); });
         }
         const auto t4 = now();

@@ -481,6 +481,33 @@ def test_cli_driver_with_a_genome_image(name, form, tmp_path):
     assert q.returncode == 255 and q.stderr.startswith(b"ERROR: ")
 
 
+@pytest.mark.parametrize("slices", ["1", "3", "8"])
+def test_cli_driver_writes_into_a_file_a_pipe_and_an_appended_file(slices, tmp_path):
+    """The table is rendered slice by slice while a thread writes the slice before: into a pipe, behind what a file already
+    holds, at the end of a file opened for appending.  Same bytes every way, whatever the number of slices.  (Writing the
+    slices at their places from several threads gained nothing -- buffered writes to one file take turns in the kernel --
+    and rendering straight into the mapped file took five times as long: both measured and dropped)"""
+    import os
+    import subprocess
+    from conftest import GOLDEN, ROOT
+    exe = os.path.join(ROOT, "breakfast_amd", "csrc", "breakfast-hip")
+    name = "hz_dedup_min_evidence"
+    fa, lines, (A, F, E), sv = load_golden(name)
+    prefix = os.path.join(GOLDEN, name)
+    argv = [exe, "detect", "--anchor-len=%d" % A, "--max-frag-len=%d" % F, "--min-evidence=%d" % E,
+            "--anchor-hits=%s.bowtie" % prefix, "unused.bam", prefix]
+    env = dict(os.environ, BREAKFAST_HIP_SV_SLICES=slices)
+    assert subprocess.run(argv, capture_output=True, timeout=120, env=env).stdout == sv                    # a pipe
+    for mode in ("wb", "ab"):
+        path = tmp_path / ("out_" + mode)
+        path.write_bytes(b"")
+        with open(path, mode) as f:
+            f.write(b"# what was there before\n"); f.flush()
+            assert subprocess.run(argv, stdout=f, stderr=subprocess.PIPE, timeout=120, env=env).returncode == 0
+            f.write(b"# what came after\n")
+        assert path.read_bytes() == b"# what was there before\n" + sv + b"# what came after\n", mode
+
+
 def test_cli_driver_error_convention(tmp_path):
     import os
     import subprocess
