@@ -76,8 +76,8 @@ def claim_stdout():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=12, help="untimed steps first (a ctx copies its records at 41 instead of 54 GB/s during its first five to nine steps: DESIGN.md section 0)")
     ap.add_argument("--config", type=int, default=1, help="index into BASELINE.json configs (default 1)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink reads AND genome (smoke runs only)")
     ap.add_argument("--cpu-sample", type=int, default=6_000_000, help="reads in the CPU baseline sample (0 = skip; the default is about 11 s of one core)")
