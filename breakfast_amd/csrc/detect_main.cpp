@@ -265,8 +265,7 @@ static void stream_fasta(const FastaScan& fs, int threads, bf_ctx* ctx) {
     parallel_for(fs.pieces.size(), threads, [&](size_t i) {
         const long sl = fs.rec_slot[fs.pieces[i].rec];
         if (sl < 0 || fs.pieces[i].len == 0) return;
-        static const bool no_fill = getenv("BREAKFAST_HIP_NO_FILL") != nullptr;        // (A/B switch)
-        if (fs.pieces[i].len <= BF_GENOME_FILL_MAX && !no_fill) {
+        if (fs.pieces[i].len <= BF_GENOME_FILL_MAX) {
             Fill f{&fs, &fs.pieces[i]};
             (void)bf_genome_fill(ctx, (uint32_t)sl, fs.pieces[i].out, fs.pieces[i].len, [](void* u, uint8_t* dst, uint64_t n) {
                 const Fill* f = (const Fill*)u;
@@ -855,7 +854,7 @@ int main(int argc, char** argv) {
             }
             ready_at = since_start();
             home.ctx = ctx;
-            if (!getenv("BREAKFAST_HIP_PAGEABLE_BATCHES")) batch_home.store(&pinned_mem, std::memory_order_release);
+            batch_home.store(&pinned_mem, std::memory_order_release);
             { std::lock_guard<std::mutex> g(gpu_mu); gpu_ready = true; }
             gpu_cv.notify_all();
             const auto t0 = std::chrono::steady_clock::now();

@@ -418,9 +418,8 @@ static int scan_impl(bf_ctx* ctx, const uint32_t* in, Out* out, uint64_t n, uint
         BF_TRY(ensure(ctx, ctx->c_tmp, tiles * 8 + 256, false));
         tot = ctx->c_tmp.as<uint64_t>();
     }
-    static const bool three = getenv("BREAKFAST_HIP_SCAN3") != nullptr;        // (A/B switch)
     hipLaunchKernelGGL((scan_totals_kernel<Op>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, in, n, tot);
-    if (tiles <= kScanSelfPrefixTiles && !three) {
+    if (tiles <= kScanSelfPrefixTiles) {
         hipLaunchKernelGGL((scan_apply2_kernel<Op, Out>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, in, out, n, tot, zero_at);
     } else {
         hipLaunchKernelGGL((scan_carry_kernel<Op>), dim3(1), dim3(256), 0, ctx->stream, tot, tiles);
