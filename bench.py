@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=12, help="untimed steps first (a ctx copies its records at 41 instead of 54 GB/s during its first five to nine steps: DESIGN.md section 0)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=1, help="index into BASELINE.json configs (default 1)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink reads AND genome (smoke runs only)")
     ap.add_argument("--cpu-sample", type=int, default=6_000_000, help="reads in the CPU baseline sample (0 = skip; the default is about 11 s of one core)")
@@ -143,6 +143,14 @@ def main():
             np.add.at(mask, np.minimum(st + ln, sq.shape[0]), -1)
             sq[np.cumsum(mask[:-1]) > 0] |= 0x20
     log(rank, "genome: %d contigs, %.3f Gb in %.1fs" % (len(contigs), sum(l for _, l in contigs) / 1e9, time.time() - t0))
+    # The genome goes into HBM first, as in detect.rs (:48-56 load it before the first read is looked at), and the reads are
+    # made after that.  Not only for the order's sake: bf_genome_end releases the 3.1 GB of raw bytes the pack read, the
+    # driver clears released device memory in the background, and for the next 0.1-0.2 s device-to-host copies run at 41
+    # instead of 54 GB/s (tools/step_series4.py: a pause between the genome and the reads, and every step is a later one).
+    eng = engine.Engine(A, 5000, 2, device=local, groups=args.groups, host_threads=args.host_threads, flags=(engine.BF_FLAG_ONE_STREAM if args.one_stream else 0) | {"fused": 0, "exact": engine.BF_FLAG_FORCE_EXACT}[args.variant])
+    t2 = time.time()
+    eng.set_genome(genome.names, genome.seqs)
+    log(rank, "genome packed into HBM in %.1fs" % (time.time() - t2))
     t1 = time.time()
     strong = args.config == 2
     want_packed = args.reads == "packed" and args.variant in ("fused", "exact")
@@ -177,10 +185,6 @@ def main():
         args.no_h2h = True                             # the host-to-host legs pin a second copy of the batch: configs[1]-sized runs only
 
     # ---- resident inputs -------------------------------------------------------------------------
-    eng = engine.Engine(A, 5000, 2, device=local, groups=args.groups, host_threads=args.host_threads, flags=(engine.BF_FLAG_ONE_STREAM if args.one_stream else 0) | {"fused": 0, "exact": engine.BF_FLAG_FORCE_EXACT}[args.variant])
-    t2 = time.time()
-    eng.set_genome(genome.names, genome.seqs)
-    log(rank, "genome packed into HBM in %.1fs" % (time.time() - t2))
     t3 = time.time()
     if world > 1 or forced:
         # the sharded path runs inside the library (bf_shard_*): rank 0 makes the RCCL id, the launcher's process
@@ -330,6 +334,7 @@ def main():
             e3 = engine.Engine(A, 5000, 2, device=local, groups=args.groups if args.roh_groups < 0 else args.roh_groups, host_threads=args.host_threads,
                                flags=engine.BF_FLAG_READS_ON_HOST | (engine.BF_FLAG_ONE_STREAM if args.one_stream else 0))
             e3.set_genome(genome.names, genome.seqs)
+            time.sleep(0.5)                            # (the driver clears the raw bytes bf_genome_end released: see above)
             e3.submit(batch)
             e3.submit_wait()
             for _ in range(max(args.warmup, 1)):
