@@ -118,7 +118,7 @@ def random_case(seed, tmp_path):
     return str(fa), str(bt), A, int(rng.choice([300, 5000])), int(rng.choice([1, 2, 3]))
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(64))
 def test_independent_derivation_on_random_cases(seed, tmp_path):
     """The derivation of tests/golden/derive_tables.py (flanks as slices, closed-form mm[k], clusters as a fixed point,
     dedup from ids and scores; no code shared with oracle/) against BOTH restatements on random cases, not only on the
@@ -139,6 +139,24 @@ def test_independent_derivation_on_random_cases(seed, tmp_path):
     want = sv_from_table(t)
     assert po.detect(fa_bytes, lines.split(b"\n")[:-1], A, F, E) == want
     assert ol.detect_text(ol.OracleGenome.from_fasta(fa_bytes), lines, A, F, E).sv == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_gpu_against_the_independent_derivation_on_random_cases(seed, tmp_path):
+    """The GPU path against the third derivation directly (no restatement in between): the printed table of random cases,
+    packed kernel, byte-exact kernel and contig groups."""
+    import importlib.util
+    from breakfast_amd import engine
+    spec = importlib.util.spec_from_file_location("derive_tables", os.path.join(GOLDEN, "derive_tables.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fa, bt, A, F, E = random_case(seed, tmp_path)
+    want = sv_from_table(mod.derive_files(fa, bt, A, F, E))
+    g = po.parse_fasta(open(fa, "rb").read())
+    lines = open(bt, "rb").read().split(b"\n")[:-1]
+    for flags in (0, engine.BF_FLAG_FORCE_EXACT, engine.BF_FLAG_GROUPS_ALWAYS):
+        assert engine.detect(g, lines, A, F, E, flags=flags) == want, flags
 
 
 @pytest.mark.gpu
