@@ -508,7 +508,9 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
     // clustered.  Measured on one MI355X through RCCL, configs[1]: 7.57 ms per step against 7.93 in one go, three groups
     // 7.97 -- a group costs some sixty launches, two collectives and five host round trips.  (While a place and an offset
     // per read still travelled the copy was the longer part either way and groups bought nothing: 9.19 against 9.24.)
-    else if (max_owned >= (1ull << 22)) G = 2;
+    // (Round 3, with a third of a group's launches and half of its waits gone: 7.03 ms in one go, two groups 6.50, three
+    // 6.37, four 6.70 -- one group per 3.3M records an owner holds, as bf_finish cuts them on one GPU.)
+    else if (max_owned >= (1ull << 22)) G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(max_owned / 3300000, 2), 8);
     std::vector<uint64_t> hist;                                      // imported records per left contig rank: counted behind the import
     BF_TRY(run_import(ctx, sh->d_recv.p, src_counts.data(), G > 1 ? &hist : nullptr, (const uint8_t*)d_packed + self_off, me));
 
