@@ -463,6 +463,7 @@ extern "C++" int bf::genome_begin(bf_ctx* ctx, uint32_t n_contigs, const char* c
     ctx->genome_bases = total;
     const uint64_t n_blocks = total / 64;
     ctx->genome_image = image;
+    ctx->n_runs = 0; ctx->n_lower_runs = 0;              // (an image's tables arrive with bf_genome_write_image; none: no runs)
     BF_TRY(ensure(ctx, ctx->g_raw, image ? n_blocks * sizeof(GenomeBlock) + 64 : total + 4096));
     BF_TRY(ensure(ctx, ctx->g_blocks, block_image_slots(n_blocks) * sizeof(GenomeBlock)));
     BF_TRY(ensure(ctx, ctx->g_exc, exc_image_slots(n_blocks) * 8));

@@ -509,6 +509,12 @@ def test_damaged_images_are_refused_by_the_device_checks(tmp_path):
         eng.set_genome_image(img)
         assert np.array_equal(eng.genome_read(0, 0, seqs[0].size), seqs[0])
         img.close()
+        # bf_genome_begin_image + bf_genome_end with nothing in between: a genome of 'A's (as unwritten bytes are after
+        # bf_genome_begin), not the tables of the genome before
+        n2 = 2
+        eng._check(eng.lib.bf_genome_begin_image(eng.h, n2, (C.c_char_p * n2)(*names[:n2]), (C.c_uint64 * n2)(*[x.size for x in seqs[:n2]])))
+        eng._check(eng.lib.bf_genome_end(eng.h))
+        assert eng.genome_read(0, 0, seqs[0].size).tobytes() == b"A" * seqs[0].size
         with pytest.raises(engine.BreakfastError):                             # bytes after bf_genome_begin_image
             n = len(names)
             eng._check(eng.lib.bf_genome_begin_image(eng.h, n, (C.c_char_p * n)(*names), (C.c_uint64 * n)(*[x.size for x in seqs])))
