@@ -1142,7 +1142,7 @@ static int clusterise_in_groups(bf_ctx* ctx, const OwnerView& v, bool* done) {
             // bound (all records' bytes) came along with the first group's waits (cluster_groups itself waits for nothing)
             if (grp.m == 0) BF_SYNC(ctx, ctx->stream);             // (a group without evidence returns before its first wait)
             bound = ctx->h_mail[kMailRecordBytes];
-            BF_TRY(ensure(ctx, ctx->c_jbytes, bound ? bound : 1, false));
+            BF_TRY(ensure(ctx, ctx->c_jbytes, bound + kRenderSlack, false));    // (the render kernels run before the host has the sizes)
             BF_TRY(ensure_host(ctx, ctx->out.junction, bound));
             sized = true;
         }
@@ -1152,16 +1152,32 @@ static int clusterise_in_groups(bf_ctx* ctx, const OwnerView& v, bool* done) {
         constexpr int kMaxChunks = 2;
         const int nc = grp.nr >= (1u << 16) ? kMaxChunks : 1;
         uint64_t off[kMaxChunks + 1];
-        BF_TRY(render_prepare(ctx, grp.nr, d_idx, ctx->c_joff, nc, off, ctx->c_rsrc.as<uint32_t>() + 3 * stride + rd_base));
-        const uint64_t total = off[nc];
-        if (byte_base + total > bound) return fail(ctx, BF_ERR_HIP, "group records exceed the bound computed from all reads");
+        // The record offsets are computed on the device and the render kernels read them there; only the copies to the host
+        // need sizes.  So the chunk offsets travel to the mailbox while the render kernels are being queued and run, and the
+        // host asks for them after that (the wait in front of the render kernels was 30-40 us of idle GPU per group).
+        BF_TRY(render_prepare(ctx, grp.nr, d_idx, ctx->c_joff, nc, off, ctx->c_rsrc.as<uint32_t>() + 3 * stride + rd_base, false));
         BF_TRY(ensure(ctx, ctx->c_cjo, (cl_base + grp.ns + 1) * 8, true));                  // earlier groups' offsets stay
         BF_TRY(cluster_record_offsets(ctx, ctx->c_joff.as<uint64_t>(), ctx->c_cjo.as<uint64_t>() + cl_base, grp.ns, byte_base));
+        // (a read can print in two clusters, detect.rs:215-226, so a group's records are not bound by ALL reads' record sizes:
+        // the kernels skip what would start beyond the buffer, the check below reports it)
         for (int c = 0; c < nc; c++) {
             BF_TRY(render_range_at(ctx, grp.nr * (uint64_t)c / nc, grp.nr * (uint64_t)(c + 1) / nc, d_idx, ctx->c_joff.as<uint64_t>(),
-                                   ctx->c_jbytes.as<uint8_t>() + byte_base));
+                                   ctx->c_jbytes.as<uint8_t>() + byte_base, bound - byte_base));
+            BF_HIP(ctx, hipEventRecord(ctx->ev[1 + c], ctx->stream));
+        }
+        BF_TRY(patch_reads_off(ctx, ctx->c_joff.as<uint64_t>(), grp.nr, rd_base, byte_base));   // the table, for bf_result_reads
+        BF_TRY(render_prepare_wait(ctx, grp.nr, nc, off));
+        const uint64_t total = off[nc];
+        if (byte_base + total > bound) {
+            // more record bytes than ALL reads' records add up to (reads printed in several clusters): the buffers were
+            // sized for that sum before the first group was clustered.  The stage in one go sizes them from what is printed.
+            BF_SYNC(ctx, ctx->stream);
+            BF_SYNC(ctx, ctx->copy_stream);
+            ctx->out.n_clusters = ctx->out.n_reads = ctx->out.junction_size = 0;
+            return BF_OK;                                          // *done stays false
+        }
+        for (int c = 0; c < nc; c++) {
             if (off[c + 1] > off[c]) {
-                BF_HIP(ctx, hipEventRecord(ctx->ev[1 + c], ctx->stream));
                 BF_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[1 + c], 0));
                 // (diagnosis: BREAKFAST_HIP_TIME_COPIES=1 puts every record copy's own duration into bf_kernel_times as "d2h")
                 static const bool time_copies = getenv("BREAKFAST_HIP_TIME_COPIES") != nullptr;
@@ -1172,7 +1188,6 @@ static int clusterise_in_groups(bf_ctx* ctx, const OwnerView& v, bool* done) {
                 if (t_a && t_b && hipEventRecord(t_b, ctx->copy_stream) == hipSuccess) pending(ctx).push_back(PendingEvent{"d2h", t_a, t_b});
             }
         }
-        BF_TRY(patch_reads_off(ctx, ctx->c_joff.as<uint64_t>(), grp.nr, rd_base, byte_base));   // the table, for bf_result_reads
         cl_base += grp.ns; rd_base += grp.nr; byte_base += total;
     }
     ctx->clustered = true;

@@ -473,10 +473,13 @@ int offsets_from_lengths(bf_ctx* ctx, uint64_t n_uploaded, uint32_t max_len);   
 int grow_reads(bf_ctx* ctx, uint64_t cap);          // per-read arrays for `cap` reads, contents kept
 int settle_counts(bf_ctx* ctx);                     // n_exact / n_sigx / n_text_records valid on return
 int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, int n_chunks, uint64_t* chunk_off,
-                   const uint32_t* d_sizes = nullptr);   // d_sizes: record bytes per list entry when the caller has them
+                   const uint32_t* d_sizes = nullptr, bool wait = true);
+int render_prepare_wait(bf_ctx* ctx, uint64_t n, int n_chunks, uint64_t* chunk_off);     // after render_prepare(..., wait = false)   // d_sizes: record bytes per list entry when the caller has them
 int64_t junction_decode(const uint8_t* rec, uint64_t avail, uint8_t* out, uint64_t cap, uint64_t* stored = nullptr, const bf_ctx* ctx = nullptr);   // api.hip, host
 int render_range(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const DevBuf& d_off, DevBuf& d_bytes);
-int render_range_at(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const uint64_t* d_off, uint8_t* d_bytes);
+constexpr uint64_t kRenderSlack = 1u << 17;    // room of one junction record (a text record of a 65535-base read)
+int render_range_at(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const uint64_t* d_off, uint8_t* d_bytes,
+                    uint64_t cap = ~0ull);        // records that would start at or beyond d_bytes + cap are not written
 int run_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, DevBuf& d_bytes,
                uint64_t* total_bytes);              // junction strings for local reads
 

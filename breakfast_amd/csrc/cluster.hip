@@ -1323,10 +1323,27 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
 
     // 5. emit rows + surviving reads
     const uint64_t cl_base = grp ? grp->cl_base : 0, rd_base = grp ? grp->rd_base : 0;
-    const uint64_t stride = grp ? grp->cap : total_r;      // the per-read arrays: sized for every read when groups append
-    if (grp && rd_base + total_r > stride) return fail(ctx, BF_ERR_RANGE, "group results exceed their capacity");
+    // the per-read arrays: sized for every evidence record when groups append -- which is not a bound: a read that an
+    // earlier seed reported joins a later seed's cluster as well (detect.rs:215-226), so more reads can print than there
+    // is evidence.  Then the four planes of c_rsrc move apart (earlier groups' entries kept) and the table grows.
+    uint64_t stride = grp ? std::max<uint64_t>(grp->cap, rd_base ? ctx->rsrc_stride : 0) : total_r;
+    if (grp && rd_base + total_r > stride) {
+        const uint64_t wider = std::max(rd_base + total_r, stride + stride / 2);
+        if (rd_base) {
+            DevBuf moved;
+            BF_TRY(ensure(ctx, moved, wider * 4 * 4));
+            for (int pl = 0; pl < 4; pl++)
+                if (hipMemcpyAsync(moved.as<uint32_t>() + (size_t)pl * wider, ctx->c_rsrc.as<uint32_t>() + (size_t)pl * stride, rd_base * 4,
+                                   hipMemcpyDeviceToDevice, st) != hipSuccess) { release(ctx, moved); return fail(ctx, BF_ERR_HIP, "device copy failed"); }
+            if (hipStreamSynchronize(st) != hipSuccess) { release(ctx, moved); return fail(ctx, BF_ERR_HIP, "device copy failed"); }
+            release(ctx, ctx->c_rsrc);
+            ctx->c_rsrc = moved;
+        }
+        stride = wider;
+        grp->cap = wider;
+    }
     BF_TRY(ensure(ctx, ctx->c_clusters, (cl_base + ns) * sizeof(bf_cluster), grp != nullptr));   // earlier groups' rows stay
-    BF_TRY(ensure(ctx, ctx->c_reads, std::max<uint64_t>(grp ? stride : total_r, 1) * sizeof(bf_read)));
+    BF_TRY(ensure(ctx, ctx->c_reads, std::max<uint64_t>(grp ? stride : total_r, 1) * sizeof(bf_read), grp != nullptr && rd_base != 0));
     BF_TRY(ensure(ctx, ctx->c_rsrc, std::max<uint64_t>(stride, 1) * 4 * 4));
     ctx->rsrc_stride = stride;
     std::vector<uint64_t> bases = ctx->src_index_base;

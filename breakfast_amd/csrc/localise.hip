@@ -15,6 +15,8 @@
 
 #include "bf_internal.h"
 
+#include <chrono>
+
 namespace bf {
 
 __constant__ uint8_t kComp[256] = {
@@ -835,7 +837,7 @@ render_kernel(uint64_t n, const uint32_t* __restrict__ idx,
                                                      const uint8_t* __restrict__ seq,
                                                      const uint64_t* __restrict__ seq_off,
                                                      const uint64_t* __restrict__ meta, int meta_stride,
-                                                     uint32_t max_packed, uint8_t* __restrict__ out) {
+                                                     uint32_t max_packed, uint8_t* __restrict__ out, uint64_t cap) {
     __shared__ uint8_t comp[256];
     __shared__ uint32_t stage[16][kRenderStageDw];
     __shared__ uint64_t smask[16][kRenderMaskW];
@@ -851,6 +853,7 @@ render_kernel(uint64_t n, const uint32_t* __restrict__ idx,
     const int64_t bp = (int64_t)(tail & 0xffff), L = (int64_t)((tail >> 32) & 0xffff);
     const bool swapped = ((tail >> 16) & kEvSwapped) != 0;
     if (junction_packable((uint32_t)L, (uint32_t)(tail >> 48), max_packed)) return;      // render_packed_kernel's
+    if (joff[i] >= cap) return;                                          // (beyond the caller's buffer: the caller reports it)
     if (l16 == 0) {                                                      // text record: {head, len} + the string
         uint32_t* hd = (uint32_t*)(out + joff[i]);                       // records start on 4-byte boundaries
         hd[0] = junction_head_text(swapped, (uint32_t)bp); hd[1] = (uint32_t)L;
@@ -915,7 +918,7 @@ __global__ void __launch_bounds__(256) render_text_nibbles_kernel(uint64_t n, co
                                                                   const uint8_t* __restrict__ seq,
                                                                   const uint64_t* __restrict__ seq_off,
                                                                   const uint64_t* __restrict__ meta, int meta_stride,
-                                                                  uint32_t max_packed, uint8_t* __restrict__ out) {
+                                                                  uint32_t max_packed, uint8_t* __restrict__ out, uint64_t cap) {
     const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15;
     const uint64_t i = (uint64_t)blockIdx.x * 16 + g;
     if (i >= n) return;
@@ -926,6 +929,7 @@ __global__ void __launch_bounds__(256) render_text_nibbles_kernel(uint64_t n, co
     const int bp = (int)(tail & 0xffff), L = (int)((tail >> 32) & 0xffff);
     const bool swapped = ((tail >> 16) & kEvSwapped) != 0;
     if (junction_packable((uint32_t)L, (uint32_t)(tail >> 48), max_packed)) return;      // render_packed_kernel's
+    if (joff[i] >= cap) return;
     uint8_t* o = out + joff[i];
     if (l16 == 0) {
         uint32_t* hd = (uint32_t*)o;
@@ -957,9 +961,11 @@ __global__ void __launch_bounds__(256) render_packed_kernel(uint64_t n, const ui
                                                             const uint8_t* __restrict__ seq,
                                                             const uint64_t* __restrict__ seq_off,
                                                             const uint64_t* __restrict__ meta, int meta_stride,
-                                                            uint8_t* __restrict__ out, bool packed) {
+                                                            uint8_t* __restrict__ out, bool packed, uint64_t cap) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const uint64_t at0 = joff[i];
+    if (at0 >= cap) return;                                              // (beyond the caller's buffer: the caller reports it)
     const uint32_t r = idx[i];
     const uint64_t* __restrict__ rec = meta + (uint64_t)r * meta_stride;
     const uint64_t tail = rec[meta_stride - 1];
@@ -982,7 +988,7 @@ __global__ void __launch_bounds__(256) render_packed_kernel(uint64_t n, const ui
     for (int w = 0; w < W; w++) n_lower += (uint32_t)__popcll(cs[w]);
     const bool sparse = junction_sparse((uint32_t)L, n_lower);
     // the record as a byte stream, written a dword at a time (zero padding at the end comes with the last one)
-    uint32_t* __restrict__ o32 = (uint32_t*)(out + joff[i]);
+    uint32_t* __restrict__ o32 = (uint32_t*)(out + at0);
     uint64_t acc = 0;
     int have = 0, at = 0;
     auto put = [&](uint32_t v, int nbytes) {
@@ -1033,9 +1039,9 @@ __global__ void __launch_bounds__(256) render_packed_kernel(uint64_t n, const ui
 __global__ void __launch_bounds__(256) render_ref_kernel(uint64_t n, const uint32_t* __restrict__ idx,
                                                          const uint64_t* __restrict__ joff,
                                                          const uint64_t* __restrict__ meta, int meta_stride,
-                                                         uint8_t* __restrict__ out) {
+                                                         uint8_t* __restrict__ out, uint64_t cap) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || joff[i] >= cap) return;
     const uint32_t r = idx[i];
     const uint64_t* __restrict__ rec = meta + (uint64_t)r * meta_stride;
     // the record's first words and its tail in one round trip (the usual record has three mask words)
@@ -1457,8 +1463,11 @@ __global__ void pick_offsets_kernel(const uint64_t* __restrict__ off, uint64_t n
 
 // Junction offsets of n surviving reads (exclusive scan of len+1).  chunk_off[c] = byte offset of
 // read n*c/n_chunks, so that the caller can render and copy out the text chunk by chunk.
+// wait = false: everything is queued and the chunk offsets are on their way to the mailbox behind ctx->ev[13];
+// render_prepare_wait() brings them in -- a caller that has kernels to queue which do not need the offsets on the host (the
+// render kernels read them on the device; only the copies to the host need sizes) queues those first.
 int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf& d_off, int n_chunks,
-                   uint64_t* chunk_off, const uint32_t* d_sizes) {
+                   uint64_t* chunk_off, const uint32_t* d_sizes, bool wait) {
     for (int c = 0; c <= n_chunks; c++) chunk_off[c] = 0;
     BF_TRY(ensure(ctx, d_off, (n + 1) * 8));
     if (n == 0) {
@@ -1479,14 +1488,34 @@ int render_prepare(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, DevBuf&
     // ... into the ctx's pinned mailbox (a copy into the caller's pageable array is staged by the runtime: a round trip more)
     if (n_chunks + 1 > kMailWords - 8) return fail(ctx, BF_ERR_RANGE, "render_prepare: %d chunks", n_chunks);
     BF_TRY(mail_fetch(ctx, 8, d_pick, n_chunks + 1));
+    if (!wait) {
+        BF_HIP(ctx, hipEventRecord(ctx->ev[13], ctx->stream));
+        return BF_OK;
+    }
     BF_SYNC(ctx, ctx->stream);
+    for (int c = 0; c <= n_chunks; c++) chunk_off[c] = ctx->h_mail[8 + c];
+    return BF_OK;
+}
+
+int render_prepare_wait(bf_ctx* ctx, uint64_t n, int n_chunks, uint64_t* chunk_off) {
+    for (int c = 0; c <= n_chunks; c++) chunk_off[c] = 0;
+    if (n == 0) return BF_OK;
+    // (polled like the stream waits: the offsets are usually there before the host has queued what it had to queue)
+    hipError_t e = hipErrorNotReady;
+    const auto t0 = std::chrono::steady_clock::now();
+    while ((e = hipEventQuery(ctx->ev[13])) == hipErrorNotReady)
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+    if (e != hipSuccess && e != hipErrorNotReady) (void)hipGetLastError();
+    if (e != hipSuccess) BF_HIP(ctx, hipEventSynchronize(ctx->ev[13]));
     for (int c = 0; c <= n_chunks; c++) chunk_off[c] = ctx->h_mail[8 + c];
     return BF_OK;
 }
 
 // Junction records of n listed reads at the given (absolute) offsets: packed records by one kernel, the
 // text records of the reads that cannot be packed (too long, many bases outside ACGT) by the other.
-static int launch_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_idx, const uint64_t* d_off, uint8_t* d_bytes) {
+// cap: a record that would START at or beyond d_bytes + cap is not written (the caller's buffer ends there plus the room of
+// one record, kRenderSlack; callers that size the buffer from the offsets pass no limit)
+static int launch_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_idx, const uint64_t* d_off, uint8_t* d_bytes, uint64_t cap = ~0ull) {
     const int stride = (int)ctx->mask_words + 1;
     const uint32_t W = ctx->plane_words;
     const dim3 g(grid_for(n, 256)), b(256);
@@ -1495,20 +1524,20 @@ static int launch_render(bf_ctx* ctx, uint64_t n, const uint32_t* d_idx, const u
     const uint64_t* meta = ctx->d_mask.as<uint64_t>();
     const bool packed = ctx->packed_reads;
     if (ctx->cfg.flags & BF_FLAG_READS_ON_HOST) {
-        hipLaunchKernelGGL(render_ref_kernel, g, b, 0, ctx->stream, n, d_idx, d_off, meta, stride, d_bytes);
+        hipLaunchKernelGGL(render_ref_kernel, g, b, 0, ctx->stream, n, d_idx, d_off, meta, stride, d_bytes, cap);
         BF_HIP(ctx, hipGetLastError());
         return BF_OK;
     }
-    if (W == 2) hipLaunchKernelGGL(render_packed_kernel<2>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes, packed);
-    else if (W == 3) hipLaunchKernelGGL(render_packed_kernel<3>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes, packed);
-    else hipLaunchKernelGGL(render_packed_kernel<4>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes, packed);
+    if (W == 2) hipLaunchKernelGGL(render_packed_kernel<2>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes, packed, cap);
+    else if (W == 3) hipLaunchKernelGGL(render_packed_kernel<3>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes, packed, cap);
+    else hipLaunchKernelGGL(render_packed_kernel<4>, g, b, 0, ctx->stream, n, d_idx, d_off, seq, so, meta, stride, d_bytes, packed, cap);
     BF_TRY(settle_counts(ctx));
     if (ctx->n_text_records && packed)
         hipLaunchKernelGGL(render_text_nibbles_kernel, dim3(grid_for(n * 16, 256)), dim3(256), 0, ctx->stream, n, d_idx, d_off, seq, so,
-                           meta, stride, 64u * W, d_bytes);
+                           meta, stride, 64u * W, d_bytes, cap);
     else if (ctx->n_text_records)
         hipLaunchKernelGGL(render_kernel, dim3(grid_for(n * 16, 256)), dim3(256), 0, ctx->stream, n, d_idx, d_off, seq, so, meta,
-                           stride, 64u * W, d_bytes);
+                           stride, 64u * W, d_bytes, cap);
     BF_HIP(ctx, hipGetLastError());
     return BF_OK;
 }
@@ -1521,10 +1550,10 @@ int render_range(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_id
 }
 
 // The same with plain pointers: offsets relative to d_bytes (a group's part of the junction buffer).
-int render_range_at(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const uint64_t* d_off, uint8_t* d_bytes) {
+int render_range_at(bf_ctx* ctx, uint64_t a, uint64_t b, const uint32_t* d_local_idx, const uint64_t* d_off, uint8_t* d_bytes, uint64_t cap) {
     if (b <= a) return BF_OK;
     Scope t(ctx, "render");
-    return launch_render(ctx, b - a, d_local_idx + a, d_off + a, d_bytes);
+    return launch_render(ctx, b - a, d_local_idx + a, d_off + a, d_bytes, cap);
 }
 
 int render_sizes_checked(bf_ctx* ctx, uint64_t n, const uint32_t* d_local_idx, uint32_t* d_len, uint32_t* d_bad) {

@@ -550,7 +550,7 @@ int bf_shard_finish(bf_ctx* ctx, bf_shard_result* out) {
         // the owner's side: cluster the group
         uint64_t nr_g = 0, ns_g = 0;
         if (g < my_groups && gb[g + 1] > gb[g]) {
-            if (G == 1) {
+            if (G == 1 || my_groups == 1) {               // (an owner whose records cut into one group: cluster_groups made no id list)
                 BF_TRY(run_cluster(ctx, v));
                 nr_g = ctx->out.n_reads; ns_g = ctx->out.n_clusters;
             } else {

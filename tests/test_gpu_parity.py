@@ -740,6 +740,49 @@ def test_classes_that_share_a_signature():
     check_against_oracle(g, b, A, flags=BF_FLAG_SORTED_DEDUP)
 
 
+def case_reads_printed_twice(pile_on_last_contig, n_pile=400):
+    """detect.rs:215-226 lets a read that an earlier seed reported join a later seed's cluster as well, so the printed reads
+    can outnumber the evidence: two seeds whose right positions lie too far apart for one cluster, and a pile of reads
+    within reach of both; ordinary junctions on another contig, so that there are groups to cut -> (genome, batch, A, F)."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    A, L, F = 20, 100, 5000
+    g = synth.make_genome([("c0", 300000), ("c1", 300000), ("c2", 300000), ("c3", 300000)], seed=41)
+    cp, co = (2, 0) if pile_on_last_contig else (0, 2)     # left contigs of the pile and of the ordinary junctions (right: + 1)
+    x0, y0 = 100000, 150000
+    for dx in (1000, 2000):                                 # the left flank twice more, the right flank twice more
+        g.seqs[cp][x0 + dx - 300:x0 + dx + 300] = g.seqs[cp][x0 - 300:x0 + 300]
+    for dy in (6000, 3000):
+        g.seqs[cp + 1][y0 + dy - 300:y0 + dy + 300] = g.seqs[cp + 1][y0 - 300:y0 + 300]
+    seqs, frags, hits = [], [], []
+
+    def add_reads(cl, x1, y1, count, tag, b=50):
+        for i in range(count):
+            read = np.concatenate([g.seqs[cl][x1 - b + 1:x1 + 1], g.seqs[cl + 1][y1:y1 + L - b]]).copy()
+            seqs.append(read.tobytes())
+            frags.append(b"%s_%d" % (tag, i))
+            hits.append((x1 - b + 2, y1 + L - A - b + 1, cl, cl + 1, 3))
+    add_reads(cp, x0, y0, 3, b"s1")                         # seed 1 and company
+    add_reads(cp, x0 + 1000, y0 + 6000, 3, b"s2")           # seed 2: right positions 6000 from seed 1's, no common cluster
+    add_reads(cp, x0 + 2000, y0 + 3000, n_pile, b"both")    # within reach of both seeds: printed twice
+    for k in range(40):
+        add_reads(co, 20000 + 1000 * k, 30000 + 1000 * k, 4, b"o%d" % k, b=45)
+    order = rng.permutation(len(seqs))
+    return g, engine.make_batch([seqs[i] for i in order], [frags[i] for i in order], [hits[i] for i in order]), A, F
+
+
+@pytest.mark.parametrize("pile_on_last_contig", [False, True])
+def test_reads_printed_in_two_clusters_outgrow_the_evidence(pile_on_last_contig):
+    """More reads print than there is evidence.  Contig groups size their per-read arrays for the evidence and their record
+    buffers from ALL reads' record sizes before the first group is clustered: the arrays must grow (with earlier groups'
+    entries in them when the pile is in the last group), and the stage must fall back to one go for the records."""
+    g, b, A, F = case_reads_printed_twice(pile_on_last_contig)
+    res, ref = check_against_oracle(g, b, A, F=F)
+    assert res.reads.shape[0] > b.n                         # more printed reads than evidence
+    for flags in (BF_FLAG_GROUPS_ALWAYS, BF_FLAG_GROUPS_ALWAYS | BF_FLAG_FORCE_EXACT):
+        check_against_oracle(g, b, A, F=F, flags=flags)
+    check_against_oracle(g, b, A, F=F, flags=BF_FLAG_GROUPS_ALWAYS, packed=True)
+
+
 def test_print_order_ties_and_the_fallback_to_the_full_sort():
     """The print order is (contig, left position, input index of the seed).  The short sort orders on contig and position
     and puts seeds that share both into input order run by run: 5 clusters at one left position (a run the fix-up handles),

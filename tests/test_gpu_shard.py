@@ -259,6 +259,20 @@ def test_config2_scaled_over_ranks(world):
     assert merged(g, results, spec.anchor_len) == ref.sv
 
 
+@pytest.mark.parametrize("pile_on_last_contig", [False, True])
+@pytest.mark.parametrize("flags", [0, engine.BF_FLAG_GROUPS_ALWAYS])
+def test_more_printed_reads_than_evidence_over_ranks(pile_on_last_contig, flags):
+    """A read reported by an earlier seed joins a later seed's cluster as well (detect.rs:215-226): an owner prints more
+    reads than it holds evidence, in one go and in contig groups (whose per-read arrays were sized for the evidence)."""
+    import test_gpu_parity as tgp
+    g, b, A, F = tgp.case_reads_printed_twice(pile_on_last_contig)
+    ref = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, A, F, 2)
+    cut = b.n // 3
+    results = run_as_threads(g, [b.slice(0, cut), b.slice(cut, b.n)], [0, cut], A, F=F, flags=flags)
+    assert sum(x.src_rank.size for x in results) > b.n
+    assert merged(g, results, A, F=F) == ref.sv
+
+
 def test_eight_ranks_uneven_empty_shards_and_a_hot_class():
     """World size 8 (what configs[2] shards over): owner = mix64(class) % 8, arrival order = input order, merged print
     order; uneven shards, two of them empty, one holding a single read; a third of the reads on two hot junctions, so
