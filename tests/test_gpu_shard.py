@@ -273,6 +273,29 @@ def test_more_printed_reads_than_evidence_over_ranks(pile_on_last_contig, flags)
     assert merged(g, results, A, F=F) == ref.sv
 
 
+@pytest.mark.parametrize("seed", range(200, 224))
+def test_small_random_cases_over_ranks(seed, tmp_path):
+    """Small random cases (60-220 reads on three contigs: owners with a handful of records, with none, with records on one
+    contig only) over two and three ranks, in one go and in contig groups, against the oracle's table."""
+    import detect_oracle as po
+    import test_hand_tables as tht
+    fa, bt, A, F, E = tht.random_case(seed, tmp_path)
+    fa_bytes, lines = open(fa, "rb").read(), open(bt, "rb").read()
+    want = ol.detect_text(ol.OracleGenome.from_fasta(fa_bytes), lines, A, F, E).sv
+    gd = po.parse_fasta(fa_bytes)
+    names = list(gd.keys())
+    g = synth.Genome(names, [np.frombuffer(gd[n], np.uint8) for n in names])
+    b = engine.parse_bowtie_lines(lines.split(b"\n")[:-1], {n: i for i, n in enumerate(names)})
+    world = 2 + seed % 2
+    cuts = [b.n * r // world for r in range(world + 1)]
+    if seed % 5 == 0:
+        cuts[1] = cuts[0]                                   # a rank without reads
+    parts = [b.slice(cuts[r], cuts[r + 1]) if cuts[r + 1] > cuts[r] else None for r in range(world)]
+    for flags in (0, engine.BF_FLAG_GROUPS_ALWAYS):
+        results = run_as_threads(g, parts, cuts[:-1], A, F=F, E=E, flags=flags, timeout=100)
+        assert merged(g, results, A, F=F, E=E) == want, flags
+
+
 def test_eight_ranks_uneven_empty_shards_and_a_hot_class():
     """World size 8 (what configs[2] shards over): owner = mix64(class) % 8, arrival order = input order, merged print
     order; uneven shards, two of them empty, one holding a single read; a third of the reads on two hot junctions, so

@@ -142,7 +142,7 @@ def test_independent_derivation_on_random_cases(seed, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(100, 116))
+@pytest.mark.parametrize("seed", range(100, 132))
 def test_gpu_against_the_independent_derivation_on_random_cases(seed, tmp_path):
     """The GPU path against the third derivation directly (no restatement in between): the printed table of random cases,
     packed kernel, byte-exact kernel and contig groups."""
@@ -155,8 +155,13 @@ def test_gpu_against_the_independent_derivation_on_random_cases(seed, tmp_path):
     want = sv_from_table(mod.derive_files(fa, bt, A, F, E))
     g = po.parse_fasta(open(fa, "rb").read())
     lines = open(bt, "rb").read().split(b"\n")[:-1]
-    for flags in (0, engine.BF_FLAG_FORCE_EXACT, engine.BF_FLAG_GROUPS_ALWAYS):
+    for flags in (0, engine.BF_FLAG_FORCE_EXACT, engine.BF_FLAG_GROUPS_ALWAYS, engine.BF_FLAG_GROUPS_ALWAYS | engine.BF_FLAG_FORCE_EXACT,
+                  engine.BF_FLAG_SORTED_DEDUP, engine.BF_FLAG_WEAK_DEDUP_HASH | engine.BF_FLAG_GROUPS_ALWAYS, engine.BF_FLAG_ONE_STREAM):
         assert engine.detect(g, lines, A, F, E, flags=flags) == want, flags
+        try:                                             # the reads as 4-bit codes (lower-case reads are outside BAM's alphabet)
+            assert engine.detect(g, lines, A, F, E, flags=flags, packed=True) == want, ("packed", flags)
+        except ValueError:
+            pass
 
 
 @pytest.mark.gpu
