@@ -296,6 +296,43 @@ def test_small_random_cases_over_ranks(seed, tmp_path):
         assert merged(g, results, A, F=F, E=E) == want, flags
 
 
+def odd_case(seed):
+    """Genomes of one, two or seven contigs (names that sort unlike their order), windows that reach over contig ends,
+    max_frag_len from 0 to 2^31 - 1, min_evidence 1 to 4, everything on one contig or spread -> (genome, batch, A, F, E)."""
+    rng = np.random.default_rng(seed)
+    n_contigs = int(rng.choice([1, 2, 7]))
+    names = ["chr%d" % k for k in rng.permutation(20)[:n_contigs]]
+    contigs = [(nm, int(rng.integers(3000, 30000))) for nm in names]
+    g = synth.make_genome(contigs, seed=3000 + seed, end_n=int(rng.integers(0, 30)))
+    A = int(rng.choice([12, 20]))
+    L = int(rng.choice([2 * A + 4, 60, 100]))
+    spec = synth.ReadSpec(n_reads=int(rng.integers(20, 300)), read_len=L, anchor_len=A, n_events=int(rng.integers(1, 10)),
+                          singleton_frac=float(rng.choice([0.0, 0.3])), mate_frac=0.5, hot_frac=float(rng.choice([0.0, 0.5])), hot_events=1,
+                          subst_rate=0.02, n_rate=0.003, seed=4000 + seed, margin=0)
+    b = synth.make_reads(g, spec)
+    return g, b, A, int(rng.choice([0, 1, 50, 5000, 2 ** 31 - 1])), int(rng.integers(1, 5))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_odd_small_cases_on_one_gpu_and_over_ranks(seed):
+    g, b, A, F, E = odd_case(seed)
+    want = ol.detect_batch(ol.OracleGenome(g.names, g.seqs), g.names, b, A, F, E).sv
+    for flags in (0, engine.BF_FLAG_GROUPS_ALWAYS, engine.BF_FLAG_FORCE_EXACT | engine.BF_FLAG_GROUPS_ALWAYS):
+        eng = engine.Engine(A, F, E, flags=flags)
+        try:
+            eng.set_genome(g.names, g.seqs)
+            eng.submit(b)
+            assert eng.format_sv(eng.finish(reads=False)) == want, ("one GPU", flags)
+        finally:
+            eng.close()
+    world = 2 + seed % 2
+    cuts = [b.n * r // world for r in range(world + 1)]
+    parts = [b.slice(cuts[r], cuts[r + 1]) if cuts[r + 1] > cuts[r] else None for r in range(world)]
+    for flags in (0, engine.BF_FLAG_GROUPS_ALWAYS):
+        results = run_as_threads(g, parts, cuts[:-1], A, F=F, E=E, flags=flags, timeout=100)
+        assert merged(g, results, A, F=F, E=E) == want, ("ranks", flags)
+
+
 def test_eight_ranks_uneven_empty_shards_and_a_hot_class():
     """World size 8 (what configs[2] shards over): owner = mix64(class) % 8, arrival order = input order, merged print
     order; uneven shards, two of them empty, one holding a single read; a third of the reads on two hot junctions, so
