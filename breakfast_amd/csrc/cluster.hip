@@ -261,10 +261,13 @@ __global__ void compact_seeds_kernel(const uint32_t* __restrict__ flag, const ui
     }
 }
 // out[k] = value[i] (or i) of the k-th flagged i; with `look`: out2[k] = look[out[k]] as well (one launch instead of two)
+// keep_total: scan[n], the number of flagged entries, is left there for kernels queued behind (the scan array is reused)
 __global__ void compact_index_kernel(const uint32_t* __restrict__ flag, const uint64_t* __restrict__ scan,
                                      uint32_t* out, uint64_t n, const uint32_t* __restrict__ value = nullptr,
-                                     const uint32_t* __restrict__ look = nullptr, uint32_t* __restrict__ out2 = nullptr) {
+                                     const uint32_t* __restrict__ look = nullptr, uint32_t* __restrict__ out2 = nullptr,
+                                     unsigned long long* __restrict__ keep_total = nullptr) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && keep_total) *keep_total = scan[n];
     if (i < n && flag[i]) {
         const uint32_t x = value ? value[i] : (uint32_t)i;
         out[scan[i]] = x;
@@ -652,10 +655,14 @@ struct EmitView {
 
 // One wave per reported cluster: the printed row (detect.rs:233-235) and its surviving reads in
 // cluster order (a group's representative sits at the slot of the group's first member, :284).
-__global__ void __launch_bounds__(256) emit_kernel(const EmitView e, uint64_t ns) {
+// The number of surviving clusters is read on the device (the grid is sized for the qualifying ones), so that the kernel can be
+// queued before the host has the counts; when the reads to print do not fit what is left of the per-read arrays it writes
+// nothing (the host sees the count, makes room and launches it again).
+__global__ void __launch_bounds__(256) emit_kernel(const EmitView e, const unsigned long long* __restrict__ ns_dev, uint64_t room) {
     const uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (k >= ns) return;
+    const uint64_t ns = *ns_dev;
+    if (k >= ns || e.roff[ns] > room) return;
     const uint32_t q = e.ord[k];
     const uint64_t base = e.qoff[q];
     const uint32_t c = e.qsize[q];
@@ -1294,6 +1301,10 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
     BF_HIP(ctx, hipGetLastError());
 
     // 4. surviving clusters in the reference's print order: the survivors of the order computed beside the dedup
+    // 5. emit rows + surviving reads.  In contig groups emit is queued BEFORE the host knows how many clusters survive and how
+    //    many reads print (it reads the count on the device; its grid and the row buffer are sized for the qualifying
+    //    clusters, the per-read arrays have the group's capacity): the round trip for the counts runs beside it instead of
+    //    in front of it (round 3: 0.1 ms of idle GPU per group, select and emit being a dozen launches of a few us each).
     uint64_t ns = 0, total_r = 0;
     BF_TRY(ensure(ctx, ctx->c_flag, std::max(nq, n) * 4, false));
     BF_TRY(ensure(ctx, ctx->c_ord, nq * 4));
@@ -1301,6 +1312,56 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
         Scope t(ctx, "order_wait");                      // what the main stream idles for the print-order sorts on the side stream
         BF_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[12], 0));
     }
+    const uint64_t cl_base = grp ? grp->cl_base : 0, rd_base = grp ? grp->rd_base : 0;
+    unsigned long long* ns_dev = (unsigned long long*)(ctx->c_big.as<uint32_t>() + 14);      // a control word pair nothing else uses
+    uint32_t* d_rank2id = nullptr;
+    auto tables = [&]() -> int {
+        // the two small tables emit reads (index base per source rank, contig id per rank): uploaded when they change, not
+        // per call (two copies from pageable memory in front of every emit were two round trips)
+        std::vector<uint64_t> bases = ctx->src_index_base;
+        if (bases.empty()) bases.assign(1, ctx->index_base);
+        std::vector<uint64_t> key = bases;
+        key.push_back(ctx->n_contigs);
+        for (uint32_t r = 0; r < ctx->n_contigs; r++) key.push_back(ctx->contig_by_rank[r]);
+        const size_t need = bases.size() * 8 + (size_t)ctx->n_contigs * 4 + 16;
+        const bool fresh = ctx->c_tables.cap < need || key != ctx->tables_key;
+        BF_TRY(ensure(ctx, ctx->c_tables, need));
+        d_rank2id = (uint32_t*)((uint8_t*)ctx->c_tables.p + bases.size() * 8);
+        if (fresh) {
+            BF_HIP(ctx, hipMemcpyAsync(ctx->c_tables.p, bases.data(), bases.size() * 8, hipMemcpyHostToDevice, st));
+            BF_HIP(ctx, hipMemcpyAsync(d_rank2id, ctx->contig_by_rank.data(), (size_t)ctx->n_contigs * 4, hipMemcpyHostToDevice, st));
+            BF_SYNC(ctx, st);                             // (the sources are host vectors)
+            ctx->tables_key = key;
+        }
+        return BF_OK;
+    };
+    auto emit = [&](uint64_t rows, uint64_t stride) -> int {          // rows: how many the row buffer must hold beyond cl_base
+        BF_TRY(ensure(ctx, ctx->c_clusters, (cl_base + rows) * sizeof(bf_cluster), grp != nullptr));   // earlier groups' rows stay
+        BF_TRY(ensure(ctx, ctx->c_reads, std::max<uint64_t>(stride, 1) * sizeof(bf_read), grp != nullptr && rd_base != 0));
+        BF_TRY(ensure(ctx, ctx->c_rsrc, std::max<uint64_t>(stride, 1) * 4 * 4));
+        ctx->rsrc_stride = stride;
+        BF_TRY(tables());
+        EmitView ev{};
+        ev.ord = ctx->c_ord.as<uint32_t>(); ev.roff = ctx->c_scan.as<uint64_t>();
+        ev.qseed = ctx->c_qseed.as<uint32_t>(); ev.qsize = ctx->c_qsize.as<uint32_t>(); ev.qoff = ctx->c_qoff.as<uint64_t>();
+        ev.mrec = ctx->c_mrec.as<uint32_t>(); ev.mjrec = ctx->c_mjrec.as<uint32_t>(); ev.rep = ctx->c_rep.as<uint32_t>();
+        ev.skey = sv.skey; ev.slpos = sv.slpos; ev.srpos = sv.srpos; ev.perm = perm;
+        ev.src = v.src; ev.src_base = (const uint64_t*)ctx->c_tables.p;
+        ev.rank2id = d_rank2id; ev.cb = ctx->contig_bits;
+        ev.clusters = ctx->c_clusters.as<bf_cluster>() + cl_base; ev.reads = ctx->c_reads.as<bf_read>() + rd_base;
+        ev.out_src_rank = ctx->c_rsrc.as<uint32_t>() + rd_base; ev.out_src_idx = ev.out_src_rank + stride;
+        ev.out_rec = ev.out_src_idx + stride; ev.out_jrec = ev.out_rec + stride;
+        ev.rd_base = rd_base;
+        Scope t(ctx, "emit");
+        hipLaunchKernelGGL(emit_kernel, dim3(grid_for(rows * 64, B)), dim3(B), 0, st, ev, ns_dev, stride - rd_base);
+        BF_HIP(ctx, hipGetLastError());
+        return BF_OK;
+    };
+    // the per-read arrays: sized for every evidence record when groups append -- which is not a bound: a read that an
+    // earlier seed reported joins a later seed's cluster as well (detect.rs:215-226), so more reads can print than there
+    // is evidence.  Then the four planes of c_rsrc move apart (earlier groups' entries kept) and the table grows.
+    uint64_t stride = grp ? std::max<uint64_t>(grp->cap, rd_base ? ctx->rsrc_stride : 0) : 0;
+    bool emitted = false;
     {
         Scope t(ctx, "select");
         const uint32_t* qord = ctx->c_qord.as<uint32_t>();
@@ -1310,23 +1371,19 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
         BF_TRY(mail_fetch(ctx, 0, sums + 2));              // the reads that will be printed
         BF_TRY(mail_fetch(ctx, 1, ctx->c_scan.as<uint64_t>() + nq));
         if (order_flag) BF_TRY(mail_fetch(ctx, 2, ctx->c_big.as<uint32_t>() + 12));      // (8 bytes: the flag and its neighbour)
-        BF_SYNC(ctx, st);
-        total_r = ctx->h_mail[0]; ns = ctx->h_mail[1];
-        if (order_flag && (uint32_t)ctx->h_mail[2] != 0) { ctx->order_full = true; *redo = true; return BF_OK; }
-        if (ns == 0) return BF_OK;
-        // ord[k'] = the k'-th surviving cluster in print order; nrep in that order -> read offsets
+        // ord[k'] = the k'-th surviving cluster in print order; nrep in that order -> read offsets (over the qualifying
+        // clusters' slots: what lies behind the survivors' is never read)
         uint32_t* vb = ctx->c_c32.as<uint32_t>();
         hipLaunchKernelGGL(compact_index_kernel, dim3(grid_for(nq, B)), dim3(B), 0, st, ctx->c_flag.as<uint32_t>(),
-                           ctx->c_scan.as<uint64_t>(), ctx->c_ord.as<uint32_t>(), nq, qord, ctx->c_qnrep.as<uint32_t>(), vb);
-        BF_TRY(scan_u32_to_u64(ctx, vb, ctx->c_scan.as<uint64_t>(), ns));
+                           ctx->c_scan.as<uint64_t>(), ctx->c_ord.as<uint32_t>(), nq, qord, ctx->c_qnrep.as<uint32_t>(), vb, ns_dev);
+        BF_TRY(scan_u32_to_u64(ctx, vb, ctx->c_scan.as<uint64_t>(), nq));
     }
-
-    // 5. emit rows + surviving reads
-    const uint64_t cl_base = grp ? grp->cl_base : 0, rd_base = grp ? grp->rd_base : 0;
-    // the per-read arrays: sized for every evidence record when groups append -- which is not a bound: a read that an
-    // earlier seed reported joins a later seed's cluster as well (detect.rs:215-226), so more reads can print than there
-    // is evidence.  Then the four planes of c_rsrc move apart (earlier groups' entries kept) and the table grows.
-    uint64_t stride = grp ? std::max<uint64_t>(grp->cap, rd_base ? ctx->rsrc_stride : 0) : total_r;
+    if (grp) { BF_TRY(emit(nq, stride)); emitted = true; }
+    BF_SYNC(ctx, st);
+    total_r = ctx->h_mail[0]; ns = ctx->h_mail[1];
+    if (order_flag && (uint32_t)ctx->h_mail[2] != 0) { ctx->order_full = true; *redo = true; return BF_OK; }
+    if (ns == 0) return BF_OK;
+    if (!grp) stride = total_r;
     if (grp && rd_base + total_r > stride) {
         const uint64_t wider = std::max(rd_base + total_r, stride + stride / 2);
         if (rd_base) {
@@ -1341,47 +1398,9 @@ static int run_cluster_once(bf_ctx* ctx, const OwnerView& v, ClusterGroup* grp, 
         }
         stride = wider;
         grp->cap = wider;
+        emitted = false;                                   // (the queued emit saw that its reads do not fit and wrote nothing)
     }
-    BF_TRY(ensure(ctx, ctx->c_clusters, (cl_base + ns) * sizeof(bf_cluster), grp != nullptr));   // earlier groups' rows stay
-    BF_TRY(ensure(ctx, ctx->c_reads, std::max<uint64_t>(grp ? stride : total_r, 1) * sizeof(bf_read), grp != nullptr && rd_base != 0));
-    BF_TRY(ensure(ctx, ctx->c_rsrc, std::max<uint64_t>(stride, 1) * 4 * 4));
-    ctx->rsrc_stride = stride;
-    std::vector<uint64_t> bases = ctx->src_index_base;
-    if (bases.empty()) bases.assign(1, ctx->index_base);
-    uint32_t* d_rank2id = nullptr;
-    {
-        // the two small tables emit reads (index base per source rank, contig id per rank): uploaded when they change, not
-        // per call (two copies from pageable memory in front of every emit were two round trips)
-        std::vector<uint64_t> key = bases;
-        key.push_back(ctx->n_contigs);
-        for (uint32_t r = 0; r < ctx->n_contigs; r++) key.push_back(ctx->contig_by_rank[r]);
-        const size_t need = bases.size() * 8 + (size_t)ctx->n_contigs * 4 + 16;
-        const bool fresh = ctx->c_tables.cap < need || key != ctx->tables_key;
-        BF_TRY(ensure(ctx, ctx->c_tables, need));
-        d_rank2id = (uint32_t*)((uint8_t*)ctx->c_tables.p + bases.size() * 8);
-        if (fresh) {
-            BF_HIP(ctx, hipMemcpyAsync(ctx->c_tables.p, bases.data(), bases.size() * 8, hipMemcpyHostToDevice, st));
-            BF_HIP(ctx, hipMemcpyAsync(d_rank2id, ctx->contig_by_rank.data(), (size_t)ctx->n_contigs * 4, hipMemcpyHostToDevice, st));
-            BF_SYNC(ctx, st);                             // (the sources are host vectors)
-            ctx->tables_key = key;
-        }
-    }
-    EmitView ev{};
-    ev.ord = ctx->c_ord.as<uint32_t>(); ev.roff = ctx->c_scan.as<uint64_t>();
-    ev.qseed = ctx->c_qseed.as<uint32_t>(); ev.qsize = ctx->c_qsize.as<uint32_t>(); ev.qoff = ctx->c_qoff.as<uint64_t>();
-    ev.mrec = ctx->c_mrec.as<uint32_t>(); ev.mjrec = ctx->c_mjrec.as<uint32_t>(); ev.rep = ctx->c_rep.as<uint32_t>();
-    ev.skey = sv.skey; ev.slpos = sv.slpos; ev.srpos = sv.srpos; ev.perm = perm;
-    ev.src = v.src; ev.src_base = (const uint64_t*)ctx->c_tables.p;
-    ev.rank2id = d_rank2id; ev.cb = ctx->contig_bits;
-    ev.clusters = ctx->c_clusters.as<bf_cluster>() + cl_base; ev.reads = ctx->c_reads.as<bf_read>() + rd_base;
-    ev.out_src_rank = ctx->c_rsrc.as<uint32_t>() + rd_base; ev.out_src_idx = ev.out_src_rank + stride;
-    ev.out_rec = ev.out_src_idx + stride; ev.out_jrec = ev.out_rec + stride;
-    ev.rd_base = rd_base;
-    {
-        Scope t(ctx, "emit");
-        hipLaunchKernelGGL(emit_kernel, dim3(grid_for(ns * 64, B)), dim3(B), 0, st, ev, ns);
-    }
-    BF_HIP(ctx, hipGetLastError());
+    if (!emitted) BF_TRY(emit(ns, stride));
     // host copies: the rows now; the reads after the junction offsets are patched in (api.hip)
     if (grp) {                                            // the caller copies the rows when the last group is through
         grp->ns = ns; grp->nr = total_r;
