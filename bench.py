@@ -99,6 +99,7 @@ def main():
                          "command line's parser produces, the shipped path) or ASCII (bf_submit)")
     ap.add_argument("--roh-groups", type=int, default=-1, help="contig groups of the reads-on-host leg (-1: like --groups)")
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host loops (resident-input value only)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC passes instead of two live rocprofv3 passes")
     ap.add_argument("--host-threads", type=int, default=0, help="staging threads of bf_submit (0 = library default)")
     args = ap.parse_args()
 
@@ -421,9 +422,17 @@ def main():
     loc_avg_ms = loc_ms / max(loc_n, 1)
     bpr = algorithmic_bytes_per_read(L)
     achieved = n_local * bpr / (loc_avg_ms * 1e-3) / 1e9 if loc_avg_ms > 0 else 0.0
+    traffic, traffic_source = None, None
+    if rank == 0 and world == 1 and not sharded and not args.no_live_traffic and not args.no_h2h:
+        traffic, traffic_source = live_pmc_traffic(args)
+    if traffic is None:
+        why = traffic_source
+        traffic = pmc_traffic(args, n_local, L)
+        traffic_source = None if traffic is None else "committed passes of this workload (profiles/*_pmc_traffic.json, tools/pmc_traffic.py)" + (
+            "; live passes: %s" % why if why else "")
     roofline = {"bound": "hbm", "kernel": "localise_fast_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": pmc_traffic(args, n_local, L),
+                "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_read": bpr, "reads_per_launch": n_local, "avg_launch_ms": round(loc_avg_ms, 4)}
     # per step (a stage runs once per contig group and step; the roofline kernel above once per step)
     stages = {k: round(v[0] / args.steps, 4) for k, v in ktimes.items()}
@@ -535,6 +544,43 @@ def pipeline_headline(n_local, L, ms_per_step):
     gbps = n_local * (b_a + b_s) / (ms_per_step * 1e-3) / 1e9
     return {"algorithmic_bytes_per_read": b_a + b_s, "achieved": round(gbps, 1), "unit": "GB/s",
             "frac": round(gbps / HBM_PEAK_GBPS, 4), "note": "whole device pipeline incl. the PCIe copy of the result"}
+
+
+def live_pmc_traffic(args):
+    """HBM bytes per launch of the localise kernel, measured NOW: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE: separate, as
+    the TCC counter slots demand) of a short run of this very command in a child process each, turned into bytes as
+    tools/pmc_traffic.py does (FETCH_SIZE counts 128-byte requests at 64 bytes on gfx950: the read side is doubled).
+    -> (bytes, where they came from) or (None, why not)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_traffic as pt
+        t0 = time.time()
+        per_launch = {}
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(td, counter)
+                cmd = ["timeout", "-s", "KILL", "170", exe, "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--",
+                       sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--no-h2h",
+                       "--one-stream", "--config", str(args.config), "--scale", str(args.scale), "--reads", args.reads,
+                       "--variant", args.variant, "--no-live-traffic"]
+                r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", timeout=200)
+                if r.returncode != 0:
+                    return None, "rocprofv3 --pmc %s ended with status %d" % (counter, r.returncode)
+                vals = [v for k, v in pt.per_kernel(d, counter).items() if "localise_fast_kernel" in k]
+                if not vals or not vals[0]:
+                    return None, "no localise_fast_kernel in the %s pass" % counter
+                per_launch[counter] = sum(vals[0]) / len(vals[0])
+        total = per_launch["FETCH_SIZE"] * 1024 * 2 + per_launch["WRITE_SIZE"] * 1024
+        print("[bench] live PMC passes: %.2f GB per launch of the localise kernel (%.0f s)" % (total / 1e9, time.time() - t0), file=sys.stderr, flush=True)
+        return int(round(total)), "two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this command during this run, per launch over the whole input"
+    except Exception as e:                         # an extra leg must not cost the bench line
+        return None, repr(e)
 
 
 def pmc_traffic(args, n_local, L):
