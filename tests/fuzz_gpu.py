@@ -14,7 +14,9 @@ A checker run by hand, not collected by pytest (it lives in tests/ because only 
 """
 import argparse
 import os
+import shutil
 import sys
+import tempfile
 import threading
 import time
 import uuid
@@ -148,12 +150,38 @@ def over_ranks(g, b, A, F, E, world, flags):
     return engine.shard_format_sv(g.names, results)
 
 
+EXE = os.path.join(ROOT, "breakfast_amd", "csrc", "breakfast-hip")
+
+
+def command_line(g, b, A, F, E, tmp, extra, image=False):
+    """`breakfast-hip detect --anchor-hits=...`: from a FASTA (or its image) and bowtie's lines on disk to stdout."""
+    import subprocess
+    prefix = os.path.join(tmp, "g")
+    if not os.path.exists(prefix + ".fa"):
+        open(prefix + ".fa", "wb").write(g.fasta())
+        open(os.path.join(tmp, "hits.txt"), "wb").write(synth.bowtie_lines(b, g.names))
+    if image and not os.path.exists(prefix + ".bf2bit"):
+        subprocess.run([EXE, "index", prefix], check=True, capture_output=True, timeout=100)
+    env = dict(os.environ)
+    if not image:
+        env["BREAKFAST_HIP_NO_IMAGE"] = "1"
+    if bool((b.seq_bytes & 0x20).any()):
+        extra = extra + ["--ascii-reads"]
+    p = subprocess.run([EXE, "detect", "--anchor-len=%d" % A, "--max-frag-len=%d" % F, "--min-evidence=%d" % E,
+                        "--anchor-hits=" + os.path.join(tmp, "hits.txt")] + extra + ["unused.bam", prefix],
+                       capture_output=True, timeout=200, env=env)
+    if p.returncode != 0:
+        raise RuntimeError("exit %d: %s" % (p.returncode, p.stderr.decode(errors="replace")[-300:]))
+    return p.stdout
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--seed0", type=int, default=0)
     ap.add_argument("--seeds", type=int, default=10 ** 9)
     ap.add_argument("--log", default=None)
+    ap.add_argument("--cli", action="store_true", help="also through the command line (FASTA, genome image, two ranks on one GPU)")
     ap.add_argument("--time-dense", type=int, default=None, metavar="SEED",
                     help="no oracle: time the GPU alone on this seed's case WITHOUT the bound on reads per window (the reference is "
                          "quadratic there; this shows what the GPU path does)")
@@ -196,6 +224,11 @@ def main():
                 ("reads_on_host+groups", lambda: one_gpu(g, b, A, F, E, H | G, "packed")),
                 ("ranks2", lambda: over_ranks(g, b, A, F, E, 2, 0)),
                 ("ranks3+groups", lambda: over_ranks(g, b, A, F, E, 3, G))]
+        if args.cli:
+            tmp = tempfile.mkdtemp(prefix="bf_fuzz_")
+            ways += [("cli", lambda: command_line(g, b, A, F, E, tmp, ["--threads=%d" % (1 + seed % 7), "--block-bytes=%d" % (1000 + 37 * (seed % 5000))])),
+                     ("cli image", lambda: command_line(g, b, A, F, E, tmp, [], image=True)),
+                     ("cli devices=0,0", lambda: command_line(g, b, A, F, E, tmp, ["--devices=0,0"], image=bool(seed & 1)))]
         t0 = time.time()
         failed = []
         for name, fn in ways:
@@ -207,6 +240,8 @@ def main():
                 failed.append(name + ":" + repr(e)[:160])
         say("seed", seed, "ok" if not failed else "FAILED " + "; ".join(failed), "| clusters=%d sv=%d bytes | oracle %.1fs gpu %.1fs |" % (
             ref.n_clusters, len(ref.sv), t_or, time.time() - t0), what)
+        if args.cli:
+            shutil.rmtree(tmp, ignore_errors=True)
         if failed:
             bad.append((seed, failed))
         cases += 1
