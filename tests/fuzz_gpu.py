@@ -48,11 +48,13 @@ def repeat_genome(rng, contigs, seed, unit_len, n_units, mut):
     return synth.Genome([n.encode() for n, _ in contigs], seqs)
 
 
-def make_case(seed, dense=False):
+def make_case(seed, dense=False, large=False):
     rng = np.random.default_rng(1_000_003 * seed + 17)
     n_contigs = int(rng.choice([1, 2, 3, 5, 12, 25, 60]))
     order = rng.permutation(200)[:n_contigs]
     total = int(rng.choice([40_000, 300_000, 3_000_000, 20_000_000]))
+    if large:
+        total = int(rng.choice([20_000_000, 60_000_000, 200_000_000]))
     w = rng.random(n_contigs) + 0.05
     A = int(rng.choice([10, 12, 16, 20, 25, 30]))
     L = int(rng.choice([2 * A, 2 * A + 1, 2 * A + 7, 76, 100, 150, 250]))
@@ -75,10 +77,17 @@ def make_case(seed, dense=False):
                 lower_runs.append((ci, a, int(rng.integers(1, min(contigs[ci][1] // 2 + 2, contigs[ci][1] - a)))))
         g = synth.make_genome(contigs, seed=77_000 + seed, end_n=end_n, n_runs=n_runs, lower_runs=lower_runs)
     n_reads = int(rng.choice([2_000, 10_000, 40_000, 120_000, 400_000]))
+    if large:
+        n_reads = int(rng.choice([1_000_000, 2_000_000, 4_500_000]))
     hot = float(rng.choice([0.0, 0.0, 0.3, 0.8]))
     hot_events = int(rng.choice([1, 3, 40])) if hot else 0
     n_events = int(rng.choice([1, 5, 50, max(n_reads // 60, 1), max(n_reads // 8, 1)]))
+    if large:
+        n_events = int(rng.choice([max(n_reads // 300, 1), max(n_reads // 60, 1), max(n_reads // 8, 1)]))
     single = float(rng.choice([0.0, 0.2, 0.5, 0.9]))
+    if large and hot:
+        hot, hot_events = 0.02, 40
+    single = min(single, 1.0 - hot)
     # the reference's sweep is quadratic in the reads of one junction (so is the restatement): n_reads x (reads of a pile) stays below 1e9
     pile = max(hot / max(hot_events, 1), max(1.0 - single - hot, 0.0) / n_events)
     n_reads = max(min(n_reads, int((1e9 / max(pile, 1e-9)) ** 0.5)), 500)
@@ -181,6 +190,7 @@ def main():
     ap.add_argument("--seed0", type=int, default=0)
     ap.add_argument("--seeds", type=int, default=10 ** 9)
     ap.add_argument("--log", default=None)
+    ap.add_argument("--large", action="store_true", help="1M - 4.5M reads on 20M - 200M bases, four ways a case")
     ap.add_argument("--cli", action="store_true", help="also through the command line (FASTA, genome image, two ranks on one GPU)")
     ap.add_argument("--time-dense", type=int, default=None, metavar="SEED",
                     help="no oracle: time the GPU alone on this seed's case WITHOUT the bound on reads per window (the reference is "
@@ -208,7 +218,7 @@ def main():
     bad, cases, seed = [], 0, args.seed0
     while time.time() < t_end and seed < args.seed0 + args.seeds:
         try:
-            g, b, A, F, E, what = make_case(seed)
+            g, b, A, F, E, what = make_case(seed, large=args.large)
         except Exception as e:  # noqa: BLE001   (a spec the generator cannot place: not a finding)
             say("seed", seed, "generator:", repr(e)[:200])
             seed += 1
@@ -224,6 +234,9 @@ def main():
                 ("reads_on_host+groups", lambda: one_gpu(g, b, A, F, E, H | G, "packed")),
                 ("ranks2", lambda: over_ranks(g, b, A, F, E, 2, 0)),
                 ("ranks3+groups", lambda: over_ranks(g, b, A, F, E, 3, G))]
+        if args.large:
+            ways = [("packed2", ways[2][1]), ("packed, as the library cuts it", lambda: one_gpu(g, b, A, F, E, 0, "packed")),
+                    ("reads_on_host+groups", ways[4][1]), ("ranks2", ways[5][1])]
         if args.cli:
             tmp = tempfile.mkdtemp(prefix="bf_fuzz_")
             ways += [("cli", lambda: command_line(g, b, A, F, E, tmp, ["--threads=%d" % (1 + seed % 7), "--block-bytes=%d" % (1000 + 37 * (seed % 5000))])),
