@@ -130,8 +130,8 @@ def one_gpu(g, b, A, F, E, flags, reads_as):
         eng.close()
 
 
-def over_ranks(g, b, A, F, E, world, flags):
-    cuts = [b.n * r // world for r in range(world + 1)]
+def over_ranks(g, b, A, F, E, world, flags, slot_bytes=8 << 20, cuts=None):
+    cuts = cuts or [b.n * r // world for r in range(world + 1)]
     name = "/bf_fuzz_%s" % uuid.uuid4().hex[:12]
     results, errors = [None] * world, []
 
@@ -140,7 +140,7 @@ def over_ranks(g, b, A, F, E, world, flags):
             eng = engine.Engine(A, F, E, device=0, flags=flags)
             try:
                 eng.set_genome(g.names, g.seqs)
-                eng.shard_init_host(rank, world, cuts[rank], name, 8 << 20)
+                eng.shard_init_host(rank, world, cuts[rank], name, slot_bytes)
                 if cuts[rank + 1] > cuts[rank]:
                     eng.submit(b.slice(cuts[rank], cuts[rank + 1]))
                 results[rank] = eng.shard_finish()
@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--seeds", type=int, default=10 ** 9)
     ap.add_argument("--log", default=None)
     ap.add_argument("--large", action="store_true", help="1M - 4.5M reads on 20M - 200M bases, four ways a case")
+    ap.add_argument("--ranks", action="store_true", help="the sharded path only: three random (world, shard cuts, slot size, flags) a case")
     ap.add_argument("--cli", action="store_true", help="also through the command line (FASTA, genome image, two ranks on one GPU)")
     ap.add_argument("--time-dense", type=int, default=None, metavar="SEED",
                     help="no oracle: time the GPU alone on this seed's case WITHOUT the bound on reads per window (the reference is "
@@ -237,6 +238,18 @@ def main():
         if args.large:
             ways = [("packed2", ways[2][1]), ("packed, as the library cuts it", lambda: one_gpu(g, b, A, F, E, 0, "packed")),
                     ("reads_on_host+groups", ways[4][1]), ("ranks2", ways[5][1])]
+        if args.ranks:
+            # the sharded path alone: 2 - 8 ranks, uneven and empty shards, slots from 64 KB (many rounds of the host transport) up
+            r2 = np.random.default_rng(seed)
+            ways = []
+            for _ in range(3):
+                world = int(r2.choice([2, 3, 4, 5, 8]))
+                inner = np.sort(r2.integers(0, b.n + 1, size=world - 1)) if r2.random() < 0.5 else np.array([b.n * r // world for r in range(1, world)])
+                cuts = [0] + [int(x) for x in inner] + [b.n]
+                slot = int(r2.choice([1 << 16, 1 << 20, 8 << 20]))
+                fl = int(r2.choice([0, G, X, G | X]))
+                ways.append(("ranks%d slot=%d flags=%d cuts=%s" % (world, slot, fl, cuts),
+                             lambda world=world, fl=fl, slot=slot, cuts=cuts: over_ranks(g, b, A, F, E, world, fl, slot, cuts)))
         if args.cli:
             tmp = tempfile.mkdtemp(prefix="bf_fuzz_")
             ways += [("cli", lambda: command_line(g, b, A, F, E, tmp, ["--threads=%d" % (1 + seed % 7), "--block-bytes=%d" % (1000 + 37 * (seed % 5000))])),
