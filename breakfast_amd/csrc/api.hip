@@ -1123,7 +1123,7 @@ static int clusterise_in_groups(bf_ctx* ctx, const OwnerView& v, bool* done) {
     uint64_t bound = 0;
     // a group costs about 0.25 ms of launches and host round trips whatever its size (0.35 until round 3 took a third of the
     // launches and half of the waits out of the stage): one per 3.3M reads, 2 to 8 (configs[2], 100M reads on one GPU: 8 groups 56.9 ms, 16 groups 60.9)
-    // (bf_config.reserved[0] overrides; measured on configs[1], round 3: 2 groups 5.69 ms, 3: 5.42, 4: 5.55)
+    // (bf_config.reserved[0] overrides; measured on configs[1], round 3: 2 groups 5.69 ms, 3: 5.42, 4: 5.55; at the round's end 3: 5.32, 4: 5.36, 5: 5.61)
     const uint32_t fit = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(v.n / 3300000, 2), kMaxGroups);
     const uint32_t want = ctx->cfg.reserved[0] ? std::min<uint32_t>(ctx->cfg.reserved[0], 64u) : fit;
     BF_TRY(cluster_groups(ctx, v, want, gb, true));
