@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--seeds", type=int, default=10 ** 9)
     ap.add_argument("--log", default=None)
     ap.add_argument("--large", action="store_true", help="1M - 4.5M reads on 20M - 200M bases, four ways a case")
+    ap.add_argument("--stress", action="store_true", help="the rarely taken branches: few class buckets, a weak dedup hash, the sorted-run dedup")
     ap.add_argument("--ranks", action="store_true", help="the sharded path only: three random (world, shard cuts, slot size, flags) a case")
     ap.add_argument("--cli", action="store_true", help="also through the command line (FASTA, genome image, two ranks on one GPU)")
     ap.add_argument("--time-dense", type=int, default=None, metavar="SEED",
@@ -238,6 +239,24 @@ def main():
         if args.large:
             ways = [("packed2", ways[2][1]), ("packed, as the library cuts it", lambda: one_gpu(g, b, A, F, E, 0, "packed")),
                     ("reads_on_host+groups", ways[4][1]), ("ranks2", ways[5][1])]
+        if args.stress:
+            # the rarely taken branches: few buckets (chunks overflow their LDS sort and are set aside), a 3-bit dedup hash (every
+            # group decided on the id bytes), the sorted-run dedup for every cluster
+            Wk, Sd = engine.BF_FLAG_WEAK_DEDUP_HASH, engine.BF_FLAG_SORTED_DEDUP
+
+            def with_bits(bits, fn):
+                os.environ["BREAKFAST_HIP_BUCKET_BITS"] = str(bits)
+                try:
+                    return fn()
+                finally:
+                    del os.environ["BREAKFAST_HIP_BUCKET_BITS"]
+            ways = [("weak hash", lambda: one_gpu(g, b, A, F, E, Wk, "packed")),
+                    ("weak hash+groups", lambda: one_gpu(g, b, A, F, E, Wk | G, "ascii")),
+                    ("sorted dedup", lambda: one_gpu(g, b, A, F, E, Sd, "packed2")),
+                    ("sorted dedup+weak+groups", lambda: one_gpu(g, b, A, F, E, Sd | Wk | G, "pieces")),
+                    ("2 bucket bits", lambda: with_bits(2, lambda: one_gpu(g, b, A, F, E, 0, "packed"))),
+                    ("5 bucket bits+groups", lambda: with_bits(5, lambda: one_gpu(g, b, A, F, E, G, "ascii"))),
+                    ("1 bucket bit, ranks3, weak", lambda: with_bits(1, lambda: over_ranks(g, b, A, F, E, 3, Wk)))]
         if args.ranks:
             # the sharded path alone: 2 - 8 ranks, uneven and empty shards, slots from 64 KB (many rounds of the host transport) up
             r2 = np.random.default_rng(seed)
