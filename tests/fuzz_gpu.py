@@ -78,7 +78,7 @@ def make_case(seed, dense=False, large=False):
         g = synth.make_genome(contigs, seed=77_000 + seed, end_n=end_n, n_runs=n_runs, lower_runs=lower_runs)
     n_reads = int(rng.choice([2_000, 10_000, 40_000, 120_000, 400_000]))
     if large:
-        n_reads = int(rng.choice([1_000_000, 2_000_000, 4_500_000]))
+        n_reads = int(rng.choice([1_000_000, 2_000_000, 4_500_000, 9_000_000]))
     hot = float(rng.choice([0.0, 0.0, 0.3, 0.8]))
     hot_events = int(rng.choice([1, 3, 40])) if hot else 0
     n_events = int(rng.choice([1, 5, 50, max(n_reads // 60, 1), max(n_reads // 8, 1)]))
