@@ -557,6 +557,8 @@ def live_pmc_traffic(args):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler"
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         import pmc_traffic as pt
